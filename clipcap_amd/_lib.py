@@ -1,0 +1,105 @@
+"""ctypes binding of libclipcap_hip.so (C ABI: include/clipcap_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or a kernel call fails, this raises.
+Build the library with ``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C clipcap_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libclipcap_hip.so")
+
+ERR = {0: "ok", -1: "invalid argument", -2: "unsupported shape / alignment", -3: "kernel launch failed", -4: "invalid state"}
+
+
+class HipExtensionMissing(RuntimeError):
+    pass
+
+
+class CCError(RuntimeError):
+    pass
+
+
+class MapperCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("E", "D", "P", "L", "H", "N", "Hm", "W", "use_pos")]
+
+
+class Gpt2Cfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("D", "H", "NL", "V", "Vp", "NPOS")]
+
+
+class Gpt2Shape(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "L", "T", "cap", "mode")]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+_MC, _GC, _GS = C.POINTER(MapperCfg), C.POINTER(Gpt2Cfg), C.POINTER(Gpt2Shape)
+
+# name -> (restype, argtypes): one entry per symbol declared in include/clipcap_hip.h
+SIGNATURES = {
+    "cc_abi_version": (_I, []),
+    "cc_mapper_param_count": (_L, [_MC]),
+    "cc_mapper_param_offsets": (_I, [_MC, C.POINTER(_L)]),
+    "cc_mapper_ws_bytes": (_L, [_MC, _I, _I]),
+    "cc_mapper_fwd": (_I, [_MC, _I, _P, _P, _P, _P, _P, _I, _P]),
+    "cc_mapper_bwd": (_I, [_MC, _I, _P, _P, _P, _P, _P, _P]),
+    "cc_gpt2_param_count": (_L, [_GC]),
+    "cc_gpt2_param_offsets": (_I, [_GC, C.POINTER(_L)]),
+    "cc_gpt2_ws_bytes": (_L, [_GC, _GS]),
+    "cc_gpt2_embed": (_I, [_GC, _GS, _P, _P, _P, _P, _P]),
+    "cc_gpt2_embed_from": (_I, [_GC, _GS, _P, _P, _P, _P]),
+    "cc_gpt2_fwd": (_I, [_GC, _GS, _P, _P, _P, _P]),
+    "cc_gpt2_logits": (_I, [_GC, _GS, _P, _P, _P, _P, _L, _P]),
+    "cc_lmhead_ce_fwd": (_I, [_GC, _GS, _P, _P, _P, _P, _P, _P]),
+    "cc_lmhead_ce_bwd": (_I, [_GC, _GS, _P, _P, _P, _P, _P, _P]),
+    "cc_gpt2_bwd": (_I, [_GC, _GS, _P, _P, _P, _P, _P, _P, _P]),
+    "cc_decode_ws_bytes": (_L, [_GC, _I, _I]),
+    "cc_decode_fwd": (_I, [_GC, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "cc_decode_reorder": (_I, [_GC, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "cc_beam_step": (_I, [_I, _I, _I, _P, _L, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "cc_beam_ws_bytes": (_L, [_I, _I, _I]),
+    "cc_embed_tokens": (_I, [_GC, _I, _P, _P, _P, _P]),
+    "cc_adamw_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P]),
+    "cc_cast_bf16": (_I, [_P, _P, _L, _P]),
+    "cc_gemm_bf16_f32": (_I, [_I, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P]),
+    "cc_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "cc_attention_fwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "cc_attention_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib() -> C.CDLL:
+    """Loads the HIP library once; raises HipExtensionMissing (never falls back to a CPU path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise HipExtensionMissing(
+                    f"{LIB_PATH} not found: build it with `make -C clipcap_amd/csrc` (hipcc, gfx950). "
+                    "clipcap_amd has no CPU fallback.")
+            try:
+                l = C.CDLL(LIB_PATH)
+            except OSError as e:  # pragma: no cover
+                raise HipExtensionMissing(f"cannot load {LIB_PATH}: {e}") from e
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(l, name)
+                fn.restype = res
+                fn.argtypes = args
+            if l.cc_abi_version() != 1:
+                raise HipExtensionMissing("libclipcap_hip.so ABI version mismatch; rebuild")
+            _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = "") -> int:
+    if rc < 0:
+        raise CCError(f"{what or 'clipcap_hip call'} failed: {ERR.get(rc, rc)} ({rc})")
+    return rc

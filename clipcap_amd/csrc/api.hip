@@ -1,0 +1,585 @@
+// C ABI (include/clipcap_hip.h) — orchestration of the mapper and GPT-2 training/inference passes out of the HIP
+// kernels in gemm.cuh / kernels.hip.  No state, no allocation, no synchronisation: everything is enqueued on the
+// caller's stream and lives in caller-owned arenas / workspaces.
+#include "../../include/clipcap_hip.h"
+#include "gemm_api.h"
+#include "kernels.h"
+
+using namespace cc;
+
+#define CC_TRY(expr)                 \
+    do {                             \
+        int _e = (expr);             \
+        if (_e != CC_OK) return _e;  \
+    } while (0)
+
+namespace {
+
+constexpr int MAX_LAYERS = 96;
+
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(void* p) : base(static_cast<char*>(p)) {}
+    template <class T>
+    T* take(size_t n) {
+        off = (off + 255) & ~size_t(255);
+        T* r = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return r;
+    }
+};
+
+inline hipStream_t S_(void* s) { return static_cast<hipStream_t>(s); }
+inline int rup(int x, int m) { return (x + m - 1) / m * m; }
+
+// ------------------------------------------------------------------------------------------------------------
+// mapper
+// ------------------------------------------------------------------------------------------------------------
+struct MapperOff {
+    int64_t lin_w, lin_b, prefix, pos;
+    struct Layer {
+        int64_t n1w, n1b, wq, wkv, wp, bp, n2w, n2b, w1, b1, w2, b2;
+    } layer[MAX_LAYERS];
+    int64_t total;
+};
+
+bool mapper_cfg_ok(const cc_mapper_cfg* c) {
+    return c && c->E > 0 && c->D > 0 && c->P > 0 && c->L > 0 && c->H > 0 && c->N >= 0 && c->N <= MAX_LAYERS && c->Hm > 0 && c->W >= 1 &&
+           (c->E % 8) == 0 && (c->D % 8) == 0 && (c->Hm % 8) == 0 && (c->D % c->H) == 0 && ((c->D / c->H) % 8) == 0;
+}
+
+void mapper_offsets(const cc_mapper_cfg* c, MapperOff& o) {
+    int64_t p = 0;
+    const int64_t D = c->D, E = c->E, PD = (int64_t)c->P * D, Hm = c->Hm;
+    o.lin_w = p; p += PD * E;
+    o.lin_b = p; p += PD;
+    o.prefix = p; p += (int64_t)c->L * D;
+    if (c->W > 1 && c->use_pos) { o.pos = p; p += (int64_t)c->W * PD; } else o.pos = -1;
+    for (int l = 0; l < c->N; l++) {
+        auto& y = o.layer[l];
+        y.n1w = p; p += D;
+        y.n1b = p; p += D;
+        y.wq = p; p += D * D;
+        y.wkv = p; p += 2 * D * D;
+        y.wp = p; p += D * D;
+        y.bp = p; p += D;
+        y.n2w = p; p += D;
+        y.n2b = p; p += D;
+        y.w1 = p; p += Hm * D;
+        y.b1 = p; p += Hm;
+        y.w2 = p; p += D * Hm;
+        y.b2 = p; p += D;
+    }
+    o.total = p;
+}
+
+struct MapperWS {
+    bf16_t* emb16;
+    float* lin_tmp;
+    float* x[MAX_LAYERS + 1];
+    float* x1[MAX_LAYERS];
+    bf16_t *xn1[MAX_LAYERS], *xn2[MAX_LAYERS], *qkv[MAX_LAYERS], *att[MAX_LAYERS], *h[MAX_LAYERS];
+    float *lse[MAX_LAYERS], *mean1[MAX_LAYERS], *rstd1[MAX_LAYERS], *mean2[MAX_LAYERS], *rstd2[MAX_LAYERS];
+    // backward scratch
+    float* dx32;
+    bf16_t *dx16, *dh16, *dxn16, *datt16, *dqkv16, *dlin16;
+    size_t bytes;
+};
+
+void mapper_carve(const cc_mapper_cfg* c, int B, int save, void* ws, MapperWS& w) {
+    Carver cv(ws);
+    const int S = c->W * c->P + c->L;
+    const size_t M = (size_t)B * S, D = c->D;
+    w.emb16 = cv.take<bf16_t>((size_t)B * c->W * c->E);
+    w.lin_tmp = c->W > 1 ? cv.take<float>((size_t)B * c->W * c->P * D) : nullptr;
+    const int nx = save ? c->N + 1 : 2;
+    float* xb[MAX_LAYERS + 1];
+    for (int i = 0; i < nx; i++) xb[i] = cv.take<float>(M * D);
+    for (int l = 0; l <= c->N; l++) w.x[l] = save ? xb[l] : xb[l & 1];
+    const int nl = save ? c->N : 1;
+    for (int l = 0; l < c->N; l++) {
+        const bool fresh = l < nl;
+        const int s = fresh ? l : 0;
+        if (fresh) {
+            w.x1[l] = cv.take<float>(M * D);
+            w.xn1[l] = cv.take<bf16_t>(M * D);
+            w.xn2[l] = cv.take<bf16_t>(M * D);
+            w.qkv[l] = cv.take<bf16_t>(M * 3 * D);
+            w.att[l] = cv.take<bf16_t>(M * D);
+            w.h[l] = cv.take<bf16_t>(M * c->Hm);
+            w.lse[l] = cv.take<float>((size_t)B * c->H * S);
+            w.mean1[l] = cv.take<float>(M);
+            w.rstd1[l] = cv.take<float>(M);
+            w.mean2[l] = cv.take<float>(M);
+            w.rstd2[l] = cv.take<float>(M);
+        } else {
+            w.x1[l] = w.x1[s]; w.xn1[l] = w.xn1[s]; w.xn2[l] = w.xn2[s]; w.qkv[l] = w.qkv[s]; w.att[l] = w.att[s]; w.h[l] = w.h[s];
+            w.lse[l] = w.lse[s]; w.mean1[l] = w.mean1[s]; w.rstd1[l] = w.rstd1[s]; w.mean2[l] = w.mean2[s]; w.rstd2[l] = w.rstd2[s];
+        }
+    }
+    if (save) {
+        w.dx32 = cv.take<float>(M * D);
+        w.dx16 = cv.take<bf16_t>(M * D);
+        w.dh16 = cv.take<bf16_t>(M * c->Hm);
+        w.dxn16 = cv.take<bf16_t>(M * D);
+        w.datt16 = cv.take<bf16_t>(M * D);
+        w.dqkv16 = cv.take<bf16_t>(M * 3 * D);
+        w.dlin16 = cv.take<bf16_t>((size_t)B * c->W * c->P * D);
+    } else {
+        w.dx32 = nullptr; w.dx16 = w.dh16 = w.dxn16 = w.datt16 = w.dqkv16 = w.dlin16 = nullptr;
+    }
+    w.bytes = (cv.off + 255) & ~size_t(255);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// GPT-2
+// ------------------------------------------------------------------------------------------------------------
+struct Gpt2Off {
+    int64_t wte, wpe, lnf_w, lnf_b;
+    struct Layer {
+        int64_t l1w, l1b, aw, ab, pw, pb, l2w, l2b, fw, fb, p2w, p2b;
+    } layer[MAX_LAYERS];
+    int64_t total;
+};
+
+bool gpt2_cfg_ok(const cc_gpt2_cfg* c) {
+    return c && c->D > 0 && c->H > 0 && c->NL > 0 && c->NL <= MAX_LAYERS && c->V > 0 && c->Vp >= c->V && (c->Vp % 128) == 0 &&
+           c->NPOS > 0 && (c->D % 8) == 0 && (c->D % c->H) == 0 && ((c->D / c->H) % 8) == 0;
+}
+
+void gpt2_offsets(const cc_gpt2_cfg* c, Gpt2Off& o) {
+    int64_t p = 0;
+    const int64_t D = c->D;
+    o.wte = p; p += (int64_t)c->Vp * D;
+    o.wpe = p; p += (int64_t)c->NPOS * D;
+    for (int l = 0; l < c->NL; l++) {
+        auto& y = o.layer[l];
+        y.l1w = p; p += D;
+        y.l1b = p; p += D;
+        y.aw = p; p += D * 3 * D;
+        y.ab = p; p += 3 * D;
+        y.pw = p; p += D * D;
+        y.pb = p; p += D;
+        y.l2w = p; p += D;
+        y.l2b = p; p += D;
+        y.fw = p; p += D * 4 * D;
+        y.fb = p; p += 4 * D;
+        y.p2w = p; p += 4 * D * D;
+        y.p2b = p; p += D;
+    }
+    o.lnf_w = p; p += D;
+    o.lnf_b = p; p += D;
+    o.total = p;
+}
+
+struct Gpt2WS {
+    float* x[MAX_LAYERS + 1];
+    float* x1[MAX_LAYERS];
+    bf16_t *xn1[MAX_LAYERS], *xn2[MAX_LAYERS], *qkv[MAX_LAYERS], *att[MAX_LAYERS], *u[MAX_LAYERS], *hact[MAX_LAYERS];
+    float *lse[MAX_LAYERS], *mean1[MAX_LAYERS], *rstd1[MAX_LAYERS], *mean2[MAX_LAYERS], *rstd2[MAX_LAYERS];
+    // lm head / loss
+    bf16_t* hf16;      // [Mh, D]   ln_f output rows (Mh = max(B*cap, B*T) so the parity API can use it too)
+    float *meanf, *rstdf;
+    int *target, *row_map;
+    bf16_t* logits16;  // [B*cap, Vp]
+    float *pmax, *psum, *tgt_logit, *lse_row, *row_loss;
+    // backward
+    float* dx32;
+    bf16_t *dx16, *dhf16, *du16, *dxn16, *datt16, *dqkv16;
+    size_t bytes;
+};
+
+void gpt2_carve(const cc_gpt2_cfg* c, int B, int T, int cap, int mode, void* ws, Gpt2WS& w) {
+    Carver cv(ws);
+    const size_t M = (size_t)B * T, D = c->D, Mc = (size_t)B * cap;
+    const bool keep = mode >= 1, full = mode >= 2;
+    const int nx = keep ? c->NL + 1 : 2;
+    float* xb[MAX_LAYERS + 1];
+    for (int i = 0; i < nx; i++) xb[i] = cv.take<float>(M * D);
+    for (int l = 0; l <= c->NL; l++) w.x[l] = keep ? xb[l] : xb[l & 1];
+    for (int l = 0; l < c->NL; l++) {
+        const bool k0 = keep || l == 0, f0 = full || l == 0;
+        w.x1[l] = k0 ? cv.take<float>(M * D) : w.x1[0];
+        w.qkv[l] = k0 ? cv.take<bf16_t>(M * 3 * D) : w.qkv[0];
+        w.u[l] = k0 ? cv.take<bf16_t>(M * 4 * D) : w.u[0];
+        w.lse[l] = k0 ? cv.take<float>((size_t)B * c->H * T) : w.lse[0];
+        w.mean1[l] = k0 ? cv.take<float>(M) : w.mean1[0];
+        w.rstd1[l] = k0 ? cv.take<float>(M) : w.rstd1[0];
+        w.mean2[l] = k0 ? cv.take<float>(M) : w.mean2[0];
+        w.rstd2[l] = k0 ? cv.take<float>(M) : w.rstd2[0];
+        w.xn1[l] = f0 ? cv.take<bf16_t>(M * D) : w.xn1[0];
+        w.xn2[l] = f0 ? cv.take<bf16_t>(M * D) : w.xn2[0];
+        w.att[l] = f0 ? cv.take<bf16_t>(M * D) : w.att[0];
+        w.hact[l] = f0 ? cv.take<bf16_t>(M * 4 * D) : w.hact[0];
+    }
+    const size_t Mh = std::max(M, Mc);
+    w.hf16 = cv.take<bf16_t>(Mh * D);
+    w.meanf = cv.take<float>(Mh);
+    w.rstdf = cv.take<float>(Mh);
+    w.target = cv.take<int>(Mh);
+    w.row_map = cv.take<int>(Mh);
+    if (keep) {
+        const int npart = c->Vp / 64;
+        w.logits16 = cv.take<bf16_t>(Mc * c->Vp);
+        w.pmax = cv.take<float>(Mc * npart);
+        w.psum = cv.take<float>(Mc * npart);
+        w.tgt_logit = cv.take<float>(Mc);
+        w.lse_row = cv.take<float>(Mc);
+        w.row_loss = cv.take<float>(Mc);
+        w.dx32 = cv.take<float>(M * D);
+        w.dx16 = cv.take<bf16_t>(M * D);
+        w.dhf16 = cv.take<bf16_t>(Mc * D);
+        w.du16 = cv.take<bf16_t>(M * 4 * D);
+        w.dxn16 = cv.take<bf16_t>(M * D);
+        w.datt16 = cv.take<bf16_t>(M * D);
+        w.dqkv16 = cv.take<bf16_t>(M * 3 * D);
+    } else {
+        w.logits16 = nullptr; w.pmax = w.psum = w.tgt_logit = w.lse_row = w.row_loss = nullptr;
+        w.dx32 = nullptr; w.dx16 = w.dhf16 = w.du16 = w.dxn16 = w.datt16 = w.dqkv16 = nullptr;
+    }
+    w.bytes = (cv.off + 255) & ~size_t(255);
+}
+
+}  // namespace
+
+extern "C" {
+
+int cc_abi_version(void) { return CC_ABI_VERSION; }
+
+// ---------------------------------------------------------------- mapper ----------------------------------------
+int64_t cc_mapper_param_count(const cc_mapper_cfg* cfg) {
+    if (!mapper_cfg_ok(cfg)) return CC_ERR_SHAPE;
+    MapperOff o;
+    mapper_offsets(cfg, o);
+    return o.total;
+}
+
+int cc_mapper_param_offsets(const cc_mapper_cfg* cfg, int64_t* offs) {
+    if (!mapper_cfg_ok(cfg) || !offs) return CC_ERR_SHAPE;
+    MapperOff o;
+    mapper_offsets(cfg, o);
+    int k = 0;
+    offs[k++] = o.lin_w; offs[k++] = o.lin_b; offs[k++] = o.prefix; offs[k++] = o.pos;
+    for (int l = 0; l < cfg->N; l++) {
+        const auto& y = o.layer[l];
+        const int64_t v[12] = {y.n1w, y.n1b, y.wq, y.wkv, y.wp, y.bp, y.n2w, y.n2b, y.w1, y.b1, y.w2, y.b2};
+        for (int i = 0; i < 12; i++) offs[k++] = v[i];
+    }
+    return CC_OK;
+}
+
+int64_t cc_mapper_ws_bytes(const cc_mapper_cfg* cfg, int32_t B, int32_t save) {
+    if (!mapper_cfg_ok(cfg) || B <= 0) return CC_ERR_SHAPE;
+    MapperWS w;
+    mapper_carve(cfg, B, save, nullptr, w);
+    return (int64_t)w.bytes;
+}
+
+int cc_mapper_fwd(const cc_mapper_cfg* c, int32_t B, const float* w32, const uint16_t* w16, const float* emb, void* ws, float* out,
+                  int32_t save, void* stream) {
+    if (!mapper_cfg_ok(c) || B <= 0 || !w32 || !w16 || !emb || !ws || !out) return CC_ERR_ARG;
+    hipStream_t st = S_(stream);
+    MapperOff o;
+    mapper_offsets(c, o);
+    MapperWS w;
+    mapper_carve(c, B, save, ws, w);
+    const int D = c->D, PP = c->W * c->P, S = PP + c->L, M = B * S, H = c->H, hd = D / H, Hm = c->Hm;
+    const int PD = c->P * D;
+    // linear (mapper.py:123): [B*W, E] x [P*D, E]^T + b -> rows 0..PP-1 of every sample of x[0]
+    CC_TRY(f32_to_bf16(emb, w.emb16, (size_t)B * c->W * c->E, st));
+    if (c->W == 1) {
+        CC_TRY(gemm_f32out(0, 0, w.emb16, c->E, w16 + o.lin_w, c->E, B, PD, c->E, w.x[0], S * D, w32 + o.lin_b, 0, 1.0f, 1, st));
+    } else {
+        CC_TRY(gemm_f32out(0, 0, w.emb16, c->E, w16 + o.lin_w, c->E, B * c->W, PD, c->E, w.lin_tmp, PD, w32 + o.lin_b, 0, 1.0f, 1, st));
+        CC_TRY(copy_rows(w.lin_tmp, (size_t)PP * D, w.x[0], (size_t)S * D, PP * D, B, st));
+        if (o.pos >= 0) CC_TRY(add_rows(w.x[0], (size_t)S * D, w32 + o.pos, PP * D, B, st));
+    }
+    // cat learned prefix_const (mapper.py:125-126)
+    CC_TRY(broadcast_rows(w.x[0] + (size_t)PP * D, (size_t)S * D, w32 + o.prefix, c->L * D, B, st));
+    for (int l = 0; l < c->N; l++) {
+        const auto& y = o.layer[l];
+        // x1 = x + project(attn(LN1 x))  (mapper.py:108, attention.py:17-43)
+        CC_TRY(ln_fwd(w.x[l], D, nullptr, w32 + y.n1w, w32 + y.n1b, w.xn1[l], nullptr, w.mean1[l], w.rstd1[l], M, D, st));
+        CC_TRY(gemm_bf16out(0, 0, w.xn1[l], D, w16 + y.wq, D, M, 3 * D, D, w.qkv[l], 3 * D, nullptr, 0, nullptr, st));
+        CC_TRY(attn_fwd(w.qkv[l], B, S, H, hd, false, w.att[l], w.lse[l], st));
+        CC_TRY(gemm_resid(0, 0, w.att[l], D, w16 + y.wp, D, M, D, D, w.x1[l], w.x[l], D, w32 + y.bp, st));
+        // x = x1 + fc2(relu(fc1(LN2 x1)))  (mapper.py:109, :82-88)
+        CC_TRY(ln_fwd(w.x1[l], D, nullptr, w32 + y.n2w, w32 + y.n2b, w.xn2[l], nullptr, w.mean2[l], w.rstd2[l], M, D, st));
+        CC_TRY(gemm_bf16out(0, 0, w.xn2[l], D, w16 + y.w1, D, M, Hm, D, w.h[l], Hm, w32 + y.b1, 1, nullptr, st));
+        CC_TRY(gemm_resid(0, 0, w.h[l], Hm, w16 + y.w2, Hm, M, D, Hm, w.x[l + 1], w.x1[l], D, w32 + y.b2, st));
+    }
+    // out = rows [PP:] (mapper.py:128)
+    CC_TRY(copy_rows(w.x[c->N] + (size_t)PP * D, (size_t)S * D, out, (size_t)c->L * D, c->L * D, B, st));
+    return CC_OK;
+}
+
+int cc_mapper_bwd(const cc_mapper_cfg* c, int32_t B, const float* w32, const uint16_t* w16, void* ws, const float* dout, float* g32,
+                  void* stream) {
+    if (!mapper_cfg_ok(c) || B <= 0 || !w32 || !w16 || !ws || !dout || !g32) return CC_ERR_ARG;
+    hipStream_t st = S_(stream);
+    MapperOff o;
+    mapper_offsets(c, o);
+    MapperWS w;
+    mapper_carve(c, B, 1, ws, w);
+    const int D = c->D, PP = c->W * c->P, S = PP + c->L, M = B * S, H = c->H, hd = D / H, Hm = c->Hm;
+    const int PD = c->P * D;
+    // seed: d x[N][:, PP:, :] = dout, rows [0:PP] = 0
+    if (hipMemsetAsync(w.dx32, 0, (size_t)M * D * sizeof(float), st) != hipSuccess) return CC_ERR_LAUNCH;
+    CC_TRY(copy_rows(dout, (size_t)c->L * D, w.dx32 + (size_t)PP * D, (size_t)S * D, c->L * D, B, st));
+    CC_TRY(f32_to_bf16(w.dx32, w.dx16, (size_t)M * D, st));
+    for (int l = c->N - 1; l >= 0; l--) {
+        const auto& y = o.layer[l];
+        // fc2: y = h W2^T + b2
+        CC_TRY(gemm_wgrad(w.dx16, D, w.h[l], Hm, D, Hm, M, g32 + y.w2, Hm, st));
+        CC_TRY(colsum_bf16(w.dx16, D, M, D, g32 + y.b2, st));
+        CC_TRY(gemm_dact(0, 1, w.dx16, D, w16 + y.w2, Hm, M, Hm, D, w.dh16, Hm, w.h[l], 1, st));
+        // fc1
+        CC_TRY(gemm_wgrad(w.dh16, Hm, w.xn2[l], D, Hm, D, M, g32 + y.w1, D, st));
+        CC_TRY(colsum_bf16(w.dh16, Hm, M, Hm, g32 + y.b1, st));
+        CC_TRY(gemm_bf16out(0, 1, w.dh16, Hm, w16 + y.w1, D, M, D, Hm, w.dxn16, D, nullptr, 0, nullptr, st));
+        CC_TRY(ln_bwd(w.dxn16, w.x1[l], D, nullptr, w.mean2[l], w.rstd2[l], w32 + y.n2w, w.dx32, w.dx32, w.dx16, g32 + y.n2w,
+                      g32 + y.n2b, M, D, st));
+        // project
+        CC_TRY(gemm_wgrad(w.dx16, D, w.att[l], D, D, D, M, g32 + y.wp, D, st));
+        CC_TRY(colsum_bf16(w.dx16, D, M, D, g32 + y.bp, st));
+        CC_TRY(gemm_bf16out(0, 1, w.dx16, D, w16 + y.wp, D, M, D, D, w.datt16, D, nullptr, 0, nullptr, st));
+        CC_TRY(attn_bwd(w.qkv[l], w.datt16, w.lse[l], B, S, H, hd, false, w.dqkv16, st));
+        // fused q/kv projection (to_queries.weight ++ to_keys_values.weight = [3D, D])
+        CC_TRY(gemm_wgrad(w.dqkv16, 3 * D, w.xn1[l], D, 3 * D, D, M, g32 + y.wq, D, st));
+        CC_TRY(gemm_bf16out(0, 1, w.dqkv16, 3 * D, w16 + y.wq, D, M, D, 3 * D, w.dxn16, D, nullptr, 0, nullptr, st));
+        CC_TRY(ln_bwd(w.dxn16, w.x[l], D, nullptr, w.mean1[l], w.rstd1[l], w32 + y.n1w, w.dx32, w.dx32, w.dx16, g32 + y.n1w,
+                      g32 + y.n1b, M, D, st));
+    }
+    // prefix_const, pos_embeddings, linear
+    CC_TRY(batch_sum(w.dx32 + (size_t)PP * D, (size_t)S * D, g32 + o.prefix, c->L * D, B, st));
+    if (o.pos >= 0) CC_TRY(batch_sum(w.dx32, (size_t)S * D, g32 + o.pos, PP * D, B, st));
+    CC_TRY(slice_f32_to_bf16(w.dx32, (size_t)S * D, w.dlin16, (size_t)PP * D, PP * D, B, st));
+    CC_TRY(gemm_wgrad(w.dlin16, PD, w.emb16, c->E, PD, c->E, B * c->W, g32 + o.lin_w, c->E, st));
+    CC_TRY(colsum_bf16(w.dlin16, PD, B * c->W, PD, g32 + o.lin_b, st));
+    return CC_OK;
+}
+
+// ---------------------------------------------------------------- GPT-2 -----------------------------------------
+namespace {
+bool shape_ok(const cc_gpt2_cfg* c, const cc_gpt2_shape* s) {
+    return s && s->B > 0 && s->T > 0 && s->L >= 0 && s->L <= s->T && s->cap >= s->T - s->L && s->mode >= 0 && s->mode <= 2 && s->T <= c->NPOS;
+}
+}  // namespace
+
+int64_t cc_gpt2_param_count(const cc_gpt2_cfg* cfg) {
+    if (!gpt2_cfg_ok(cfg)) return CC_ERR_SHAPE;
+    Gpt2Off o;
+    gpt2_offsets(cfg, o);
+    return o.total;
+}
+
+int cc_gpt2_param_offsets(const cc_gpt2_cfg* cfg, int64_t* offs) {
+    if (!gpt2_cfg_ok(cfg) || !offs) return CC_ERR_SHAPE;
+    Gpt2Off o;
+    gpt2_offsets(cfg, o);
+    int k = 0;
+    offs[k++] = o.wte; offs[k++] = o.wpe;
+    for (int l = 0; l < cfg->NL; l++) {
+        const auto& y = o.layer[l];
+        const int64_t v[12] = {y.l1w, y.l1b, y.aw, y.ab, y.pw, y.pb, y.l2w, y.l2b, y.fw, y.fb, y.p2w, y.p2b};
+        for (int i = 0; i < 12; i++) offs[k++] = v[i];
+    }
+    offs[k++] = o.lnf_w; offs[k++] = o.lnf_b;
+    return CC_OK;
+}
+
+int64_t cc_gpt2_ws_bytes(const cc_gpt2_cfg* cfg, const cc_gpt2_shape* s) {
+    if (!gpt2_cfg_ok(cfg) || !shape_ok(cfg, s)) return CC_ERR_SHAPE;
+    Gpt2WS w;
+    gpt2_carve(cfg, s->B, s->T, s->T - s->L, s->mode, nullptr, w);
+    return (int64_t)w.bytes;
+}
+
+int cc_gpt2_embed(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, const float* prefix, const int64_t* tokens, void* ws,
+                  void* stream) {
+    if (!gpt2_cfg_ok(c) || !shape_ok(c, s) || !w32 || !ws || (s->L > 0 && !prefix) || (s->T > s->L && !tokens)) return CC_ERR_ARG;
+    Gpt2Off o;
+    gpt2_offsets(c, o);
+    Gpt2WS w;
+    gpt2_carve(c, s->B, s->T, s->T - s->L, s->mode, ws, w);
+    return embed_concat(prefix, reinterpret_cast<const long long*>(tokens), s->cap, w32 + o.wte, w32 + o.wpe, w.x[0], s->B, s->L, s->T,
+                        c->D, 0, S_(stream));
+}
+
+int cc_gpt2_embed_from(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, const float* inputs_embeds, void* ws,
+                       void* stream) {
+    if (!gpt2_cfg_ok(c) || !shape_ok(c, s) || !w32 || !ws || !inputs_embeds) return CC_ERR_ARG;
+    Gpt2Off o;
+    gpt2_offsets(c, o);
+    Gpt2WS w;
+    gpt2_carve(c, s->B, s->T, s->T - s->L, s->mode, ws, w);
+    return embed_concat(inputs_embeds, nullptr, 0, w32 + o.wte, w32 + o.wpe, w.x[0], s->B, s->T, s->T, c->D, 0, S_(stream));
+}
+
+int cc_gpt2_fwd(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, const uint16_t* w16, void* ws, void* stream) {
+    if (!gpt2_cfg_ok(c) || !shape_ok(c, s) || !w32 || !w16 || !ws) return CC_ERR_ARG;
+    hipStream_t st = S_(stream);
+    Gpt2Off o;
+    gpt2_offsets(c, o);
+    Gpt2WS w;
+    gpt2_carve(c, s->B, s->T, s->T - s->L, s->mode, ws, w);
+    const int D = c->D, M = s->B * s->T, H = c->H, hd = D / H;
+    for (int l = 0; l < c->NL; l++) {
+        const auto& y = o.layer[l];
+        // hf :262-310: x1 = x + c_proj(attn(c_attn(ln_1 x)))
+        CC_TRY(ln_fwd(w.x[l], D, nullptr, w32 + y.l1w, w32 + y.l1b, w.xn1[l], nullptr, w.mean1[l], w.rstd1[l], M, D, st));
+        CC_TRY(gemm_bf16out(0, 1, w.xn1[l], D, w16 + y.aw, 3 * D, M, 3 * D, D, w.qkv[l], 3 * D, w32 + y.ab, 0, nullptr, st));
+        CC_TRY(attn_fwd(w.qkv[l], s->B, s->T, H, hd, true, w.att[l], w.lse[l], st));
+        CC_TRY(gemm_resid(0, 1, w.att[l], D, w16 + y.pw, D, M, D, D, w.x1[l], w.x[l], D, w32 + y.pb, st));
+        // x = x1 + c_proj(gelu_new(c_fc(ln_2 x1)))   (hf :229-243)
+        CC_TRY(ln_fwd(w.x1[l], D, nullptr, w32 + y.l2w, w32 + y.l2b, w.xn2[l], nullptr, w.mean2[l], w.rstd2[l], M, D, st));
+        CC_TRY(gemm_bf16out(0, 1, w.xn2[l], D, w16 + y.fw, 4 * D, M, 4 * D, D, w.hact[l], 4 * D, w32 + y.fb, 2,
+                            s->mode >= 1 ? w.u[l] : nullptr, st));
+        CC_TRY(gemm_resid(0, 1, w.hact[l], 4 * D, w16 + y.p2w, D, M, D, 4 * D, w.x[l + 1], w.x1[l], D, w32 + y.p2b, st));
+    }
+    return CC_OK;
+}
+
+int cc_gpt2_logits(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, const uint16_t* w16, void* ws, float* logits,
+                   int64_t ldl, void* stream) {
+    if (!gpt2_cfg_ok(c) || !shape_ok(c, s) || !w32 || !w16 || !ws || !logits) return CC_ERR_ARG;
+    const int Ns = std::min(c->Vp, rup(c->V, 8));
+    if (ldl < Ns || (ldl & 3) || ldl > 0x7fffffff) return CC_ERR_SHAPE;
+    hipStream_t st = S_(stream);
+    Gpt2Off o;
+    gpt2_offsets(c, o);
+    Gpt2WS w;
+    gpt2_carve(c, s->B, s->T, s->T - s->L, s->mode, ws, w);
+    const int D = c->D, M = s->B * s->T;
+    CC_TRY(ln_fwd(w.x[c->NL], D, nullptr, w32 + o.lnf_w, w32 + o.lnf_b, w.hf16, nullptr, w.meanf, w.rstdf, M, D, st));
+    return gemm_f32out(0, 0, w.hf16, D, w16 + o.wte, D, M, Ns, D, logits, (int)ldl, nullptr, 0, 1.0f, 1, st);
+}
+
+int cc_lmhead_ce_fwd(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, const uint16_t* w16, void* ws, const int64_t* tokens,
+                     float* stats, void* stream) {
+    if (!gpt2_cfg_ok(c) || !shape_ok(c, s) || s->mode < 1 || s->L < 1 || !w32 || !w16 || !ws || !tokens || !stats) return CC_ERR_ARG;
+    hipStream_t st = S_(stream);
+    Gpt2Off o;
+    gpt2_offsets(c, o);
+    Gpt2WS w;
+    const int cap = s->T - s->L;
+    gpt2_carve(c, s->B, s->T, cap, s->mode, ws, w);
+    const int D = c->D, Mc = s->B * cap, npart = c->Vp / 64;
+    if (cap != s->cap) return CC_ERR_SHAPE;  // the loss consumes every token column (model.py:108-109)
+    if (hipMemsetAsync(stats, 0, 2 * sizeof(float), st) != hipSuccess) return CC_ERR_LAUNCH;
+    CC_TRY(ce_targets(reinterpret_cast<const long long*>(tokens), w.target, w.row_map, s->B, cap, s->L, s->T, st));
+    // ln_f only on the rows the loss reads: L-1 .. T-2 of every sample (model.py:108)
+    CC_TRY(ln_fwd(w.x[c->NL], D, w.row_map, w32 + o.lnf_w, w32 + o.lnf_b, w.hf16, nullptr, w.meanf, w.rstdf, Mc, D, st));
+    CC_TRY(gemm_lmhead(w.hf16, D, w16 + o.wte, D, Mc, c->Vp, c->V, D, w.logits16, c->Vp, w.pmax, w.psum, npart, w.target, w.tgt_logit, st));
+    CC_TRY(ce_rows(w.pmax, w.psum, npart, w.target, w.tgt_logit, w.lse_row, w.row_loss, stats, Mc, st));
+    return CC_OK;
+}
+
+int cc_lmhead_ce_bwd(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, const uint16_t* w16, void* ws, const float* denom,
+                     float* g32, void* stream) {
+    if (!gpt2_cfg_ok(c) || !shape_ok(c, s) || s->mode < 1 || !w32 || !w16 || !ws || !denom || (s->mode == 2 && !g32)) return CC_ERR_ARG;
+    hipStream_t st = S_(stream);
+    Gpt2Off o;
+    gpt2_offsets(c, o);
+    Gpt2WS w;
+    const int cap = s->T - s->L;
+    gpt2_carve(c, s->B, s->T, cap, s->mode, ws, w);
+    const int D = c->D, Mc = s->B * cap, M = s->B * s->T;
+    const bool full = s->mode == 2;
+    CC_TRY(ce_dlogits(w.logits16, c->Vp, c->V, w.target, w.lse_row, denom, Mc, st));
+    // d hf = dlogits · wte   ([Mc,Vp] x [Vp(k), D(n)])
+    CC_TRY(gemm_bf16out(0, 1, w.logits16, c->Vp, w16 + o.wte, D, Mc, D, c->Vp, w.dhf16, D, nullptr, 0, nullptr, st));
+    if (full) CC_TRY(gemm_wgrad(w.logits16, c->Vp, w.hf16, D, c->Vp, D, Mc, g32 + o.wte, D, st));  // tied lm_head: d wte += dlogits^T hf
+    if (hipMemsetAsync(w.dx32, 0, (size_t)M * D * sizeof(float), st) != hipSuccess) return CC_ERR_LAUNCH;
+    if (hipMemsetAsync(w.dx16, 0, (size_t)M * D * sizeof(bf16_t), st) != hipSuccess) return CC_ERR_LAUNCH;
+    CC_TRY(ln_bwd(w.dhf16, w.x[c->NL], D, w.row_map, w.meanf, w.rstdf, w32 + o.lnf_w, nullptr, w.dx32, w.dx16, full ? g32 + o.lnf_w : nullptr,
+                  full ? g32 + o.lnf_b : nullptr, Mc, D, st));
+    return CC_OK;
+}
+
+int cc_gpt2_bwd(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, const uint16_t* w16, void* ws, const int64_t* tokens,
+                float* dprefix, float* g32, void* stream) {
+    if (!gpt2_cfg_ok(c) || !shape_ok(c, s) || s->mode < 1 || !w32 || !w16 || !ws || (s->L > 0 && !dprefix) || (s->mode == 2 && (!g32 || !tokens)))
+        return CC_ERR_ARG;
+    hipStream_t st = S_(stream);
+    Gpt2Off o;
+    gpt2_offsets(c, o);
+    Gpt2WS w;
+    gpt2_carve(c, s->B, s->T, s->T - s->L, s->mode, ws, w);
+    const int D = c->D, M = s->B * s->T, H = c->H, hd = D / H, D3 = 3 * D, D4 = 4 * D;
+    const bool full = s->mode == 2;
+    for (int l = c->NL - 1; l >= 0; l--) {
+        const auto& y = o.layer[l];
+        // mlp.c_proj (Conv1D [4D, D]): y = hact W + b
+        if (full) {
+            CC_TRY(gemm_wgrad(w.hact[l], D4, w.dx16, D, D4, D, M, g32 + y.p2w, D, st));
+            CC_TRY(colsum_bf16(w.dx16, D, M, D, g32 + y.p2b, st));
+        }
+        CC_TRY(gemm_dact(0, 0, w.dx16, D, w16 + y.p2w, D, M, D4, D, w.du16, D4, w.u[l], 2, st));
+        // mlp.c_fc (Conv1D [D, 4D])
+        if (full) {
+            CC_TRY(gemm_wgrad(w.xn2[l], D, w.du16, D4, D, D4, M, g32 + y.fw, D4, st));
+            CC_TRY(colsum_bf16(w.du16, D4, M, D4, g32 + y.fb, st));
+        }
+        CC_TRY(gemm_bf16out(0, 0, w.du16, D4, w16 + y.fw, D4, M, D, D4, w.dxn16, D, nullptr, 0, nullptr, st));
+        CC_TRY(ln_bwd(w.dxn16, w.x1[l], D, nullptr, w.mean2[l], w.rstd2[l], w32 + y.l2w, w.dx32, w.dx32, w.dx16, full ? g32 + y.l2w : nullptr,
+                      full ? g32 + y.l2b : nullptr, M, D, st));
+        // attn.c_proj (Conv1D [D, D])
+        if (full) {
+            CC_TRY(gemm_wgrad(w.att[l], D, w.dx16, D, D, D, M, g32 + y.pw, D, st));
+            CC_TRY(colsum_bf16(w.dx16, D, M, D, g32 + y.pb, st));
+        }
+        CC_TRY(gemm_bf16out(0, 0, w.dx16, D, w16 + y.pw, D, M, D, D, w.datt16, D, nullptr, 0, nullptr, st));
+        CC_TRY(attn_bwd(w.qkv[l], w.datt16, w.lse[l], s->B, s->T, H, hd, true, w.dqkv16, st));
+        // attn.c_attn (Conv1D [D, 3D])
+        if (full) {
+            CC_TRY(gemm_wgrad(w.xn1[l], D, w.dqkv16, D3, D, D3, M, g32 + y.aw, D3, st));
+            CC_TRY(colsum_bf16(w.dqkv16, D3, M, D3, g32 + y.ab, st));
+        }
+        CC_TRY(gemm_bf16out(0, 0, w.dqkv16, D3, w16 + y.aw, D3, M, D, D3, w.dxn16, D, nullptr, 0, nullptr, st));
+        CC_TRY(ln_bwd(w.dxn16, w.x[l], D, nullptr, w.mean1[l], w.rstd1[l], w32 + y.l1w, w.dx32, w.dx32, w.dx16, full ? g32 + y.l1w : nullptr,
+                      full ? g32 + y.l1b : nullptr, M, D, st));
+    }
+    if (s->L > 0) CC_TRY(copy_rows(w.dx32, (size_t)s->T * D, dprefix, (size_t)s->L * D, s->L * D, s->B, st));
+    if (full)
+        CC_TRY(embed_bwd(w.dx32, reinterpret_cast<const long long*>(tokens), s->cap, g32 + o.wte, g32 + o.wpe, s->B, s->L, s->T, D, st));
+    return CC_OK;
+}
+
+// ---------------------------------------------------------------- optimizer / casts / test hooks -----------------
+int cc_adamw_step(float* p32, const float* g32, float* m, float* v, uint16_t* p16, int64_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int32_t step, float grad_scale, void* stream) {
+    if (!p32 || !g32 || !m || !v || n < 0 || step < 1) return CC_ERR_ARG;
+    return adamw(p32, g32, m, v, p16, (size_t)n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, S_(stream));
+}
+
+int cc_cast_bf16(const float* src, uint16_t* dst, int64_t n, void* stream) {
+    if (!src || !dst || n < 0) return CC_ERR_ARG;
+    return f32_to_bf16(src, dst, (size_t)n, S_(stream));
+}
+
+int cc_gemm_bf16_f32(int32_t al, int32_t bl, const uint16_t* A, int32_t lda, const uint16_t* B, int32_t ldb, int32_t M, int32_t N, int32_t K,
+                     float* C, int32_t ldc, const float* bias, int32_t ksplit, void* stream) {
+    if (!A || !B || !C) return CC_ERR_ARG;
+    return gemm_f32out(al, bl, A, lda, B, ldb, M, N, K, C, ldc, ksplit > 1 ? nullptr : bias, ksplit > 1 ? 2 : 0, 1.0f, ksplit, S_(stream));
+}
+
+int cc_layernorm_fwd(const float* x, const float* gamma, const float* beta, uint16_t* y, float* mean, float* rstd, int32_t rows, int32_t D,
+                     void* stream) {
+    if (!x || !gamma || !beta || !y) return CC_ERR_ARG;
+    return ln_fwd(x, D, nullptr, gamma, beta, y, nullptr, mean, rstd, rows, D, S_(stream));
+}
+
+int cc_attention_fwd(const uint16_t* qkv, int32_t B, int32_t S, int32_t H, int32_t hd, int32_t causal, uint16_t* out, float* lse, void* stream) {
+    if (!qkv || !out) return CC_ERR_ARG;
+    return attn_fwd(qkv, B, S, H, hd, causal != 0, out, lse, S_(stream));
+}
+
+int cc_attention_bwd(const uint16_t* qkv, const uint16_t* dout, const float* lse, int32_t B, int32_t S, int32_t H, int32_t hd, int32_t causal,
+                     uint16_t* dqkv, void* stream) {
+    if (!qkv || !dout || !lse || !dqkv) return CC_ERR_ARG;
+    return attn_bwd(qkv, dout, lse, B, S, H, hd, causal != 0, dqkv, S_(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,63 @@
+// Shared device helpers for the ClipCap gfx950 kernels (wave64, CDNA4 only — no portability shims).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cc {
+
+typedef unsigned short bf16_t;  // raw bf16 storage (bit pattern); conversions below are round-to-nearest-even like torch
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+__device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+    return make_uint4(pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7]));
+}
+
+// gelu_new (tanh approximation) and its derivative — transformers.activations.NewGELUActivation.
+__device__ __forceinline__ float gelu_new_f(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    float t = tanhf(k0 * (x + k1 * x * x * x));
+    return 0.5f * x * (1.0f + t);
+}
+__device__ __forceinline__ float gelu_new_grad(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    float t = tanhf(k0 * (x + k1 * x * x * x));
+    float dt = (1.0f - t * t) * k0 * (1.0f + 3.0f * k1 * x * x);
+    return 0.5f * (1.0f + t) + 0.5f * x * dt;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+}  // namespace cc
+
+// status codes returned across the C ABI (same values as include/clipcap_hip.h)
+#ifndef CC_OK
+#define CC_OK 0
+#define CC_ERR_ARG (-1)
+#define CC_ERR_SHAPE (-2)
+#define CC_ERR_LAUNCH (-3)
+#define CC_ERR_STATE (-4)
+#endif

@@ -1,0 +1,372 @@
+// KV-cached caption decode for gfx950: replaces the reference's full GPT-2 re-forward per generated token
+// (clipcap/inference/base.py:81) with an O(ctx) step, plus the device-side beam-search update of base.py:84-119.
+// Decode is HBM-bound (every weight byte is read once per step); the GEMMs reuse gemm.cuh, attention over the
+// cache is one wave per (row, head, new position).
+#include "../../include/clipcap_hip.h"
+#include "gemm_api.h"
+#include "kernels.h"
+
+using namespace cc;
+
+#define CC_TRY(expr)                 \
+    do {                             \
+        int _e = (expr);             \
+        if (_e != CC_OK) return _e;  \
+    } while (0)
+
+namespace {
+
+inline hipStream_t S_(void* s) { return static_cast<hipStream_t>(s); }
+
+// x[r,t,:] += wpe[pos0+t,:]
+__global__ void k_add_wpe(const float* __restrict__ xin, const float* __restrict__ wpe, float* __restrict__ x, int R, int Tn, int D, int pos0) {
+    const int d4n = D >> 2;
+    const size_t total = (size_t)R * Tn * d4n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % d4n), t = (int)((i / d4n) % Tn);
+        const float4 a = reinterpret_cast<const float4*>(xin)[i];
+        const float4 p = reinterpret_cast<const float4*>(wpe + (size_t)(pos0 + t) * D)[c];
+        reinterpret_cast<float4*>(x)[i] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+    }
+}
+
+// append the new K / V rows of qkv [R*Tn, 3D] to the cache [2][R][ctx_max][D] of one layer
+__global__ void k_kv_append(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ kc, bf16_t* __restrict__ vc, int R, int Tn, int D, int pos0,
+                            int ctx_max) {
+    const int d8n = D >> 3;
+    const size_t total = (size_t)R * Tn * d8n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % d8n), t = (int)((i / d8n) % Tn), r = (int)(i / ((size_t)d8n * Tn));
+        const bf16_t* src = qkv + ((size_t)r * Tn + t) * 3 * D + c * 8;
+        const size_t dst = ((size_t)r * ctx_max + pos0 + t) * D + c * 8;
+        *reinterpret_cast<uint4*>(kc + dst) = *reinterpret_cast<const uint4*>(src + D);
+        *reinterpret_cast<uint4*>(vc + dst) = *reinterpret_cast<const uint4*>(src + 2 * D);
+    }
+}
+
+// attention of the Tn new queries of every row against the cache (ctx = pos0 + Tn, causal): one wave per (r,h,t)
+__global__ __launch_bounds__(256) void k_decode_attn(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ kc,
+                                                     const bf16_t* __restrict__ vc, bf16_t* __restrict__ out, int R, int Tn, int H, int hd,
+                                                     int pos0, int ctx_max, float scale) {
+    extern __shared__ float psm[];  // [4][ctx_max]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gid = blockIdx.x * 4 + wave;
+    if (gid >= R * H * Tn) return;
+    const int t = gid % Tn, h = (gid / Tn) % H, r = gid / (Tn * H);
+    const int D = H * hd, nkeys = pos0 + t + 1;
+    float* p = psm + wave * ctx_max;
+    const bf16_t* q = qkv + ((size_t)r * Tn + t) * 3 * D + h * hd;
+    const bf16_t* kb = kc + (size_t)r * ctx_max * D + h * hd;
+    const bf16_t* vb = vc + (size_t)r * ctx_max * D + h * hd;
+    float m = -INFINITY;
+    for (int j = lane; j < nkeys; j += 64) {
+        float s = 0.f;
+        for (int d = 0; d < hd; d += 8) {
+            float a[8], b[8];
+            unpack8(*reinterpret_cast<const uint4*>(q + d), a);
+            unpack8(*reinterpret_cast<const uint4*>(kb + (size_t)j * D + d), b);
+#pragma unroll
+            for (int e = 0; e < 8; e++) s += a[e] * b[e];
+        }
+        s *= scale;
+        p[j] = s;
+        m = fmaxf(m, s);
+    }
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int j = lane; j < nkeys; j += 64) {
+        const float e = __expf(p[j] - m);
+        p[j] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    // wave-private LDS: same-wave writes above are visible to the reads below (in-order DS queue)
+    for (int d = lane; d < hd; d += 64) {
+        float o = 0.f;
+        for (int j = 0; j < nkeys; j++) o += p[j] * bf2f(vb[(size_t)j * D + d]);
+        out[((size_t)r * Tn + t) * D + h * hd + d] = f2bf(o * inv);
+    }
+}
+
+__global__ void k_kv_reorder(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, const int* __restrict__ map, int R_src, int R_dst,
+                             int ctx, int ctx_max, int D, int NL2) {
+    const int d8n = D >> 3;
+    const size_t per_row = (size_t)ctx * d8n;
+    const size_t total = (size_t)NL2 * R_dst * per_row;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i % per_row;
+        const int r = (int)((i / per_row) % R_dst), l = (int)(i / (per_row * R_dst));
+        const int sr = map[r];
+        const uint4* s = reinterpret_cast<const uint4*>(src + ((size_t)l * R_src + sr) * ctx_max * D);
+        uint4* d = reinterpret_cast<uint4*>(dst + ((size_t)l * R_dst + r) * ctx_max * D);
+        d[e] = s[e];
+    }
+}
+
+__global__ void k_last_rows(int* __restrict__ map, int R, int Tn) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < R) map[i] = i * Tn + Tn - 1;
+}
+
+__global__ void k_embed_tokens(const float* __restrict__ wte, const int* __restrict__ tok, float* __restrict__ out, int R, int D) {
+    const int d4n = D >> 2;
+    const size_t total = (size_t)R * d4n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % d4n), r = (int)(i / d4n);
+        int id = tok[r];
+        if (id < 0) id = 0;
+        reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(wte + (size_t)id * D)[c];
+    }
+}
+
+// ---- beam step: one block per sample ------------------------------------------------------------------------
+constexpr int BEAM_MAX = 16;
+
+__device__ __forceinline__ bool cand_better(float a, int ia, float b, int ib) { return a > b || (a == b && ia < ib); }
+
+__global__ __launch_bounds__(256) void k_beam_step(const float* __restrict__ logits, size_t ldl, int beam, int V, float inv_temp, int first,
+                                                   int stop_token, float* __restrict__ scores, float* __restrict__ seq_len,
+                                                   unsigned char* __restrict__ stopped, int* __restrict__ next_tok, int* __restrict__ src_row) {
+    __shared__ float red[256];
+    __shared__ int redi[256];
+    __shared__ float row_m[BEAM_MAX], row_s[BEAM_MAX];
+    __shared__ float cval[256 * BEAM_MAX];
+    __shared__ int cidx[256 * BEAM_MAX];
+    __shared__ float sel_v[BEAM_MAX];
+    __shared__ int sel_i[BEAM_MAX];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int nrows = first ? 1 : beam;
+    const float* lg = logits + (size_t)s * beam * ldl;
+    // per-row softmax statistics (base.py:83-84: logits/temperature -> softmax -> log)
+    for (int b = 0; b < nrows; b++) {
+        float m = -INFINITY;
+        for (int v = tid; v < V; v += 256) m = fmaxf(m, lg[(size_t)b * ldl + v] * inv_temp);
+        red[tid] = m;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]);
+            __syncthreads();
+        }
+        m = red[0];
+        __syncthreads();
+        float sum = 0.f;
+        for (int v = tid; v < V; v += 256) sum += expf(lg[(size_t)b * ldl + v] * inv_temp - m);
+        red[tid] = sum;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) red[tid] += red[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) { row_m[b] = m; row_s[b] = red[0]; }
+        __syncthreads();
+    }
+    // thread-local top-`beam` of the length-normalised candidate scores
+    float lv[BEAM_MAX];
+    int li[BEAM_MAX];
+#pragma unroll
+    for (int k = 0; k < BEAM_MAX; k++) { lv[k] = -INFINITY; li[k] = 0x7fffffff; }
+    for (int b = 0; b < nrows; b++) {
+        const bool st = !first && stopped[s * beam + b];
+        const float sc = first ? 0.f : scores[s * beam + b];
+        const float len = first ? 1.f : seq_len[s * beam + b] + (st ? 0.f : 1.f);
+        for (int v = tid; v < V; v += 256) {
+            float lp;
+            if (st) lp = (v == 0) ? 0.f : -INFINITY;                                              // base.py:96-97
+            else lp = logf(expf(lg[(size_t)b * ldl + v] * inv_temp - row_m[b]) / row_s[b]);       // softmax().log()
+            const float val = first ? lp : (sc + lp) / len;                                       // base.py:99-101
+            const int idx = b * V + v;
+            if (cand_better(val, idx, lv[beam - 1], li[beam - 1])) {
+                int k = beam - 1;
+                while (k > 0 && cand_better(val, idx, lv[k - 1], li[k - 1])) { lv[k] = lv[k - 1]; li[k] = li[k - 1]; k--; }
+                lv[k] = val; li[k] = idx;
+            }
+        }
+    }
+    for (int k = 0; k < beam; k++) { cval[tid * beam + k] = lv[k]; cidx[tid * beam + k] = li[k]; }
+    __syncthreads();
+    // `beam` rounds of block-wide arg-best over the 256*beam candidates
+    const int ncand = 256 * beam;
+    for (int k = 0; k < beam; k++) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff, bp = -1;
+        for (int c = tid; c < ncand; c += 256)
+            if (cidx[c] != 0x7fffffff && (bp < 0 || cand_better(cval[c], cidx[c], bv, bi))) { bv = cval[c]; bi = cidx[c]; bp = c; }
+        red[tid] = bv; redi[tid] = bp;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) {
+                const int pa = redi[tid], pb = redi[tid + o];
+                if (pb >= 0 && (pa < 0 || cand_better(red[tid + o], cidx[pb], red[tid], cidx[pa]))) { red[tid] = red[tid + o]; redi[tid] = pb; }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const int pos = redi[0];
+            sel_v[k] = cval[pos]; sel_i[k] = cidx[pos];
+            cidx[pos] = 0x7fffffff;  // consumed
+        }
+        __syncthreads();
+    }
+    // gather / update state (base.py:86-119)
+    if (tid < beam) {
+        const int idx = sel_i[tid];
+        const int b = idx / V, v = idx % V;
+        float nl, ns;
+        unsigned char hs;
+        if (first) { nl = 1.f; ns = sel_v[tid]; hs = 0; }
+        else {
+            const bool st = stopped[s * beam + b];
+            nl = seq_len[s * beam + b] + (st ? 0.f : 1.f);
+            ns = sel_v[tid] * nl;      // scores = scores_sum_average * seq_lengths (base.py:114)
+            hs = st;
+        }
+        red[tid] = ns; red[32 + tid] = nl; redi[tid] = (int)hs | ((v == stop_token) ? 1 : 0);
+        next_tok[s * beam + tid] = v;
+        src_row[s * beam + tid] = b;
+    }
+    __syncthreads();
+    if (tid < beam) {
+        scores[s * beam + tid] = red[tid];
+        seq_len[s * beam + tid] = red[32 + tid];
+        stopped[s * beam + tid] = (unsigned char)redi[tid];
+    }
+}
+
+struct DecWS {
+    float *x, *x1;
+    bf16_t *xn, *qkv, *att, *hact, *hf;
+    float *meanf, *rstdf;
+    int* last;
+    size_t bytes;
+};
+void dec_carve(const cc_gpt2_cfg* c, int R, int Tn, void* ws, DecWS& w) {
+    char* base = static_cast<char*>(ws);
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        off = (off + 255) & ~size_t(255);
+        char* r = base ? base + off : nullptr;
+        off += bytes;
+        return r;
+    };
+    const size_t M = (size_t)R * Tn, D = c->D;
+    w.x = (float*)take(M * D * 4);
+    w.x1 = (float*)take(M * D * 4);
+    w.xn = (bf16_t*)take(M * D * 2);
+    w.qkv = (bf16_t*)take(M * 3 * D * 2);
+    w.att = (bf16_t*)take(M * D * 2);
+    w.hact = (bf16_t*)take(M * 4 * D * 2);
+    w.hf = (bf16_t*)take((size_t)R * D * 2);
+    w.meanf = (float*)take((size_t)R * 4);
+    w.rstdf = (float*)take((size_t)R * 4);
+    w.last = (int*)take((size_t)R * 4);
+    w.bytes = (off + 255) & ~size_t(255);
+}
+
+bool cfg_ok(const cc_gpt2_cfg* c) {
+    return c && c->D > 0 && c->H > 0 && c->NL > 0 && c->V > 0 && c->Vp >= c->V && (c->Vp % 128) == 0 && (c->D % 8) == 0 && (c->D % c->H) == 0 &&
+           ((c->D / c->H) % 8) == 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t cc_decode_ws_bytes(const cc_gpt2_cfg* cfg, int32_t R, int32_t Tnew) {
+    if (!cfg_ok(cfg) || R <= 0 || Tnew <= 0) return CC_ERR_SHAPE;
+    DecWS w;
+    dec_carve(cfg, R, Tnew, nullptr, w);
+    return (int64_t)w.bytes;
+}
+
+int cc_decode_fwd(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int32_t ctx_max, const float* w32, const uint16_t* w16,
+                  const float* x, uint16_t* kv, void* ws, float* logits, int64_t ldl, void* stream) {
+    if (!cfg_ok(c) || R <= 0 || Tn <= 0 || pos0 < 0 || !w32 || !w16 || !x || !kv || !ws || !logits) return CC_ERR_ARG;
+    const int Ns = std::min(c->Vp, (c->V + 7) / 8 * 8);
+    if (pos0 + Tn > ctx_max || pos0 + Tn > c->NPOS || ldl < Ns || (ldl & 3) || ldl > 0x7fffffff) return CC_ERR_SHAPE;
+    if ((size_t)4 * ctx_max * sizeof(float) > 64 * 1024) return CC_ERR_SHAPE;
+    hipStream_t st = S_(stream);
+    DecWS w;
+    dec_carve(c, R, Tn, ws, w);
+    const int D = c->D, M = R * Tn, H = c->H, hd = D / H;
+    // arena offsets (same order as api.hip::gpt2_offsets)
+    int64_t p = 0;
+    const int64_t wte = p; p += (int64_t)c->Vp * D;
+    const int64_t wpe = p; p += (int64_t)c->NPOS * D;
+    {
+        const size_t total = (size_t)M * (D >> 2);
+        hipLaunchKernelGGL(k_add_wpe, dim3((int)std::min<size_t>((total + 255) / 256, 2048)), dim3(256), 0, st, x, w32 + wpe, w.x, R, Tn, D, pos0);
+    }
+    const size_t cache_layer = (size_t)2 * R * ctx_max * D;
+    const float scale = 1.0f / sqrtf((float)hd);
+    for (int l = 0; l < c->NL; l++) {
+        const int64_t l1w = p; p += D;
+        const int64_t l1b = p; p += D;
+        const int64_t aw = p; p += (int64_t)D * 3 * D;
+        const int64_t ab = p; p += 3 * D;
+        const int64_t pw = p; p += (int64_t)D * D;
+        const int64_t pb = p; p += D;
+        const int64_t l2w = p; p += D;
+        const int64_t l2b = p; p += D;
+        const int64_t fw = p; p += (int64_t)D * 4 * D;
+        const int64_t fb = p; p += 4 * D;
+        const int64_t p2w = p; p += (int64_t)4 * D * D;
+        const int64_t p2b = p; p += D;
+        bf16_t* kc = kv + (size_t)l * cache_layer;
+        bf16_t* vc = kc + (size_t)R * ctx_max * D;
+        CC_TRY(ln_fwd(w.x, D, nullptr, w32 + l1w, w32 + l1b, w.xn, nullptr, nullptr, nullptr, M, D, st));
+        CC_TRY(gemm_bf16out(0, 1, w.xn, D, w16 + aw, 3 * D, M, 3 * D, D, w.qkv, 3 * D, w32 + ab, 0, nullptr, st));
+        {
+            const size_t total = (size_t)M * (D >> 3);
+            hipLaunchKernelGGL(k_kv_append, dim3((int)std::min<size_t>((total + 255) / 256, 2048)), dim3(256), 0, st, w.qkv, kc, vc, R, Tn, D, pos0,
+                               ctx_max);
+            const int nw = R * H * Tn;
+            hipLaunchKernelGGL(k_decode_attn, dim3((nw + 3) / 4), dim3(256), (size_t)4 * ctx_max * sizeof(float), st, w.qkv, kc, vc, w.att, R, Tn, H,
+                               hd, pos0, ctx_max, scale);
+        }
+        CC_TRY(gemm_resid(0, 1, w.att, D, w16 + pw, D, M, D, D, w.x1, w.x, D, w32 + pb, st));
+        CC_TRY(ln_fwd(w.x1, D, nullptr, w32 + l2w, w32 + l2b, w.xn, nullptr, nullptr, nullptr, M, D, st));
+        CC_TRY(gemm_bf16out(0, 1, w.xn, D, w16 + fw, 4 * D, M, 4 * D, D, w.hact, 4 * D, w32 + fb, 2, nullptr, st));
+        CC_TRY(gemm_resid(0, 1, w.hact, 4 * D, w16 + p2w, D, M, D, 4 * D, w.x, w.x1, D, w32 + p2b, st));
+    }
+    const int64_t lnf_w = p, lnf_b = p + D;
+    hipLaunchKernelGGL(k_last_rows, dim3((R + 255) / 256), dim3(256), 0, st, w.last, R, Tn);
+    CC_TRY(ln_fwd(w.x, D, w.last, w32 + lnf_w, w32 + lnf_b, w.hf, nullptr, w.meanf, w.rstdf, R, D, st));
+    CC_TRY(gemm_f32out(0, 0, w.hf, D, w16 + wte, D, R, Ns, D, logits, (int)ldl, nullptr, 0, 1.0f, 1, st));
+    return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+}
+
+int cc_decode_reorder(const cc_gpt2_cfg* c, int32_t R_src, int32_t R_dst, int32_t ctx, int32_t ctx_max, const uint16_t* kv_src, uint16_t* kv_dst,
+                      const int32_t* src, void* stream) {
+    if (!cfg_ok(c) || R_src <= 0 || R_dst <= 0 || ctx < 0 || ctx > ctx_max || !kv_src || !kv_dst || !src || kv_src == kv_dst) return CC_ERR_ARG;
+    if (ctx == 0) return CC_OK;
+    const size_t total = (size_t)c->NL * 2 * R_dst * ctx * (c->D >> 3);
+    hipLaunchKernelGGL(k_kv_reorder, dim3((int)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, S_(stream), kv_src, kv_dst, src, R_src,
+                       R_dst, ctx, ctx_max, c->D, c->NL * 2);
+    return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+}
+
+int64_t cc_beam_ws_bytes(int32_t S, int32_t beam, int32_t V) {
+    (void)S; (void)beam; (void)V;
+    return 256;  // the update runs entirely in LDS; a token workspace keeps the call shape stable
+}
+
+int cc_beam_step(int32_t S, int32_t beam, int32_t V, const float* logits, int64_t ldl, float temperature, int32_t first, int32_t stop_token,
+                 float* scores, float* seq_lengths, uint8_t* has_stopped, int32_t* next_tokens, int32_t* src_rows, void* ws, void* stream) {
+    (void)ws;
+    if (S <= 0 || beam <= 0 || beam > BEAM_MAX || V <= 0 || !logits || ldl < V || !scores || !seq_lengths || !has_stopped || !next_tokens || !src_rows)
+        return CC_ERR_ARG;
+    const float inv_temp = 1.0f / (temperature > 0.f ? temperature : 1.0f);   // base.py:83
+    hipLaunchKernelGGL(k_beam_step, dim3(S), dim3(256), 0, S_(stream), logits, (size_t)ldl, beam, V, inv_temp, first, stop_token, scores,
+                       seq_lengths, has_stopped, next_tokens, src_rows);
+    return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+}
+
+int cc_embed_tokens(const cc_gpt2_cfg* c, int32_t R, const float* w32, const int32_t* tokens, float* out, void* stream) {
+    if (!cfg_ok(c) || R <= 0 || !w32 || !tokens || !out) return CC_ERR_ARG;
+    const size_t total = (size_t)R * (c->D >> 2);
+    hipLaunchKernelGGL(k_embed_tokens, dim3((int)std::min<size_t>((total + 255) / 256, 2048)), dim3(256), 0, S_(stream), w32, tokens, out, R, c->D);
+    return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+}
+
+}  // extern "C"

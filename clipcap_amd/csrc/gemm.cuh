@@ -1,0 +1,380 @@
+// bf16 MFMA GEMM for gfx950 (MI355X): C[M,N] = A · B with fp32 accumulation and a fused, vectorised epilogue.
+//
+// One kernel template covers the three operand layouts the ClipCap path needs, so that neither weights nor
+// activations are ever transposed in HBM:
+//   AL=0: A stored [M][K] (K contiguous)        AL=1: A stored [K][M] (M contiguous; wgrad: dY^T)
+//   BL=0: B stored [N][K] (torch.nn.Linear W)   BL=1: B stored [K][N] (HF Conv1D W, dgrad of Linear, wgrad: X)
+//
+// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave a 64x64 sub-tile = 4x4 v_mfma_f32_16x16x32_bf16.
+// LDS image is always [row][k] (128 B rows, 16-B chunks XOR-swizzled) so fragments are single ds_read_b128:
+//   chunk' = chunk ^ ((row>>1)&7) ^ ((row>>4)&3)
+// -> ds_read_b128 fragment reads, ds_write_b128 (K-contiguous staging) and ds_write_b64 (transposing staging) are all
+// bank-conflict free (derivation in DESIGN.md §GEMM).  K-strided operands are transposed in registers on the way
+// to LDS (4 k-rows x 8 columns per thread, v_perm_b32 16-bit interleave).  Global->register loads for tile t+1
+// are issued before the MFMAs of tile t and written to the other LDS buffer after them (one barrier per K-step).
+// The epilogue transposes each wave's accumulators through a wave-private LDS strip so that every lane owns 8
+// consecutive columns of one row: bias/residual/activation loads and the C stores are 16-B/32-B vectors.
+//
+// Constraints (checked by the host launcher): leading dims and the contiguous extent of every operand are
+// multiples of 8 elements, base pointers 16-B aligned.  M, N (row counts) and K of a K-strided operand are free.
+#pragma once
+#include "common.cuh"
+
+namespace cc {
+
+constexpr int G_BM = 128, G_BN = 128, G_BK = 64, G_THREADS = 256;
+constexpr int G_TILE_BYTES = G_BM * G_BK * 2;  // 16 KiB per operand per buffer
+constexpr int G_EPI_LD = 68;                    // floats per row of the epilogue strip (64 + pad, keeps 16-B alignment)
+
+struct GemmShape {
+    int M, N, K;
+    int lda, ldb;
+    int k_chunk;  // K extent handled by one blockIdx.z slice (multiple of 64); == K rounded up when no split
+};
+
+__device__ __forceinline__ int g_lds_off(int row, int chunk) {
+    return row * 128 + (((chunk ^ (row >> 1) ^ ((row >> 4) & 3)) & 7) << 4);
+}
+
+struct StageRegs {
+    uint4 v[4];
+};
+
+// ---- K-contiguous operand: global [rows][ld]; thread -> (chunk = tid&7, rows tid>>3 + 32 i) ----
+__device__ __forceinline__ void g_load_kc(StageRegs& s, const bf16_t* __restrict__ base, int ld, int rows, int r0,
+                                          int k0, int kend, int tid) {
+    const int c = tid & 7, rr = tid >> 3;
+    const int k = k0 + c * 8;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int r = r0 + rr + 32 * i;
+        if (r < rows && k < kend)
+            s.v[i] = *reinterpret_cast<const uint4*>(base + (size_t)r * ld + k);
+        else
+            s.v[i] = make_uint4(0, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void l_store_kc(const StageRegs& s, char* lds, int tid) {
+    const int c = tid & 7, rr = tid >> 3;
+#pragma unroll
+    for (int i = 0; i < 4; i++) *reinterpret_cast<uint4*>(lds + g_lds_off(rr + 32 * i, c)) = s.v[i];
+}
+
+// ---- K-strided operand: global [k][ld] with the tile's rows contiguous; thread -> 4 k-rows x 8 rows ----
+__device__ __forceinline__ void g_load_ks(StageRegs& s, const bf16_t* __restrict__ base, int ld, int rows, int r0,
+                                          int k0, int kend, int tid) {
+    const int ng = (tid & 7) | (((tid >> 4) & 1) << 3);
+    const int kg = ((tid >> 3) & 1) | ((tid >> 5) << 1);
+    const int r = r0 + ng * 8;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int k = k0 + kg * 4 + j;
+        if (k < kend && r < rows)
+            s.v[j] = *reinterpret_cast<const uint4*>(base + (size_t)k * ld + r);
+        else
+            s.v[j] = make_uint4(0, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void l_store_ks(const StageRegs& s, char* lds, int tid) {
+    const int ng = (tid & 7) | (((tid >> 4) & 1) << 3);
+    const int kg = ((tid >> 3) & 1) | ((tid >> 5) << 1);
+    const int kc = kg >> 1, half = (kg & 1) * 8;
+    const unsigned in[4][4] = {{s.v[0].x, s.v[0].y, s.v[0].z, s.v[0].w},
+                               {s.v[1].x, s.v[1].y, s.v[1].z, s.v[1].w},
+                               {s.v[2].x, s.v[2].y, s.v[2].z, s.v[2].w},
+                               {s.v[3].x, s.v[3].y, s.v[3].z, s.v[3].w}};
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        // even column: low halves of the 4 k-rows; odd column: high halves
+        uint2 ev, od;
+        ev.x = __builtin_amdgcn_perm(in[1][c], in[0][c], 0x05040100u);
+        ev.y = __builtin_amdgcn_perm(in[3][c], in[2][c], 0x05040100u);
+        od.x = __builtin_amdgcn_perm(in[1][c], in[0][c], 0x07060302u);
+        od.y = __builtin_amdgcn_perm(in[3][c], in[2][c], 0x07060302u);
+        const int n = ng * 8 + 2 * c;
+        *reinterpret_cast<uint2*>(lds + g_lds_off(n, kc) + half) = ev;
+        *reinterpret_cast<uint2*>(lds + g_lds_off(n + 1, kc) + half) = od;
+    }
+}
+
+template <int L>
+__device__ __forceinline__ void g_load(StageRegs& s, const bf16_t* base, int ld, int rows, int r0, int k0, int kend,
+                                       int tid) {
+    if constexpr (L == 0)
+        g_load_kc(s, base, ld, rows, r0, k0, kend, tid);
+    else
+        g_load_ks(s, base, ld, rows, r0, k0, kend, tid);
+}
+template <int L>
+__device__ __forceinline__ void l_store(const StageRegs& s, char* lds, int tid) {
+    if constexpr (L == 0)
+        l_store_kc(s, lds, tid);
+    else
+        l_store_ks(s, lds, tid);
+}
+
+// XCD-aware tile order: the dispatcher places block b on XCD b%8; give each XCD a contiguous run of tiles
+// (bijective for any grid size) so neighbouring tiles that share an A row-panel hit the same L2.
+__device__ __forceinline__ int xcd_remap(int b, int nb) {
+    const int q = nb >> 3, r = nb & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
+template <int AL, int BL, class Epi>
+__global__ __launch_bounds__(G_THREADS, 2) void gemm_bf16_kernel(const bf16_t* __restrict__ A,
+                                                                  const bf16_t* __restrict__ B, GemmShape g, Epi epi) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * G_TILE_BYTES];  // [buf][A|B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (g.N + G_BN - 1) / G_BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / tiles_n) * G_BM, n0 = (tile % tiles_n) * G_BN;
+    const int kbeg = blockIdx.z * g.k_chunk;
+    const int kend = min(g.K, kbeg + g.k_chunk);
+    const int nk = (kend - kbeg + G_BK - 1) / G_BK;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    StageRegs ra, rb;
+    if (nk > 0) {
+        g_load<AL>(ra, A, g.lda, g.M, m0, kbeg, kend, tid);
+        g_load<BL>(rb, B, g.ldb, g.N, n0, kbeg, kend, tid);
+        l_store<AL>(ra, smem, tid);
+        l_store<BL>(rb, smem + G_TILE_BYTES, tid);
+    }
+    __syncthreads();
+
+    const int frow = lane & 15, fchunk = lane >> 4;
+    for (int kt = 0; kt < nk; kt++) {
+        char* cur = smem + (kt & 1) * 2 * G_TILE_BYTES;
+        char* nxt = smem + ((kt + 1) & 1) * 2 * G_TILE_BYTES;
+        const bool more = (kt + 1 < nk);
+        if (more) {
+            const int k0 = kbeg + (kt + 1) * G_BK;
+            g_load<AL>(ra, A, g.lda, g.M, m0, k0, kend, tid);
+            g_load<BL>(rb, B, g.ldb, g.N, n0, k0, kend, tid);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                af[i] = *reinterpret_cast<const bf16x8*>(cur + g_lds_off(wm * 64 + i * 16 + frow, ks * 4 + fchunk));
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                bfr[j] = *reinterpret_cast<const bf16x8*>(cur + G_TILE_BYTES +
+                                                          g_lds_off(wn * 64 + j * 16 + frow, ks * 4 + fchunk));
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            l_store<AL>(ra, nxt, tid);
+            l_store<BL>(rb, nxt + G_TILE_BYTES, tid);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: wave-private LDS strip [16][68] fp32; C layout of 16x16x32: col = lane&15, row = (lane>>4)*4 + reg
+    float* strip = reinterpret_cast<float*>(smem) + wave * (16 * G_EPI_LD);
+    const int er = (lane >> 4) * 4, ec = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) strip[(er + r) * G_EPI_LD + j * 16 + ec] = acc[i][j][r];
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const int q = lane + 64 * s;
+            const int lr = q >> 3, c8 = q & 7;
+            float v[8];
+            const float4 a = *reinterpret_cast<const float4*>(strip + lr * G_EPI_LD + c8 * 8);
+            const float4 b = *reinterpret_cast<const float4*>(strip + lr * G_EPI_LD + c8 * 8 + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            epi(m0 + wm * 64 + i * 16 + lr, n0 + wn * 64 + c8 * 8, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Epilogues.  operator()(row, col, v[8]) is called by EVERY lane (wave-uniform call site): lanes q..q+7 of
+// a wave hold the 64 consecutive columns [col&~63, +64) of one row, so row-wise reductions are 3 shuffles.
+// ------------------------------------------------------------------------------------------------
+
+// C(bf16) = act(acc + bias); optionally also stores the pre-activation (needed by gelu backward).
+struct EpiBF16 {
+    bf16_t* C;
+    bf16_t* pre;        // nullable
+    const float* bias;  // nullable
+    int ldc, M, Ns;     // Ns: columns to store (multiple of 8)
+    int act;            // 0 none, 1 relu, 2 gelu_new
+    __device__ __forceinline__ void operator()(int row, int col, float (&v)[8]) const {
+        if (row >= M || col >= Ns) return;
+        if (bias) {
+            const float4 b0 = *reinterpret_cast<const float4*>(bias + col);
+            const float4 b1 = *reinterpret_cast<const float4*>(bias + col + 4);
+            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        }
+        if (pre) *reinterpret_cast<uint4*>(pre + (size_t)row * ldc + col) = pack8(v);
+        if (act == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
+        } else if (act == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = gelu_new_f(v[e]);
+        }
+        *reinterpret_cast<uint4*>(C + (size_t)row * ldc + col) = pack8(v);
+    }
+};
+
+// out(fp32) = res + acc + bias   (residual stream update; out may alias res)
+struct EpiResid {
+    float* out;
+    const float* res;
+    const float* bias;  // nullable
+    int ld, M, Ns;
+    __device__ __forceinline__ void operator()(int row, int col, float (&v)[8]) const {
+        if (row >= M || col >= Ns) return;
+        const size_t o = (size_t)row * ld + col;
+        const float4 r0 = *reinterpret_cast<const float4*>(res + o);
+        const float4 r1 = *reinterpret_cast<const float4*>(res + o + 4);
+        float4 b0 = make_float4(0, 0, 0, 0), b1 = b0;
+        if (bias) {
+            b0 = *reinterpret_cast<const float4*>(bias + col);
+            b1 = *reinterpret_cast<const float4*>(bias + col + 4);
+        }
+        *reinterpret_cast<float4*>(out + o) = make_float4(r0.x + v[0] + b0.x, r0.y + v[1] + b0.y, r0.z + v[2] + b0.z, r0.w + v[3] + b0.w);
+        *reinterpret_cast<float4*>(out + o + 4) = make_float4(r1.x + v[4] + b1.x, r1.y + v[5] + b1.y, r1.z + v[6] + b1.z, r1.w + v[7] + b1.w);
+    }
+};
+
+// C(fp32) = / += / atomic+= alpha*acc (+bias)   (logits for the parity API, weight gradients with split-K)
+struct EpiF32 {
+    float* C;
+    const float* bias;  // nullable (mode 0 only)
+    int ldc, M, Ns;
+    int mode;  // 0 store, 1 add, 2 atomic add
+    float alpha;
+    __device__ __forceinline__ void operator()(int row, int col, float (&v)[8]) const {
+        if (row >= M || col >= Ns) return;
+        float* p = C + (size_t)row * ldc + col;
+        if (mode == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) __hip_atomic_fetch_add(p + e, alpha * v[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        float4 o0 = make_float4(alpha * v[0], alpha * v[1], alpha * v[2], alpha * v[3]);
+        float4 o1 = make_float4(alpha * v[4], alpha * v[5], alpha * v[6], alpha * v[7]);
+        if (mode == 0 && bias) {
+            const float4 b0 = *reinterpret_cast<const float4*>(bias + col);
+            const float4 b1 = *reinterpret_cast<const float4*>(bias + col + 4);
+            o0.x += b0.x; o0.y += b0.y; o0.z += b0.z; o0.w += b0.w; o1.x += b1.x; o1.y += b1.y; o1.z += b1.z; o1.w += b1.w;
+        }
+        if (mode == 1) {
+            const float4 c0 = *reinterpret_cast<const float4*>(p);
+            const float4 c1 = *reinterpret_cast<const float4*>(p + 4);
+            o0.x += c0.x; o0.y += c0.y; o0.z += c0.z; o0.w += c0.w; o1.x += c1.x; o1.y += c1.y; o1.z += c1.z; o1.w += c1.w;
+        }
+        *reinterpret_cast<float4*>(p) = o0;
+        *reinterpret_cast<float4*>(p + 4) = o1;
+    }
+};
+
+// C(bf16) = acc * act'(aux)   (dgrad through relu: aux = post-activation h; through gelu_new: aux = pre-activation u)
+struct EpiDAct {
+    bf16_t* C;
+    const bf16_t* aux;
+    int ldc, M, Ns;
+    int act;  // 1 relu, 2 gelu_new
+    __device__ __forceinline__ void operator()(int row, int col, float (&v)[8]) const {
+        if (row >= M || col >= Ns) return;
+        const size_t o = (size_t)row * ldc + col;
+        float a[8];
+        unpack8(*reinterpret_cast<const uint4*>(aux + o), a);
+        if (act == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = a[e] > 0.f ? v[e] : 0.f;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] *= gelu_new_grad(a[e]);
+        }
+        *reinterpret_cast<uint4*>(C + o) = pack8(v);
+    }
+};
+
+// lm_head: bf16 logits + per-(row, 64-column block) softmax partials from the fp32 accumulators + exact target logit.
+struct EpiLMHead {
+    bf16_t* C;
+    float* pmax;
+    float* psum;           // [M][npart]
+    const int* target;     // [M] token id per row (>=0)
+    float* tgt_logit;      // [M]
+    int ldc, M, V, npart;  // V = true vocab (columns >= V are padding: stored as 0, excluded from the partials)
+    __device__ __forceinline__ void operator()(int row, int col, float (&v)[8]) const {
+        const bool ok = row < M && col < ldc;
+        float m = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            if (col + e >= V) v[e] = 0.f; else m = fmaxf(m, v[e]);
+        }
+        m = fmaxf(m, __shfl_xor(m, 1, 64));
+        m = fmaxf(m, __shfl_xor(m, 2, 64));
+        m = fmaxf(m, __shfl_xor(m, 4, 64));
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+            if (col + e < V) s += __expf(v[e] - m);
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        if (!ok) return;
+        if ((col & 63) == 0) {
+            const int blk = col >> 6;
+            pmax[(size_t)row * npart + blk] = m;
+            psum[(size_t)row * npart + blk] = (m == -INFINITY) ? 0.f : s;
+        }
+        const int t = target[row] - col;
+        if (t >= 0 && t < 8) tgt_logit[row] = v[t];
+        *reinterpret_cast<uint4*>(C + (size_t)row * ldc + col) = pack8(v);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Host launcher
+// ------------------------------------------------------------------------------------------------
+template <class Epi>
+inline int launch_gemm(int al, int bl, const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K,
+                       int ksplit, const Epi& epi, hipStream_t st) {
+    if (M <= 0 || N <= 0 || K <= 0) return CC_OK;
+    if ((lda & 7) || (ldb & 7) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return CC_ERR_SHAPE;
+    if (al == 0 && (K & 7)) return CC_ERR_SHAPE;
+    if (bl == 0 && (K & 7)) return CC_ERR_SHAPE;
+    if (al == 1 && (M & 7)) return CC_ERR_SHAPE;
+    if (bl == 1 && (N & 7)) return CC_ERR_SHAPE;
+    GemmShape g;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
+    if (ksplit < 1) ksplit = 1;
+    int kt = (K + G_BK - 1) / G_BK;
+    int per = (kt + ksplit - 1) / ksplit;
+    ksplit = (kt + per - 1) / per;
+    g.k_chunk = per * G_BK;
+    dim3 grid(((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN), 1, ksplit);
+    if (al == 0 && bl == 0)
+        hipLaunchKernelGGL((gemm_bf16_kernel<0, 0, Epi>), grid, dim3(G_THREADS), 0, st, A, B, g, epi);
+    else if (al == 0 && bl == 1)
+        hipLaunchKernelGGL((gemm_bf16_kernel<0, 1, Epi>), grid, dim3(G_THREADS), 0, st, A, B, g, epi);
+    else if (al == 1 && bl == 1)
+        hipLaunchKernelGGL((gemm_bf16_kernel<1, 1, Epi>), grid, dim3(G_THREADS), 0, st, A, B, g, epi);
+    else
+        return CC_ERR_ARG;
+    return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+}
+
+}  // namespace cc

@@ -1,0 +1,20 @@
+// Host entry points of the GEMM instantiations (one translation unit per epilogue so they build in parallel).
+#pragma once
+#include "common.cuh"
+
+namespace cc {
+// al/bl: 0 = K-contiguous operand ([rows][K]), 1 = K-strided operand ([K][rows]).  See gemm.cuh.
+int gemm_bf16out(int al, int bl, const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, bf16_t* C, int ldc,
+                 const float* bias, int act, bf16_t* pre, hipStream_t st);
+int gemm_resid(int al, int bl, const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, float* out, const float* res,
+               int ld, const float* bias, hipStream_t st);
+// mode 0 store (+bias), 1 add, 2 atomic add (required when ksplit > 1)
+int gemm_f32out(int al, int bl, const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, float* C, int ldc,
+                const float* bias, int mode, float alpha, int ksplit, hipStream_t st);
+int gemm_dact(int al, int bl, const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, bf16_t* C, int ldc,
+              const bf16_t* aux, int act, hipStream_t st);
+int gemm_lmhead(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int Vp, int V, int K, bf16_t* C, int ldc, float* pmax,
+                float* psum, int npart, const int* target, float* tgt_logit, hipStream_t st);
+// weight gradient dW[Mw][Nw] += X^T Y with X stored [K][Mw], Y stored [K][Nw]; picks a split-K for occupancy
+int gemm_wgrad(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int Mw, int Nw, int K, float* dW, int ldw, hipStream_t st);
+}  // namespace cc

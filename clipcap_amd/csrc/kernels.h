@@ -1,0 +1,38 @@
+// Host-side launchers of the non-GEMM kernels (definitions in kernels.hip / decode.hip).  Internal to the library.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include "common.cuh"
+
+namespace cc {
+
+int f32_to_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t st);
+int slice_f32_to_bf16(const float* src, size_t src_stride, bf16_t* dst, size_t dst_stride, int len, int B, hipStream_t st);
+int broadcast_rows(float* dst, size_t dst_stride, const float* src, int len, int B, hipStream_t st);
+int add_rows(float* dst, size_t dst_stride, const float* add, int len, int B, hipStream_t st);
+int batch_sum(const float* src, size_t src_stride, float* dst, int len, int B, hipStream_t st);
+int copy_rows(const float* src, size_t src_stride, float* dst, size_t dst_stride, int len, int B, hipStream_t st);
+
+int ln_fwd(const float* x, int ldx, const int* row_map, const float* gamma, const float* beta, bf16_t* y, float* y32, float* mean,
+           float* rstd, int rows, int D, hipStream_t st);
+int ln_bwd(const bf16_t* dy, const float* x, int ldx, const int* row_map, const float* mean, const float* rstd, const float* gamma,
+           const float* dres, float* dx32, bf16_t* dx16, float* dgamma, float* dbeta, int rows, int D, hipStream_t st);
+int colsum_bf16(const bf16_t* X, int ld, int M, int N, float* out, hipStream_t st);
+
+int attn_fwd(const bf16_t* qkv, int B, int S, int H, int hd, bool causal, bf16_t* out, float* lse, hipStream_t st);
+int attn_bwd(const bf16_t* qkv, const bf16_t* dout, const float* lse, int B, int S, int H, int hd, bool causal, bf16_t* dqkv,
+             hipStream_t st);
+
+int embed_concat(const float* prefix, const long long* tokens, int cap, const float* wte, const float* wpe, float* x0, int B, int L,
+                 int T, int D, int pos0, hipStream_t st);
+int embed_bwd(const float* dx0, const long long* tokens, int cap, float* dwte, float* dwpe, int B, int L, int T, int D, hipStream_t st);
+
+int ce_rows(const float* pmax, const float* psum, int npart, const int* target, const float* tgt_logit, float* lse, float* row_loss,
+            float* stats, int M, hipStream_t st);
+int ce_dlogits(bf16_t* logits, int ld, int V, const int* target, const float* lse, const float* denom, int M, hipStream_t st);
+int ce_targets(const long long* tokens, int* target, int* row_map, int B, int cap, int L, int T, hipStream_t st);
+
+int adamw(float* p, const float* g, float* m, float* v, bf16_t* p16, size_t n, float lr, float b1, float b2, float eps, float wd,
+          int step, float gscale, hipStream_t st);
+
+}  // namespace cc

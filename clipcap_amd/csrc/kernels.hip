@@ -1,0 +1,693 @@
+// HBM-/LDS-bound kernels of the ClipCap path for gfx950: LayerNorm fwd/bwd, small-sequence attention fwd/bwd,
+// embedding assembly, softmax-cross-entropy pieces, column sums, AdamW, KV-cached decode attention and beam update.
+// All are wave64 code; memory accesses are 16-B vectors wherever the layout allows.
+#include "kernels.h"
+
+namespace cc {
+
+// ------------------------------------------------------------------------------------------------------------
+// element-wise helpers
+// ------------------------------------------------------------------------------------------------------------
+__global__ void k_f32_to_bf16(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+        float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        reinterpret_cast<uint4*>(dst)[i] = pack8(v);
+    }
+}
+int f32_to_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t st) {
+    if (n & 7) return CC_ERR_SHAPE;
+    const size_t n8 = n >> 3;
+    if (!n8) return CC_OK;
+    const int grid = (int)std::min<size_t>((n8 + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_f32_to_bf16, dim3(grid), dim3(256), 0, st, src, dst, n8);
+    return CC_OK;
+}
+
+// dst[b*dst_stride + i] = (bf16) src[b*src_stride + i], i < len (len % 8 == 0)
+__global__ void k_slice_f32_to_bf16(const float* __restrict__ src, size_t src_stride, bf16_t* __restrict__ dst,
+                                    size_t dst_stride, int len8, int B) {
+    const size_t total = (size_t)len8 * B;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / len8), c = (int)(i % len8);
+        const float* s = src + b * src_stride + (size_t)c * 8;
+        const float4 x = *reinterpret_cast<const float4*>(s), y = *reinterpret_cast<const float4*>(s + 4);
+        float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+        *reinterpret_cast<uint4*>(dst + b * dst_stride + (size_t)c * 8) = pack8(v);
+    }
+}
+int slice_f32_to_bf16(const float* src, size_t src_stride, bf16_t* dst, size_t dst_stride, int len, int B, hipStream_t st) {
+    if (len & 7) return CC_ERR_SHAPE;
+    const size_t total = (size_t)(len >> 3) * B;
+    if (!total) return CC_OK;
+    hipLaunchKernelGGL(k_slice_f32_to_bf16, dim3((int)std::min<size_t>((total + 255) / 256, 2048)), dim3(256), 0, st, src,
+                       src_stride, dst, dst_stride, len >> 3, B);
+    return CC_OK;
+}
+
+// dst[b*dst_stride + i] = src[i] (+ add[i])  — broadcast a learned block (prefix_const) into every sample
+__global__ void k_broadcast_rows(float* __restrict__ dst, size_t dst_stride, const float* __restrict__ src, int len4, int B) {
+    const size_t total = (size_t)len4 * B;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / len4), c = (int)(i % len4);
+        reinterpret_cast<float4*>(dst + b * dst_stride)[c] = reinterpret_cast<const float4*>(src)[c];
+    }
+}
+int broadcast_rows(float* dst, size_t dst_stride, const float* src, int len, int B, hipStream_t st) {
+    if (len & 3) return CC_ERR_SHAPE;
+    const size_t total = (size_t)(len >> 2) * B;
+    if (!total) return CC_OK;
+    hipLaunchKernelGGL(k_broadcast_rows, dim3((int)std::min<size_t>((total + 255) / 256, 2048)), dim3(256), 0, st, dst, dst_stride,
+                       src, len >> 2, B);
+    return CC_OK;
+}
+
+// dst[b*dst_stride + i] += add[i]  (positional embeddings of the windowed mapper)
+__global__ void k_add_rows(float* __restrict__ dst, size_t dst_stride, const float* __restrict__ add, int len, int B) {
+    const size_t total = (size_t)len * B;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / len), c = (int)(i % len);
+        dst[b * dst_stride + c] += add[c];
+    }
+}
+int add_rows(float* dst, size_t dst_stride, const float* add, int len, int B, hipStream_t st) {
+    const size_t total = (size_t)len * B;
+    if (!total) return CC_OK;
+    hipLaunchKernelGGL(k_add_rows, dim3((int)std::min<size_t>((total + 255) / 256, 2048)), dim3(256), 0, st, dst, dst_stride, add, len, B);
+    return CC_OK;
+}
+
+// dst[i] += sum_b src[b*src_stride + i]   (gradient of a broadcast block)
+__global__ void k_batch_sum(const float* __restrict__ src, size_t src_stride, float* __restrict__ dst, int len, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    float s = 0.f;
+    for (int b = 0; b < B; b++) s += src[b * src_stride + i];
+    dst[i] += s;
+}
+int batch_sum(const float* src, size_t src_stride, float* dst, int len, int B, hipStream_t st) {
+    if (!len) return CC_OK;
+    hipLaunchKernelGGL(k_batch_sum, dim3((len + 255) / 256), dim3(256), 0, st, src, src_stride, dst, len, B);
+    return CC_OK;
+}
+
+// dst[b*dst_stride + i] = src[b*src_stride + i]  fp32 strided copy (len % 4 == 0)
+__global__ void k_copy_rows(const float* __restrict__ src, size_t src_stride, float* __restrict__ dst, size_t dst_stride, int len4, int B) {
+    const size_t total = (size_t)len4 * B;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / len4), c = (int)(i % len4);
+        reinterpret_cast<float4*>(dst + b * dst_stride)[c] = reinterpret_cast<const float4*>(src + b * src_stride)[c];
+    }
+}
+int copy_rows(const float* src, size_t src_stride, float* dst, size_t dst_stride, int len, int B, hipStream_t st) {
+    if (len & 3) return CC_ERR_SHAPE;
+    const size_t total = (size_t)(len >> 2) * B;
+    if (!total) return CC_OK;
+    hipLaunchKernelGGL(k_copy_rows, dim3((int)std::min<size_t>((total + 255) / 256, 2048)), dim3(256), 0, st, src, src_stride, dst,
+                       dst_stride, len >> 2, B);
+    return CC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// LayerNorm forward: one wave per row, row cached in registers (D <= 2048, D % 4 == 0).
+// y(bf16)[r] = (x[map(r)] - mean) * rstd * gamma + beta ; saves mean / rstd per output row.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int LN_MAXV = 8;  // float4 per lane -> D <= 2048
+
+__global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ x, int ldx, const int* __restrict__ row_map,
+                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                bf16_t* __restrict__ y, float* __restrict__ y32, float* __restrict__ mean,
+                                                float* __restrict__ rstd, int rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)(row_map ? row_map[row] : row) * ldx;
+    float4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < LN_MAXV; it++) {
+        const int c = lane * 4 + it * 256;
+        if (c < D) {
+            v[it] = *reinterpret_cast<const float4*>(xr + c);
+            s += v[it].x + v[it].y + v[it].z + v[it].w;
+        }
+    }
+    const float mu = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < LN_MAXV; it++) {
+        const int c = lane * 4 + it * 256;
+        if (c < D) {
+            const float a = v[it].x - mu, b = v[it].y - mu, cc_ = v[it].z - mu, d = v[it].w - mu;
+            q += a * a + b * b + cc_ * cc_ + d * d;
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / D + eps);
+    if (lane == 0) {
+        if (mean) mean[row] = mu;
+        if (rstd) rstd[row] = rs;
+    }
+#pragma unroll
+    for (int it = 0; it < LN_MAXV; it++) {
+        const int c = lane * 4 + it * 256;
+        if (c < D) {
+            const float4 g = *reinterpret_cast<const float4*>(gamma + c), b = *reinterpret_cast<const float4*>(beta + c);
+            const float o0 = (v[it].x - mu) * rs * g.x + b.x, o1 = (v[it].y - mu) * rs * g.y + b.y;
+            const float o2 = (v[it].z - mu) * rs * g.z + b.z, o3 = (v[it].w - mu) * rs * g.w + b.w;
+            if (y) *reinterpret_cast<uint2*>(y + (size_t)row * D + c) = make_uint2(pack2bf(o0, o1), pack2bf(o2, o3));
+            if (y32) *reinterpret_cast<float4*>(y32 + (size_t)row * D + c) = make_float4(o0, o1, o2, o3);
+        }
+    }
+}
+int ln_fwd(const float* x, int ldx, const int* row_map, const float* gamma, const float* beta, bf16_t* y, float* y32,
+           float* mean, float* rstd, int rows, int D, hipStream_t st) {
+    if (D > LN_MAXV * 256 || (D & 3) || (ldx & 3)) return CC_ERR_SHAPE;
+    if (rows <= 0) return CC_OK;
+    hipLaunchKernelGGL(k_ln_fwd, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, row_map, gamma, beta, y, y32, mean, rstd, rows, D, 1e-5f);
+    return CC_OK;
+}
+
+// LayerNorm backward.  dy(bf16)[r]; x[map(r)]; mean/rstd[r].  dx_out[map(r)] = (dres ? dres[map(r)] : 0) + dLN ; also a
+// bf16 copy of dx_out for the next dgrad GEMM.  Optional dgamma/dbeta (atomic fp32 accumulation, one atomic per
+// column per block).  Each wave walks rows  row = blockIdx*4 + wave + k*gridDim*4.
+__global__ __launch_bounds__(256) void k_ln_bwd(const bf16_t* __restrict__ dy, const float* __restrict__ x, int ldx,
+                                                const int* __restrict__ row_map, const float* __restrict__ mean,
+                                                const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                const float* __restrict__ dres, float* __restrict__ dx32,
+                                                bf16_t* __restrict__ dx16, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                int rows, int D) {
+    extern __shared__ __attribute__((aligned(16))) float ln_red[];  // [2][4][D] when dgamma
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 pg[LN_MAXV], pb[LN_MAXV];
+#pragma unroll
+    for (int it = 0; it < LN_MAXV; it++) pg[it] = pb[it] = make_float4(0, 0, 0, 0);
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const size_t xr = (size_t)(row_map ? row_map[row] : row) * ldx;
+        const float mu = mean[row], rs = rstd[row];
+        float4 g[LN_MAXV], xh[LN_MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < LN_MAXV; it++) {
+            const int c = lane * 4 + it * 256;
+            if (c < D) {
+                const uint2 d = *reinterpret_cast<const uint2*>(dy + (size_t)row * D + c);
+                const float d0 = __uint_as_float(d.x << 16), d1 = __uint_as_float(d.x & 0xffff0000u);
+                const float d2 = __uint_as_float(d.y << 16), d3 = __uint_as_float(d.y & 0xffff0000u);
+                const float4 xv = *reinterpret_cast<const float4*>(x + xr + c);
+                const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
+                xh[it] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+                g[it] = make_float4(d0 * gm.x, d1 * gm.y, d2 * gm.z, d3 * gm.w);
+                s1 += g[it].x + g[it].y + g[it].z + g[it].w;
+                s2 += g[it].x * xh[it].x + g[it].y * xh[it].y + g[it].z * xh[it].z + g[it].w * xh[it].w;
+                if (dgamma) {
+                    pg[it].x += d0 * xh[it].x; pg[it].y += d1 * xh[it].y; pg[it].z += d2 * xh[it].z; pg[it].w += d3 * xh[it].w;
+                    pb[it].x += d0; pb[it].y += d1; pb[it].z += d2; pb[it].w += d3;
+                }
+            }
+        }
+        const float m1 = wave_sum(s1) / D, m2 = wave_sum(s2) / D;
+#pragma unroll
+        for (int it = 0; it < LN_MAXV; it++) {
+            const int c = lane * 4 + it * 256;
+            if (c < D) {
+                float4 o = make_float4(rs * (g[it].x - m1 - xh[it].x * m2), rs * (g[it].y - m1 - xh[it].y * m2),
+                                       rs * (g[it].z - m1 - xh[it].z * m2), rs * (g[it].w - m1 - xh[it].w * m2));
+                if (dres) {
+                    const float4 r = *reinterpret_cast<const float4*>(dres + xr + c);
+                    o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+                }
+                *reinterpret_cast<float4*>(dx32 + xr + c) = o;
+                if (dx16) *reinterpret_cast<uint2*>(dx16 + xr + c) = make_uint2(pack2bf(o.x, o.y), pack2bf(o.z, o.w));
+            }
+        }
+    }
+    if (dgamma) {
+        float* rg = ln_red;
+        float* rb = ln_red + 4 * D;
+#pragma unroll
+        for (int it = 0; it < LN_MAXV; it++) {
+            const int c = lane * 4 + it * 256;
+            if (c < D) {
+                *reinterpret_cast<float4*>(rg + wave * D + c) = pg[it];
+                *reinterpret_cast<float4*>(rb + wave * D + c) = pb[it];
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < D; c += 256) {
+            const float sg = rg[c] + rg[D + c] + rg[2 * D + c] + rg[3 * D + c];
+            const float sb = rb[c] + rb[D + c] + rb[2 * D + c] + rb[3 * D + c];
+            __hip_atomic_fetch_add(dgamma + c, sg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(dbeta + c, sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+int ln_bwd(const bf16_t* dy, const float* x, int ldx, const int* row_map, const float* mean, const float* rstd,
+           const float* gamma, const float* dres, float* dx32, bf16_t* dx16, float* dgamma, float* dbeta, int rows, int D,
+           hipStream_t st) {
+    if (D > LN_MAXV * 256 || (D & 3) || (ldx & 3)) return CC_ERR_SHAPE;
+    if (rows <= 0) return CC_OK;
+    const int grid = std::min((rows + 3) / 4, 1024);
+    const size_t sh = dgamma ? (size_t)8 * D * sizeof(float) : 0;
+    hipLaunchKernelGGL(k_ln_bwd, dim3(grid), dim3(256), sh, st, dy, x, ldx, row_map, mean, rstd, gamma, dres, dx32, dx16, dgamma,
+                       dbeta, rows, D);
+    return CC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Column sums of a bf16 matrix (bias gradients): out[n] += sum_m X[m][n].  Block = 64 columns x a row slice.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_colsum_bf16(const bf16_t* __restrict__ X, int ld, int M, int N, float* __restrict__ out,
+                                                     int rows_per_slice) {
+    __shared__ float red[32][65];
+    const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int col = blockIdx.x * 64 + cg * 8;
+    const int r0 = blockIdx.y * rows_per_slice, r1 = min(M, r0 + rows_per_slice);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (col < N) {
+        for (int r = r0 + rl; r < r1; r += 32) {
+            float f[8];
+            unpack8(*reinterpret_cast<const uint4*>(X + (size_t)r * ld + col), f);
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc[e] += f[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) red[rl][cg * 8 + e] = acc[e];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; r++) s += red[r][threadIdx.x];
+        const int c = blockIdx.x * 64 + threadIdx.x;
+        if (c < N) __hip_atomic_fetch_add(out + c, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+int colsum_bf16(const bf16_t* X, int ld, int M, int N, float* out, hipStream_t st) {
+    if ((N & 7) || (ld & 7)) return CC_ERR_SHAPE;
+    if (M <= 0 || N <= 0) return CC_OK;
+    const int cb = (N + 63) / 64;
+    int slices = std::max(1, std::min((M + 255) / 256, 1024 / cb));
+    const int rps = ((M + slices - 1) / slices + 31) / 32 * 32;
+    slices = (M + rps - 1) / rps;
+    hipLaunchKernelGGL(k_colsum_bf16, dim3(cb, slices), dim3(256), 0, st, X, ld, M, N, out, rps);
+    return CC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Small-sequence attention (mapper: S=20, hd=96, full; GPT-2 training: T<=74, hd=64, causal).  One workgroup per
+// (batch, head); Q/K/V staged in LDS as fp32 rows of hd+4 floats (16-B aligned, rows 4 banks apart so that a
+// wave's b128 reads of consecutive rows are conflict-free).  qkv is [B*S][3*D] = [q | k | v], head h at h*hd.
+// Saves the log-sum-exp per (b,h,row) for the backward pass (probabilities are recomputed there).
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_head_rows(float* dst, int hdp, const bf16_t* src, size_t ld, int S, int hd) {
+    const int c8n = hd >> 3;
+    for (int idx = threadIdx.x; idx < S * c8n; idx += blockDim.x) {
+        const int r = idx / c8n, c = idx % c8n;
+        float f[8];
+        unpack8(*reinterpret_cast<const uint4*>(src + (size_t)r * ld + c * 8), f);
+        float* d = dst + r * hdp + c * 8;
+        *reinterpret_cast<float4*>(d) = make_float4(f[0], f[1], f[2], f[3]);
+        *reinterpret_cast<float4*>(d + 4) = make_float4(f[4], f[5], f[6], f[7]);
+    }
+}
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) void k_attn_fwd(const bf16_t* __restrict__ qkv, int S, int H, int hd, float scale,
+                                                  bf16_t* __restrict__ out, float* __restrict__ lse) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int D = H * hd, hdp = hd + 4, Sp = S + 1;
+    float* Qs = sm;
+    float* Ks = Qs + S * hdp;
+    float* Vs = Ks + S * hdp;
+    float* Ps = Vs + S * hdp;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const bf16_t* base = qkv + (size_t)b * S * 3 * D + h * hd;
+    load_head_rows(Qs, hdp, base, 3 * D, S, hd);
+    load_head_rows(Ks, hdp, base + D, 3 * D, S, hd);
+    load_head_rows(Vs, hdp, base + 2 * D, 3 * D, S, hd);
+    __syncthreads();
+    // scores: thread -> (block of 4 queries, key j)
+    const int nib = (S + 3) >> 2;
+    for (int idx = threadIdx.x; idx < nib * S; idx += 256) {
+        const int ib = idx / S, j = idx % S, i0 = ib * 4;
+        if (CAUSAL && j > i0 + 3) {
+#pragma unroll
+            for (int ii = 0; ii < 4; ii++)
+                if (i0 + ii < S) Ps[(i0 + ii) * Sp + j] = -INFINITY;
+            continue;
+        }
+        float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        const float* kr = Ks + j * hdp;
+        const float* q0 = Qs + min(i0, S - 1) * hdp;
+        const float* q1 = Qs + min(i0 + 1, S - 1) * hdp;
+        const float* q2 = Qs + min(i0 + 2, S - 1) * hdp;
+        const float* q3 = Qs + min(i0 + 3, S - 1) * hdp;
+        for (int d = 0; d < hd; d += 4) {
+            const float4 k = *reinterpret_cast<const float4*>(kr + d);
+            const float4 x0 = *reinterpret_cast<const float4*>(q0 + d), x1 = *reinterpret_cast<const float4*>(q1 + d);
+            const float4 x2 = *reinterpret_cast<const float4*>(q2 + d), x3 = *reinterpret_cast<const float4*>(q3 + d);
+            a0 += x0.x * k.x + x0.y * k.y + x0.z * k.z + x0.w * k.w;
+            a1 += x1.x * k.x + x1.y * k.y + x1.z * k.z + x1.w * k.w;
+            a2 += x2.x * k.x + x2.y * k.y + x2.z * k.z + x2.w * k.w;
+            a3 += x3.x * k.x + x3.y * k.y + x3.z * k.z + x3.w * k.w;
+        }
+        const float a[4] = {a0, a1, a2, a3};
+#pragma unroll
+        for (int ii = 0; ii < 4; ii++)
+            if (i0 + ii < S) Ps[(i0 + ii) * Sp + j] = (CAUSAL && j > i0 + ii) ? -INFINITY : a[ii] * scale;
+    }
+    __syncthreads();
+    // softmax: one wave per row
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = wave; i < S; i += 4) {
+        float m = -INFINITY;
+        for (int j = lane; j < S; j += 64) m = fmaxf(m, Ps[i * Sp + j]);
+        m = wave_max(m);
+        float s = 0.f;
+        for (int j = lane; j < S; j += 64) {
+            const float e = __expf(Ps[i * Sp + j] - m);
+            Ps[i * Sp + j] = e;
+            s += e;
+        }
+        s = wave_sum(s);
+        const float inv = 1.f / s;
+        for (int j = lane; j < S; j += 64) Ps[i * Sp + j] *= inv;
+        if (lane == 0 && lse) lse[((size_t)b * H + h) * S + i] = m + __logf(s);
+    }
+    __syncthreads();
+    // O = P V: thread -> (row i, 4 columns)
+    const int d4n = hd >> 2;
+    for (int idx = threadIdx.x; idx < S * d4n; idx += 256) {
+        const int i = idx / d4n, d0 = (idx % d4n) * 4;
+        float4 o = make_float4(0, 0, 0, 0);
+        const int jmax = CAUSAL ? i + 1 : S;
+        for (int j = 0; j < jmax; j++) {
+            const float p = Ps[i * Sp + j];
+            const float4 v = *reinterpret_cast<const float4*>(Vs + j * hdp + d0);
+            o.x += p * v.x; o.y += p * v.y; o.z += p * v.z; o.w += p * v.w;
+        }
+        *reinterpret_cast<uint2*>(out + ((size_t)b * S + i) * D + h * hd + d0) = make_uint2(pack2bf(o.x, o.y), pack2bf(o.z, o.w));
+    }
+}
+
+static size_t attn_fwd_lds(int S, int hd) { return ((size_t)3 * S * (hd + 4) + (size_t)S * (S + 1)) * 4; }
+static size_t attn_bwd_lds(int S, int hd) { return ((size_t)4 * S * (hd + 4) + (size_t)2 * S * (S + 1)) * 4; }
+
+int attn_fwd(const bf16_t* qkv, int B, int S, int H, int hd, bool causal, bf16_t* out, float* lse, hipStream_t st) {
+    if ((hd & 7) || S <= 0) return CC_ERR_SHAPE;
+    const size_t sh = attn_fwd_lds(S, hd);
+    if (sh > 160 * 1024) return CC_ERR_SHAPE;
+    const float scale = 1.0f / sqrtf((float)hd);
+    if (causal) {
+        if (sh > 64 * 1024) hipFuncSetAttribute((const void*)k_attn_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL(k_attn_fwd<true>, dim3(B * H), dim3(256), sh, st, qkv, S, H, hd, scale, out, lse);
+    } else {
+        if (sh > 64 * 1024) hipFuncSetAttribute((const void*)k_attn_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL(k_attn_fwd<false>, dim3(B * H), dim3(256), sh, st, qkv, S, H, hd, scale, out, lse);
+    }
+    return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+}
+
+// Backward: recompute P from the saved lse; dP = dO V^T; delta_i = sum_j P_ij dP_ij (== dO_i . O_i);
+// dS = P (dP - delta) * scale; dQ = dS K; dK = dS^T Q; dV = P^T dO.  Writes dqkv (bf16) in the qkv layout.
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) void k_attn_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                  const float* __restrict__ lse, int S, int H, int hd, float scale,
+                                                  bf16_t* __restrict__ dqkv) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int D = H * hd, hdp = hd + 4, Sp = S + 1;
+    float* Qs = sm;
+    float* Ks = Qs + S * hdp;
+    float* Vs = Ks + S * hdp;
+    float* Os = Vs + S * hdp;  // dO
+    float* Ps = Os + S * hdp;
+    float* Ds = Ps + S * Sp;   // dP then dS
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const bf16_t* base = qkv + (size_t)b * S * 3 * D + h * hd;
+    load_head_rows(Qs, hdp, base, 3 * D, S, hd);
+    load_head_rows(Ks, hdp, base + D, 3 * D, S, hd);
+    load_head_rows(Vs, hdp, base + 2 * D, 3 * D, S, hd);
+    load_head_rows(Os, hdp, dout + (size_t)b * S * D + h * hd, D, S, hd);
+    __syncthreads();
+    const float* lrow = lse + ((size_t)b * H + h) * S;
+    const int nib = (S + 3) >> 2;
+    for (int idx = threadIdx.x; idx < nib * S; idx += 256) {
+        const int ib = idx / S, j = idx % S, i0 = ib * 4;
+        if (CAUSAL && j > i0 + 3) {
+#pragma unroll
+            for (int ii = 0; ii < 4; ii++)
+                if (i0 + ii < S) { Ps[(i0 + ii) * Sp + j] = 0.f; Ds[(i0 + ii) * Sp + j] = 0.f; }
+            continue;
+        }
+        float s[4] = {0, 0, 0, 0}, dp[4] = {0, 0, 0, 0};
+        const float* kr = Ks + j * hdp;
+        const float* vr = Vs + j * hdp;
+        for (int d = 0; d < hd; d += 4) {
+            const float4 k = *reinterpret_cast<const float4*>(kr + d), v = *reinterpret_cast<const float4*>(vr + d);
+#pragma unroll
+            for (int ii = 0; ii < 4; ii++) {
+                const int i = min(i0 + ii, S - 1);
+                const float4 q = *reinterpret_cast<const float4*>(Qs + i * hdp + d);
+                const float4 o = *reinterpret_cast<const float4*>(Os + i * hdp + d);
+                s[ii] += q.x * k.x + q.y * k.y + q.z * k.z + q.w * k.w;
+                dp[ii] += o.x * v.x + o.y * v.y + o.z * v.z + o.w * v.w;
+            }
+        }
+#pragma unroll
+        for (int ii = 0; ii < 4; ii++) {
+            const int i = i0 + ii;
+            if (i < S) {
+                const bool masked = CAUSAL && j > i;
+                Ps[i * Sp + j] = masked ? 0.f : __expf(s[ii] * scale - lrow[i]);
+                Ds[i * Sp + j] = masked ? 0.f : dp[ii];
+            }
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = wave; i < S; i += 4) {
+        float dl = 0.f;
+        for (int j = lane; j < S; j += 64) dl += Ps[i * Sp + j] * Ds[i * Sp + j];
+        dl = wave_sum(dl);
+        for (int j = lane; j < S; j += 64) Ds[i * Sp + j] = Ps[i * Sp + j] * (Ds[i * Sp + j] - dl) * scale;
+    }
+    __syncthreads();
+    const int d4n = hd >> 2;
+    for (int idx = threadIdx.x; idx < S * d4n; idx += 256) {
+        const int r = idx / d4n, d0 = (idx % d4n) * 4;
+        float4 dq = make_float4(0, 0, 0, 0), dk = dq, dv = dq;
+        const int jhi = CAUSAL ? r + 1 : S;   // dQ_r: keys j <= r
+        for (int j = 0; j < jhi; j++) {
+            const float w = Ds[r * Sp + j];
+            const float4 k = *reinterpret_cast<const float4*>(Ks + j * hdp + d0);
+            dq.x += w * k.x; dq.y += w * k.y; dq.z += w * k.z; dq.w += w * k.w;
+        }
+        const int ilo = CAUSAL ? r : 0;       // dK_r, dV_r: queries i >= r
+        for (int i = ilo; i < S; i++) {
+            const float w = Ds[i * Sp + r], p = Ps[i * Sp + r];
+            const float4 q = *reinterpret_cast<const float4*>(Qs + i * hdp + d0);
+            const float4 o = *reinterpret_cast<const float4*>(Os + i * hdp + d0);
+            dk.x += w * q.x; dk.y += w * q.y; dk.z += w * q.z; dk.w += w * q.w;
+            dv.x += p * o.x; dv.y += p * o.y; dv.z += p * o.z; dv.w += p * o.w;
+        }
+        bf16_t* o = dqkv + ((size_t)b * S + r) * 3 * D + h * hd + d0;
+        *reinterpret_cast<uint2*>(o) = make_uint2(pack2bf(dq.x, dq.y), pack2bf(dq.z, dq.w));
+        *reinterpret_cast<uint2*>(o + D) = make_uint2(pack2bf(dk.x, dk.y), pack2bf(dk.z, dk.w));
+        *reinterpret_cast<uint2*>(o + 2 * D) = make_uint2(pack2bf(dv.x, dv.y), pack2bf(dv.z, dv.w));
+    }
+}
+int attn_bwd(const bf16_t* qkv, const bf16_t* dout, const float* lse, int B, int S, int H, int hd, bool causal, bf16_t* dqkv,
+             hipStream_t st) {
+    if ((hd & 7) || S <= 0) return CC_ERR_SHAPE;
+    const size_t sh = attn_bwd_lds(S, hd);
+    if (sh > 160 * 1024) return CC_ERR_SHAPE;
+    const float scale = 1.0f / sqrtf((float)hd);
+    if (causal) {
+        if (sh > 64 * 1024) hipFuncSetAttribute((const void*)k_attn_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL(k_attn_bwd<true>, dim3(B * H), dim3(256), sh, st, qkv, dout, lse, S, H, hd, scale, dqkv);
+    } else {
+        if (sh > 64 * 1024) hipFuncSetAttribute((const void*)k_attn_bwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL(k_attn_bwd<false>, dim3(B * H), dim3(256), sh, st, qkv, dout, lse, S, H, hd, scale, dqkv);
+    }
+    return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// GPT-2 input assembly: x0[b,t,:] = (t < L ? prefix[b,t,:] : wte[tok[b,t-L],:]) + wpe[pos0 + t,:]   (fp32)
+// (clipcap/model/model.py:45-49 + hf modeling_gpt2.py:571-577).  tokens < 0 (pads) are read as id 0 (model.py:104).
+// ------------------------------------------------------------------------------------------------------------
+__global__ void k_embed_concat(const float* __restrict__ prefix, const long long* __restrict__ tokens, int cap,
+                               const float* __restrict__ wte, const float* __restrict__ wpe, float* __restrict__ x0,
+                               int B, int L, int T, int D, int pos0) {
+    const int d4n = D >> 2;
+    const size_t total = (size_t)B * T * d4n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % d4n);
+        const int t = (int)((i / d4n) % T), b = (int)(i / ((size_t)d4n * T));
+        float4 v;
+        if (t < L)
+            v = reinterpret_cast<const float4*>(prefix + ((size_t)b * L + t) * D)[c];
+        else {
+            long long id = tokens[(size_t)b * cap + (t - L)];
+            if (id < 0) id = 0;
+            v = reinterpret_cast<const float4*>(wte + (size_t)id * D)[c];
+        }
+        const float4 p = reinterpret_cast<const float4*>(wpe + (size_t)(pos0 + t) * D)[c];
+        reinterpret_cast<float4*>(x0)[i] = make_float4(v.x + p.x, v.y + p.y, v.z + p.z, v.w + p.w);
+    }
+}
+int embed_concat(const float* prefix, const long long* tokens, int cap, const float* wte, const float* wpe, float* x0, int B, int L,
+                 int T, int D, int pos0, hipStream_t st) {
+    if (D & 3) return CC_ERR_SHAPE;
+    const size_t total = (size_t)B * T * (D >> 2);
+    if (!total) return CC_OK;
+    hipLaunchKernelGGL(k_embed_concat, dim3((int)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, st, prefix, tokens, cap,
+                       wte, wpe, x0, B, L, T, D, pos0);
+    return CC_OK;
+}
+
+// Embedding-gradient scatter (full finetune): dwte[tok[b,c],:] += dx0[b,L+c,:] ; dwpe[t,:] += sum_b dx0[b,t,:]
+__global__ void k_embed_bwd(const float* __restrict__ dx0, const long long* __restrict__ tokens, int cap, float* __restrict__ dwte,
+                            float* __restrict__ dwpe, int B, int L, int T, int D) {
+    const size_t total = (size_t)B * T * D;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const int t = (int)((i / D) % T), b = (int)(i / ((size_t)D * T));
+        const float g = dx0[i];
+        __hip_atomic_fetch_add(dwpe + (size_t)t * D + d, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t >= L) {
+            long long id = tokens[(size_t)b * cap + (t - L)];
+            if (id < 0) id = 0;
+            __hip_atomic_fetch_add(dwte + (size_t)id * D + d, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+int embed_bwd(const float* dx0, const long long* tokens, int cap, float* dwte, float* dwpe, int B, int L, int T, int D, hipStream_t st) {
+    const size_t total = (size_t)B * T * D;
+    if (!total) return CC_OK;
+    hipLaunchKernelGGL(k_embed_bwd, dim3((int)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, st, dx0, tokens, cap, dwte,
+                       dwpe, B, L, T, D);
+    return CC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Cross-entropy over the lm_head partials (clipcap/model/model.py:108-109: ignore_index=0, mean over kept targets).
+// k_ce_rows: lse[row] from the per-64-column (max,sumexp) partials; row loss = lse - target_logit for kept rows;
+//            stats[0] += sum of kept row losses, stats[1] += number of kept rows.
+// k_ce_dlogits: in place over the bf16 logits: dl = (softmax - onehot) * (kept ? 1/denom : 0); padding columns -> 0.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ce_rows(const float* __restrict__ pmax, const float* __restrict__ psum, int npart,
+                                                 const int* __restrict__ target, const float* __restrict__ tgt_logit,
+                                                 float* __restrict__ lse, float* __restrict__ row_loss, float* __restrict__ stats,
+                                                 int M) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float m = -INFINITY;
+    for (int p = lane; p < npart; p += 64) m = fmaxf(m, pmax[(size_t)row * npart + p]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int p = lane; p < npart; p += 64) {
+        const float pm = pmax[(size_t)row * npart + p];
+        if (pm != -INFINITY) s += psum[(size_t)row * npart + p] * __expf(pm - m);
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+        const float l = m + logf(s);
+        lse[row] = l;
+        const bool kept = target[row] != 0;
+        const float rl = kept ? l - tgt_logit[row] : 0.f;
+        row_loss[row] = rl;
+        if (kept) {
+            __hip_atomic_fetch_add(stats, rl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(stats + 1, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+int ce_rows(const float* pmax, const float* psum, int npart, const int* target, const float* tgt_logit, float* lse, float* row_loss,
+            float* stats, int M, hipStream_t st) {
+    if (M <= 0) return CC_OK;
+    hipLaunchKernelGGL(k_ce_rows, dim3((M + 3) / 4), dim3(256), 0, st, pmax, psum, npart, target, tgt_logit, lse, row_loss, stats, M);
+    return CC_OK;
+}
+
+__global__ __launch_bounds__(256) void k_ce_dlogits(bf16_t* __restrict__ logits, int ld, int V, const int* __restrict__ target,
+                                                    const float* __restrict__ lse, const float* __restrict__ denom, int M) {
+    const int row = blockIdx.y;
+    const int col = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (col >= ld) return;
+    const int t = target[row];
+    const float l = lse[row];
+    const float w = (t != 0) ? 1.0f / fmaxf(denom[0], 1.0f) : 0.f;
+    bf16_t* p = logits + (size_t)row * ld + col;
+    float f[8];
+    unpack8(*reinterpret_cast<const uint4*>(p), f);
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int c = col + e;
+        f[e] = (c < V) ? (__expf(f[e] - l) - (c == t ? 1.f : 0.f)) * w : 0.f;
+    }
+    *reinterpret_cast<uint4*>(p) = pack8(f);
+}
+int ce_dlogits(bf16_t* logits, int ld, int V, const int* target, const float* lse, const float* denom, int M, hipStream_t st) {
+    if (ld & 7) return CC_ERR_SHAPE;
+    if (M <= 0) return CC_OK;
+    hipLaunchKernelGGL(k_ce_dlogits, dim3((ld / 8 + 255) / 256, M), dim3(256), 0, st, logits, ld, V, target, lse, denom, M);
+    return CC_OK;
+}
+
+// Targets of the caption rows: target[b*cap + c] = max(tokens[b,c], 0) (model.py:103-104); row_map[b*cap+c] = b*T + L-1+c.
+__global__ void k_ce_targets(const long long* __restrict__ tokens, int* __restrict__ target, int* __restrict__ row_map, int B, int cap,
+                             int L, int T) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * cap) return;
+    const int b = i / cap, c = i % cap;
+    long long id = tokens[i];
+    target[i] = id < 0 ? 0 : (int)id;
+    row_map[i] = b * T + L - 1 + c;
+}
+int ce_targets(const long long* tokens, int* target, int* row_map, int B, int cap, int L, int T, hipStream_t st) {
+    if (B * cap <= 0) return CC_OK;
+    hipLaunchKernelGGL(k_ce_targets, dim3((B * cap + 255) / 256), dim3(256), 0, st, tokens, target, row_map, B, cap, L, T);
+    return CC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Flat AdamW (torch.optim.AdamW math, decoupled decay) over one parameter arena; also refreshes the bf16 copy the
+// GEMMs read.  HBM-bound: 16 B read + 14 B written per parameter.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                               float* __restrict__ v, bf16_t* __restrict__ p16, size_t n4, float lr, float b1, float b2,
+                                               float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 P = reinterpret_cast<float4*>(p)[i], G = reinterpret_cast<const float4*>(g)[i];
+        float4 M = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i];
+        float* pp = &P.x; float* gg = &G.x; float* mm = &M.x; float* vv = &V.x;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const float gr = gg[e] * gscale;
+            pp[e] *= (1.0f - lr * wd);
+            mm[e] = b1 * mm[e] + (1.0f - b1) * gr;
+            vv[e] = b2 * vv[e] + (1.0f - b2) * gr * gr;
+            const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
+            pp[e] -= (lr / bc1) * (mm[e] / denom);
+        }
+        reinterpret_cast<float4*>(p)[i] = P;
+        reinterpret_cast<float4*>(m)[i] = M;
+        reinterpret_cast<float4*>(v)[i] = V;
+        if (p16) reinterpret_cast<uint2*>(p16)[i] = make_uint2(pack2bf(P.x, P.y), pack2bf(P.z, P.w));
+    }
+}
+int adamw(float* p, const float* g, float* m, float* v, bf16_t* p16, size_t n, float lr, float b1, float b2, float eps, float wd,
+          int step, float gscale, hipStream_t st) {
+    if (n & 3) return CC_ERR_SHAPE;
+    if (!n) return CC_OK;
+    const float bc1 = 1.0f - powf(b1, (float)step);
+    const float bc2s = sqrtf(1.0f - powf(b2, (float)step));
+    const size_t n4 = n >> 2;
+    hipLaunchKernelGGL(k_adamw, dim3((int)std::min<size_t>((n4 + 255) / 256, 4096)), dim3(256), 0, st, p, g, m, v, p16, n4, lr, b1, b2,
+                       eps, wd, bc1, bc2s, gscale);
+    return CC_OK;
+}
+
+}  // namespace cc

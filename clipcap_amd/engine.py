@@ -1,0 +1,284 @@
+"""Device-side engines: flat parameter arenas + workspaces + calls into libclipcap_hip.so.
+
+``MapperEngine`` / ``Gpt2Engine`` own the arenas the C ABI works on (fp32 master ``w32``, bf16 operand copy ``w16``,
+fp32 gradient arena ``g32``) and hand out named views with the reference's state-dict names and layouts
+(clipcap/model/mapper.py, clipcap/model/attention.py; HF GPT-2 names).  ``ClipCapEngine`` chains them into the
+training step of clipcap/model/model.py:94-113 (forward + backward, no autograd graph).
+
+PyTorch is used for device memory and streams only; all arithmetic runs in the HIP library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from clipcap_amd import _lib
+from clipcap_amd._lib import Gpt2Cfg, Gpt2Shape, MapperCfg, check
+
+
+def _p(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _require_cuda(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: clipcap_amd runs on an MI355X only (tensor is on {t.device}); there is no CPU fallback")
+
+
+MAPPER_LAYER_NAMES = ["norm1.weight", "norm1.bias", "attn.to_queries.weight", "attn.to_keys_values.weight", "attn.project.weight",
+                      "attn.project.bias", "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight",
+                      "mlp.fc2.bias"]
+GPT2_LAYER_NAMES = ["ln_1.weight", "ln_1.bias", "attn.c_attn.weight", "attn.c_attn.bias", "attn.c_proj.weight", "attn.c_proj.bias",
+                    "ln_2.weight", "ln_2.bias", "mlp.c_fc.weight", "mlp.c_fc.bias", "mlp.c_proj.weight", "mlp.c_proj.bias"]
+
+
+class _Arena:
+    """fp32 master + bf16 operand copy (+ lazily a gradient arena and AdamW state) for one parameter family."""
+
+    def __init__(self, n: int, device):
+        self.n = n
+        self.device = torch.device(device)
+        self.w32 = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.w16 = torch.zeros(n, dtype=torch.bfloat16, device=self.device) if self.device.type == "cuda" else None
+        self.g32: Optional[torch.Tensor] = None
+        self.m: Optional[torch.Tensor] = None
+        self.v: Optional[torch.Tensor] = None
+        self._w16_version = -1
+
+    def sync_bf16(self):
+        """Refresh the bf16 copy if the master changed (version counter is shared by all views)."""
+        if self.w32._version != self._w16_version:
+            check(_lib.lib().cc_cast_bf16(_p(self.w32), _p(self.w16), self.n, _stream(self.device)), "cc_cast_bf16")
+            self._w16_version = self.w32._version
+
+    def grads(self) -> torch.Tensor:
+        if self.g32 is None:
+            self.g32 = torch.zeros(self.n, dtype=torch.float32, device=self.device)
+        return self.g32
+
+    def adamw_step(self, lr: float, step: int, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, grad_scale: float = 1.0):
+        """torch.optim.AdamW math (reference model.py:73-77) over the whole arena, refreshing the bf16 copy."""
+        if self.m is None:
+            self.m = torch.zeros_like(self.w32)
+            self.v = torch.zeros_like(self.w32)
+        check(_lib.lib().cc_adamw_step(_p(self.w32), _p(self.grads()), _p(self.m), _p(self.v), _p(self.w16), self.n, lr, betas[0], betas[1],
+                                       eps, weight_decay, step, grad_scale, _stream(self.device)), "cc_adamw_step")
+        self.w32._version  # (in-place by the kernel: keep the cached bf16 copy marked fresh)
+        self._w16_version = self.w32._version
+
+
+class MapperEngine:
+    """TransformerMapper / TransformerMapperWindowed (reference clipcap/model/mapper.py:113-160) on the HIP library."""
+
+    def __init__(self, E: int, D: int, prefix_length: int, projection_length: int, num_heads: int, num_layers: int, window: int = 1,
+                 use_pos: bool = False, device="cpu"):
+        self.dims = dict(E=E, D=D, P=projection_length, L=prefix_length, H=num_heads, N=num_layers, Hm=int(D * 2.0), W=window,
+                         use_pos=int(bool(use_pos) and window > 1))
+        self.cfg = MapperCfg(**self.dims)
+        l = _lib.lib()
+        n = l.cc_mapper_param_count(C.byref(self.cfg))
+        if n < 0:
+            raise _lib.CCError(f"unsupported mapper configuration {self.dims}: dims must be multiples of 8 (head dim too)")
+        self.arena = _Arena(n, device)
+        offs = (C.c_int64 * (4 + 12 * num_layers))()
+        check(l.cc_mapper_param_offsets(C.byref(self.cfg), offs))
+        self.offsets = list(offs)
+        self._ws: Dict[Tuple[int, int], torch.Tensor] = {}
+
+    # ---- named views (reference state-dict names / layouts) ----
+    def shapes(self) -> List[Tuple[str, int, Tuple[int, ...]]]:
+        d = self.dims
+        E, D, P, L, N, Hm, W = d["E"], d["D"], d["P"], d["L"], d["N"], d["Hm"], d["W"]
+        out = [("linear.weight", self.offsets[0], (P * D, E)), ("linear.bias", self.offsets[1], (P * D,)),
+               ("prefix_const", self.offsets[2], (L, D))]
+        if self.offsets[3] >= 0:
+            out.append(("pos_embeddings", self.offsets[3], (W * P, D)))
+        shp = [(D,), (D,), (D, D), (2 * D, D), (D, D), (D,), (D,), (D,), (Hm, D), (Hm,), (D, Hm), (D,)]
+        for i in range(N):
+            for j, nm in enumerate(MAPPER_LAYER_NAMES):
+                out.append((f"transformer.layers.{i}.{nm}", self.offsets[4 + 12 * i + j], shp[j]))
+        return out
+
+    def views(self, arena: torch.Tensor) -> Dict[str, torch.Tensor]:
+        res = {}
+        for name, off, shape in self.shapes():
+            n = 1
+            for s in shape:
+                n *= s
+            res[name] = arena[off:off + n].view(shape)
+        return res
+
+    def to(self, device):
+        device = torch.device(device)
+        if device == self.arena.device:
+            return self
+        old = self.arena
+        self.arena = _Arena(old.n, device)
+        self.arena.w32.copy_(old.w32)
+        self._ws.clear()
+        return self
+
+    def _workspace(self, B: int, save: int) -> torch.Tensor:
+        key = (B, save)
+        ws = self._ws.get(key)
+        if ws is None:
+            nbytes = _lib.lib().cc_mapper_ws_bytes(C.byref(self.cfg), B, save)
+            check(nbytes, "cc_mapper_ws_bytes")
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.arena.device)
+            self._ws[key] = ws
+        return ws
+
+    def forward(self, emb: torch.Tensor, save: bool = False) -> torch.Tensor:
+        """emb fp32 (B,E) or (B,W,E) -> prefix fp32 (B,L,D)."""
+        _require_cuda(self.arena.w32, "MapperEngine.forward")
+        d = self.dims
+        emb = emb.to(device=self.arena.device, dtype=torch.float32).contiguous()
+        B = emb.shape[0]
+        if emb.numel() != B * d["W"] * d["E"]:
+            raise ValueError(f"expected embeddings of shape ({B},{d['W']},{d['E']}), got {tuple(emb.shape)}")
+        self.arena.sync_bf16()
+        out = torch.empty(B, d["L"], d["D"], dtype=torch.float32, device=self.arena.device)
+        ws = self._workspace(B, int(save))
+        check(_lib.lib().cc_mapper_fwd(C.byref(self.cfg), B, _p(self.arena.w32), _p(self.arena.w16), _p(emb), _p(ws), _p(out), int(save),
+                                      _stream(self.arena.device)), "cc_mapper_fwd")
+        self._last = (B, emb)  # keep the input alive until backward has consumed the workspace
+        return out
+
+    def backward(self, dout: torch.Tensor):
+        """Accumulates d loss / d params into the gradient arena; needs a preceding forward(save=True)."""
+        B = dout.shape[0]
+        dout = dout.to(dtype=torch.float32).contiguous()
+        ws = self._ws.get((B, 1))
+        if ws is None:
+            raise RuntimeError("MapperEngine.backward without forward(save=True)")
+        check(_lib.lib().cc_mapper_bwd(C.byref(self.cfg), B, _p(self.arena.w32), _p(self.arena.w16), _p(ws), _p(dout), _p(self.arena.grads()),
+                                      _stream(self.arena.device)), "cc_mapper_bwd")
+
+
+class Gpt2Engine:
+    """HF GPT2LMHeadModel arithmetic (transformers modeling_gpt2.py) on the HIP library; arena keeps HF layouts."""
+
+    def __init__(self, n_embd: int, n_head: int, n_layer: int, vocab_size: int, n_positions: int, device="cpu"):
+        self.dims = dict(D=n_embd, H=n_head, NL=n_layer, V=vocab_size, Vp=(vocab_size + 127) // 128 * 128, NPOS=n_positions)
+        self.cfg = Gpt2Cfg(**self.dims)
+        l = _lib.lib()
+        n = l.cc_gpt2_param_count(C.byref(self.cfg))
+        if n < 0:
+            raise _lib.CCError(f"unsupported GPT-2 configuration {self.dims}")
+        self.arena = _Arena(n, device)
+        offs = (C.c_int64 * (2 + 12 * n_layer + 2))()
+        check(l.cc_gpt2_param_offsets(C.byref(self.cfg), offs))
+        self.offsets = list(offs)
+        self._ws: Dict[Tuple[int, int, int, int, int], torch.Tensor] = {}
+        self._dec_ws: Dict[Tuple[int, int], torch.Tensor] = {}
+
+    def shapes(self) -> List[Tuple[str, int, Tuple[int, ...]]]:
+        d = self.dims
+        D, NL, V, NPOS = d["D"], d["NL"], d["V"], d["NPOS"]
+        out = [("transformer.wte.weight", self.offsets[0], (V, D)), ("transformer.wpe.weight", self.offsets[1], (NPOS, D))]
+        shp = [(D,), (D,), (D, 3 * D), (3 * D,), (D, D), (D,), (D,), (D,), (D, 4 * D), (4 * D,), (4 * D, D), (D,)]
+        for i in range(NL):
+            for j, nm in enumerate(GPT2_LAYER_NAMES):
+                out.append((f"transformer.h.{i}.{nm}", self.offsets[2 + 12 * i + j], shp[j]))
+        out.append(("transformer.ln_f.weight", self.offsets[2 + 12 * NL], (D,)))
+        out.append(("transformer.ln_f.bias", self.offsets[3 + 12 * NL], (D,)))
+        return out
+
+    views = MapperEngine.views
+    to = MapperEngine.to
+
+    def shape(self, B: int, L: int, T: int, cap: int, mode: int) -> Gpt2Shape:
+        return Gpt2Shape(B, L, T, cap, mode)
+
+    def workspace(self, shp: Gpt2Shape) -> torch.Tensor:
+        key = (shp.B, shp.L, shp.T, shp.cap, shp.mode)
+        ws = self._ws.get(key)
+        if ws is None:
+            nbytes = _lib.lib().cc_gpt2_ws_bytes(C.byref(self.cfg), C.byref(shp))
+            check(nbytes, "cc_gpt2_ws_bytes")
+            # one live workspace per mode keeps memory bounded when batch shapes vary
+            for k in [k for k in self._ws if k[4] == shp.mode]:
+                del self._ws[k]
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.arena.device)
+            self._ws[key] = ws
+        return ws
+
+    # -- inference-style forward: logits for all rows (ClipCapModel.forward / language_model(inputs_embeds=...)) --
+    def logits(self, inputs_embeds: torch.Tensor) -> torch.Tensor:
+        """inputs_embeds fp32 (B,T,D) (no positional embedding) -> fp32 logits (B,T,V)."""
+        _require_cuda(self.arena.w32, "Gpt2Engine.logits")
+        l = _lib.lib()
+        x = inputs_embeds.to(device=self.arena.device, dtype=torch.float32).contiguous()
+        B, T, D = x.shape
+        shp = self.shape(B, T, T, 0, 0)
+        ws = self.workspace(shp)
+        self.arena.sync_bf16()
+        st = _stream(self.arena.device)
+        a = self.arena
+        check(l.cc_gpt2_embed_from(C.byref(self.cfg), C.byref(shp), _p(a.w32), _p(x), _p(ws), st), "cc_gpt2_embed_from")
+        check(l.cc_gpt2_fwd(C.byref(self.cfg), C.byref(shp), _p(a.w32), _p(a.w16), _p(ws), st), "cc_gpt2_fwd")
+        Vp = self.dims["Vp"]
+        out = torch.empty(B * T, Vp, dtype=torch.float32, device=a.device)
+        check(l.cc_gpt2_logits(C.byref(self.cfg), C.byref(shp), _p(a.w32), _p(a.w16), _p(ws), _p(out), Vp, st), "cc_gpt2_logits")
+        return out.view(B, T, Vp)[:, :, : self.dims["V"]]
+
+
+class ClipCapEngine:
+    """Training step of ClipCapModel (reference model.py:94-113) as straight-line forward + backward kernel chains."""
+
+    def __init__(self, mapper: MapperEngine, gpt2: Gpt2Engine, train_lm: bool):
+        self.mapper = mapper
+        self.gpt2 = gpt2
+        self.train_lm = train_lm
+        self.stats: Optional[torch.Tensor] = None
+
+    def forward_backward(self, tokens: torch.Tensor, embeds: torch.Tensor, reduce_stats=None, backward: bool = True) -> torch.Tensor:
+        """tokens int64 (B,cap) padded with -1; embeds fp32 (B,E)/(B,W,E).
+
+        Returns the mean loss over kept targets (device scalar).  Gradients are ACCUMULATED into the arenas' g32.
+        ``reduce_stats(stats)``: optional in-place all-reduce of the 2-float [loss_sum, kept_count] tensor, so the divisor is the
+        global kept-token count (N-rank == 1-rank gradients).
+        """
+        l = _lib.lib()
+        g, m = self.gpt2, self.mapper
+        dev = g.arena.device
+        _require_cuda(g.arena.w32, "ClipCapEngine.forward_backward")
+        tokens = tokens.to(device=dev, dtype=torch.int64).contiguous()
+        B, cap = tokens.shape
+        L = m.dims["L"]
+        T = L + cap
+        mode = 2 if self.train_lm else 1
+        shp = g.shape(B, L, T, cap, mode)
+        ws = g.workspace(shp)
+        g.arena.sync_bf16()
+        st = _stream(dev)
+        ga = g.arena
+        prefix = m.forward(embeds, save=True)
+        check(l.cc_gpt2_embed(C.byref(g.cfg), C.byref(shp), _p(ga.w32), _p(prefix), _p(tokens), _p(ws), st), "cc_gpt2_embed")
+        check(l.cc_gpt2_fwd(C.byref(g.cfg), C.byref(shp), _p(ga.w32), _p(ga.w16), _p(ws), st), "cc_gpt2_fwd")
+        if self.stats is None or self.stats.device != dev:
+            self.stats = torch.zeros(2, dtype=torch.float32, device=dev)
+        stats = self.stats
+        check(l.cc_lmhead_ce_fwd(C.byref(g.cfg), C.byref(shp), _p(ga.w32), _p(ga.w16), _p(ws), _p(tokens), _p(stats), st), "cc_lmhead_ce_fwd")
+        if reduce_stats is not None:
+            reduce_stats(stats)
+        if backward:
+            g32 = ga.grads() if self.train_lm else None
+            denom = stats[1:2]
+            check(l.cc_lmhead_ce_bwd(C.byref(g.cfg), C.byref(shp), _p(ga.w32), _p(ga.w16), _p(ws), _p(denom), _p(g32), st), "cc_lmhead_ce_bwd")
+            dprefix = torch.empty_like(prefix)
+            check(l.cc_gpt2_bwd(C.byref(g.cfg), C.byref(shp), _p(ga.w32), _p(ga.w16), _p(ws), _p(tokens), _p(dprefix), _p(g32), st), "cc_gpt2_bwd")
+            m.backward(dprefix)
+        return stats[0] / stats[1].clamp_min(1.0)
+
+    def zero_grad(self):
+        if self.mapper.arena.g32 is not None:
+            self.mapper.arena.g32.zero_()
+        if self.train_lm and self.gpt2.arena.g32 is not None:
+            self.gpt2.arena.g32.zero_()

@@ -1,0 +1,184 @@
+/* clipcap_hip.h — C ABI of libclipcap_hip.so: the MI355X (gfx950) ClipCap hot path.
+ *
+ * The reference (TheoCoombes/ClipCap) is 100 % Python and has NO plugin / FFI / operator interface for this path
+ * (SURVEY.md §8b): the effective boundary is the nn.Module surface of clipcap/model/{mapper,attention,model}.py and
+ * the HF GPT-2 it instantiates.  Each entry point below therefore cites the reference *Python call* it replaces;
+ * INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless it says "host".
+ *   - the caller owns every buffer (parameters, gradients, optimizer state, workspace, KV cache).  The library keeps
+ *     no global state and never allocates or synchronises; all work is enqueued on the caller's hipStream_t
+ *     (passed as void*; NULL = default stream).
+ *   - return value: 0 = ok, <0 = error (CC_ERR_*), never throws across the ABI.
+ *   - bf16 tensors are raw 16-bit patterns (uint16_t), round-to-nearest-even like torch.bfloat16.
+ *   - parameters live in flat arenas whose element offsets are defined by cc_*_param_offsets(); the fp32 arena is
+ *     the master copy (nn.Parameter views alias it), the bf16 arena is the GEMM operand copy refreshed by
+ *     cc_adamw_step / cc_cast_bf16.  Tensor layouts inside the arenas are exactly the reference state-dict layouts
+ *     (torch.nn.Linear weight [out,in]; HF Conv1D weight [in,out]).
+ */
+#ifndef CLIPCAP_HIP_H
+#define CLIPCAP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CC_OK 0
+#define CC_ERR_ARG (-1)
+#define CC_ERR_SHAPE (-2)
+#define CC_ERR_LAUNCH (-3)
+#define CC_ERR_STATE (-4)
+
+#define CC_ABI_VERSION 1
+int cc_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Mapper: clipcap/model/mapper.py:113-130 TransformerMapper (+ :133-160 windowed), layers :91-110, MLP :70-88,
+ * attention clipcap/model/attention.py:4-43.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t E;       /* encoder_embedding_size */
+    int32_t D;       /* lm_embedding_size */
+    int32_t P;       /* projection_length */
+    int32_t L;       /* prefix_length */
+    int32_t H;       /* num_heads */
+    int32_t N;       /* num_layers */
+    int32_t Hm;      /* MLP hidden = int(D * 2.0) (mapper.py:10,100) */
+    int32_t W;       /* window count (1 = TransformerMapper; window_size+1 for TransformerMapperWindowed, model.py:28) */
+    int32_t use_pos; /* windowed: learned pos_embeddings present (mapper.py:142-145) */
+} cc_mapper_cfg;
+
+/* number of per-model tensors ahead of the layers (linear.weight, linear.bias, prefix_const, pos_embeddings) */
+#define CC_MAPPER_HEAD_TENSORS 4
+/* per layer, in arena order: norm1.weight norm1.bias attn.to_queries.weight attn.to_keys_values.weight
+ * attn.project.weight attn.project.bias norm2.weight norm2.bias mlp.fc1.weight mlp.fc1.bias mlp.fc2.weight mlp.fc2.bias
+ * (to_queries.weight [D,D] is immediately followed by to_keys_values.weight [2D,D]: one fused [3D,D] QKV operand) */
+#define CC_MAPPER_LAYER_TENSORS 12
+
+int64_t cc_mapper_param_count(const cc_mapper_cfg* cfg);
+/* offsets[CC_MAPPER_HEAD_TENSORS + N*CC_MAPPER_LAYER_TENSORS] element offsets into the arenas (host array);
+ * pos_embeddings offset is -1 when absent. */
+int cc_mapper_param_offsets(const cc_mapper_cfg* cfg, int64_t* offsets);
+/* workspace bytes for batch B; save=1 keeps every layer's activations for cc_mapper_bwd */
+int64_t cc_mapper_ws_bytes(const cc_mapper_cfg* cfg, int32_t B, int32_t save);
+
+/* replaces model.transformer_mapper(embeddings) (mapper.py:122-130; callers model.py:46, inference/generate.py:31,
+ * docs/inference.md:24).  emb fp32 [B, W, E]; out fp32 [B, L, D]. */
+int cc_mapper_fwd(const cc_mapper_cfg* cfg, int32_t B, const float* w32, const uint16_t* w16, const float* emb, void* ws,
+                  float* out, int32_t save, void* stream);
+/* autograd of the above (what loss.backward() does to mapper.py in the reference).  dout fp32 [B, L, D];
+ * g32 (flat, same offsets as w32) is ACCUMULATED into.  Requires the workspace of a save=1 forward. */
+int cc_mapper_bwd(const cc_mapper_cfg* cfg, int32_t B, const float* w32, const uint16_t* w16, void* ws, const float* dout,
+                  float* g32, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * GPT-2: transformers GPT2LMHeadModel as called by model.py:56 / inference/base.py:81 with inputs_embeds
+ * (hf modeling_gpt2.py:514-634, blocks :262-310, attention :54-72,:144-226, MLP :229-243, lm_head :637-725).
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t D;     /* n_embd */
+    int32_t H;     /* n_head */
+    int32_t NL;    /* n_layer */
+    int32_t V;     /* vocab_size */
+    int32_t Vp;    /* vocab rows of the arenas' wte: V rounded up to a multiple of 128 (zero rows) */
+    int32_t NPOS;  /* n_positions */
+} cc_gpt2_cfg;
+
+#define CC_GPT2_HEAD_TENSORS 2   /* wte [Vp,D], wpe [NPOS,D] */
+/* per layer: ln_1.weight ln_1.bias attn.c_attn.weight[D,3D] attn.c_attn.bias attn.c_proj.weight[D,D] attn.c_proj.bias
+ * ln_2.weight ln_2.bias mlp.c_fc.weight[D,4D] mlp.c_fc.bias mlp.c_proj.weight[4D,D] mlp.c_proj.bias */
+#define CC_GPT2_LAYER_TENSORS 12
+#define CC_GPT2_TAIL_TENSORS 2   /* ln_f.weight ln_f.bias */
+
+/* one training / scoring pass: every GPT-2 entry point of a pass must be given the SAME shape (it fixes the
+ * workspace layout).  T = L + cap_used (cap_used <= cap columns of `tokens` are consumed: T - L). */
+typedef struct {
+    int32_t B;     /* samples */
+    int32_t L;     /* prefix rows per sample */
+    int32_t T;     /* total rows per sample (prefix + caption tokens) */
+    int32_t cap;   /* row stride of `tokens` (int64 [B, cap]); the loss uses T-L = cap columns */
+    int32_t mode;  /* 0 inference (no activations kept); 1 training, frozen LM (dgrad only); 2 full finetune (+wgrad) */
+} cc_gpt2_shape;
+
+int64_t cc_gpt2_param_count(const cc_gpt2_cfg* cfg);
+int cc_gpt2_param_offsets(const cc_gpt2_cfg* cfg, int64_t* offsets);
+int64_t cc_gpt2_ws_bytes(const cc_gpt2_cfg* cfg, const cc_gpt2_shape* shp);
+
+/* x0[b,t,:] = (t<L ? prefix[b,t,:] : wte[max(tok[b,t-L],0),:]) + wpe[t,:]  — model.py:45-49 + hf :571-577.
+ * prefix fp32 [B,L,D]; tokens int64 [B, cap] (may be NULL when L == T).  Writes the workspace's layer-0 input. */
+int cc_gpt2_embed(const cc_gpt2_cfg* cfg, const cc_gpt2_shape* shp, const float* w32, const float* prefix, const int64_t* tokens,
+                  void* ws, void* stream);
+/* same, but from a caller-provided inputs_embeds fp32 [B,T,D] (the `language_model(inputs_embeds=...)` call of
+ * inference/base.py:81): x0 = inputs_embeds + wpe[arange(T)] */
+int cc_gpt2_embed_from(const cc_gpt2_cfg* cfg, const cc_gpt2_shape* shp, const float* w32, const float* inputs_embeds, void* ws,
+                       void* stream);
+/* transformer body (all blocks; ln_f is applied by the lm_head entry points). */
+int cc_gpt2_fwd(const cc_gpt2_cfg* cfg, const cc_gpt2_shape* shp, const float* w32, const uint16_t* w16, void* ws, void* stream);
+/* ln_f + tied lm_head on ALL rows -> fp32 logits [B*T, ldl] (what `.logits` holds; hf :703); ldl >= roundup(V,8). */
+int cc_gpt2_logits(const cc_gpt2_cfg* cfg, const cc_gpt2_shape* shp, const float* w32, const uint16_t* w16, void* ws, float* logits,
+                   int64_t ldl, void* stream);
+
+/* training loss of model.py:94-113 on rows L-1..T-2: fused ln_f + lm_head + softmax cross-entropy (ignore_index=0,
+ * pads(-1)->0).  stats (2 device floats, zeroed by this call): [0] sum of kept-row losses, [1] number of kept rows. */
+int cc_lmhead_ce_fwd(const cc_gpt2_cfg* cfg, const cc_gpt2_shape* shp, const float* w32, const uint16_t* w16, void* ws,
+                     const int64_t* tokens, float* stats, void* stream);
+/* backward of the above through lm_head and ln_f into the residual-stream gradient kept in the workspace.
+ * denom (device float[1]) = divisor of the mean (local or all-reduced kept-row count).  g32 may be NULL unless mode 2. */
+int cc_lmhead_ce_bwd(const cc_gpt2_cfg* cfg, const cc_gpt2_shape* shp, const float* w32, const uint16_t* w16, void* ws,
+                     const float* denom, float* g32, void* stream);
+/* backward through the blocks.  dprefix fp32 [B, L, D] receives d loss / d prefix (rows 0..L-1 of d x0).
+ * mode 2 additionally accumulates all GPT-2 weight gradients (incl. wte/wpe) into g32. */
+int cc_gpt2_bwd(const cc_gpt2_cfg* cfg, const cc_gpt2_shape* shp, const float* w32, const uint16_t* w16, void* ws,
+                const int64_t* tokens, float* dprefix, float* g32, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * KV-cached decode (replaces the full re-forward of inference/base.py:81 per step).
+ * kv cache: bf16 [NL][2][R][ctx_max][D] owned by the caller (R rows = beams * samples).
+ * ------------------------------------------------------------------------------------------------------------ */
+int64_t cc_decode_ws_bytes(const cc_gpt2_cfg* cfg, int32_t R, int32_t Tnew);
+/* processes Tnew new positions per row (prefill: Tnew = prefix length; step: Tnew = 1) starting at position pos0,
+ * appends K/V to the cache and returns fp32 logits of the LAST new position [R, ldl]. x fp32 [R,Tnew,D] WITHOUT wpe. */
+int cc_decode_fwd(const cc_gpt2_cfg* cfg, int32_t R, int32_t Tnew, int32_t pos0, int32_t ctx_max, const float* w32,
+                  const uint16_t* w16, const float* x, uint16_t* kv, void* ws, float* logits, int64_t ldl, void* stream);
+/* reorder / expand cache rows after a beam step: kv_dst[:, :, r] = kv_src[:, :, src[r]] for positions < ctx and
+ * r < R_dst (base.py:93,113: embeds.expand / embeds[next_tokens_source]); the two caches may have different row counts. */
+int cc_decode_reorder(const cc_gpt2_cfg* cfg, int32_t R_src, int32_t R_dst, int32_t ctx, int32_t ctx_max, const uint16_t* kv_src,
+                      uint16_t* kv_dst, const int32_t* src, void* stream);
+/* one beam-search update for S independent samples of `beam` rows each (base.py:84-119): log-softmax of logits/T,
+ * stopped rows -> -inf except col 0 -> 0, length-normalised top-`beam` over beam*V, outputs next token / source row /
+ * updated scores, seq_lengths, has_stopped.  first!=0: step 0 (top-beam of the single row, base.py:86-94). */
+int cc_beam_step(int32_t S, int32_t beam, int32_t V, const float* logits, int64_t ldl, float temperature, int32_t first,
+                 int32_t stop_token, float* scores, float* seq_lengths, uint8_t* has_stopped, int32_t* next_tokens,
+                 int32_t* src_rows, void* ws, void* stream);
+int64_t cc_beam_ws_bytes(int32_t S, int32_t beam, int32_t V);
+/* gathers wte rows for next tokens: out fp32 [R, D] (base.py:117) */
+int cc_embed_tokens(const cc_gpt2_cfg* cfg, int32_t R, const float* w32, const int32_t* tokens, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Optimizer / casts: torch.optim.AdamW as configured by model.py:73-77 (lr schedule is computed by the caller,
+ * model.py:79-83).  Flat over one arena; refreshes the bf16 operand copy (p16 may be NULL).
+ * ------------------------------------------------------------------------------------------------------------ */
+int cc_adamw_step(float* p32, const float* g32, float* m, float* v, uint16_t* p16, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int32_t step, float grad_scale, void* stream);
+int cc_cast_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Unit-test hook: one bf16 MFMA GEMM C = A·B (+bias) with fp32 output, any of the three operand layouts
+ * (al/bl: 0 = [rows][K], 1 = [K][rows]); ksplit>1 accumulates atomically into C (caller zeroes C).
+ * ------------------------------------------------------------------------------------------------------------ */
+int cc_gemm_bf16_f32(int32_t al, int32_t bl, const uint16_t* A, int32_t lda, const uint16_t* B, int32_t ldb, int32_t M, int32_t N,
+                     int32_t K, float* C, int32_t ldc, const float* bias, int32_t ksplit, void* stream);
+int cc_layernorm_fwd(const float* x, const float* gamma, const float* beta, uint16_t* y, float* mean, float* rstd, int32_t rows,
+                     int32_t D, void* stream);
+int cc_attention_fwd(const uint16_t* qkv, int32_t B, int32_t S, int32_t H, int32_t hd, int32_t causal, uint16_t* out, float* lse,
+                     void* stream);
+int cc_attention_bwd(const uint16_t* qkv, const uint16_t* dout, const float* lse, int32_t B, int32_t S, int32_t H, int32_t hd,
+                     int32_t causal, uint16_t* dqkv, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLIPCAP_HIP_H */

@@ -129,7 +129,7 @@ def main():
     # ---------------- (3) training_step + 3 AdamW/scheduler steps ----------------
     tmp = tempfile.mkdtemp()
     torch.manual_seed(104)
-    gcfg = GPT2Config(n_embd=48, n_layer=2, n_head=4, vocab_size=157, n_positions=40,
+    gcfg = GPT2Config(n_embd=64, n_layer=2, n_head=4, vocab_size=157, n_positions=40,
                       resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0)
     lm0 = GPT2LMHeadModel(gcfg)
     with torch.no_grad():
@@ -155,7 +155,7 @@ def main():
         tokens[1, 2] = 0          # explicit token id 0 (ignored by the loss as a side effect, model.py:109)
         embeds = torch.randn(Bt, 24)
         d = {"in.tokens": tokens.numpy().copy(), "in.embeds": embeds.numpy(),
-             "cfg": np.array([24, 48, 2, 3, 4, 2, 4, 2, 157, 40])}  # E D P L H N n_head n_layer V n_pos
+             "cfg": np.array([24, 64, 2, 3, 4, 2, 4, 2, 157, 40])}  # E D P L H N n_head n_layer V n_pos
         for k, v in model.state_dict().items():
             d["sd." + k] = v.numpy().copy()
         oc = model.configure_optimizers()

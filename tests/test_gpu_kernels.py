@@ -1,0 +1,138 @@
+"""GPU parity of the individual HIP kernels, called through the C ABI (ctypes), against torch fp32 math on the SAME
+bf16-rounded inputs.  Asymmetric random operands everywhere (a transposed result cannot pass)."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from clipcap_amd import _lib
+    return _lib.lib()
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("al,bl", [(0, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 192), (264, 72, 520), (8, 8, 8), (1000, 384, 1024)])
+def test_gemm_layouts(al, bl, M, N, K):
+    torch.manual_seed(M * 7 + N * 3 + K + al * 2 + bl)
+    dev = "cuda"
+    A = _bf(torch.randn(M, K, device=dev))
+    B = _bf(torch.randn(K, N, device=dev) * 0.5 + 0.1)
+    bias = torch.randn(N, device=dev)
+    ref = A.float() @ B.float() + bias
+    Ast = A.t().contiguous() if al else A.contiguous()            # al=1: stored [K][M]
+    Bst = B.contiguous() if bl else B.t().contiguous()            # bl=0: stored [N][K]
+    Cm = torch.full((M, N + 8), float("nan"), device=dev)
+    rc = _lib().cc_gemm_bf16_f32(al, bl, _p(Ast), Ast.shape[1], _p(Bst), Bst.shape[1], M, N, K, _p(Cm), N + 8, _p(bias), 1, _st())
+    assert rc == 0
+    torch.cuda.synchronize()
+    err = (Cm[:, :N] - ref).abs().max().item()
+    assert err <= 2e-3 * max(1.0, ref.abs().max().item() / 10), err
+    assert torch.isnan(Cm[:, N:]).all()   # nothing written outside the N columns
+
+
+@pytest.mark.parametrize("ksplit", [2, 5, 16])
+def test_gemm_wgrad_split_k_atomic(ksplit):
+    torch.manual_seed(ksplit)
+    dev = "cuda"
+    Kk, Mw, Nw = 1237, 192, 264      # K (rows of the activations) is free: not a multiple of anything
+    X = _bf(torch.randn(Kk, Mw, device=dev))
+    Y = _bf(torch.randn(Kk, Nw, device=dev))
+    ref = X.float().t() @ Y.float()
+    Cm = torch.zeros(Mw, Nw, device=dev)
+    rc = _lib().cc_gemm_bf16_f32(1, 1, _p(X), Mw, _p(Y), Nw, Mw, Nw, Kk, _p(Cm), Nw, None, ksplit, _st())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert (Cm - ref).abs().max().item() <= 5e-3
+
+
+def test_gemm_rejects_misaligned():
+    dev = "cuda"
+    A = _bf(torch.randn(16, 20, device=dev))
+    B = _bf(torch.randn(16, 20, device=dev))
+    Cm = torch.zeros(16, 16, device=dev)
+    assert _lib().cc_gemm_bf16_f32(0, 0, _p(A), 20, _p(B), 20, 16, 16, 20, _p(Cm), 16, None, 1, _st()) == -2
+
+
+@pytest.mark.parametrize("rows,D", [(7, 64), (130, 768), (33, 1024), (5, 1600)])
+def test_layernorm_fwd(rows, D):
+    torch.manual_seed(rows + D)
+    x = torch.randn(rows, D, device="cuda") * 2 + 0.3
+    g = torch.randn(D, device="cuda")
+    b = torch.randn(D, device="cuda")
+    y = torch.empty(rows, D, dtype=torch.bfloat16, device="cuda")
+    mean = torch.empty(rows, device="cuda")
+    rstd = torch.empty(rows, device="cuda")
+    assert _lib().cc_layernorm_fwd(_p(x), _p(g), _p(b), _p(y), _p(mean), _p(rstd), rows, D, _st()) == 0
+    ref = torch.nn.functional.layer_norm(x, (D,), g, b, 1e-5)
+    torch.cuda.synchronize()
+    assert (mean - x.mean(1)).abs().max() <= 1e-5
+    assert (y.float() - ref).abs().max().item() <= 2 ** -7 * ref.abs().max().item() + 1e-3
+
+
+def _attn_ref(qkv, B, S, H, hd, causal):
+    D = H * hd
+    q, k, v = qkv.float().view(B, S, 3, H, hd).unbind(2)
+    att = torch.einsum("bnhd,bmhd->bhnm", q, k) * hd ** -0.5
+    if causal:
+        att = att.masked_fill(torch.triu(torch.ones(S, S, dtype=torch.bool, device=qkv.device), 1), float("-inf"))
+    lse = torch.logsumexp(att, -1)
+    p = att.softmax(-1)
+    out = torch.einsum("bhnm,bmhd->bnhd", p, v).reshape(B, S, D)
+    return out, lse
+
+
+@pytest.mark.parametrize("B,S,H,hd,causal", [(3, 20, 8, 96, 0), (2, 50, 12, 64, 1), (2, 74, 4, 64, 1), (1, 7, 2, 8, 0), (2, 33, 2, 128, 1)])
+def test_attention_fwd_bwd(B, S, H, hd, causal):
+    torch.manual_seed(S * 3 + hd)
+    D = H * hd
+    qkv = _bf(torch.randn(B * S, 3 * D, device="cuda"))
+    out = torch.empty(B * S, D, dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(B, H, S, device="cuda")
+    assert _lib().cc_attention_fwd(_p(qkv), B, S, H, hd, causal, _p(out), _p(lse), _st()) == 0
+    qkv_r = qkv.float().requires_grad_(True)
+    ref, lse_ref = _attn_ref(qkv_r, B, S, H, hd, causal)
+    torch.cuda.synchronize()
+    assert (lse - lse_ref).abs().max().item() <= 1e-4
+    assert (out.float().view(B, S, D) - ref).abs().max().item() <= 2e-2
+    dout = _bf(torch.randn(B * S, D, device="cuda"))
+    dqkv = torch.empty_like(qkv)
+    assert _lib().cc_attention_bwd(_p(qkv), _p(dout), _p(lse), B, S, H, hd, causal, _p(dqkv), _st()) == 0
+    ref.backward(dout.float().view(B, S, D))
+    torch.cuda.synchronize()
+    g = qkv_r.grad
+    err = (dqkv.float() - g).abs().max().item()
+    assert err <= 2e-2 * max(1.0, g.abs().max().item()), err
+
+
+def test_adamw_matches_torch():
+    torch.manual_seed(0)
+    n = 4096 + 64
+    p = torch.randn(n, device="cuda")
+    ref_p = torch.nn.Parameter(p.clone())
+    opt = torch.optim.AdamW([ref_p], lr=3e-3)
+    m = torch.zeros(n, device="cuda")
+    v = torch.zeros(n, device="cuda")
+    p16 = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+    for step in range(1, 4):
+        g = torch.randn(n, device="cuda")
+        ref_p.grad = g.clone()
+        opt.step()
+        assert _lib().cc_adamw_step(_p(p), _p(g), _p(m), _p(v), _p(p16), n, 3e-3, 0.9, 0.999, 1e-8, 0.01, step, 1.0, _st()) == 0
+    torch.cuda.synchronize()
+    assert (p - ref_p.detach()).abs().max().item() <= 2e-6
+    assert torch.equal(p16, p.to(torch.bfloat16))
