@@ -98,8 +98,11 @@ def test_mapper_config2_shape_one_layer_pair():
     e1 = (out.cpu() - ref).abs().max().item()
     e2 = (out.cpu() - ref32).abs().max().item()
     print(f"config-2 mapper (2 layers): vs oracle(bf16 points) {e1:.3e}; vs fp32 oracle {e2:.3e}; |out|max {ref32.abs().max():.2f}")
-    assert e1 <= 3e-3
-    assert e2 <= 5e-2
+    scale = ref32.abs().max().item()
+    # O(1) weights make |out| ~ 6.6: a bf16 ulp there is 3e-2, so rounding-boundary flips of intermediate activations
+    # dominate; bound the error relative to the output range instead of absolutely.
+    assert e1 <= 3e-3 * scale
+    assert e2 <= 1e-2 * scale
 
 
 def _gpt2_engine(sd, D, n_layer, n_head, V, npos):
