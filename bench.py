@@ -1,0 +1,242 @@
+#!/usr/bin/env python
+"""bench.py — ClipCap training-step throughput on MI355X (BASELINE.json metric: train samples/sec, 512-d prefix input,
+40-token captions), one process per GPU, weak scaling (per-GPU batch fixed).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = one pass of the hot path over one batch of synthetic (embedding, caption) pairs already resident in HBM:
+mapper forward -> [prefix ; tokens] -> GPT-2 forward -> fused lm_head + cross-entropy -> backward through GPT-2 (dgrad;
++wgrad when --config 3) -> mapper backward -> (N>1: RCCL all-reduce of the gradient arena) -> fused AdamW + LR schedule.
+Nothing is skipped inside the timed region.  Rank 0 prints ONE JSON line (see DESIGN.md §Measurement for every field).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # BASELINE.json configs[1]: TransformerMapper (8 layers, prefix_len=10) + frozen GPT-2-small, bf16, batch 256
+    "2": dict(name="TransformerMapper(8L,P=L=10,H=8)+frozen GPT-2-small", E=512, P=10, L=10, H=8, N=8, D=768, n_head=12, n_layer=12,
+              V=50257, npos=1024, B=256, cap=40, train_lm=False),
+    # configs[2]: same mapper, GPT-2-small unfrozen
+    "3": dict(name="TransformerMapper(8L)+GPT-2-small full finetune", E=512, P=10, L=10, H=8, N=8, D=768, n_head=12, n_layer=12, V=50257,
+              npos=1024, B=256, cap=40, train_lm=True),
+    # configs[3]: CLAP 1024-d -> GPT-2-medium
+    "4": dict(name="TransformerMapper(8L,E=1024)+GPT-2-medium full finetune", E=1024, P=10, L=10, H=8, N=8, D=1024, n_head=16, n_layer=24,
+              V=50257, npos=1024, B=128, cap=40, train_lm=True),
+    # configs[0]-like small case (what the CPU baseline runs): B=16
+    "1": dict(name="TransformerMapper(8L)+frozen GPT-2-small, B=16", E=512, P=10, L=10, H=8, N=8, D=768, n_head=12, n_layer=12, V=50257,
+              npos=1024, B=16, cap=40, train_lm=False),
+}
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def mapper_flops_fwd(c):   # 2*E*P*D + N*[S*2*D*(D+2D+D+rD+rD) + 4*S^2*D], r=2
+    S = c["P"] + c["L"]
+    D = c["D"]
+    return 2 * c["E"] * c["P"] * D + c["N"] * (S * 2 * D * (D + 2 * D + D + 2 * D + 2 * D) + 4 * S * S * D)
+
+
+def gpt2_flops_fwd(c):     # n_layer*[T*24*D^2 + 4*T^2*D] + 2*D*V*T
+    T = c["L"] + c["cap"]
+    D = c["D"]
+    return c["n_layer"] * (T * 24 * D * D + 4 * T * T * D) + 2 * D * c["V"] * T
+
+
+def step_flops(c):         # frozen: 3*mapper + 2*LM ; full: 3*(mapper+LM)   (per sample)
+    m, g = mapper_flops_fwd(c), gpt2_flops_fwd(c)
+    return 3 * m + (3 if c["train_lm"] else 2) * g
+
+
+def init_engines(c, device, seed=1234):
+    from clipcap_amd.engine import ClipCapEngine, Gpt2Engine, MapperEngine
+    gen = torch.Generator(device=device).manual_seed(seed)
+    me = MapperEngine(c["E"], c["D"], c["L"], c["P"], c["H"], c["N"], device=device)
+    ge = Gpt2Engine(c["D"], c["n_head"], c["n_layer"], c["V"], c["npos"], device=device)
+    for k, v in me.views(me.arena.w32).items():   # torch default init of the reference modules (mapper.py:118-120)
+        if "norm" in k:
+            v.fill_(1.0 if k.endswith("weight") else 0.0)
+        elif k == "prefix_const":
+            v.copy_(torch.randn(v.shape, generator=gen, device=device))
+        else:
+            fan_in = v.shape[-1] if v.dim() == 2 else {"linear.bias": c["E"]}.get(k, c["D"])
+            bound = 1.0 / fan_in ** 0.5
+            v.copy_((torch.rand(v.shape, generator=gen, device=device) * 2 - 1) * bound)
+    for k, v in ge.views(ge.arena.w32).items():   # GPT2Config init: N(0, 0.02), LN = identity, biases 0
+        if "ln_" in k:
+            v.fill_(1.0 if k.endswith("weight") else 0.0)
+        elif k.endswith(".bias"):
+            v.zero_()
+        else:
+            v.copy_(torch.randn(v.shape, generator=gen, device=device) * 0.02)
+    return me, ge, ClipCapEngine(me, ge, c["train_lm"])
+
+
+def cpu_baseline(c, max_seconds=25.0):
+    """The CPU oracle (oracle/clipcap_oracle.py, fp32 torch-CPU restatement pinned to the reference's golden outputs) timed on
+    this box's host cores on a bounded sample of the same workload: the same model, batch 8 instead of 256."""
+    from oracle import clipcap_oracle as O
+    torch.manual_seed(0)
+    Bc = 8
+    me, ge, _ = None, None, None
+    from clipcap_amd.engine import Gpt2Engine, MapperEngine
+    me = MapperEngine(c["E"], c["D"], c["L"], c["P"], c["H"], c["N"], device="cpu")
+    ge = Gpt2Engine(c["D"], c["n_head"], c["n_layer"], c["V"], c["npos"], device="cpu")
+    sd = {}
+    for pre, eng in (("transformer_mapper.", me), ("language_model.", ge)):
+        for k, v in eng.views(eng.arena.w32).items():
+            if "norm" in k or "ln_" in k:
+                v.fill_(1.0 if k.endswith("weight") else 0.0)
+            else:
+                v.normal_(0, 0.02)
+            sd[pre + k] = v
+    train = [k for k in sd if k.startswith("transformer_mapper.") or c["train_lm"]]
+    for k in train:
+        sd[k].requires_grad_(True)
+    tokens = torch.randint(1, c["V"], (Bc, c["cap"]))
+    embeds = torch.randn(Bc, c["E"])
+    cfg = dict(projection_length=c["P"], prefix_length=c["L"], heads=c["H"], layers=c["N"], n_head=c["n_head"], n_layer=c["n_layer"])
+    m = {k: torch.zeros_like(sd[k]) for k in train}
+    v = {k: torch.zeros_like(sd[k]) for k in train}
+    times = []
+    t_begin = time.time()
+    step = 0
+    while True:
+        t0 = time.time()
+        for k in train:
+            sd[k].grad = None
+        loss = O.clipcap_loss(sd, tokens, embeds, cfg=cfg)
+        loss.backward()
+        with torch.no_grad():
+            for k in train:
+                pn, m[k], v[k] = O.adamw_step(sd[k], sd[k].grad, m[k], v[k], step + 1, 2e-5)
+                sd[k].copy_(pn)
+        times.append(time.time() - t0)
+        step += 1
+        if step >= 4 or time.time() - t_begin > max_seconds:
+            break
+    steady = sorted(times[1:] or times)[len(times[1:] or times) // 2]
+    return {"value": Bc / steady, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle fp32 torch-CPU training step (fwd+bwd+AdamW), same model, batch {Bc}, {len(times)} steps, median of steady steps"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="2", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
+    ap.add_argument("--site", default="lmhead_fwd", help="GEMM call site timed for the roofline object")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)   # "nccl" is RCCL on ROCm
+    c = dict(CONFIGS[args.config])
+    if args.batch:
+        c["B"] = args.batch
+    B, cap = c["B"], c["cap"]
+
+    from clipcap_amd import _lib
+    from clipcap_amd.train.ddp import GradReducer
+    from oracle.clipcap_oracle import linear_schedule_factor  # schedule arithmetic only (host scalar)
+    me, ge, eng = init_engines(c, device)
+    gen = torch.Generator(device=device).manual_seed(1234 + rank)
+    embeds = torch.randn(B, c["E"], generator=gen, device=device)
+    tokens = torch.randint(1, c["V"], (B, cap), generator=gen, device=device)
+    arenas = [me.arena] + ([ge.arena] if c["train_lm"] else [])
+    reducer = GradReducer([a.grads() for a in arenas]) if world > 1 else None
+    total_steps = args.steps + args.warmup
+    base_lr, warm = 2e-5, 2
+
+    def one_step(i):
+        eng.zero_grad()
+        loss = eng.forward_backward(tokens, embeds, reduce_stats=(reducer.reduce_stats if reducer else None))
+        if reducer:
+            reducer.all_reduce()
+        lr = base_lr * linear_schedule_factor(i, warm, total_steps + 1)
+        for a in arenas:
+            a.adamw_step(lr, i + 1)
+        return loss
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        loss = one_step(i)
+    sync()
+    lib = _lib.lib()
+    site_id = _lib.SITES[args.site]
+    per_step = {"lmhead_fwd": 1, "lmhead_dgrad": 1, "gpt2_fc_fwd": c["n_layer"], "gpt2_proj2_fwd": c["n_layer"], "gpt2_fc_dgrad": c["n_layer"],
+                "mapper_fc1_fwd": c["N"], "mapper_qkv_fwd": c["N"], "mapper_wgrad_fc2": c["N"]}[args.site]
+    if rank == 0:
+        lib.cc_prof_start(site_id, per_step * args.steps)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        loss = one_step(i)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+    n = C.c_int32(per_step * args.steps)
+    ms = (C.c_float * n.value)()
+    lib.cc_prof_stop(ms, C.byref(n))
+    avg_ms = sum(ms[i] for i in range(n.value)) / max(1, n.value)
+    T, D, Mc, M = c["L"] + cap, c["D"], B * cap, B * (c["L"] + cap)
+    S = c["P"] + c["L"]
+    site_flops = {"lmhead_fwd": 2.0 * Mc * c["V"] * D, "lmhead_dgrad": 2.0 * Mc * c["V"] * D, "gpt2_fc_fwd": 2.0 * M * D * 4 * D,
+                  "gpt2_proj2_fwd": 2.0 * M * D * 4 * D, "gpt2_fc_dgrad": 2.0 * M * D * 4 * D, "mapper_fc1_fwd": 2.0 * B * S * D * 2 * D,
+                  "mapper_qkv_fwd": 2.0 * B * S * D * 3 * D, "mapper_wgrad_fc2": 2.0 * B * S * D * 2 * D}[args.site]
+    ach = site_flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    value = B * world * args.steps / dt
+    step_tflops = step_flops(c) * B * world * args.steps / dt / 1e12
+    out = {
+        "metric": "train samples/sec (512-d prefix, 40-tok caption)", "value": round(value, 2), "unit": "samples/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[{int(args.config) - 1}]: {c['name']}", "per_gpu_batch": B, "global_batch": B * world,
+                   "caption_tokens": cap, "encoder_dim": c["E"], "train_language_model": c["train_lm"],
+                   "parallelism": f"dp{world}", "final_loss": round(float(loss.item()), 4)},
+        "step_algorithmic_tflops": round(step_tflops, 1),
+        "step_frac_of_bf16_peak": round(step_tflops / (PEAK_BF16_TFLOPS * world), 4),
+        "roofline": {"bound": "mfma", "kernel": f"gemm_bf16_kernel @ {args.site}", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "avg_launch_ms": round(avg_ms, 4), "launches": n.value,
+                     "traffic": None},
+    }
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(c)
+    print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

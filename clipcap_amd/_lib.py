@@ -68,7 +68,12 @@ SIGNATURES = {
     "cc_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "cc_attention_fwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "cc_attention_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "cc_prof_start": (_I, [_I, _I]),
+    "cc_prof_stop": (_I, [C.POINTER(C.c_float), C.POINTER(_I)]),
 }
+
+SITES = {"lmhead_fwd": 1, "lmhead_dgrad": 2, "gpt2_fc_fwd": 3, "gpt2_proj2_fwd": 4, "gpt2_fc_dgrad": 5, "mapper_fc1_fwd": 6,
+         "mapper_qkv_fwd": 7, "mapper_wgrad_fc2": 8}
 
 _lib = None
 _lock = threading.Lock()

@@ -13,9 +13,39 @@ using namespace cc;
         if (_e != CC_OK) return _e;  \
     } while (0)
 
+#include <vector>
+
 namespace {
 
 constexpr int MAX_LAYERS = 96;
+
+// ---- optional per-call-site timing (cc_prof_start / cc_prof_stop) ----
+struct Prof {
+    int site = 0;
+    int cap = 0;
+    std::vector<hipEvent_t> ev;  // 2 per sample
+    int n = 0;
+} g_prof;
+
+struct ProfScope {
+    hipStream_t st;
+    bool on;
+    ProfScope(int site, hipStream_t s) : st(s), on(g_prof.site == site && g_prof.n < g_prof.cap) {
+        if (on) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], st);
+    }
+    ~ProfScope() {
+        if (on) {
+            (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st);
+            g_prof.n++;
+        }
+    }
+};
+#define CC_TIMED(site, st, expr)  \
+    do {                          \
+        ProfScope _ps(site, st);  \
+        int _e = (expr);          \
+        if (_e != CC_OK) return _e; \
+    } while (0)
 
 struct Carver {
     char* base;
@@ -247,6 +277,36 @@ extern "C" {
 
 int cc_abi_version(void) { return CC_ABI_VERSION; }
 
+int cc_prof_start(int32_t site, int32_t max_samples) {
+    if (site < 0 || max_samples < 0 || max_samples > (1 << 16)) return CC_ERR_ARG;
+    for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
+    g_prof.ev.clear();
+    g_prof.n = 0;
+    g_prof.cap = max_samples;
+    g_prof.site = site;
+    for (int i = 0; i < 2 * max_samples; i++) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return CC_ERR_LAUNCH;
+        g_prof.ev.push_back(e);
+    }
+    return CC_OK;
+}
+
+int cc_prof_stop(float* ms_host, int32_t* n_host) {
+    if (!ms_host || !n_host) return CC_ERR_ARG;
+    const int n = std::min(g_prof.n, (int)*n_host);
+    for (int i = 0; i < n; i++) {
+        if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) return CC_ERR_LAUNCH;
+        if (hipEventElapsedTime(&ms_host[i], g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) return CC_ERR_LAUNCH;
+    }
+    *n_host = n;
+    g_prof.site = 0;
+    for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
+    g_prof.ev.clear();
+    g_prof.n = g_prof.cap = 0;
+    return CC_OK;
+}
+
 // ---------------------------------------------------------------- mapper ----------------------------------------
 int64_t cc_mapper_param_count(const cc_mapper_cfg* cfg) {
     if (!mapper_cfg_ok(cfg)) return CC_ERR_SHAPE;
@@ -301,12 +361,12 @@ int cc_mapper_fwd(const cc_mapper_cfg* c, int32_t B, const float* w32, const uin
         const auto& y = o.layer[l];
         // x1 = x + project(attn(LN1 x))  (mapper.py:108, attention.py:17-43)
         CC_TRY(ln_fwd(w.x[l], D, nullptr, w32 + y.n1w, w32 + y.n1b, w.xn1[l], nullptr, w.mean1[l], w.rstd1[l], M, D, st));
-        CC_TRY(gemm_bf16out(0, 0, w.xn1[l], D, w16 + y.wq, D, M, 3 * D, D, w.qkv[l], 3 * D, nullptr, 0, nullptr, st));
+        CC_TIMED(CC_SITE_MAPPER_QKV_FWD, st, gemm_bf16out(0, 0, w.xn1[l], D, w16 + y.wq, D, M, 3 * D, D, w.qkv[l], 3 * D, nullptr, 0, nullptr, st));
         CC_TRY(attn_fwd(w.qkv[l], B, S, H, hd, false, w.att[l], w.lse[l], st));
         CC_TRY(gemm_resid(0, 0, w.att[l], D, w16 + y.wp, D, M, D, D, w.x1[l], w.x[l], D, w32 + y.bp, st));
         // x = x1 + fc2(relu(fc1(LN2 x1)))  (mapper.py:109, :82-88)
         CC_TRY(ln_fwd(w.x1[l], D, nullptr, w32 + y.n2w, w32 + y.n2b, w.xn2[l], nullptr, w.mean2[l], w.rstd2[l], M, D, st));
-        CC_TRY(gemm_bf16out(0, 0, w.xn2[l], D, w16 + y.w1, D, M, Hm, D, w.h[l], Hm, w32 + y.b1, 1, nullptr, st));
+        CC_TIMED(CC_SITE_MAPPER_FC1_FWD, st, gemm_bf16out(0, 0, w.xn2[l], D, w16 + y.w1, D, M, Hm, D, w.h[l], Hm, w32 + y.b1, 1, nullptr, st));
         CC_TRY(gemm_resid(0, 0, w.h[l], Hm, w16 + y.w2, Hm, M, D, Hm, w.x[l + 1], w.x1[l], D, w32 + y.b2, st));
     }
     // out = rows [PP:] (mapper.py:128)
@@ -331,7 +391,7 @@ int cc_mapper_bwd(const cc_mapper_cfg* c, int32_t B, const float* w32, const uin
     for (int l = c->N - 1; l >= 0; l--) {
         const auto& y = o.layer[l];
         // fc2: y = h W2^T + b2
-        CC_TRY(gemm_wgrad(w.dx16, D, w.h[l], Hm, D, Hm, M, g32 + y.w2, Hm, st));
+        CC_TIMED(CC_SITE_MAPPER_WGRAD_FC2, st, gemm_wgrad(w.dx16, D, w.h[l], Hm, D, Hm, M, g32 + y.w2, Hm, st));
         CC_TRY(colsum_bf16(w.dx16, D, M, D, g32 + y.b2, st));
         CC_TRY(gemm_dact(0, 1, w.dx16, D, w16 + y.w2, Hm, M, Hm, D, w.dh16, Hm, w.h[l], 1, st));
         // fc1
@@ -434,9 +494,9 @@ int cc_gpt2_fwd(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, 
         CC_TRY(gemm_resid(0, 1, w.att[l], D, w16 + y.pw, D, M, D, D, w.x1[l], w.x[l], D, w32 + y.pb, st));
         // x = x1 + c_proj(gelu_new(c_fc(ln_2 x1)))   (hf :229-243)
         CC_TRY(ln_fwd(w.x1[l], D, nullptr, w32 + y.l2w, w32 + y.l2b, w.xn2[l], nullptr, w.mean2[l], w.rstd2[l], M, D, st));
-        CC_TRY(gemm_bf16out(0, 1, w.xn2[l], D, w16 + y.fw, 4 * D, M, 4 * D, D, w.hact[l], 4 * D, w32 + y.fb, 2,
-                            s->mode >= 1 ? w.u[l] : nullptr, st));
-        CC_TRY(gemm_resid(0, 1, w.hact[l], 4 * D, w16 + y.p2w, D, M, D, 4 * D, w.x[l + 1], w.x1[l], D, w32 + y.p2b, st));
+        CC_TIMED(CC_SITE_GPT2_FC_FWD, st, gemm_bf16out(0, 1, w.xn2[l], D, w16 + y.fw, 4 * D, M, 4 * D, D, w.hact[l], 4 * D, w32 + y.fb, 2,
+                                                        s->mode >= 1 ? w.u[l] : nullptr, st));
+        CC_TIMED(CC_SITE_GPT2_PROJ2_FWD, st, gemm_resid(0, 1, w.hact[l], 4 * D, w16 + y.p2w, D, M, D, 4 * D, w.x[l + 1], w.x1[l], D, w32 + y.p2b, st));
     }
     return CC_OK;
 }
@@ -471,7 +531,7 @@ int cc_lmhead_ce_fwd(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* 
     CC_TRY(ce_targets(reinterpret_cast<const long long*>(tokens), w.target, w.row_map, s->B, cap, s->L, s->T, st));
     // ln_f only on the rows the loss reads: L-1 .. T-2 of every sample (model.py:108)
     CC_TRY(ln_fwd(w.x[c->NL], D, w.row_map, w32 + o.lnf_w, w32 + o.lnf_b, w.hf16, nullptr, w.meanf, w.rstdf, Mc, D, st));
-    CC_TRY(gemm_lmhead(w.hf16, D, w16 + o.wte, D, Mc, c->Vp, c->V, D, w.logits16, c->Vp, w.pmax, w.psum, npart, w.target, w.tgt_logit, st));
+    CC_TIMED(CC_SITE_LMHEAD_FWD, st, gemm_lmhead(w.hf16, D, w16 + o.wte, D, Mc, c->Vp, c->V, D, w.logits16, c->Vp, w.pmax, w.psum, npart, w.target, w.tgt_logit, st));
     CC_TRY(ce_rows(w.pmax, w.psum, npart, w.target, w.tgt_logit, w.lse_row, w.row_loss, stats, Mc, st));
     return CC_OK;
 }
@@ -489,7 +549,7 @@ int cc_lmhead_ce_bwd(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* 
     const bool full = s->mode == 2;
     CC_TRY(ce_dlogits(w.logits16, c->Vp, c->V, w.target, w.lse_row, denom, Mc, st));
     // d hf = dlogits · wte   ([Mc,Vp] x [Vp(k), D(n)])
-    CC_TRY(gemm_bf16out(0, 1, w.logits16, c->Vp, w16 + o.wte, D, Mc, D, c->Vp, w.dhf16, D, nullptr, 0, nullptr, st));
+    CC_TIMED(CC_SITE_LMHEAD_DGRAD, st, gemm_bf16out(0, 1, w.logits16, c->Vp, w16 + o.wte, D, Mc, D, c->Vp, w.dhf16, D, nullptr, 0, nullptr, st));
     if (full) CC_TRY(gemm_wgrad(w.logits16, c->Vp, w.hf16, D, c->Vp, D, Mc, g32 + o.wte, D, st));  // tied lm_head: d wte += dlogits^T hf
     if (hipMemsetAsync(w.dx32, 0, (size_t)M * D * sizeof(float), st) != hipSuccess) return CC_ERR_LAUNCH;
     if (hipMemsetAsync(w.dx16, 0, (size_t)M * D * sizeof(bf16_t), st) != hipSuccess) return CC_ERR_LAUNCH;
@@ -522,7 +582,7 @@ int cc_gpt2_bwd(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, 
             CC_TRY(gemm_wgrad(w.xn2[l], D, w.du16, D4, D, D4, M, g32 + y.fw, D4, st));
             CC_TRY(colsum_bf16(w.du16, D4, M, D4, g32 + y.fb, st));
         }
-        CC_TRY(gemm_bf16out(0, 0, w.du16, D4, w16 + y.fw, D4, M, D, D4, w.dxn16, D, nullptr, 0, nullptr, st));
+        CC_TIMED(CC_SITE_GPT2_FC_DGRAD, st, gemm_bf16out(0, 0, w.du16, D4, w16 + y.fw, D4, M, D, D4, w.dxn16, D, nullptr, 0, nullptr, st));
         CC_TRY(ln_bwd(w.dxn16, w.x1[l], D, nullptr, w.mean2[l], w.rstd2[l], w32 + y.l2w, w.dx32, w.dx32, w.dx16, full ? g32 + y.l2w : nullptr,
                       full ? g32 + y.l2b : nullptr, M, D, st));
         // attn.c_proj (Conv1D [D, D])

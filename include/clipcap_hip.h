@@ -178,6 +178,22 @@ int cc_attention_fwd(const uint16_t* qkv, int32_t B, int32_t S, int32_t H, int32
 int cc_attention_bwd(const uint16_t* qkv, const uint16_t* dout, const float* lse, int32_t B, int32_t S, int32_t H, int32_t hd,
                      int32_t causal, uint16_t* dqkv, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Measurement aid for bench.py's roofline line: brackets every launch of ONE GEMM call site with HIP events recorded
+ * on the launch stream.  This is the only process-global state in the library and is off by default.
+ * ------------------------------------------------------------------------------------------------------------ */
+#define CC_SITE_LMHEAD_FWD 1      /* [B*cap, D] x wte^T           (cc_lmhead_ce_fwd) */
+#define CC_SITE_LMHEAD_DGRAD 2    /* dlogits [B*cap, Vp] x wte    (cc_lmhead_ce_bwd) */
+#define CC_SITE_GPT2_FC_FWD 3     /* c_fc  [B*T, D] x [D, 4D]     (cc_gpt2_fwd, per layer) */
+#define CC_SITE_GPT2_PROJ2_FWD 4  /* mlp.c_proj [B*T, 4D] x [4D, D] (cc_gpt2_fwd) */
+#define CC_SITE_GPT2_FC_DGRAD 5   /* d u-> d xn2  [B*T, 4D] x [4D(k), D] (cc_gpt2_bwd) */
+#define CC_SITE_MAPPER_FC1_FWD 6  /* fc1 [B*S, D] x [Hm, D]^T     (cc_mapper_fwd) */
+#define CC_SITE_MAPPER_QKV_FWD 7  /* fused q/kv projection         (cc_mapper_fwd) */
+#define CC_SITE_MAPPER_WGRAD_FC2 8 /* dW2 = dx^T h (split-K)       (cc_mapper_bwd) */
+int cc_prof_start(int32_t site, int32_t max_samples);
+/* waits for the recorded events; writes up to *n (in: capacity, out: count) durations in milliseconds (host arrays) */
+int cc_prof_stop(float* ms_host, int32_t* n_host);
+
 #ifdef __cplusplus
 }
 #endif

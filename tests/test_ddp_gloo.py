@@ -1,0 +1,96 @@
+"""world_size-2 gloo test (CPU) of the data-parallel spec in clipcap_amd/train/ddp.py: rank-sharded batches + global
+kept-token divisor + SUM all-reduce of flat gradient arenas == the single-process gradient on the global batch.
+The per-rank compute is the CPU oracle (the checker standing in for the HIP step, which needs a GPU)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import clipcap_oracle as O
+from tests.util import load_golden, sd_of
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _setup():
+    g = load_golden("train_prefix_only")
+    E, D, P, L, H, N, n_head, n_layer, V, npos = [int(v) for v in g["cfg"]]
+    cfg = dict(projection_length=P, prefix_length=L, heads=H, layers=N, n_head=n_head, n_layer=n_layer)
+    sd = sd_of(g)
+    sd.pop("language_model.lm_head.weight", None)
+    torch.manual_seed(3)
+    Bg = 6
+    tokens = torch.randint(1, V, (Bg, 8))
+    tokens[0, 3:] = -1          # ranks see different kept-token counts
+    tokens[4, 6:] = -1
+    tokens[5, 1] = 0
+    embeds = torch.randn(Bg, E)
+    return cfg, sd, tokens, embeds
+
+
+def _grads_flat(sd, names, tokens, embeds, cfg, denom):
+    for k in names:
+        sd[k].requires_grad_(True)
+        sd[k].grad = None
+    t = tokens.clone()
+    loss = O.clipcap_loss(sd, t, embeds, cfg=cfg, denom=denom)
+    loss.backward()
+    return torch.cat([sd[k].grad.reshape(-1) for k in names]), float(loss.detach())
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from clipcap_amd.train.ddp import GradReducer, shard_batch
+    cfg, sd, tokens, embeds = _setup()
+    names = sorted(k for k in sd if k.startswith("transformer_mapper."))
+    tk, em = shard_batch(tokens, embeds, rank, world)
+    kept = float(((tk > 0)).sum())
+    stats = torch.tensor([0.0, kept])
+    flat = torch.zeros(sum(sd[k].numel() for k in names))
+    red = GradReducer([flat], bucket_bytes=1 << 16)
+    assert len(red.buckets) > 1
+    red.reduce_stats(stats)                      # global kept-token count
+    g, local_sum = _grads_flat(sd, names, tk, em, cfg, denom=float(stats[1]))
+    flat.copy_(g)
+    red.all_reduce()
+    loss_stats = torch.tensor([local_sum])
+    dist.all_reduce(loss_stats)
+    if rank == 0:
+        np.save(out, np.concatenate([flat.numpy(), loss_stats.numpy()]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradients_equal_single_process(tmp_path):
+    out = str(tmp_path / "ddp.npy")
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    res = np.load(out)
+    cfg, sd, tokens, embeds = _setup()
+    names = sorted(k for k in sd if k.startswith("transformer_mapper."))
+    ref, ref_loss = _grads_flat(sd, names, tokens, embeds, cfg, denom=None)   # reference semantics: mean over kept targets
+    assert abs(res[-1] - ref_loss) <= 1e-5
+    err = np.abs(res[:-1] - ref.numpy()).max()
+    assert err <= 1e-6 * max(1.0, float(ref.abs().max())), err
+
+
+def test_shard_range_covers_batch():
+    from clipcap_amd.train.ddp import shard_range
+    for n in (1, 7, 8, 256, 257):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
