@@ -44,6 +44,8 @@ SIGNATURES = {
     "cc_mapper_param_count": (_L, [_MC]),
     "cc_mapper_param_offsets": (_I, [_MC, C.POINTER(_L)]),
     "cc_mapper_ws_bytes": (_L, [_MC, _I, _I]),
+    "cc_mapper_sync_weights": (_I, [_MC, _P, _P, _P]),
+    "cc_gpt2_sync_weights": (_I, [_GC, _P, _P, _P]),
     "cc_mapper_fwd": (_I, [_MC, _I, _P, _P, _P, _P, _P, _I, _P]),
     "cc_mapper_bwd": (_I, [_MC, _I, _P, _P, _P, _P, _P, _P]),
     "cc_gpt2_param_count": (_L, [_GC]),

@@ -114,6 +114,7 @@ struct MapperWS {
     // backward scratch
     float* dx32;
     bf16_t *dx16, *dh16, *dxn16, *datt16, *dqkv16, *dlin16;
+    float* wg_scratch;
     size_t bytes;
 };
 
@@ -156,8 +157,9 @@ void mapper_carve(const cc_mapper_cfg* c, int B, int save, void* ws, MapperWS& w
         w.datt16 = cv.take<bf16_t>(M * D);
         w.dqkv16 = cv.take<bf16_t>(M * 3 * D);
         w.dlin16 = cv.take<bf16_t>((size_t)B * c->W * c->P * D);
+        w.wg_scratch = cv.take<float>(WGRAD_SCRATCH_BYTES / sizeof(float));
     } else {
-        w.dx32 = nullptr; w.dx16 = w.dh16 = w.dxn16 = w.datt16 = w.dqkv16 = w.dlin16 = nullptr;
+        w.dx32 = nullptr; w.dx16 = w.dh16 = w.dxn16 = w.datt16 = w.dqkv16 = w.dlin16 = nullptr; w.wg_scratch = nullptr;
     }
     w.bytes = (cv.off + 255) & ~size_t(255);
 }
@@ -217,6 +219,7 @@ struct Gpt2WS {
     // backward
     float* dx32;
     bf16_t *dx16, *dhf16, *du16, *dxn16, *datt16, *dqkv16;
+    float* wg_scratch;
     size_t bytes;
 };
 
@@ -264,7 +267,9 @@ void gpt2_carve(const cc_gpt2_cfg* c, int B, int T, int cap, int mode, void* ws,
         w.dxn16 = cv.take<bf16_t>(M * D);
         w.datt16 = cv.take<bf16_t>(M * D);
         w.dqkv16 = cv.take<bf16_t>(M * 3 * D);
+        w.wg_scratch = full ? cv.take<float>(WGRAD_SCRATCH_BYTES / sizeof(float)) : nullptr;
     } else {
+        w.wg_scratch = nullptr;
         w.logits16 = nullptr; w.pmax = w.psum = w.tgt_logit = w.lse_row = w.row_loss = nullptr;
         w.dx32 = nullptr; w.dx16 = w.dhf16 = w.du16 = w.dxn16 = w.datt16 = w.dqkv16 = nullptr;
     }
@@ -336,6 +341,24 @@ int64_t cc_mapper_ws_bytes(const cc_mapper_cfg* cfg, int32_t B, int32_t save) {
     return (int64_t)w.bytes;
 }
 
+int cc_mapper_sync_weights(const cc_mapper_cfg* c, const float* w32, uint16_t* w16, void* stream) {
+    if (!mapper_cfg_ok(c) || !w32 || !w16) return CC_ERR_ARG;
+    hipStream_t st = S_(stream);
+    MapperOff o;
+    mapper_offsets(c, o);
+    CC_TRY(f32_to_bf16(w32, w16, (size_t)o.total, st));
+    bf16_t* t = w16 + o.total;
+    const int D = c->D, Hm = c->Hm;
+    for (int l = 0; l < c->N; l++) {
+        const auto& y = o.layer[l];
+        CC_TRY(transpose_bf16(w16 + y.wq, t + y.wq, 3 * D, D, st));   // fused [3D, D] -> [D, 3D]
+        CC_TRY(transpose_bf16(w16 + y.wp, t + y.wp, D, D, st));
+        CC_TRY(transpose_bf16(w16 + y.w1, t + y.w1, Hm, D, st));       // [Hm, D] -> [D, Hm]
+        CC_TRY(transpose_bf16(w16 + y.w2, t + y.w2, D, Hm, st));       // [D, Hm] -> [Hm, D]
+    }
+    return CC_OK;
+}
+
 int cc_mapper_fwd(const cc_mapper_cfg* c, int32_t B, const float* w32, const uint16_t* w16, const float* emb, void* ws, float* out,
                   int32_t save, void* stream) {
     if (!mapper_cfg_ok(c) || B <= 0 || !w32 || !w16 || !emb || !ws || !out) return CC_ERR_ARG;
@@ -384,6 +407,7 @@ int cc_mapper_bwd(const cc_mapper_cfg* c, int32_t B, const float* w32, const uin
     mapper_carve(c, B, 1, ws, w);
     const int D = c->D, PP = c->W * c->P, S = PP + c->L, M = B * S, H = c->H, hd = D / H, Hm = c->Hm;
     const int PD = c->P * D;
+    const uint16_t* w16t = w16 + o.total;   // transposed weight copies: dgrad GEMMs are NT
     // seed: d x[N][:, PP:, :] = dout, rows [0:PP] = 0
     if (hipMemsetAsync(w.dx32, 0, (size_t)M * D * sizeof(float), st) != hipSuccess) return CC_ERR_LAUNCH;
     CC_TRY(copy_rows(dout, (size_t)c->L * D, w.dx32 + (size_t)PP * D, (size_t)S * D, c->L * D, B, st));
@@ -391,23 +415,23 @@ int cc_mapper_bwd(const cc_mapper_cfg* c, int32_t B, const float* w32, const uin
     for (int l = c->N - 1; l >= 0; l--) {
         const auto& y = o.layer[l];
         // fc2: y = h W2^T + b2
-        CC_TIMED(CC_SITE_MAPPER_WGRAD_FC2, st, gemm_wgrad(w.dx16, D, w.h[l], Hm, D, Hm, M, g32 + y.w2, Hm, st));
+        CC_TIMED(CC_SITE_MAPPER_WGRAD_FC2, st, gemm_wgrad(w.dx16, D, w.h[l], Hm, D, Hm, M, g32 + y.w2, Hm, w.wg_scratch, st));
         CC_TRY(colsum_bf16(w.dx16, D, M, D, g32 + y.b2, st));
-        CC_TRY(gemm_dact(0, 1, w.dx16, D, w16 + y.w2, Hm, M, Hm, D, w.dh16, Hm, w.h[l], 1, st));
+        CC_TRY(gemm_dact(0, 0, w.dx16, D, w16t + y.w2, D, M, Hm, D, w.dh16, Hm, w.h[l], 1, st));          // W2^T [Hm, D]
         // fc1
-        CC_TRY(gemm_wgrad(w.dh16, Hm, w.xn2[l], D, Hm, D, M, g32 + y.w1, D, st));
+        CC_TRY(gemm_wgrad(w.dh16, Hm, w.xn2[l], D, Hm, D, M, g32 + y.w1, D, w.wg_scratch, st));
         CC_TRY(colsum_bf16(w.dh16, Hm, M, Hm, g32 + y.b1, st));
-        CC_TRY(gemm_bf16out(0, 1, w.dh16, Hm, w16 + y.w1, D, M, D, Hm, w.dxn16, D, nullptr, 0, nullptr, st));
+        CC_TRY(gemm_bf16out(0, 0, w.dh16, Hm, w16t + y.w1, Hm, M, D, Hm, w.dxn16, D, nullptr, 0, nullptr, st));   // W1^T [D, Hm]
         CC_TRY(ln_bwd(w.dxn16, w.x1[l], D, nullptr, w.mean2[l], w.rstd2[l], w32 + y.n2w, w.dx32, w.dx32, w.dx16, g32 + y.n2w,
                       g32 + y.n2b, M, D, st));
         // project
-        CC_TRY(gemm_wgrad(w.dx16, D, w.att[l], D, D, D, M, g32 + y.wp, D, st));
+        CC_TRY(gemm_wgrad(w.dx16, D, w.att[l], D, D, D, M, g32 + y.wp, D, w.wg_scratch, st));
         CC_TRY(colsum_bf16(w.dx16, D, M, D, g32 + y.bp, st));
-        CC_TRY(gemm_bf16out(0, 1, w.dx16, D, w16 + y.wp, D, M, D, D, w.datt16, D, nullptr, 0, nullptr, st));
+        CC_TRY(gemm_bf16out(0, 0, w.dx16, D, w16t + y.wp, D, M, D, D, w.datt16, D, nullptr, 0, nullptr, st));     // Wp^T
         CC_TRY(attn_bwd(w.qkv[l], w.datt16, w.lse[l], B, S, H, hd, false, w.dqkv16, st));
         // fused q/kv projection (to_queries.weight ++ to_keys_values.weight = [3D, D])
-        CC_TRY(gemm_wgrad(w.dqkv16, 3 * D, w.xn1[l], D, 3 * D, D, M, g32 + y.wq, D, st));
-        CC_TRY(gemm_bf16out(0, 1, w.dqkv16, 3 * D, w16 + y.wq, D, M, D, 3 * D, w.dxn16, D, nullptr, 0, nullptr, st));
+        CC_TRY(gemm_wgrad(w.dqkv16, 3 * D, w.xn1[l], D, 3 * D, D, M, g32 + y.wq, D, w.wg_scratch, st));
+        CC_TRY(gemm_bf16out(0, 0, w.dqkv16, 3 * D, w16t + y.wq, 3 * D, M, D, 3 * D, w.dxn16, D, nullptr, 0, nullptr, st));  // Wqkv^T [D, 3D]
         CC_TRY(ln_bwd(w.dxn16, w.x[l], D, nullptr, w.mean1[l], w.rstd1[l], w32 + y.n1w, w.dx32, w.dx32, w.dx16, g32 + y.n1w,
                       g32 + y.n1b, M, D, st));
     }
@@ -415,7 +439,7 @@ int cc_mapper_bwd(const cc_mapper_cfg* c, int32_t B, const float* w32, const uin
     CC_TRY(batch_sum(w.dx32 + (size_t)PP * D, (size_t)S * D, g32 + o.prefix, c->L * D, B, st));
     if (o.pos >= 0) CC_TRY(batch_sum(w.dx32, (size_t)S * D, g32 + o.pos, PP * D, B, st));
     CC_TRY(slice_f32_to_bf16(w.dx32, (size_t)S * D, w.dlin16, (size_t)PP * D, PP * D, B, st));
-    CC_TRY(gemm_wgrad(w.dlin16, PD, w.emb16, c->E, PD, c->E, B * c->W, g32 + o.lin_w, c->E, st));
+    CC_TRY(gemm_wgrad(w.dlin16, PD, w.emb16, c->E, PD, c->E, B * c->W, g32 + o.lin_w, c->E, w.wg_scratch, st));
     CC_TRY(colsum_bf16(w.dlin16, PD, B * c->W, PD, g32 + o.lin_b, st));
     return CC_OK;
 }
@@ -456,6 +480,25 @@ int64_t cc_gpt2_ws_bytes(const cc_gpt2_cfg* cfg, const cc_gpt2_shape* s) {
     return (int64_t)w.bytes;
 }
 
+int cc_gpt2_sync_weights(const cc_gpt2_cfg* c, const float* w32, uint16_t* w16, void* stream) {
+    if (!gpt2_cfg_ok(c) || !w32 || !w16) return CC_ERR_ARG;
+    hipStream_t st = S_(stream);
+    Gpt2Off o;
+    gpt2_offsets(c, o);
+    CC_TRY(f32_to_bf16(w32, w16, (size_t)o.total, st));
+    bf16_t* t = w16 + o.total;
+    const int D = c->D;
+    CC_TRY(transpose_bf16(w16 + o.wte, t + o.wte, c->Vp, D, st));     // [Vp, D] -> [D, Vp]  (lm_head dgrad)
+    for (int l = 0; l < c->NL; l++) {
+        const auto& y = o.layer[l];
+        CC_TRY(transpose_bf16(w16 + y.aw, t + y.aw, D, 3 * D, st));    // Conv1D [in,out] -> [out,in]: forward is NT on these
+        CC_TRY(transpose_bf16(w16 + y.pw, t + y.pw, D, D, st));
+        CC_TRY(transpose_bf16(w16 + y.fw, t + y.fw, D, 4 * D, st));
+        CC_TRY(transpose_bf16(w16 + y.p2w, t + y.p2w, 4 * D, D, st));
+    }
+    return CC_OK;
+}
+
 int cc_gpt2_embed(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, const float* prefix, const int64_t* tokens, void* ws,
                   void* stream) {
     if (!gpt2_cfg_ok(c) || !shape_ok(c, s) || !w32 || !ws || (s->L > 0 && !prefix) || (s->T > s->L && !tokens)) return CC_ERR_ARG;
@@ -485,18 +528,19 @@ int cc_gpt2_fwd(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, 
     Gpt2WS w;
     gpt2_carve(c, s->B, s->T, s->T - s->L, s->mode, ws, w);
     const int D = c->D, M = s->B * s->T, H = c->H, hd = D / H;
+    const uint16_t* w16t = w16 + o.total;   // Conv1D weights transposed to [out,in]: every forward GEMM is NT
     for (int l = 0; l < c->NL; l++) {
         const auto& y = o.layer[l];
         // hf :262-310: x1 = x + c_proj(attn(c_attn(ln_1 x)))
         CC_TRY(ln_fwd(w.x[l], D, nullptr, w32 + y.l1w, w32 + y.l1b, w.xn1[l], nullptr, w.mean1[l], w.rstd1[l], M, D, st));
-        CC_TRY(gemm_bf16out(0, 1, w.xn1[l], D, w16 + y.aw, 3 * D, M, 3 * D, D, w.qkv[l], 3 * D, w32 + y.ab, 0, nullptr, st));
+        CC_TRY(gemm_bf16out(0, 0, w.xn1[l], D, w16t + y.aw, D, M, 3 * D, D, w.qkv[l], 3 * D, w32 + y.ab, 0, nullptr, st));
         CC_TRY(attn_fwd(w.qkv[l], s->B, s->T, H, hd, true, w.att[l], w.lse[l], st));
-        CC_TRY(gemm_resid(0, 1, w.att[l], D, w16 + y.pw, D, M, D, D, w.x1[l], w.x[l], D, w32 + y.pb, st));
+        CC_TRY(gemm_resid(0, 0, w.att[l], D, w16t + y.pw, D, M, D, D, w.x1[l], w.x[l], D, w32 + y.pb, st));
         // x = x1 + c_proj(gelu_new(c_fc(ln_2 x1)))   (hf :229-243)
         CC_TRY(ln_fwd(w.x1[l], D, nullptr, w32 + y.l2w, w32 + y.l2b, w.xn2[l], nullptr, w.mean2[l], w.rstd2[l], M, D, st));
-        CC_TIMED(CC_SITE_GPT2_FC_FWD, st, gemm_bf16out(0, 1, w.xn2[l], D, w16 + y.fw, 4 * D, M, 4 * D, D, w.hact[l], 4 * D, w32 + y.fb, 2,
+        CC_TIMED(CC_SITE_GPT2_FC_FWD, st, gemm_bf16out(0, 0, w.xn2[l], D, w16t + y.fw, D, M, 4 * D, D, w.hact[l], 4 * D, w32 + y.fb, 2,
                                                         s->mode >= 1 ? w.u[l] : nullptr, st));
-        CC_TIMED(CC_SITE_GPT2_PROJ2_FWD, st, gemm_resid(0, 1, w.hact[l], 4 * D, w16 + y.p2w, D, M, D, 4 * D, w.x[l + 1], w.x1[l], D, w32 + y.p2b, st));
+        CC_TIMED(CC_SITE_GPT2_PROJ2_FWD, st, gemm_resid(0, 0, w.hact[l], 4 * D, w16t + y.p2w, 4 * D, M, D, 4 * D, w.x[l + 1], w.x1[l], D, w32 + y.p2b, st));
     }
     return CC_OK;
 }
@@ -549,8 +593,8 @@ int cc_lmhead_ce_bwd(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* 
     const bool full = s->mode == 2;
     CC_TRY(ce_dlogits(w.logits16, c->Vp, c->V, w.target, w.lse_row, denom, Mc, st));
     // d hf = dlogits · wte   ([Mc,Vp] x [Vp(k), D(n)])
-    CC_TIMED(CC_SITE_LMHEAD_DGRAD, st, gemm_bf16out(0, 1, w.logits16, c->Vp, w16 + o.wte, D, Mc, D, c->Vp, w.dhf16, D, nullptr, 0, nullptr, st));
-    if (full) CC_TRY(gemm_wgrad(w.logits16, c->Vp, w.hf16, D, c->Vp, D, Mc, g32 + o.wte, D, st));  // tied lm_head: d wte += dlogits^T hf
+    CC_TIMED(CC_SITE_LMHEAD_DGRAD, st, gemm_bf16out(0, 0, w.logits16, c->Vp, w16 + o.total + o.wte, c->Vp, Mc, D, c->Vp, w.dhf16, D, nullptr, 0, nullptr, st));
+    if (full) CC_TRY(gemm_wgrad(w.logits16, c->Vp, w.hf16, D, c->Vp, D, Mc, g32 + o.wte, D, w.wg_scratch, st));  // tied lm_head: d wte += dlogits^T hf
     if (hipMemsetAsync(w.dx32, 0, (size_t)M * D * sizeof(float), st) != hipSuccess) return CC_ERR_LAUNCH;
     if (hipMemsetAsync(w.dx16, 0, (size_t)M * D * sizeof(bf16_t), st) != hipSuccess) return CC_ERR_LAUNCH;
     CC_TRY(ln_bwd(w.dhf16, w.x[c->NL], D, w.row_map, w.meanf, w.rstdf, w32 + o.lnf_w, nullptr, w.dx32, w.dx16, full ? g32 + o.lnf_w : nullptr,
@@ -573,13 +617,13 @@ int cc_gpt2_bwd(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, 
         const auto& y = o.layer[l];
         // mlp.c_proj (Conv1D [4D, D]): y = hact W + b
         if (full) {
-            CC_TRY(gemm_wgrad(w.hact[l], D4, w.dx16, D, D4, D, M, g32 + y.p2w, D, st));
+            CC_TRY(gemm_wgrad(w.hact[l], D4, w.dx16, D, D4, D, M, g32 + y.p2w, D, w.wg_scratch, st));
             CC_TRY(colsum_bf16(w.dx16, D, M, D, g32 + y.p2b, st));
         }
         CC_TRY(gemm_dact(0, 0, w.dx16, D, w16 + y.p2w, D, M, D4, D, w.du16, D4, w.u[l], 2, st));
         // mlp.c_fc (Conv1D [D, 4D])
         if (full) {
-            CC_TRY(gemm_wgrad(w.xn2[l], D, w.du16, D4, D, D4, M, g32 + y.fw, D4, st));
+            CC_TRY(gemm_wgrad(w.xn2[l], D, w.du16, D4, D, D4, M, g32 + y.fw, D4, w.wg_scratch, st));
             CC_TRY(colsum_bf16(w.du16, D4, M, D4, g32 + y.fb, st));
         }
         CC_TIMED(CC_SITE_GPT2_FC_DGRAD, st, gemm_bf16out(0, 0, w.du16, D4, w16 + y.fw, D4, M, D, D4, w.dxn16, D, nullptr, 0, nullptr, st));
@@ -587,14 +631,14 @@ int cc_gpt2_bwd(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, 
                       full ? g32 + y.l2b : nullptr, M, D, st));
         // attn.c_proj (Conv1D [D, D])
         if (full) {
-            CC_TRY(gemm_wgrad(w.att[l], D, w.dx16, D, D, D, M, g32 + y.pw, D, st));
+            CC_TRY(gemm_wgrad(w.att[l], D, w.dx16, D, D, D, M, g32 + y.pw, D, w.wg_scratch, st));
             CC_TRY(colsum_bf16(w.dx16, D, M, D, g32 + y.pb, st));
         }
         CC_TRY(gemm_bf16out(0, 0, w.dx16, D, w16 + y.pw, D, M, D, D, w.datt16, D, nullptr, 0, nullptr, st));
         CC_TRY(attn_bwd(w.qkv[l], w.datt16, w.lse[l], s->B, s->T, H, hd, true, w.dqkv16, st));
         // attn.c_attn (Conv1D [D, 3D])
         if (full) {
-            CC_TRY(gemm_wgrad(w.xn1[l], D, w.dqkv16, D3, D, D3, M, g32 + y.aw, D3, st));
+            CC_TRY(gemm_wgrad(w.xn1[l], D, w.dqkv16, D3, D, D3, M, g32 + y.aw, D3, w.wg_scratch, st));
             CC_TRY(colsum_bf16(w.dqkv16, D3, M, D3, g32 + y.ab, st));
         }
         CC_TRY(gemm_bf16out(0, 0, w.dqkv16, D3, w16 + y.aw, D3, M, D, D3, w.dxn16, D, nullptr, 0, nullptr, st));

@@ -298,6 +298,8 @@ int cc_decode_fwd(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int
         hipLaunchKernelGGL(k_add_wpe, dim3((int)std::min<size_t>((total + 255) / 256, 2048)), dim3(256), 0, st, x, w32 + wpe, w.x, R, Tn, D, pos0);
     }
     const size_t cache_layer = (size_t)2 * R * ctx_max * D;
+    const int64_t total = (int64_t)c->Vp * D + (int64_t)c->NPOS * D + (int64_t)c->NL * (12 * (int64_t)D * D + 13 * (int64_t)D) + 2 * D;
+    const uint16_t* w16t = w16 + total;   // transposed Conv1D weights (cc_gpt2_sync_weights): forward GEMMs are NT
     const float scale = 1.0f / sqrtf((float)hd);
     for (int l = 0; l < c->NL; l++) {
         const int64_t l1w = p; p += D;
@@ -315,7 +317,7 @@ int cc_decode_fwd(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int
         bf16_t* kc = kv + (size_t)l * cache_layer;
         bf16_t* vc = kc + (size_t)R * ctx_max * D;
         CC_TRY(ln_fwd(w.x, D, nullptr, w32 + l1w, w32 + l1b, w.xn, nullptr, nullptr, nullptr, M, D, st));
-        CC_TRY(gemm_bf16out(0, 1, w.xn, D, w16 + aw, 3 * D, M, 3 * D, D, w.qkv, 3 * D, w32 + ab, 0, nullptr, st));
+        CC_TRY(gemm_bf16out(0, 0, w.xn, D, w16t + aw, D, M, 3 * D, D, w.qkv, 3 * D, w32 + ab, 0, nullptr, st));
         {
             const size_t total = (size_t)M * (D >> 3);
             hipLaunchKernelGGL(k_kv_append, dim3((int)std::min<size_t>((total + 255) / 256, 2048)), dim3(256), 0, st, w.qkv, kc, vc, R, Tn, D, pos0,
@@ -324,10 +326,10 @@ int cc_decode_fwd(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int
             hipLaunchKernelGGL(k_decode_attn, dim3((nw + 3) / 4), dim3(256), (size_t)4 * ctx_max * sizeof(float), st, w.qkv, kc, vc, w.att, R, Tn, H,
                                hd, pos0, ctx_max, scale);
         }
-        CC_TRY(gemm_resid(0, 1, w.att, D, w16 + pw, D, M, D, D, w.x1, w.x, D, w32 + pb, st));
+        CC_TRY(gemm_resid(0, 0, w.att, D, w16t + pw, D, M, D, D, w.x1, w.x, D, w32 + pb, st));
         CC_TRY(ln_fwd(w.x1, D, nullptr, w32 + l2w, w32 + l2b, w.xn, nullptr, nullptr, nullptr, M, D, st));
-        CC_TRY(gemm_bf16out(0, 1, w.xn, D, w16 + fw, 4 * D, M, 4 * D, D, w.hact, 4 * D, w32 + fb, 2, nullptr, st));
-        CC_TRY(gemm_resid(0, 1, w.hact, 4 * D, w16 + p2w, D, M, D, 4 * D, w.x, w.x1, D, w32 + p2b, st));
+        CC_TRY(gemm_bf16out(0, 0, w.xn, D, w16t + fw, D, M, 4 * D, D, w.hact, 4 * D, w32 + fb, 2, nullptr, st));
+        CC_TRY(gemm_resid(0, 0, w.hact, 4 * D, w16t + p2w, 4 * D, M, D, 4 * D, w.x, w.x1, D, w32 + p2b, st));
     }
     const int64_t lnf_w = p, lnf_b = p + D;
     hipLaunchKernelGGL(k_last_rows, dim3((R + 255) / 256), dim3(256), 0, st, w.last, R, Tn);

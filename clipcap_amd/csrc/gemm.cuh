@@ -18,6 +18,7 @@
 // Constraints (checked by the host launcher): leading dims and the contiguous extent of every operand are
 // multiples of 8 elements, base pointers 16-B aligned.  M, N (row counts) and K of a K-strided operand are free.
 #pragma once
+#include <cstdlib>
 #include "common.cuh"
 
 namespace cc {
@@ -30,6 +31,7 @@ struct GemmShape {
     int M, N, K;
     int lda, ldb;
     int k_chunk;  // K extent handled by one blockIdx.z slice (multiple of 64); == K rounded up when no split
+    int group_m;  // m-tiles per band of the tile order (tile_coords)
 };
 
 __device__ __forceinline__ int g_lds_off(int row, int chunk) {
@@ -120,15 +122,54 @@ __device__ __forceinline__ int xcd_remap(int b, int nb) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
+// ---- epilogue: wave-private LDS strip [16][68] fp32; C layout of 16x16x32: col = lane&15, row = (lane>>4)*4 + reg.
+// Every lane ends up with 8 consecutive columns of one row -> vector epilogue.  Caller must have passed a barrier
+// after the last LDS read of the main loop.
+template <class Epi>
+__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[4][4], char* smem, int wave, int lane, int row0, int col0, const Epi& epi) {
+    float* strip = reinterpret_cast<float*>(smem) + wave * (16 * G_EPI_LD);
+    const int er = (lane >> 4) * 4, ec = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) strip[(er + r) * G_EPI_LD + j * 16 + ec] = acc[i][j][r];
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const int q = lane + 64 * s;
+            const int lr = q >> 3, c8 = q & 7;
+            float v[8];
+            const float4 a = *reinterpret_cast<const float4*>(strip + lr * G_EPI_LD + c8 * 8);
+            const float4 b = *reinterpret_cast<const float4*>(strip + lr * G_EPI_LD + c8 * 8 + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            epi(row0 + i * 16 + lr, col0 + c8 * 8, v);
+        }
+    }
+}
+
+// tile id -> (m-tile, n-tile): ids walk GROUP_M m-tiles down, then one n-tile across (column-major inside a band of
+// GROUP_M m-tiles).  With the XCD remap above, the ~64 blocks resident on one XCD cover an 8x8 patch of tiles, whose
+// A and B panels (16 x 128 x K bf16) fit that XCD's 4 MiB L2 instead of streaming B once per m-tile.
+__device__ __forceinline__ void tile_coords(int tile, int tiles_m, int tiles_n, int G, int& tm, int& tn) {
+    const int band = tile / (G * tiles_n);
+    const int first = band * G;
+    const int gm = min(G, tiles_m - first);
+    const int r = tile - band * G * tiles_n;
+    tm = first + r % gm;
+    tn = r / gm;
+}
+
 template <int AL, int BL, class Epi>
 __global__ __launch_bounds__(G_THREADS, 2) void gemm_bf16_kernel(const bf16_t* __restrict__ A,
                                                                   const bf16_t* __restrict__ B, GemmShape g, Epi epi) {
     __shared__ __attribute__((aligned(16))) char smem[4 * G_TILE_BYTES];  // [buf][A|B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_n = (g.N + G_BN - 1) / G_BN;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (tile / tiles_n) * G_BM, n0 = (tile % tiles_n) * G_BN;
+    const int tiles_n = (g.N + G_BN - 1) / G_BN, tiles_m = (g.M + G_BM - 1) / G_BM;
+    int tm, tn;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, g.group_m, tm, tn);
+    const int m0 = tm * G_BM, n0 = tn * G_BN;
     const int kbeg = blockIdx.z * g.k_chunk;
     const int kend = min(g.K, kbeg + g.k_chunk);
     const int nk = (kend - kbeg + G_BK - 1) / G_BK;
@@ -181,26 +222,81 @@ __global__ __launch_bounds__(G_THREADS, 2) void gemm_bf16_kernel(const bf16_t* _
         __syncthreads();
     }
 
-    // ---- epilogue: wave-private LDS strip [16][68] fp32; C layout of 16x16x32: col = lane&15, row = (lane>>4)*4 + reg
-    float* strip = reinterpret_cast<float*>(smem) + wave * (16 * G_EPI_LD);
-    const int er = (lane >> 4) * 4, ec = lane & 15;
+    gemm_epilogue(acc, smem, wave, lane, m0 + wm * 64, n0 + wn * 64, epi);
+}
+
+// ------------------------------------------------------------------------------------------------
+// NT fast path: both operands K-contiguous (A [M][K], B [N][K]), K % 64 == 0.  Tiles go HBM -> LDS directly with
+// global_load_lds_dwordx4 (no VGPR round trip, no ds_write): the LDS destination of a wave instruction is
+// wave-uniform base + lane*16, so the XOR swizzle is applied on the per-lane SOURCE address (chunk ^ f(row)) and the
+// same involution on the fragment read (cdna guide rule 21).  Rows beyond M/N are clamped (their results are
+// dropped by the epilogue).  One barrier per K-step; the loads of tile t+1 are in flight during the MFMAs of tile t.
+// ------------------------------------------------------------------------------------------------
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void glds_tile(const bf16_t* __restrict__ base, int ld, int rows, int r0, int k0, char* lds, int wave, int lane) {
+    // the tile is 16 wave-segments of 1 KiB (8 rows x 128 B); wave w fills segments w, w+4, w+8, w+12
 #pragma unroll
     for (int i = 0; i < 4; i++) {
+        const int seg = wave + 4 * i;
+        const int row = seg * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7) ^ ((row >> 4) & 3);
+        const int gr = min(r0 + row, rows - 1);
+        const bf16_t* src = base + (size_t)gr * ld + k0 + chunk * 8;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + seg * 1024), 16, 0, 0);
+    }
+}
+
+template <class Epi>
+__global__ __launch_bounds__(G_THREADS, 2) void gemm_nt_glds_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                                     GemmShape g, Epi epi) {
+    __shared__ __attribute__((aligned(1024))) char smem[4 * G_TILE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (g.N + G_BN - 1) / G_BN, tiles_m = (g.M + G_BM - 1) / G_BM;
+    int tm, tn;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, g.group_m, tm, tn);
+    const int m0 = tm * G_BM, n0 = tn * G_BN;
+    const int nk = g.K / G_BK;
+
+    f32x4 acc[4][4];
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+    for (int i = 0; i < 4; i++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) strip[(er + r) * G_EPI_LD + j * 16 + ec] = acc[i][j][r];
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    glds_tile(A, g.lda, g.M, m0, 0, smem, wave, lane);
+    glds_tile(B, g.ldb, g.N, n0, 0, smem + G_TILE_BYTES, wave, lane);
+    const int frow = lane & 15, fchunk = lane >> 4;
+    for (int kt = 0; kt < nk; kt++) {
+        char* cur = smem + (kt & 1) * 2 * G_TILE_BYTES;
+        char* nxt = smem + ((kt + 1) & 1) * 2 * G_TILE_BYTES;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) {
+            glds_tile(A, g.lda, g.M, m0, (kt + 1) * G_BK, nxt, wave, lane);
+            glds_tile(B, g.ldb, g.N, n0, (kt + 1) * G_BK, nxt + G_TILE_BYTES, wave, lane);
+        }
 #pragma unroll
-        for (int s = 0; s < 2; s++) {
-            const int q = lane + 64 * s;
-            const int lr = q >> 3, c8 = q & 7;
-            float v[8];
-            const float4 a = *reinterpret_cast<const float4*>(strip + lr * G_EPI_LD + c8 * 8);
-            const float4 b = *reinterpret_cast<const float4*>(strip + lr * G_EPI_LD + c8 * 8 + 4);
-            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-            epi(m0 + wm * 64 + i * 16 + lr, n0 + wn * 64 + c8 * 8, v);
+        for (int ks = 0; ks < 2; ks++) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                af[i] = *reinterpret_cast<const bf16x8*>(cur + g_lds_off(wm * 64 + i * 16 + frow, ks * 4 + fchunk));
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                bfr[j] = *reinterpret_cast<const bf16x8*>(cur + G_TILE_BYTES + g_lds_off(wn * 64 + j * 16 + frow, ks * 4 + fchunk));
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
     }
+    __syncthreads();
+    gemm_epilogue(acc, smem, wave, lane, m0 + wm * 64, n0 + wn * 64, epi);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -260,11 +356,12 @@ struct EpiF32 {
     float* C;
     const float* bias;  // nullable (mode 0 only)
     int ldc, M, Ns;
-    int mode;  // 0 store, 1 add, 2 atomic add
+    int mode;  // 0 store, 1 add, 2 atomic add, 3 store into the split-K slab of this blockIdx.z
     float alpha;
+    size_t zstride = 0;
     __device__ __forceinline__ void operator()(int row, int col, float (&v)[8]) const {
         if (row >= M || col >= Ns) return;
-        float* p = C + (size_t)row * ldc + col;
+        float* p = C + (size_t)row * ldc + col + (mode == 3 ? blockIdx.z * zstride : 0);
         if (mode == 2) {
 #pragma unroll
             for (int e = 0; e < 8; e++) __hip_atomic_fetch_add(p + e, alpha * v[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -360,13 +457,17 @@ inline int launch_gemm(int al, int bl, const bf16_t* A, int lda, const bf16_t* B
     if (bl == 1 && (N & 7)) return CC_ERR_SHAPE;
     GemmShape g;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
+    static const int env_group = []() { const char* e = getenv("CC_GROUP_M"); return e ? atoi(e) : 0; }();
+    g.group_m = env_group > 0 ? env_group : 8;
     if (ksplit < 1) ksplit = 1;
     int kt = (K + G_BK - 1) / G_BK;
     int per = (kt + ksplit - 1) / ksplit;
     ksplit = (kt + per - 1) / per;
     g.k_chunk = per * G_BK;
     dim3 grid(((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN), 1, ksplit);
-    if (al == 0 && bl == 0)
+    if (al == 0 && bl == 0 && (K % G_BK) == 0 && ksplit == 1)
+        hipLaunchKernelGGL((gemm_nt_glds_kernel<Epi>), grid, dim3(G_THREADS), 0, st, A, B, g, epi);
+    else if (al == 0 && bl == 0)
         hipLaunchKernelGGL((gemm_bf16_kernel<0, 0, Epi>), grid, dim3(G_THREADS), 0, st, A, B, g, epi);
     else if (al == 0 && bl == 1)
         hipLaunchKernelGGL((gemm_bf16_kernel<0, 1, Epi>), grid, dim3(G_THREADS), 0, st, A, B, g, epi);

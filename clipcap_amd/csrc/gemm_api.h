@@ -15,6 +15,10 @@ int gemm_dact(int al, int bl, const bf16_t* A, int lda, const bf16_t* B, int ldb
               const bf16_t* aux, int act, hipStream_t st);
 int gemm_lmhead(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int Vp, int V, int K, bf16_t* C, int ldc, float* pmax,
                 float* psum, int npart, const int* target, float* tgt_logit, hipStream_t st);
-// weight gradient dW[Mw][Nw] += X^T Y with X stored [K][Mw], Y stored [K][Nw]; picks a split-K for occupancy
-int gemm_wgrad(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int Mw, int Nw, int K, float* dW, int ldw, hipStream_t st);
+// weight gradient dW[Mw][Nw] += X^T Y with X stored [K][Mw], Y stored [K][Nw].  Split-K for occupancy: the K slices
+// write fp32 slabs into `scratch` (plain stores) and a second kernel folds them into dW — fp32 atomics on the same
+// tile from 7-14 concurrent blocks measured 3x slower than the whole GEMM (profiles/r01_b_gemm_microbench.md).
+constexpr size_t WGRAD_SCRATCH_BYTES = size_t(48) << 20;
+int gemm_wgrad(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int Mw, int Nw, int K, float* dW, int ldw, float* scratch,
+               hipStream_t st);
 }  // namespace cc

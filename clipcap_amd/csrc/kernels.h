@@ -13,6 +13,8 @@ int add_rows(float* dst, size_t dst_stride, const float* add, int len, int B, hi
 int batch_sum(const float* src, size_t src_stride, float* dst, int len, int B, hipStream_t st);
 int copy_rows(const float* src, size_t src_stride, float* dst, size_t dst_stride, int len, int B, hipStream_t st);
 
+int transpose_bf16(const bf16_t* src, bf16_t* dst, int R, int C, hipStream_t st);
+
 int ln_fwd(const float* x, int ldx, const int* row_map, const float* gamma, const float* beta, bf16_t* y, float* y32, float* mean,
            float* rstd, int rows, int D, hipStream_t st);
 int ln_bwd(const bf16_t* dy, const float* x, int ldx, const int* row_map, const float* mean, const float* rstd, const float* gamma,

@@ -108,6 +108,39 @@ int copy_rows(const float* src, size_t src_stride, float* dst, size_t dst_stride
     return CC_OK;
 }
 
+// dst[c][r] = src[r][c] for a bf16 matrix [R][C] (R, C multiples of 8): 64x64 tiles through LDS, 16-B global accesses both ways.
+__global__ __launch_bounds__(256) void k_transpose_bf16(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int R, int C) {
+    __shared__ bf16_t tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;  // 8 column groups x 32 rows, two passes
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const int r = r0 + rl + 32 * p, c = c0 + cg * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r < R && c < C) v = *reinterpret_cast<const uint4*>(src + (size_t)r * C + c);
+        const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+#pragma unroll
+        for (int k = 0; k < 8; k++) tile[rl + 32 * p][cg * 8 + k] = e[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const int c = c0 + rl + 32 * p, r = r0 + cg * 8;   // output row = source column
+        if (c < C && r < R) {
+            bf16_t e[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) e[k] = tile[cg * 8 + k][rl + 32 * p];
+            *reinterpret_cast<uint4*>(dst + (size_t)c * R + r) = *reinterpret_cast<const uint4*>(e);
+        }
+    }
+}
+int transpose_bf16(const bf16_t* src, bf16_t* dst, int R, int C, hipStream_t st) {
+    if ((R & 7) || (C & 7)) return CC_ERR_SHAPE;
+    if (R <= 0 || C <= 0) return CC_OK;
+    hipLaunchKernelGGL(k_transpose_bf16, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, st, src, dst, R, C);
+    return CC_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // LayerNorm forward: one wave per row, row cached in registers (D <= 2048, D % 4 == 0).
 // y(bf16)[r] = (x[map(r)] - mean) * rstd * gamma + beta ; saves mean / rstd per output row.

@@ -41,11 +41,13 @@ GPT2_LAYER_NAMES = ["ln_1.weight", "ln_1.bias", "attn.c_attn.weight", "attn.c_at
 class _Arena:
     """fp32 master + bf16 operand copy (+ lazily a gradient arena and AdamW state) for one parameter family."""
 
-    def __init__(self, n: int, device):
+    def __init__(self, n: int, device, sync_fn=None):
         self.n = n
         self.device = torch.device(device)
+        self.sync_fn = sync_fn   # (w32_ptr, w16_ptr, stream) -> rc : cast + transposed GEMM-weight copies
         self.w32 = torch.zeros(n, dtype=torch.float32, device=self.device)
-        self.w16 = torch.zeros(n, dtype=torch.bfloat16, device=self.device) if self.device.type == "cuda" else None
+        # [0,n): bf16 cast of the master; [n,2n): transposed copies of the GEMM weights (include/clipcap_hip.h Conventions)
+        self.w16 = torch.zeros(2 * n, dtype=torch.bfloat16, device=self.device) if self.device.type == "cuda" else None
         self.g32: Optional[torch.Tensor] = None
         self.m: Optional[torch.Tensor] = None
         self.v: Optional[torch.Tensor] = None
@@ -54,8 +56,11 @@ class _Arena:
     def sync_bf16(self):
         """Refresh the bf16 copy if the master changed (version counter is shared by all views)."""
         if self.w32._version != self._w16_version:
-            check(_lib.lib().cc_cast_bf16(_p(self.w32), _p(self.w16), self.n, _stream(self.device)), "cc_cast_bf16")
-            self._w16_version = self.w32._version
+            self.refresh_bf16()
+
+    def refresh_bf16(self):
+        check(self.sync_fn(_p(self.w32), _p(self.w16), _stream(self.device)), "cc_*_sync_weights")
+        self._w16_version = self.w32._version
 
     def grads(self) -> torch.Tensor:
         if self.g32 is None:
@@ -67,10 +72,9 @@ class _Arena:
         if self.m is None:
             self.m = torch.zeros_like(self.w32)
             self.v = torch.zeros_like(self.w32)
-        check(_lib.lib().cc_adamw_step(_p(self.w32), _p(self.grads()), _p(self.m), _p(self.v), _p(self.w16), self.n, lr, betas[0], betas[1],
+        check(_lib.lib().cc_adamw_step(_p(self.w32), _p(self.grads()), _p(self.m), _p(self.v), None, self.n, lr, betas[0], betas[1],
                                        eps, weight_decay, step, grad_scale, _stream(self.device)), "cc_adamw_step")
-        self.w32._version  # (in-place by the kernel: keep the cached bf16 copy marked fresh)
-        self._w16_version = self.w32._version
+        self.refresh_bf16()
 
 
 class MapperEngine:
@@ -85,11 +89,14 @@ class MapperEngine:
         n = l.cc_mapper_param_count(C.byref(self.cfg))
         if n < 0:
             raise _lib.CCError(f"unsupported mapper configuration {self.dims}: dims must be multiples of 8 (head dim too)")
-        self.arena = _Arena(n, device)
+        self.arena = _Arena(n, device, self._sync)
         offs = (C.c_int64 * (4 + 12 * num_layers))()
         check(l.cc_mapper_param_offsets(C.byref(self.cfg), offs))
         self.offsets = list(offs)
         self._ws: Dict[Tuple[int, int], torch.Tensor] = {}
+
+    def _sync(self, w32, w16, st):
+        return _lib.lib().cc_mapper_sync_weights(C.byref(self.cfg), w32, w16, st)
 
     # ---- named views (reference state-dict names / layouts) ----
     def shapes(self) -> List[Tuple[str, int, Tuple[int, ...]]]:
@@ -119,7 +126,7 @@ class MapperEngine:
         if device == self.arena.device:
             return self
         old = self.arena
-        self.arena = _Arena(old.n, device)
+        self.arena = _Arena(old.n, device, self._sync)
         self.arena.w32.copy_(old.w32)
         self._ws.clear()
         return self
@@ -171,12 +178,15 @@ class Gpt2Engine:
         n = l.cc_gpt2_param_count(C.byref(self.cfg))
         if n < 0:
             raise _lib.CCError(f"unsupported GPT-2 configuration {self.dims}")
-        self.arena = _Arena(n, device)
+        self.arena = _Arena(n, device, self._sync)
         offs = (C.c_int64 * (2 + 12 * n_layer + 2))()
         check(l.cc_gpt2_param_offsets(C.byref(self.cfg), offs))
         self.offsets = list(offs)
         self._ws: Dict[Tuple[int, int, int, int, int], torch.Tensor] = {}
         self._dec_ws: Dict[Tuple[int, int], torch.Tensor] = {}
+
+    def _sync(self, w32, w16, st):
+        return _lib.lib().cc_gpt2_sync_weights(C.byref(self.cfg), w32, w16, st)
 
     def shapes(self) -> List[Tuple[str, int, Tuple[int, ...]]]:
         d = self.dims

@@ -13,9 +13,11 @@
  *   - return value: 0 = ok, <0 = error (CC_ERR_*), never throws across the ABI.
  *   - bf16 tensors are raw 16-bit patterns (uint16_t), round-to-nearest-even like torch.bfloat16.
  *   - parameters live in flat arenas whose element offsets are defined by cc_*_param_offsets(); the fp32 arena is
- *     the master copy (nn.Parameter views alias it), the bf16 arena is the GEMM operand copy refreshed by
- *     cc_adamw_step / cc_cast_bf16.  Tensor layouts inside the arenas are exactly the reference state-dict layouts
- *     (torch.nn.Linear weight [out,in]; HF Conv1D weight [in,out]).
+ *     the master copy (nn.Parameter views alias it).  The bf16 operand arena has 2*count elements: [0,count) is the
+ *     bf16 cast of the master (same offsets, reference state-dict layouts: torch.nn.Linear weight [out,in]; HF Conv1D
+ *     weight [in,out]); [count, 2*count) holds, at the same offsets, the TRANSPOSE of every 2-D GEMM weight, so that
+ *     forward and dgrad GEMMs are both "NT" (both operands K-contiguous, the direct-to-LDS fast path).  It is
+ *     refreshed from the master by cc_mapper_sync_weights / cc_gpt2_sync_weights after every optimizer step.
  */
 #ifndef CLIPCAP_HIP_H
 #define CLIPCAP_HIP_H
@@ -65,6 +67,9 @@ int cc_mapper_param_offsets(const cc_mapper_cfg* cfg, int64_t* offsets);
 /* workspace bytes for batch B; save=1 keeps every layer's activations for cc_mapper_bwd */
 int64_t cc_mapper_ws_bytes(const cc_mapper_cfg* cfg, int32_t B, int32_t save);
 
+/* w16[0:count] = bf16(w32); w16[count:2*count] = per-tensor transposes of the GEMM weights (see Conventions) */
+int cc_mapper_sync_weights(const cc_mapper_cfg* cfg, const float* w32, uint16_t* w16, void* stream);
+
 /* replaces model.transformer_mapper(embeddings) (mapper.py:122-130; callers model.py:46, inference/generate.py:31,
  * docs/inference.md:24).  emb fp32 [B, W, E]; out fp32 [B, L, D]. */
 int cc_mapper_fwd(const cc_mapper_cfg* cfg, int32_t B, const float* w32, const uint16_t* w16, const float* emb, void* ws,
@@ -106,6 +111,8 @@ typedef struct {
 int64_t cc_gpt2_param_count(const cc_gpt2_cfg* cfg);
 int cc_gpt2_param_offsets(const cc_gpt2_cfg* cfg, int64_t* offsets);
 int64_t cc_gpt2_ws_bytes(const cc_gpt2_cfg* cfg, const cc_gpt2_shape* shp);
+
+int cc_gpt2_sync_weights(const cc_gpt2_cfg* cfg, const float* w32, uint16_t* w16, void* stream);
 
 /* x0[b,t,:] = (t<L ? prefix[b,t,:] : wte[max(tok[b,t-L],0),:]) + wpe[t,:]  — model.py:45-49 + hf :571-577.
  * prefix fp32 [B,L,D]; tokens int64 [B, cap] (may be NULL when L == T).  Writes the workspace's layer-0 input. */
