@@ -292,3 +292,69 @@ class ClipCapEngine:
             self.mapper.arena.g32.zero_()
         if self.train_lm and self.gpt2.arena.g32 is not None:
             self.gpt2.arena.g32.zero_()
+
+
+class DecodeSession:
+    """KV-cached GPT-2 decode state for R independent rows (replaces the per-step full re-forward of the reference's
+    inference/base.py:81).  The cache is bf16 [n_layer][2][R][ctx_max][D], owned here; rows can be re-gathered after a
+    beam step (base.py:93,113) with ``reorder``."""
+
+    def __init__(self, gpt2: Gpt2Engine, rows: int, ctx_max: int):
+        _require_cuda(gpt2.arena.w32, "DecodeSession")
+        self.g = gpt2
+        self.R = rows
+        self.ctx_max = min(ctx_max, gpt2.dims["NPOS"])
+        self.pos = 0
+        d = gpt2.dims
+        self.kv = torch.empty(d["NL"] * 2 * rows * self.ctx_max * d["D"], dtype=torch.bfloat16, device=gpt2.arena.device)
+        self._ws: Dict[int, torch.Tensor] = {}
+
+    def _workspace(self, tn: int) -> torch.Tensor:
+        ws = self._ws.get(tn)
+        if ws is None:
+            nbytes = _lib.lib().cc_decode_ws_bytes(C.byref(self.g.cfg), self.R, tn)
+            check(nbytes, "cc_decode_ws_bytes")
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.g.arena.device)
+            self._ws[tn] = ws
+        return ws
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x fp32 (R, Tnew, D) input embeddings (no positional term) -> fp32 logits of the last new position (R, V)."""
+        g = self.g
+        x = x.to(device=g.arena.device, dtype=torch.float32).contiguous()
+        R, tn, D = x.shape
+        assert R == self.R and D == g.dims["D"]
+        if self.pos + tn > self.ctx_max:
+            raise RuntimeError(f"decode context overflow: {self.pos}+{tn} > {self.ctx_max}")
+        g.arena.sync_bf16()
+        Vp = g.dims["Vp"]
+        logits = torch.empty(R, Vp, dtype=torch.float32, device=g.arena.device)
+        check(_lib.lib().cc_decode_fwd(C.byref(g.cfg), R, tn, self.pos, self.ctx_max, _p(g.arena.w32), _p(g.arena.w16), _p(x), _p(self.kv),
+                                      _p(self._workspace(tn)), _p(logits), Vp, _stream(g.arena.device)), "cc_decode_fwd")
+        self.pos += tn
+        return logits[:, : g.dims["V"]]
+
+    def reorder(self, src_rows: torch.Tensor, rows_out: Optional[int] = None) -> "DecodeSession":
+        """Returns a session whose row r holds the history of this session's row src_rows[r] (int32 device tensor)."""
+        rows_out = int(src_rows.numel()) if rows_out is None else rows_out
+        out = DecodeSession(self.g, rows_out, self.ctx_max)
+        out.pos = self.pos
+        src = src_rows.to(device=self.g.arena.device, dtype=torch.int32).contiguous()
+        check(_lib.lib().cc_decode_reorder(C.byref(self.g.cfg), self.R, rows_out, self.pos, self.ctx_max, _p(self.kv), _p(out.kv), _p(src),
+                                          _stream(self.g.arena.device)), "cc_decode_reorder")
+        return out
+
+
+def beam_step(logits: torch.Tensor, samples: int, beam: int, temperature: float, first: bool, stop_token: int, scores: torch.Tensor,
+              seq_lengths: torch.Tensor, has_stopped: torch.Tensor):
+    """One device-side beam update for `samples` independent beam sets (reference inference/base.py:84-119).
+    logits fp32 (samples*beam, V) (a view with row stride ldl is fine); state tensors are updated IN PLACE.
+    Returns (next_tokens int32 (samples*beam,), src_rows int32 (samples*beam,) local row index inside each sample)."""
+    dev = logits.device
+    V = logits.shape[1]
+    ldl = logits.stride(0)
+    nt = torch.empty(samples * beam, dtype=torch.int32, device=dev)
+    sr = torch.empty(samples * beam, dtype=torch.int32, device=dev)
+    check(_lib.lib().cc_beam_step(samples, beam, V, _p(logits), ldl, float(temperature), int(first), int(stop_token), _p(scores), _p(seq_lengths),
+                                 _p(has_stopped), _p(nt), _p(sr), None, _stream(dev)), "cc_beam_step")
+    return nt, sr

@@ -1,0 +1,140 @@
+"""Caption decoding with a KV cache on the HIP path — same entry points as the reference's clipcap/inference/base.py
+(generate_beam :55-132, generate_nucleus_sampling :135-201, generate_no_beam :204-279) with the same arguments.
+
+Differences that do not change results: GPT-2 runs incrementally (cc_decode_fwd) instead of re-forwarding the growing
+sequence every step (base.py:81), the beam update runs in one device kernel (cc_beam_step), and ``embeds`` may carry a
+batch of prefixes (B, L, D): the reference is batch-1 only, and B == 1 reproduces its outputs.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Tuple, Union
+
+import torch
+
+from clipcap_amd.engine import DecodeSession, beam_step
+from clipcap_amd.inference.utils import (nucleus_distribution, repetition_penalty_apply, sentence_length_penalty_apply,  # noqa: F401
+                                         top_k_top_p_filtering)
+
+
+def _stop_id(tokenizer) -> int:
+    return tokenizer.encode(tokenizer.eos_token)[0]          # base.py:66
+
+
+def _with_text_prefix(model, embeds, text_prefix_tokens):
+    if text_prefix_tokens is None:
+        return embeds
+    emb = model.language_model.get_input_embeddings()(text_prefix_tokens.to(embeds.device))
+    return torch.cat((embeds, emb.expand(embeds.shape[0], -1, -1)), dim=1)   # base.py:75-77
+
+
+@torch.no_grad()
+def generate_beam_tokens(model, embeds: torch.Tensor, beam_size: int = 5, entry_length: int = 67, temperature: float = 1.0,
+                         stop_token: int = 50256) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Token-level beam search for a batch of prefixes.  embeds fp32 (S, L, D).
+    Returns (tokens int64 (S, beam, n), scores (S, beam) length-normalised, seq_lengths (S, beam))."""
+    lm = model.language_model
+    g = lm.engine
+    dev = g.arena.device
+    embeds = embeds.to(dev, torch.float32)
+    S, L0, D = embeds.shape
+    R = S * beam_size
+    V = g.dims["V"]
+    wte = lm.get_input_embeddings().weight.detach()
+    scores = torch.zeros(R, dtype=torch.float32, device=dev)
+    seq_lengths = torch.ones(R, dtype=torch.float32, device=dev)
+    has_stopped = torch.zeros(R, dtype=torch.uint8, device=dev)
+    base = (torch.arange(S, device=dev, dtype=torch.int32) * beam_size).repeat_interleave(beam_size)
+    # step 0: one row per sample (base.py:86-94), then fan the cache out to beam rows
+    sess = DecodeSession(g, S, L0 + entry_length)
+    logits0 = sess.forward(embeds)                                              # (S, V)
+    lg = torch.empty(R, V, dtype=torch.float32, device=dev)
+    lg[::beam_size] = logits0                                                   # row 0 of every beam set
+    next_tok, src = beam_step(lg, S, beam_size, temperature, True, stop_token, scores, seq_lengths, has_stopped)
+    sess = sess.reorder((base // beam_size).to(torch.int32), R)
+    tokens = next_tok.to(torch.int64).view(R, 1)
+    for _ in range(1, entry_length):
+        if bool(has_stopped.all()):                                             # base.py:120-121
+            break
+        x = wte[next_tok.to(torch.int64)].view(R, 1, D)                         # base.py:117
+        logits = sess.forward(x)
+        next_tok, src = beam_step(logits, S, beam_size, temperature, False, stop_token, scores, seq_lengths, has_stopped)
+        gsrc = base + src
+        sess = sess.reorder(gsrc, R)
+        tokens = torch.cat((tokens[gsrc.to(torch.int64)], next_tok.to(torch.int64).view(R, 1)), dim=1)
+    final = scores / seq_lengths                                                # base.py:123
+    return tokens.view(S, beam_size, -1), final.view(S, beam_size), seq_lengths.view(S, beam_size)
+
+
+def generate_beam(model, tokenizer: Callable, embeds: torch.Tensor, number_to_generate: int = 1,
+                  text_prefix_tokens: Optional[torch.Tensor] = None, beam_size: int = 5, entry_length: int = 67,
+                  temperature: float = 1.0) -> List[str]:
+    """Reference signature (base.py:55-64).  Returns the best caption per prefix row (for the reference's batch-1 input with
+    number_to_generate=1: a one-element list, exactly what base.py:125-132 returns)."""
+    stop = _stop_id(tokenizer)
+    embeds = _with_text_prefix(model, embeds, text_prefix_tokens)
+    tokens, scores, lengths = generate_beam_tokens(model, embeds, beam_size, entry_length, temperature, stop)
+    best = scores.argmax(dim=1)     # == argsort(descending)[0]; ties resolve to the first beam like a stable sort
+    out = []
+    for s in range(tokens.shape[0]):
+        b = int(best[s])
+        n = int(lengths[s, b])
+        out.append(tokenizer.decode(tokens[s, b, :n].cpu().numpy()))
+    return out * max(1, number_to_generate) if tokens.shape[0] == 1 else out
+
+
+@torch.no_grad()
+def generate_nucleus_sampling(model, tokenizer: Callable, embeds: torch.Tensor, number_to_generate: int = 1,
+                              text_prefix_tokens: Optional[torch.Tensor] = None, entry_length: int = 67, top_p: float = 0.8, top_k=None,
+                              temperature: float = 1.0) -> List[str]:
+    """base.py:135-201 with a KV cache.  One sample per call row; stops on EOS."""
+    lm = model.language_model
+    stop = _stop_id(tokenizer)
+    embeds = _with_text_prefix(model, embeds, text_prefix_tokens)
+    wte = lm.get_input_embeddings().weight.detach()
+    gens = []
+    for _ in range(number_to_generate):
+        sess = DecodeSession(lm.engine, 1, embeds.shape[1] + entry_length)
+        x = embeds[:1]
+        toks = [] if text_prefix_tokens is None else [int(t) for t in text_prefix_tokens.flatten()]
+        for _ in range(entry_length):
+            logits = sess.forward(x) / (temperature if temperature > 0 else 1.0)
+            nxt = torch.multinomial(nucleus_distribution(logits, top_p, top_k), num_samples=1)
+            toks.append(int(nxt))
+            if toks[-1] == stop:
+                break
+            x = wte[nxt].view(1, 1, -1)
+        gens.append(tokenizer.decode(toks))
+    return gens
+
+
+@torch.no_grad()
+def generate_no_beam(model, tokenizer: Callable, embeds: torch.Tensor, text_prefix_tokens: Optional[torch.Tensor] = None,
+                     top_p: float = 0.9, top_k: float = 0.0, entry_length: int = 67, temperature: float = 1.0,
+                     repetition_penalty: float = 1.2, desired_sentence_length: int = 50, sentence_length_factor: float = 1.0,
+                     sweep: bool = True) -> List[str]:
+    """base.py:204-279: the reference's debugging sweep over top_p x temperature (sweep=True reproduces it; sweep=False samples
+    once with the given top_p / temperature)."""
+    lm = model.language_model
+    stop = _stop_id(tokenizer)
+    embeds = _with_text_prefix(model, embeds, text_prefix_tokens)
+    wte = lm.get_input_embeddings().weight.detach()
+    grid = [(p, t) for p in (0.5, 0.55, 0.6, 0.65, 0.7, 0.75, 0.8, 0.85, 0.9, 0.95, 1.0) for t in (0.9, 0.95, 1.0)] if sweep \
+        else [(top_p, temperature)]
+    gens = []
+    for p, t in grid:
+        sess = DecodeSession(lm.engine, 1, embeds.shape[1] + entry_length)
+        x = embeds[:1]
+        toks: List[int] = [] if text_prefix_tokens is None else [int(v) for v in text_prefix_tokens.flatten()]
+        for _ in range(entry_length):
+            logits = sess.forward(x)[0] / (t if t > 0 else 1.0)
+            logits = top_k_top_p_filtering(logits, top_k=int(top_k), top_p=p)
+            if toks:
+                tk = torch.tensor(toks, device=logits.device)
+                logits = sentence_length_penalty_apply(logits, tk, stop, len(toks), desired_sentence_length, sentence_length_factor)
+            nxt = torch.multinomial(torch.softmax(logits, dim=-1), 1)
+            if int(nxt) == stop:
+                break
+            toks.append(int(nxt))
+            x = wte[nxt].view(1, 1, -1)
+        gens.append(tokenizer.decode(toks))
+    return gens

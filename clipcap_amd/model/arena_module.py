@@ -1,0 +1,56 @@
+"""nn.Module plumbing shared by the mapper and GPT-2 modules: parameters are views of an engine's flat fp32 arena.
+
+Why: the HIP library works on flat arenas (one fused AdamW launch, one all-reduce, bf16 operand copies refreshed in one
+call) while the reference's callers expect ordinary nn.Modules whose ``state_dict()`` carries the reference's key names
+(clipcap/model/load.py:34 ``load_state_dict(strict=False)``).  Both hold: each nn.Parameter's storage IS a slice of the
+arena, ``.to(device)`` moves the arena and re-points the parameters, and in-place updates bump the arena's version
+counter so the bf16 copy is refreshed lazily.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+import torch.nn as nn
+
+
+class ArenaModule(nn.Module):
+    """Owns ``self.engine`` (MapperEngine / Gpt2Engine) and a tree of container modules holding the parameter views."""
+
+    def _bind_parameters(self):
+        self._arena_params: Dict[str, nn.Parameter] = {}
+        views = self.engine.views(self.engine.arena.w32)
+        for name, view in views.items():
+            *path, leaf = name.split(".")
+            mod = self
+            for part in path:
+                if not hasattr(mod, part):
+                    mod.add_module(part, nn.Module())
+                mod = getattr(mod, part)
+            p = nn.Parameter(view, requires_grad=True)
+            mod.register_parameter(leaf, p)
+            self._arena_params[name] = p
+
+    def _rebind(self):
+        views = self.engine.views(self.engine.arena.w32)
+        for name, p in self._arena_params.items():
+            p.data = views[name]
+            p.grad = None
+
+    def _apply(self, fn, recurse=True):
+        # learn the target device from fn (module.to / .cuda / .cpu); dtype changes are ignored: the master stays fp32
+        probe = fn(torch.empty(0, dtype=torch.float32, device=self.engine.arena.device))
+        if probe.device != self.engine.arena.device:
+            self.engine.to(probe.device)
+            self._rebind()
+        return self
+
+    def bind_grads(self):
+        """Point every parameter's .grad at its slice of the engine's gradient arena (fused training path)."""
+        g = self.engine.views(self.engine.arena.grads())
+        for name, p in self._arena_params.items():
+            p.grad = g[name]
+
+    @property
+    def device(self):
+        return self.engine.arena.device

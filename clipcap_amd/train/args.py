@@ -1,0 +1,40 @@
+"""``add_training_args`` — the reference's training / data / deepspeed / wandb flags with identical names, types and defaults
+(clipcap/train/args.py:3-113).  Flags that configured Lightning/DeepSpeed are accepted for command-line compatibility;
+``--enable-deepspeed`` / ``--deepspeed-strategy`` select nothing here (multi-GPU is always one process per GPU + RCCL)."""
+from argparse import ArgumentParser
+
+_GROUPS = {
+    "training": [
+        ("--batch-size", int, 64, "Samples per batch (per process)."),
+        ("--epochs", int, 5, "Passes over the training data."),
+        ("--optimizer-lr", float, 2e-5, "AdamW learning rate."),
+        ("--scheduler-warmup-steps", int, 5000, "Linear warm-up length in optimizer steps."),
+        ("--fp-precision", int, 32, "Accepted for compatibility (16/32/64); GEMMs run bf16 x bf16 -> fp32, master weights fp32."),
+        ("--checkpoint-save-frequency", int, 1, "Write a checkpoint every n epochs."),
+        ("--checkpoint-filename-prefix", str, 1, "Checkpoint file name prefix."),
+        ("--device", str, "0", "GPU index, comma list, or -1 for all (one process per GPU via torchrun)."),
+    ],
+    "data": [
+        ("--input-dataset", str, "./dataset/", "Preprocessed dataset folder (embeddings/*.npy, captions/*.parquet, encoder_config.yaml)."),
+        ("--output-folder", str, "./models/", "Where checkpoints and the model config are written."),
+        ("--reader-max-piece-size", int, 50, "Accepted for compatibility with the embedding-reader flags."),
+        ("--reader-parallel-pieces", int, 10, "Accepted for compatibility with the embedding-reader flags."),
+    ],
+    "deepspeed": [
+        ("--enable-deepspeed", bool, False, "Accepted for compatibility; no effect."),
+        ("--deepspeed-strategy", str, None, "Accepted for compatibility; no effect."),
+    ],
+    "wandb": [
+        ("--enable-wandb", bool, False, "Log the loss to Weights & Biases if the package is installed."),
+        ("--wandb-project", str, "clipcap", "W&B project name."),
+        ("--logging-frequency", int, 50, "Log every n steps."),
+    ],
+}
+
+
+def add_training_args(parser: ArgumentParser) -> ArgumentParser:
+    for title, flags in _GROUPS.items():
+        group = parser.add_argument_group(title)
+        for flag, typ, default, text in flags:
+            group.add_argument(flag, type=typ, default=default, help=text)
+    return parser

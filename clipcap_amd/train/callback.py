@@ -1,0 +1,53 @@
+"""Checkpoint / config I/O with the reference's file naming (clipcap/train/callback.py:5-28):
+``<prefix>_config.yaml``, ``<prefix>_epoch_<n>.ckpt``, ``<prefix>_final.ckpt``; a ``.ckpt`` is a dict with ``"state_dict"``
+(what ``load(..., from_checkpoint=True)`` reads, load.py:31-32) plus the optimizer state for true resume (which the reference lacks)."""
+from __future__ import annotations
+
+from pathlib import Path
+
+import torch
+import yaml
+
+
+class CheckpointSaver:
+    def __init__(self, output_path: str = "./checkpoints/", filename_prefix: str = "clipclap_demo", save_every_n_epochs: int = 1,
+                 use_deepspeed: bool = False) -> None:
+        self.output_path = Path(output_path)
+        self.output_path.mkdir(parents=True, exist_ok=True)
+        self.filename_prefix = filename_prefix
+        self.save_every_n_epochs = max(1, int(save_every_n_epochs))
+        self.use_deepspeed = use_deepspeed
+
+    def save_config(self, config: dict) -> None:
+        with open(self.output_path / f"{self.filename_prefix}_config.yaml", "w+") as f:
+            yaml.dump(config, f, default_flow_style=False)
+
+    def _write(self, model, path: Path, extra: dict) -> None:
+        state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        opt = {}
+        for name, mod in (("mapper", model.transformer_mapper), ("lm", model.language_model)):
+            a = mod.engine.arena
+            if a.m is not None:
+                opt[name] = {"m": a.m.cpu(), "v": a.v.cpu()}
+        torch.save({"state_dict": state, "optimizer_state": opt, "optimizer_step": getattr(model, "_opt_step", 0), **extra}, path)
+
+    def on_epoch_end(self, model, epoch: int, **extra) -> None:
+        if epoch % self.save_every_n_epochs == 0:
+            self._write(model, self.output_path / f"{self.filename_prefix}_epoch_{epoch}.ckpt", dict(epoch=epoch, **extra))
+
+    def save_final_checkpoint(self, model, **extra) -> None:
+        self._write(model, self.output_path / f"{self.filename_prefix}_final.ckpt", extra)
+
+
+def resume(model, ckpt_path: str) -> dict:
+    """Restores weights + AdamW moments + step counter from a checkpoint written above."""
+    ck = torch.load(ckpt_path, map_location="cpu")
+    model.load_state_dict(ck["state_dict"], strict=False)
+    for name, mod in (("mapper", model.transformer_mapper), ("lm", model.language_model)):
+        st = ck.get("optimizer_state", {}).get(name)
+        if st is not None:
+            a = mod.engine.arena
+            a.m = st["m"].to(a.device)
+            a.v = st["v"].to(a.device)
+    model._opt_step = int(ck.get("optimizer_step", 0))
+    return ck

@@ -1,0 +1,85 @@
+"""``train(args)`` / ``start_training()`` — the driver of ``python -m clipcap_amd.train`` (reference clipcap/train/train.py:17-104),
+without Lightning/DeepSpeed: one process per GPU (launch N>1 with ``python -m torch.distributed.run --nproc-per-node N -m
+clipcap_amd.train ...``), rank-sharded batches, fused forward+backward+AdamW steps, RCCL all-reduce of the flat gradient
+arenas with a global kept-token divisor (clipcap_amd/train/ddp.py)."""
+from __future__ import annotations
+
+import os
+from argparse import ArgumentDefaultsHelpFormatter, ArgumentParser, Namespace
+from pathlib import Path
+
+import torch
+import yaml
+
+from clipcap_amd.encoders.config import EncoderConfig
+from clipcap_amd.model import ClipCapModel, ClipCapModelPrefixOnly, Config, TrainingConfig, add_model_args
+from clipcap_amd.model.optim import linear_warmup_decay
+from clipcap_amd.train.args import add_training_args
+from clipcap_amd.train.callback import CheckpointSaver
+from clipcap_amd.train.dataloader import DevicePrefetcher, get_dataloader
+from clipcap_amd.train.ddp import GradReducer
+
+
+def train(args: Namespace, tokenizer=None, language_model=None) -> int:
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    first = str(args.device).split(",")[0]
+    dev_index = local if world > 1 or first == "-1" else int(first)
+    device = torch.device("cuda", dev_index)
+    torch.cuda.set_device(device)
+    if world > 1 and not torch.distributed.is_initialized():
+        torch.distributed.init_process_group("nccl", device_id=device)          # RCCL over xGMI
+
+    with open(Path(args.input_dataset) / "encoder_config.yaml", "r") as f:      # train.py:26-29
+        encoder_config = EncoderConfig(**yaml.safe_load(f))
+    dataset, encoder_embedding_size = get_dataloader(args.input_dataset, args.language_model, args.batch_size, tokenizer=tokenizer,
+                                                     rank=rank, world_size=world)
+    encoder_config.encoder_embedding_size = encoder_embedding_size
+    args.total_steps = len(dataset) * args.epochs                                # train.py:40
+    config = Config.from_args(args)
+    config.training_config = TrainingConfig.from_args(args)
+    config.encoder_config = encoder_config
+    cls = ClipCapModel if args.train_language_model else ClipCapModelPrefixOnly  # train.py:46-50
+    model = cls(config, language_model=language_model).to(device)
+    model.train()
+
+    saver = CheckpointSaver(args.output_folder, args.checkpoint_filename_prefix, save_every_n_epochs=args.checkpoint_save_frequency)
+    if rank == 0:
+        saver.save_config(config.to_dict())                                      # train.py:60-68
+    arenas = [model.transformer_mapper.engine.arena] + ([model.language_model.engine.arena] if model._train_lm else [])
+    reducer = GradReducer([a.grads() for a in arenas]) if world > 1 else None
+    sched = linear_warmup_decay(args.scheduler_warmup_steps, args.total_steps)
+    logger = None
+    if args.enable_wandb and rank == 0:
+        try:
+            import wandb
+            logger = wandb.init(project=args.wandb_project)
+        except ImportError:
+            logger = None
+    step = 0
+    for epoch in range(args.epochs):
+        for batch in DevicePrefetcher(dataset, device):
+            loss = model.fused_step(batch, lr=args.optimizer_lr * sched(step), reducer=reducer)
+            step += 1
+            if rank == 0 and step % max(1, args.logging_frequency) == 0:
+                val = float(loss)
+                print(f"epoch {epoch} step {step}/{args.total_steps} loss {val:.4f}", flush=True)
+                if logger is not None:
+                    logger.log({"loss": val}, step=step)
+        if rank == 0:
+            saver.on_epoch_end(model, epoch, step=step)
+    if rank == 0:
+        saver.save_final_checkpoint(model, step=step)
+    return 0
+
+
+def start_training() -> int:
+    parser = ArgumentParser(description=__doc__, formatter_class=ArgumentDefaultsHelpFormatter)
+    parser = add_training_args(parser)
+    parser = add_model_args(parser)
+    return train(parser.parse_args())
+
+
+if __name__ == "__main__":
+    raise SystemExit(start_training())
