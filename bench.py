@@ -84,10 +84,10 @@ def init_engines(c, device, seed=1234):
 
 def cpu_baseline(c, max_seconds=25.0):
     """The CPU oracle (oracle/clipcap_oracle.py, fp32 torch-CPU restatement pinned to the reference's golden outputs) timed on
-    this box's host cores on a bounded sample of the same workload: the same model, batch 8 instead of 256."""
+    this box's host cores on a bounded sample of the same workload: the same model at batch 16 (BASELINE configs[0] size)."""
     from oracle import clipcap_oracle as O
     torch.manual_seed(0)
-    Bc = 8
+    Bc = 16
     me, ge, _ = None, None, None
     from clipcap_amd.engine import Gpt2Engine, MapperEngine
     me = MapperEngine(c["E"], c["D"], c["L"], c["P"], c["H"], c["N"], device="cpu")
@@ -123,7 +123,7 @@ def cpu_baseline(c, max_seconds=25.0):
                 sd[k].copy_(pn)
         times.append(time.time() - t0)
         step += 1
-        if step >= 4 or time.time() - t_begin > max_seconds:
+        if step >= 3 or time.time() - t_begin > max_seconds:
             break
     steady = sorted(times[1:] or times)[len(times[1:] or times) // 2]
     return {"value": Bc / steady, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",

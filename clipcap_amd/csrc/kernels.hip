@@ -611,8 +611,7 @@ int embed_bwd(const float* dx0, const long long* tokens, int cap, float* dwte, f
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ce_rows(const float* __restrict__ pmax, const float* __restrict__ psum, int npart,
                                                  const int* __restrict__ target, const float* __restrict__ tgt_logit,
-                                                 float* __restrict__ lse, float* __restrict__ row_loss, float* __restrict__ stats,
-                                                 int M) {
+                                                 float* __restrict__ lse, float* __restrict__ row_loss, int M) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -628,19 +627,34 @@ __global__ __launch_bounds__(256) void k_ce_rows(const float* __restrict__ pmax,
     if (lane == 0) {
         const float l = m + logf(s);
         lse[row] = l;
-        const bool kept = target[row] != 0;
-        const float rl = kept ? l - tgt_logit[row] : 0.f;
-        row_loss[row] = rl;
-        if (kept) {
-            __hip_atomic_fetch_add(stats, rl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(stats + 1, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        row_loss[row] = (target[row] != 0) ? l - tgt_logit[row] : 0.f;
+    }
+}
+// stats[0] = sum of kept-row losses, stats[1] = kept rows — one block, fixed summation order (deterministic, no atomics)
+__global__ __launch_bounds__(1024) void k_ce_stats(const float* __restrict__ row_loss, const int* __restrict__ target, float* __restrict__ stats,
+                                                   int M) {
+    __shared__ float sl[16], sc[16];
+    float a = 0.f, c = 0.f;
+    for (int i = threadIdx.x; i < M; i += 1024) {
+        a += row_loss[i];
+        c += (target[i] != 0) ? 1.f : 0.f;
+    }
+    a = wave_sum(a);
+    c = wave_sum(c);
+    if ((threadIdx.x & 63) == 0) { sl[threadIdx.x >> 6] = a; sc[threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float ta = 0.f, tc = 0.f;
+        for (int w = 0; w < 16; w++) { ta += sl[w]; tc += sc[w]; }
+        stats[0] = ta;
+        stats[1] = tc;
     }
 }
 int ce_rows(const float* pmax, const float* psum, int npart, const int* target, const float* tgt_logit, float* lse, float* row_loss,
             float* stats, int M, hipStream_t st) {
     if (M <= 0) return CC_OK;
-    hipLaunchKernelGGL(k_ce_rows, dim3((M + 3) / 4), dim3(256), 0, st, pmax, psum, npart, target, tgt_logit, lse, row_loss, stats, M);
+    hipLaunchKernelGGL(k_ce_rows, dim3((M + 3) / 4), dim3(256), 0, st, pmax, psum, npart, target, tgt_logit, lse, row_loss, M);
+    hipLaunchKernelGGL(k_ce_stats, dim3(1), dim3(1024), 0, st, row_loss, target, stats, M);
     return CC_OK;
 }
 
