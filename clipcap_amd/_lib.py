@@ -69,7 +69,7 @@ SIGNATURES = {
     "cc_gemm_bf16_f32": (_I, [_I, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P]),
     "cc_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "cc_attention_fwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
-    "cc_attention_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "cc_attention_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "cc_prof_start": (_I, [_I, _I]),
     "cc_prof_stop": (_I, [C.POINTER(C.c_float), C.POINTER(_I)]),
 }

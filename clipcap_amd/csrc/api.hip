@@ -115,6 +115,7 @@ struct MapperWS {
     float* dx32;
     bf16_t *dx16, *dh16, *dxn16, *datt16, *dqkv16, *dlin16;
     float* wg_scratch;
+    float* adelta;
     size_t bytes;
 };
 
@@ -158,8 +159,9 @@ void mapper_carve(const cc_mapper_cfg* c, int B, int save, void* ws, MapperWS& w
         w.dqkv16 = cv.take<bf16_t>(M * 3 * D);
         w.dlin16 = cv.take<bf16_t>((size_t)B * c->W * c->P * D);
         w.wg_scratch = cv.take<float>(WGRAD_SCRATCH_BYTES / sizeof(float));
+        w.adelta = cv.take<float>((size_t)B * c->H * S);
     } else {
-        w.dx32 = nullptr; w.dx16 = w.dh16 = w.dxn16 = w.datt16 = w.dqkv16 = w.dlin16 = nullptr; w.wg_scratch = nullptr;
+        w.dx32 = nullptr; w.dx16 = w.dh16 = w.dxn16 = w.datt16 = w.dqkv16 = w.dlin16 = nullptr; w.wg_scratch = nullptr; w.adelta = nullptr;
     }
     w.bytes = (cv.off + 255) & ~size_t(255);
 }
@@ -220,6 +222,7 @@ struct Gpt2WS {
     float* dx32;
     bf16_t *dx16, *dhf16, *du16, *dxn16, *datt16, *dqkv16;
     float* wg_scratch;
+    float* adelta;
     size_t bytes;
 };
 
@@ -243,7 +246,7 @@ void gpt2_carve(const cc_gpt2_cfg* c, int B, int T, int cap, int mode, void* ws,
         w.rstd2[l] = k0 ? cv.take<float>(M) : w.rstd2[0];
         w.xn1[l] = f0 ? cv.take<bf16_t>(M * D) : w.xn1[0];
         w.xn2[l] = f0 ? cv.take<bf16_t>(M * D) : w.xn2[0];
-        w.att[l] = f0 ? cv.take<bf16_t>(M * D) : w.att[0];
+        w.att[l] = k0 ? cv.take<bf16_t>(M * D) : w.att[0];   // attention output: needed by the backward's delta = rowsum(dO*O)
         w.hact[l] = f0 ? cv.take<bf16_t>(M * 4 * D) : w.hact[0];
     }
     const size_t Mh = std::max(M, Mc);
@@ -268,8 +271,9 @@ void gpt2_carve(const cc_gpt2_cfg* c, int B, int T, int cap, int mode, void* ws,
         w.datt16 = cv.take<bf16_t>(M * D);
         w.dqkv16 = cv.take<bf16_t>(M * 3 * D);
         w.wg_scratch = full ? cv.take<float>(WGRAD_SCRATCH_BYTES / sizeof(float)) : nullptr;
+        w.adelta = cv.take<float>((size_t)B * c->H * T);
     } else {
-        w.wg_scratch = nullptr;
+        w.wg_scratch = nullptr; w.adelta = nullptr;
         w.logits16 = nullptr; w.pmax = w.psum = w.tgt_logit = w.lse_row = w.row_loss = nullptr;
         w.dx32 = nullptr; w.dx16 = w.dhf16 = w.du16 = w.dxn16 = w.datt16 = w.dqkv16 = nullptr;
     }
@@ -428,7 +432,7 @@ int cc_mapper_bwd(const cc_mapper_cfg* c, int32_t B, const float* w32, const uin
         CC_TRY(gemm_wgrad(w.dx16, D, w.att[l], D, D, D, M, g32 + y.wp, D, w.wg_scratch, st));
         CC_TRY(colsum_bf16(w.dx16, D, M, D, g32 + y.bp, st));
         CC_TRY(gemm_bf16out(0, 0, w.dx16, D, w16t + y.wp, D, M, D, D, w.datt16, D, nullptr, 0, nullptr, st));     // Wp^T
-        CC_TRY(attn_bwd(w.qkv[l], w.datt16, w.lse[l], B, S, H, hd, false, w.dqkv16, st));
+        CC_TRY(attn_bwd(w.qkv[l], w.datt16, w.att[l], w.lse[l], w.adelta, B, S, H, hd, false, w.dqkv16, st));
         // fused q/kv projection (to_queries.weight ++ to_keys_values.weight = [3D, D])
         CC_TRY(gemm_wgrad(w.dqkv16, 3 * D, w.xn1[l], D, 3 * D, D, M, g32 + y.wq, D, w.wg_scratch, st));
         CC_TRY(gemm_bf16out(0, 0, w.dqkv16, 3 * D, w16t + y.wq, 3 * D, M, D, 3 * D, w.dxn16, D, nullptr, 0, nullptr, st));  // Wqkv^T [D, 3D]
@@ -635,7 +639,7 @@ int cc_gpt2_bwd(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, 
             CC_TRY(colsum_bf16(w.dx16, D, M, D, g32 + y.pb, st));
         }
         CC_TRY(gemm_bf16out(0, 0, w.dx16, D, w16 + y.pw, D, M, D, D, w.datt16, D, nullptr, 0, nullptr, st));
-        CC_TRY(attn_bwd(w.qkv[l], w.datt16, w.lse[l], s->B, s->T, H, hd, true, w.dqkv16, st));
+        CC_TRY(attn_bwd(w.qkv[l], w.datt16, w.att[l], w.lse[l], w.adelta, s->B, s->T, H, hd, true, w.dqkv16, st));
         // attn.c_attn (Conv1D [D, 3D])
         if (full) {
             CC_TRY(gemm_wgrad(w.xn1[l], D, w.dqkv16, D3, D, D3, M, g32 + y.aw, D3, w.wg_scratch, st));
@@ -680,10 +684,10 @@ int cc_attention_fwd(const uint16_t* qkv, int32_t B, int32_t S, int32_t H, int32
     return attn_fwd(qkv, B, S, H, hd, causal != 0, out, lse, S_(stream));
 }
 
-int cc_attention_bwd(const uint16_t* qkv, const uint16_t* dout, const float* lse, int32_t B, int32_t S, int32_t H, int32_t hd, int32_t causal,
-                     uint16_t* dqkv, void* stream) {
+int cc_attention_bwd(const uint16_t* qkv, const uint16_t* dout, const uint16_t* o, const float* lse, float* delta_ws, int32_t B, int32_t S,
+                     int32_t H, int32_t hd, int32_t causal, uint16_t* dqkv, void* stream) {
     if (!qkv || !dout || !lse || !dqkv) return CC_ERR_ARG;
-    return attn_bwd(qkv, dout, lse, B, S, H, hd, causal != 0, dqkv, S_(stream));
+    return attn_bwd(qkv, dout, o, lse, delta_ws, B, S, H, hd, causal != 0, dqkv, S_(stream));
 }
 
 }  // extern "C"

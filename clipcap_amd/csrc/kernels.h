@@ -2,6 +2,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include "common.cuh"
 
 namespace cc {
@@ -22,8 +23,9 @@ int ln_bwd(const bf16_t* dy, const float* x, int ldx, const int* row_map, const 
 int colsum_bf16(const bf16_t* X, int ld, int M, int N, float* out, hipStream_t st);
 
 int attn_fwd(const bf16_t* qkv, int B, int S, int H, int hd, bool causal, bf16_t* out, float* lse, hipStream_t st);
-int attn_bwd(const bf16_t* qkv, const bf16_t* dout, const float* lse, int B, int S, int H, int hd, bool causal, bf16_t* dqkv,
-             hipStream_t st);
+// o: forward output (for delta = rowsum(dO*O)); delta: fp32 scratch [B*H*S].  Both may be null -> VALU kernel.
+int attn_bwd(const bf16_t* qkv, const bf16_t* dout, const bf16_t* o, const float* lse, float* delta, int B, int S, int H, int hd, bool causal,
+             bf16_t* dqkv, hipStream_t st);
 
 int embed_concat(const float* prefix, const long long* tokens, int cap, const float* wte, const float* wpe, float* x0, int B, int L,
                  int T, int D, int pos0, hipStream_t st);

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const bf16_t* __restrict__ qkv
         }
         s = wave_sum(s);
         const float inv = 1.f / s;
-        for (int j = lane; j < S; j += 64) Ps[i * Sp + j] *= inv;
+        for (int j = lane; j < S; j += 64) Ps[i * Sp + j] = bf2f(f2bf(Ps[i * Sp + j] * inv));   // P enters the PV product in bf16 (as in the MFMA kernel)
         if (lane == 0 && lse) lse[((size_t)b * H + h) * S + i] = m + __logf(s);
     }
     __syncthreads();
@@ -423,11 +423,382 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const bf16_t* __restrict__ qkv
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// MFMA attention forward (head dim 64 / 96 / 128): one wave per (sample, head, 32-query block), flash-style loop
+// over 32-key blocks with v_mfma_f32_32x32x16_bf16.
+//   S^T[key][query] = K·Q^T: both operands are d-contiguous, so A (K rows) and B (Q rows) fragments are plain 16-B
+//   global loads — no LDS.  The accumulator layout puts ONE query per lane (col = lane&31) and 16 keys in its
+//   registers (the other 16 in lane^32), so softmax statistics are lane-local + one cross-half shuffle.
+//   O^T[d][query] += V^T·P^T: the B fragment of k-step t is the lane's own p[8t..8t+7] (k-slot s <-> key
+//   (s&3) + 8(2t + (s>>2)) + 4(lane>>5)); the A fragment gathers the same keys of one d column from a wave-private LDS
+//   copy of the V block (8 x ds_read_u16).
+// ------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256) void k_attn_fwd_mfma(const bf16_t* __restrict__ qkv, int B, int S, int H, float scale,
+                                                       bf16_t* __restrict__ out, float* __restrict__ lse_out) {
+    constexpr int KK = HD / 16, NB = HD / 32, C8 = HD / 8;
+    __shared__ __attribute__((aligned(16))) bf16_t vsm[4][32 * HD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nqb = (S + 31) >> 5;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= B * H * nqb) return;  // wave-uniform; no block-level barrier is used below
+    const int qb = item % nqb, h = (item / nqb) % H, b = item / (nqb * H);
+    const int D = H * HD;
+    const size_t rs = (size_t)3 * D;
+    const bf16_t* base = qkv + (size_t)b * S * rs + h * HD;
+    const int half = lane >> 5, q = qb * 32 + (lane & 31);
+    bf16_t* vs = vsm[wave];
+
+    bf16x8 qf[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; kk++) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (q < S) v = *reinterpret_cast<const uint4*>(base + (size_t)q * rs + kk * 16 + half * 8);
+        qf[kk] = __builtin_bit_cast(bf16x8, v);
+    }
+    f32x16 o[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[nb][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const int nkb = CAUSAL ? qb + 1 : nqb;
+    for (int kb = 0; kb < nkb; kb++) {
+        const int key = kb * 32 + (lane & 31);
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; r++) s[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (key < S) v = *reinterpret_cast<const uint4*>(base + D + (size_t)key * rs + kk * 16 + half * 8);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v), qf[kk], s, 0, 0, 0);
+        }
+        // V block -> wave-private LDS, row-major [32 keys][HD]
+#pragma unroll
+        for (int c = 0; c < HD / 16; c++) {
+            const int idx = lane + 64 * c;
+            const int vk = idx / C8, vc = idx % C8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (kb * 32 + vk < S) v = *reinterpret_cast<const uint4*>(base + 2 * D + (size_t)(kb * 32 + vk) * rs + vc * 8);
+            *reinterpret_cast<uint4*>(vs + vk * HD + vc * 8) = v;
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int kr = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const bool ok = kr < S && (!CAUSAL || kr <= q);
+            s[r] = ok ? s[r] * scale : -INFINITY;
+            mx = fmaxf(mx, s[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m, mx);
+        const float alpha = (m == -INFINITY) ? 0.f : __expf(m - m_new);
+        float p[16], ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            p[r] = (m_new == -INFINITY) ? 0.f : __expf(s[r] - m_new);
+            ps += p[r];
+        }
+        ps += __shfl_xor(ps, 32, 64);
+        l = l * alpha + ps;
+        m = m_new;
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) o[nb][r] *= alpha;
+        bf16x8 pf[2];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const uint4 v = make_uint4(pack2bf(p[t * 8 + 0], p[t * 8 + 1]), pack2bf(p[t * 8 + 2], p[t * 8 + 3]),
+                                       pack2bf(p[t * 8 + 4], p[t * 8 + 5]), pack2bf(p[t * 8 + 6], p[t * 8 + 7]));
+            pf[t] = __builtin_bit_cast(bf16x8, v);
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) {
+            const int d = nb * 32 + (lane & 31);
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                unsigned w[4];
+#pragma unroll
+                for (int e2 = 0; e2 < 4; e2++) {
+                    const int e0 = 2 * e2, e1 = 2 * e2 + 1;
+                    const int k0 = (e0 & 3) + 8 * (2 * t + (e0 >> 2)) + 4 * half;
+                    const int k1 = (e1 & 3) + 8 * (2 * t + (e1 >> 2)) + 4 * half;
+                    w[e2] = (unsigned)vs[k0 * HD + d] | ((unsigned)vs[k1 * HD + d] << 16);
+                }
+                const uint4 av = make_uint4(w[0], w[1], w[2], w[3]);
+                o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), pf[t], o[nb], 0, 0, 0);
+            }
+        }
+    }
+    if (q < S) {
+        const float inv = l > 0.f ? 1.f / l : 0.f;
+        bf16_t* orow = out + ((size_t)b * S + q) * D + h * HD;
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int d0 = nb * 32 + 8 * g + 4 * half;
+                *reinterpret_cast<uint2*>(orow + d0) = make_uint2(pack2bf(o[nb][g * 4 + 0] * inv, o[nb][g * 4 + 1] * inv),
+                                                                  pack2bf(o[nb][g * 4 + 2] * inv, o[nb][g * 4 + 3] * inv));
+            }
+        if (half == 0 && lse_out) lse_out[((size_t)b * H + h) * S + q] = m + __logf(l);
+    }
+}
+
+template <int HD>
+static int attn_fwd_mfma_launch(const bf16_t* qkv, int B, int S, int H, bool causal, bf16_t* out, float* lse, hipStream_t st) {
+    const int items = B * H * ((S + 31) / 32);
+    const float scale = 1.0f / sqrtf((float)HD);
+    if (causal)
+        hipLaunchKernelGGL((k_attn_fwd_mfma<HD, true>), dim3((items + 3) / 4), dim3(256), 0, st, qkv, B, S, H, scale, out, lse);
+    else
+        hipLaunchKernelGGL((k_attn_fwd_mfma<HD, false>), dim3((items + 3) / 4), dim3(256), 0, st, qkv, B, S, H, scale, out, lse);
+    return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// MFMA attention backward (head dim 64 / 96 / 128), three kernels, no atomics, no transposes through HBM:
+//   k_attn_delta : delta[b,h,q] = sum_d dO[q,d] O[q,d]
+//   k_attn_bwd_dkv (one wave per (b,h,key block j), loops over query blocks): "S orientation" — lane <-> key (col),
+//       registers <-> 16 queries — so bf16(P) and bf16(dS) are directly the B fragments of
+//       dV^T[d][key] += dO^T[d][q] P[q][key]   and   dK^T[d][key] += Q^T[d][q] dS[q][key];
+//       the A fragments (dO^T, Q^T) gather 8 queries of one d column from wave-private LDS copies of the row-major blocks.
+//   k_attn_bwd_dq (one wave per (b,h,query block i), loops over key blocks): "S^T orientation" as in the forward —
+//       lane <-> query — so bf16(dS^T) is the B fragment of dQ^T[d][q] += K^T[d][key] dS^T[key][q] (K block via LDS).
+// P is recomputed from the saved log-sum-exp; dS = P (dP - delta) * scale.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_attn_delta(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ o, float* __restrict__ delta,
+                                                    int B, int S, int H, int hd) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * S * H) return;
+    const int h = idx % H, row = idx / H;
+    const int b = row / S, q = row % S;
+    const size_t off = (size_t)row * H * hd + (size_t)h * hd;
+    float acc = 0.f;
+    for (int d = 0; d < hd; d += 8) {
+        float x[8], y[8];
+        unpack8(*reinterpret_cast<const uint4*>(dout + off + d), x);
+        unpack8(*reinterpret_cast<const uint4*>(o + off + d), y);
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc += x[e] * y[e];
+    }
+    delta[((size_t)b * H + h) * S + q] = acc;
+}
+
+template <int HD>
+__device__ __forceinline__ void stage_block(bf16_t* dst, const bf16_t* src, size_t row_stride, int row0, int S, int lane) {
+    constexpr int C8 = HD / 8;
+#pragma unroll
+    for (int c = 0; c < HD / 16; c++) {
+        const int idx = lane + 64 * c;
+        const int r = idx / C8, cc = idx % C8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row0 + r < S) v = *reinterpret_cast<const uint4*>(src + (size_t)(row0 + r) * row_stride + cc * 8);
+        *reinterpret_cast<uint4*>(dst + r * HD + cc * 8) = v;
+    }
+}
+// A fragment of k-step t: 8 rows {(e&3) + 8(2t + (e>>2)) + 4*half} of column d of a row-major [32][HD] LDS block
+template <int HD>
+__device__ __forceinline__ bf16x8 gather_col(const bf16_t* blk, int d, int t, int half) {
+    unsigned w[4];
+#pragma unroll
+    for (int e2 = 0; e2 < 4; e2++) {
+        const int e0 = 2 * e2, e1 = 2 * e2 + 1;
+        const int r0 = (e0 & 3) + 8 * (2 * t + (e0 >> 2)) + 4 * half;
+        const int r1 = (e1 & 3) + 8 * (2 * t + (e1 >> 2)) + 4 * half;
+        w[e2] = (unsigned)blk[r0 * HD + d] | ((unsigned)blk[r1 * HD + d] << 16);
+    }
+    return __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+}
+__device__ __forceinline__ bf16x8 pack_frag(const float* p) {
+    return __builtin_bit_cast(bf16x8, make_uint4(pack2bf(p[0], p[1]), pack2bf(p[2], p[3]), pack2bf(p[4], p[5]), pack2bf(p[6], p[7])));
+}
+__device__ __forceinline__ bf16x8 load_frag(const bf16_t* row_ptr, bool ok) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (ok) v = *reinterpret_cast<const uint4*>(row_ptr);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256) void k_attn_bwd_dkv(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                      const float* __restrict__ lse, const float* __restrict__ delta, int B, int S, int H,
+                                                      float scale, bf16_t* __restrict__ dqkv) {
+    constexpr int KK = HD / 16, NB = HD / 32;
+    __shared__ __attribute__((aligned(16))) bf16_t qsm[4][32 * HD];
+    __shared__ __attribute__((aligned(16))) bf16_t dsm[4][32 * HD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nblk = (S + 31) >> 5;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= B * H * nblk) return;
+    const int j = item % nblk, h = (item / nblk) % H, b = item / (nblk * H);
+    const int D = H * HD;
+    const size_t rs = (size_t)3 * D;
+    const bf16_t* base = qkv + (size_t)b * S * rs + h * HD;
+    const bf16_t* dbase = dout + (size_t)b * S * D + h * HD;
+    const float* lrow = lse + ((size_t)b * H + h) * S;
+    const float* drow = delta + ((size_t)b * H + h) * S;
+    const int half = lane >> 5, key = j * 32 + (lane & 31);
+    bf16x8 kf[KK], vf[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; kk++) {
+        kf[kk] = load_frag(base + D + (size_t)key * rs + kk * 16 + half * 8, key < S);
+        vf[kk] = load_frag(base + 2 * D + (size_t)key * rs + kk * 16 + half * 8, key < S);
+    }
+    f32x16 dk[NB], dv[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) { dk[nb][r] = 0.f; dv[nb][r] = 0.f; }
+    for (int i = CAUSAL ? j : 0; i < nblk; i++) {
+        const int qa = i * 32 + (lane & 31);
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++) {
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_frag(base + (size_t)qa * rs + kk * 16 + half * 8, qa < S), kf[kk], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_frag(dbase + (size_t)qa * D + kk * 16 + half * 8, qa < S), vf[kk], dp, 0, 0, 0);
+        }
+        stage_block<HD>(qsm[wave], base, rs, i * 32, S, lane);
+        stage_block<HD>(dsm[wave], dbase, (size_t)D, i * 32, S, lane);
+        float p[16], ds[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int qr = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const bool ok = qr < S && key < S && (!CAUSAL || key <= qr);
+            const int qc = min(qr, S - 1);
+            p[r] = ok ? __expf(s[r] * scale - lrow[qc]) : 0.f;
+            ds[r] = p[r] * (dp[r] - drow[qc]) * scale;
+        }
+        const bf16x8 pf[2] = {pack_frag(p), pack_frag(p + 8)};
+        const bf16x8 dsf[2] = {pack_frag(ds), pack_frag(ds + 8)};
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) {
+            const int d = nb * 32 + (lane & 31);
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gather_col<HD>(dsm[wave], d, t, half), pf[t], dv[nb], 0, 0, 0);
+                dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gather_col<HD>(qsm[wave], d, t, half), dsf[t], dk[nb], 0, 0, 0);
+            }
+        }
+    }
+    if (key < S) {
+        bf16_t* orow = dqkv + ((size_t)b * S + key) * rs + h * HD;
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int d0 = nb * 32 + 8 * g + 4 * half;
+                *reinterpret_cast<uint2*>(orow + D + d0) =
+                    make_uint2(pack2bf(dk[nb][g * 4 + 0], dk[nb][g * 4 + 1]), pack2bf(dk[nb][g * 4 + 2], dk[nb][g * 4 + 3]));
+                *reinterpret_cast<uint2*>(orow + 2 * D + d0) =
+                    make_uint2(pack2bf(dv[nb][g * 4 + 0], dv[nb][g * 4 + 1]), pack2bf(dv[nb][g * 4 + 2], dv[nb][g * 4 + 3]));
+            }
+    }
+}
+
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256) void k_attn_bwd_dq(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                     const float* __restrict__ lse, const float* __restrict__ delta, int B, int S, int H,
+                                                     float scale, bf16_t* __restrict__ dqkv) {
+    constexpr int KK = HD / 16, NB = HD / 32;
+    __shared__ __attribute__((aligned(16))) bf16_t ksm[4][32 * HD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nblk = (S + 31) >> 5;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= B * H * nblk) return;
+    const int i = item % nblk, h = (item / nblk) % H, b = item / (nblk * H);
+    const int D = H * HD;
+    const size_t rs = (size_t)3 * D;
+    const bf16_t* base = qkv + (size_t)b * S * rs + h * HD;
+    const bf16_t* dbase = dout + (size_t)b * S * D + h * HD;
+    const int half = lane >> 5, q = i * 32 + (lane & 31);
+    const float my_lse = q < S ? lse[((size_t)b * H + h) * S + q] : 0.f;
+    const float my_delta = q < S ? delta[((size_t)b * H + h) * S + q] : 0.f;
+    bf16x8 qf[KK], dof[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; kk++) {
+        qf[kk] = load_frag(base + (size_t)q * rs + kk * 16 + half * 8, q < S);
+        dof[kk] = load_frag(dbase + (size_t)q * D + kk * 16 + half * 8, q < S);
+    }
+    f32x16 dq[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) dq[nb][r] = 0.f;
+    const int jend = CAUSAL ? i + 1 : nblk;
+    for (int j = 0; j < jend; j++) {
+        const int key = j * 32 + (lane & 31);
+        f32x16 st, dpt;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { st[r] = 0.f; dpt[r] = 0.f; }
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++) {
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_frag(base + D + (size_t)key * rs + kk * 16 + half * 8, key < S), qf[kk], st, 0, 0, 0);
+            dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_frag(base + 2 * D + (size_t)key * rs + kk * 16 + half * 8, key < S), dof[kk], dpt, 0, 0, 0);
+        }
+        stage_block<HD>(ksm[wave], base + D, rs, j * 32, S, lane);
+        float ds[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int kr = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const bool ok = kr < S && q < S && (!CAUSAL || kr <= q);
+            const float p = ok ? __expf(st[r] * scale - my_lse) : 0.f;
+            ds[r] = p * (dpt[r] - my_delta) * scale;
+        }
+        const bf16x8 dsf[2] = {pack_frag(ds), pack_frag(ds + 8)};
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) {
+            const int d = nb * 32 + (lane & 31);
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+                dq[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gather_col<HD>(ksm[wave], d, t, half), dsf[t], dq[nb], 0, 0, 0);
+        }
+    }
+    if (q < S) {
+        bf16_t* orow = dqkv + ((size_t)b * S + q) * rs + h * HD;
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int d0 = nb * 32 + 8 * g + 4 * half;
+                *reinterpret_cast<uint2*>(orow + d0) =
+                    make_uint2(pack2bf(dq[nb][g * 4 + 0], dq[nb][g * 4 + 1]), pack2bf(dq[nb][g * 4 + 2], dq[nb][g * 4 + 3]));
+            }
+    }
+}
+
+template <int HD>
+static int attn_bwd_mfma_launch(const bf16_t* qkv, const bf16_t* dout, const bf16_t* o, const float* lse, float* delta, int B, int S, int H,
+                                bool causal, bf16_t* dqkv, hipStream_t st) {
+    const int items = B * H * ((S + 31) / 32);
+    const float scale = 1.0f / sqrtf((float)HD);
+    hipLaunchKernelGGL(k_attn_delta, dim3((B * S * H + 255) / 256), dim3(256), 0, st, dout, o, delta, B, S, H, HD);
+    if (causal) {
+        hipLaunchKernelGGL((k_attn_bwd_dkv<HD, true>), dim3((items + 3) / 4), dim3(256), 0, st, qkv, dout, lse, delta, B, S, H, scale, dqkv);
+        hipLaunchKernelGGL((k_attn_bwd_dq<HD, true>), dim3((items + 3) / 4), dim3(256), 0, st, qkv, dout, lse, delta, B, S, H, scale, dqkv);
+    } else {
+        hipLaunchKernelGGL((k_attn_bwd_dkv<HD, false>), dim3((items + 3) / 4), dim3(256), 0, st, qkv, dout, lse, delta, B, S, H, scale, dqkv);
+        hipLaunchKernelGGL((k_attn_bwd_dq<HD, false>), dim3((items + 3) / 4), dim3(256), 0, st, qkv, dout, lse, delta, B, S, H, scale, dqkv);
+    }
+    return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+}
+
 static size_t attn_fwd_lds(int S, int hd) { return ((size_t)3 * S * (hd + 4) + (size_t)S * (S + 1)) * 4; }
 static size_t attn_bwd_lds(int S, int hd) { return ((size_t)4 * S * (hd + 4) + (size_t)2 * S * (S + 1)) * 4; }
 
 int attn_fwd(const bf16_t* qkv, int B, int S, int H, int hd, bool causal, bf16_t* out, float* lse, hipStream_t st) {
     if ((hd & 7) || S <= 0) return CC_ERR_SHAPE;
+    static const bool no_mfma = getenv("CC_ATTN_VALU") != nullptr;   // A/B switch for profiling
+    if (!no_mfma) {
+        if (hd == 64) return attn_fwd_mfma_launch<64>(qkv, B, S, H, causal, out, lse, st);
+        if (hd == 96) return attn_fwd_mfma_launch<96>(qkv, B, S, H, causal, out, lse, st);
+        if (hd == 128) return attn_fwd_mfma_launch<128>(qkv, B, S, H, causal, out, lse, st);
+    }
     const size_t sh = attn_fwd_lds(S, hd);
     if (sh > 160 * 1024) return CC_ERR_SHAPE;
     const float scale = 1.0f / sqrtf((float)hd);
@@ -529,9 +900,15 @@ __global__ __launch_bounds__(256) void k_attn_bwd(const bf16_t* __restrict__ qkv
         *reinterpret_cast<uint2*>(o + 2 * D) = make_uint2(pack2bf(dv.x, dv.y), pack2bf(dv.z, dv.w));
     }
 }
-int attn_bwd(const bf16_t* qkv, const bf16_t* dout, const float* lse, int B, int S, int H, int hd, bool causal, bf16_t* dqkv,
-             hipStream_t st) {
+int attn_bwd(const bf16_t* qkv, const bf16_t* dout, const bf16_t* o, const float* lse, float* delta, int B, int S, int H, int hd, bool causal,
+             bf16_t* dqkv, hipStream_t st) {
     if ((hd & 7) || S <= 0) return CC_ERR_SHAPE;
+    static const bool no_mfma = getenv("CC_ATTN_VALU") != nullptr;
+    if (!no_mfma && o && delta) {
+        if (hd == 64) return attn_bwd_mfma_launch<64>(qkv, dout, o, lse, delta, B, S, H, causal, dqkv, st);
+        if (hd == 96) return attn_bwd_mfma_launch<96>(qkv, dout, o, lse, delta, B, S, H, causal, dqkv, st);
+        if (hd == 128) return attn_bwd_mfma_launch<128>(qkv, dout, o, lse, delta, B, S, H, causal, dqkv, st);
+    }
     const size_t sh = attn_bwd_lds(S, hd);
     if (sh > 160 * 1024) return CC_ERR_SHAPE;
     const float scale = 1.0f / sqrtf((float)hd);

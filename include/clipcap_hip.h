@@ -182,8 +182,9 @@ int cc_layernorm_fwd(const float* x, const float* gamma, const float* beta, uint
                      int32_t D, void* stream);
 int cc_attention_fwd(const uint16_t* qkv, int32_t B, int32_t S, int32_t H, int32_t hd, int32_t causal, uint16_t* out, float* lse,
                      void* stream);
-int cc_attention_bwd(const uint16_t* qkv, const uint16_t* dout, const float* lse, int32_t B, int32_t S, int32_t H, int32_t hd,
-                     int32_t causal, uint16_t* dqkv, void* stream);
+/* o = forward output and delta_ws = fp32 scratch [B*H*S] select the MFMA kernels (hd 64/96/128); NULL -> LDS/VALU kernel */
+int cc_attention_bwd(const uint16_t* qkv, const uint16_t* dout, const uint16_t* o, const float* lse, float* delta_ws, int32_t B, int32_t S,
+                     int32_t H, int32_t hd, int32_t causal, uint16_t* dqkv, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Measurement aid for bench.py's roofline line: brackets every launch of ONE GEMM call site with HIP events recorded

@@ -53,7 +53,7 @@ def mha_forward(p: Dict[str, Tensor], pre: str, x: Tensor, num_heads: int, rb: b
     k, v = kv[:, :, 0], kv[:, :, 1]
     att = torch.einsum("bnhd,bmhd->bnmh", q, k) * (hd ** -0.5)
     att = att.softmax(dim=2)
-    out = torch.einsum("bnmh,bmhd->bnhd", att, v).reshape(b, n, c)
+    out = torch.einsum("bnmh,bmhd->bnhd", _r(att, rb), v).reshape(b, n, c)   # the MFMA kernel feeds P to the PV product in bf16
     out = _r(out, rb)
     out = _linear(out, p[pre + "project.weight"], p[pre + "project.bias"], rb)
     return out, att
@@ -140,7 +140,7 @@ def gpt2_block_forward(p, pre, x, n_head, rb=False, past_kv=None):
     kj = torch.arange(ctx).unsqueeze(0)
     att = att.masked_fill(kj > qi, float("-inf"))
     att = att.softmax(dim=-1)
-    a = _r((att @ v).transpose(1, 2).reshape(bsz, t, d), rb)
+    a = _r((_r(att, rb) @ v).transpose(1, 2).reshape(bsz, t, d), rb)
     x = x + _conv1d(a, p[pre + "attn.c_proj.weight"], p[pre + "attn.c_proj.bias"], rb)
     h = F.layer_norm(x, (d,), p[pre + "ln_2.weight"], p[pre + "ln_2.bias"], 1e-5)
     h = _r(gelu_new(_conv1d(h, p[pre + "mlp.c_fc.weight"], p[pre + "mlp.c_fc.bias"], rb)), rb)

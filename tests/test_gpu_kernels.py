@@ -96,8 +96,14 @@ def _attn_ref(qkv, B, S, H, hd, causal):
     return out, lse
 
 
-@pytest.mark.parametrize("B,S,H,hd,causal", [(3, 20, 8, 96, 0), (2, 50, 12, 64, 1), (2, 74, 4, 64, 1), (1, 7, 2, 8, 0), (2, 33, 2, 128, 1)])
-def test_attention_fwd_bwd(B, S, H, hd, causal):
+@pytest.mark.parametrize("B,S,H,hd,causal", [(3, 20, 8, 96, 0), (2, 50, 12, 64, 1), (2, 74, 4, 64, 1), (1, 7, 2, 8, 0), (2, 33, 2, 128, 1),
+                                             (2, 64, 2, 64, 0), (1, 97, 2, 64, 1), (2, 32, 3, 96, 1)])
+@pytest.mark.parametrize("mfma_bwd", [0, 1])
+def test_attention_fwd_bwd(B, S, H, hd, causal, mfma_bwd):
+    """hd in {64,96,128}: MFMA forward (and, with mfma_bwd, the MFMA delta/dKV/dQ backward); otherwise the LDS/VALU kernels.
+    Reference: fp32 torch math on the same bf16 inputs; P is bf16-rounded before PV like the kernels do."""
+    if not mfma_bwd and S > 80:
+        pytest.skip("the LDS/VALU backward keeps whole S x S tiles in LDS (S <= ~80); longer sequences use the MFMA kernels")
     torch.manual_seed(S * 3 + hd)
     D = H * hd
     qkv = _bf(torch.randn(B * S, 3 * D, device="cuda"))
@@ -108,15 +114,22 @@ def test_attention_fwd_bwd(B, S, H, hd, causal):
     ref, lse_ref = _attn_ref(qkv_r, B, S, H, hd, causal)
     torch.cuda.synchronize()
     assert (lse - lse_ref).abs().max().item() <= 1e-4
-    assert (out.float().view(B, S, D) - ref).abs().max().item() <= 2e-2
+    # bf16 output: <= 1 ulp of the value plus the bf16-P contribution
+    tol = 2 ** -7 * ref.abs().clamp_min(0.25) + 4e-3
+    assert ((out.float().view(B, S, D) - ref).abs() <= tol).all(), (out.float().view(B, S, D) - ref).abs().max().item()
     dout = _bf(torch.randn(B * S, D, device="cuda"))
-    dqkv = torch.empty_like(qkv)
-    assert _lib().cc_attention_bwd(_p(qkv), _p(dout), _p(lse), B, S, H, hd, causal, _p(dqkv), _st()) == 0
+    dqkv = torch.full_like(qkv, float("nan"))
+    delta = torch.empty(B * H * S, device="cuda")
+    rc = _lib().cc_attention_bwd(_p(qkv), _p(dout), _p(out) if mfma_bwd else None, _p(lse), _p(delta) if mfma_bwd else None, B, S, H, hd, causal,
+                                 _p(dqkv), _st())
+    assert rc == 0
     ref.backward(dout.float().view(B, S, D))
     torch.cuda.synchronize()
     g = qkv_r.grad
+    assert torch.isfinite(dqkv.float()).all()
     err = (dqkv.float() - g).abs().max().item()
-    assert err <= 2e-2 * max(1.0, g.abs().max().item()), err
+    rel = ((dqkv.float() - g).norm() / g.norm()).item()
+    assert rel <= 1e-2 and err <= 3e-2 * max(1.0, g.abs().max().item()), (rel, err)
 
 
 def test_adamw_matches_torch():
