@@ -28,15 +28,18 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
 }
 
 // gelu_new (tanh approximation) and its derivative — transformers.activations.NewGELUActivation.
+// tanh(u) = 1 - 2/(exp(2u)+1) on the hardware exp/rcp units (v_exp_f32 / v_rcp_f32, ~1e-6 relative): libm's tanhf doubled the
+// run time of the GEMMs carrying these epilogues.  Saturates correctly: exp->inf gives 1, exp->0 gives -1.
+__device__ __forceinline__ float fast_tanh(float u) { return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * u) + 1.0f); }
 __device__ __forceinline__ float gelu_new_f(float x) {
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    float t = tanhf(k0 * (x + k1 * x * x * x));
+    const float t = fast_tanh(k0 * (x + k1 * x * x * x));
     return 0.5f * x * (1.0f + t);
 }
 __device__ __forceinline__ float gelu_new_grad(float x) {
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    float t = tanhf(k0 * (x + k1 * x * x * x));
-    float dt = (1.0f - t * t) * k0 * (1.0f + 3.0f * k1 * x * x);
+    const float t = fast_tanh(k0 * (x + k1 * x * x * x));
+    const float dt = (1.0f - t * t) * k0 * (1.0f + 3.0f * k1 * x * x);
     return 0.5f * (1.0f + t) + 0.5f * x * dt;
 }
 
