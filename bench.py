@@ -170,9 +170,12 @@ def main():
 
     def one_step(i):
         eng.zero_grad()
-        loss = eng.forward_backward(tokens, embeds, reduce_stats=(reducer.reduce_stats if reducer else None))
-        if reducer:
-            reducer.all_reduce()
+        if reducer:   # all-reduce of each layer slice starts as soon as its backward kernels are enqueued
+            reducer.begin()
+            loss = eng.forward_backward(tokens, embeds, reduce_stats=reducer.reduce_stats, on_grads_ready=reducer.on_grads_ready)
+            reducer.finish()
+        else:
+            loss = eng.forward_backward(tokens, embeds)
         lr = base_lr * linear_schedule_factor(i, warm, total_steps + 1)
         for a in arenas:
             a.adamw_step(lr, i + 1)

@@ -48,6 +48,8 @@ SIGNATURES = {
     "cc_gpt2_sync_weights": (_I, [_GC, _P, _P, _P]),
     "cc_mapper_fwd": (_I, [_MC, _I, _P, _P, _P, _P, _P, _I, _P]),
     "cc_mapper_bwd": (_I, [_MC, _I, _P, _P, _P, _P, _P, _P]),
+    "cc_mapper_bwd_range": (_I, [_MC, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "cc_gpt2_bwd_range": (_I, [_GC, _GS, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "cc_gpt2_param_count": (_L, [_GC]),
     "cc_gpt2_param_offsets": (_I, [_GC, C.POINTER(_L)]),
     "cc_gpt2_ws_bytes": (_L, [_GC, _GS]),

@@ -403,7 +403,13 @@ int cc_mapper_fwd(const cc_mapper_cfg* c, int32_t B, const float* w32, const uin
 
 int cc_mapper_bwd(const cc_mapper_cfg* c, int32_t B, const float* w32, const uint16_t* w16, void* ws, const float* dout, float* g32,
                   void* stream) {
-    if (!mapper_cfg_ok(c) || B <= 0 || !w32 || !w16 || !ws || !dout || !g32) return CC_ERR_ARG;
+    if (!mapper_cfg_ok(c)) return CC_ERR_ARG;
+    return cc_mapper_bwd_range(c, B, w32, w16, ws, dout, g32, c->N, 0, stream);
+}
+
+int cc_mapper_bwd_range(const cc_mapper_cfg* c, int32_t B, const float* w32, const uint16_t* w16, void* ws, const float* dout, float* g32,
+                        int32_t l_hi, int32_t l_lo, void* stream) {
+    if (!mapper_cfg_ok(c) || B <= 0 || !w32 || !w16 || !ws || !dout || !g32 || l_lo < 0 || l_hi > c->N || l_lo > l_hi) return CC_ERR_ARG;
     hipStream_t st = S_(stream);
     MapperOff o;
     mapper_offsets(c, o);
@@ -412,11 +418,12 @@ int cc_mapper_bwd(const cc_mapper_cfg* c, int32_t B, const float* w32, const uin
     const int D = c->D, PP = c->W * c->P, S = PP + c->L, M = B * S, H = c->H, hd = D / H, Hm = c->Hm;
     const int PD = c->P * D;
     const uint16_t* w16t = w16 + o.total;   // transposed weight copies: dgrad GEMMs are NT
-    // seed: d x[N][:, PP:, :] = dout, rows [0:PP] = 0
-    if (hipMemsetAsync(w.dx32, 0, (size_t)M * D * sizeof(float), st) != hipSuccess) return CC_ERR_LAUNCH;
-    CC_TRY(copy_rows(dout, (size_t)c->L * D, w.dx32 + (size_t)PP * D, (size_t)S * D, c->L * D, B, st));
-    CC_TRY(f32_to_bf16(w.dx32, w.dx16, (size_t)M * D, st));
-    for (int l = c->N - 1; l >= 0; l--) {
+    if (l_hi == c->N) {   // seed: d x[N][:, PP:, :] = dout, rows [0:PP] = 0
+        if (hipMemsetAsync(w.dx32, 0, (size_t)M * D * sizeof(float), st) != hipSuccess) return CC_ERR_LAUNCH;
+        CC_TRY(copy_rows(dout, (size_t)c->L * D, w.dx32 + (size_t)PP * D, (size_t)S * D, c->L * D, B, st));
+        CC_TRY(f32_to_bf16(w.dx32, w.dx16, (size_t)M * D, st));
+    }
+    for (int l = l_hi - 1; l >= l_lo; l--) {
         const auto& y = o.layer[l];
         // fc2: y = h W2^T + b2
         CC_TIMED(CC_SITE_MAPPER_WGRAD_FC2, st, gemm_wgrad(w.dx16, D, w.h[l], Hm, D, Hm, M, g32 + y.w2, Hm, w.wg_scratch, st));
@@ -439,6 +446,7 @@ int cc_mapper_bwd(const cc_mapper_cfg* c, int32_t B, const float* w32, const uin
         CC_TRY(ln_bwd(w.dxn16, w.x[l], D, nullptr, w.mean1[l], w.rstd1[l], w32 + y.n1w, w.dx32, w.dx32, w.dx16, g32 + y.n1w,
                       g32 + y.n1b, M, D, st));
     }
+    if (l_lo > 0) return CC_OK;
     // prefix_const, pos_embeddings, linear
     CC_TRY(batch_sum(w.dx32 + (size_t)PP * D, (size_t)S * D, g32 + o.prefix, c->L * D, B, st));
     if (o.pos >= 0) CC_TRY(batch_sum(w.dx32, (size_t)S * D, g32 + o.pos, PP * D, B, st));
@@ -608,7 +616,14 @@ int cc_lmhead_ce_bwd(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* 
 
 int cc_gpt2_bwd(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, const uint16_t* w16, void* ws, const int64_t* tokens,
                 float* dprefix, float* g32, void* stream) {
-    if (!gpt2_cfg_ok(c) || !shape_ok(c, s) || s->mode < 1 || !w32 || !w16 || !ws || (s->L > 0 && !dprefix) || (s->mode == 2 && (!g32 || !tokens)))
+    if (!gpt2_cfg_ok(c)) return CC_ERR_ARG;
+    return cc_gpt2_bwd_range(c, s, w32, w16, ws, tokens, dprefix, g32, c->NL, 0, stream);
+}
+
+int cc_gpt2_bwd_range(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, const uint16_t* w16, void* ws, const int64_t* tokens,
+                      float* dprefix, float* g32, int32_t l_hi, int32_t l_lo, void* stream) {
+    if (!gpt2_cfg_ok(c) || !shape_ok(c, s) || s->mode < 1 || !w32 || !w16 || !ws || (s->L > 0 && !dprefix) || (s->mode == 2 && (!g32 || !tokens)) ||
+        l_lo < 0 || l_hi > c->NL || l_lo > l_hi)
         return CC_ERR_ARG;
     hipStream_t st = S_(stream);
     Gpt2Off o;
@@ -617,7 +632,7 @@ int cc_gpt2_bwd(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, 
     gpt2_carve(c, s->B, s->T, s->T - s->L, s->mode, ws, w);
     const int D = c->D, M = s->B * s->T, H = c->H, hd = D / H, D3 = 3 * D, D4 = 4 * D;
     const bool full = s->mode == 2;
-    for (int l = c->NL - 1; l >= 0; l--) {
+    for (int l = l_hi - 1; l >= l_lo; l--) {
         const auto& y = o.layer[l];
         // mlp.c_proj (Conv1D [4D, D]): y = hact W + b
         if (full) {
@@ -649,6 +664,7 @@ int cc_gpt2_bwd(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, 
         CC_TRY(ln_bwd(w.dxn16, w.x[l], D, nullptr, w.mean1[l], w.rstd1[l], w32 + y.l1w, w.dx32, w.dx32, w.dx16, full ? g32 + y.l1w : nullptr,
                       full ? g32 + y.l1b : nullptr, M, D, st));
     }
+    if (l_lo > 0) return CC_OK;
     if (s->L > 0) CC_TRY(copy_rows(w.dx32, (size_t)s->T * D, dprefix, (size_t)s->L * D, s->L * D, s->B, st));
     if (full)
         CC_TRY(embed_bwd(w.dx32, reinterpret_cast<const long long*>(tokens), s->cap, g32 + o.wte, g32 + o.wpe, s->B, s->L, s->T, D, st));

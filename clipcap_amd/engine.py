@@ -157,15 +157,41 @@ class MapperEngine:
         self._last = (B, emb)  # keep the input alive until backward has consumed the workspace
         return out
 
-    def backward(self, dout: torch.Tensor):
-        """Accumulates d loss / d params into the gradient arena; needs a preceding forward(save=True)."""
+    def layer_span(self, l: int) -> Tuple[int, int]:
+        """[lo, hi) element range of layer l's parameters in the arenas (layers are contiguous, head tensors come first)."""
+        lo = self.offsets[4 + 12 * l]
+        hi = self.offsets[4 + 12 * (l + 1)] if l + 1 < self.dims["N"] else self.arena.n
+        return lo, hi
+
+    def backward(self, dout: torch.Tensor, on_layers_done=None, group: int = 2):
+        """Accumulates d loss / d params into the gradient arena; needs a preceding forward(save=True).
+        on_layers_done(lo, hi): called right after the kernels of a slice of layers are enqueued, with the arena element range
+        whose gradients are then final — the hook the DDP reducer uses to overlap its all-reduce with the rest of backward."""
         B = dout.shape[0]
         dout = dout.to(dtype=torch.float32).contiguous()
         ws = self._ws.get((B, 1))
         if ws is None:
             raise RuntimeError("MapperEngine.backward without forward(save=True)")
-        check(_lib.lib().cc_mapper_bwd(C.byref(self.cfg), B, _p(self.arena.w32), _p(self.arena.w16), _p(ws), _p(dout), _p(self.arena.grads()),
-                                      _stream(self.arena.device)), "cc_mapper_bwd")
+        l = _lib.lib()
+        a = self.arena
+        N = self.dims["N"]
+        if on_layers_done is None:
+            check(l.cc_mapper_bwd(C.byref(self.cfg), B, _p(a.w32), _p(a.w16), _p(ws), _p(dout), _p(a.grads()), _stream(a.device)), "cc_mapper_bwd")
+            return
+        hi = N
+        while hi > 0:
+            lo = max(0, hi - group)
+            check(l.cc_mapper_bwd_range(C.byref(self.cfg), B, _p(a.w32), _p(a.w16), _p(ws), _p(dout), _p(a.grads()), hi, lo, _stream(a.device)),
+                  "cc_mapper_bwd_range")
+            if lo > 0:
+                on_layers_done(self.layer_span(lo)[0], self.layer_span(hi - 1)[1])
+            else:   # the l_lo == 0 call also produced the head tensors' gradients
+                on_layers_done(0, self.layer_span(hi - 1)[1])
+            hi = lo
+        if N == 0:
+            check(l.cc_mapper_bwd_range(C.byref(self.cfg), B, _p(a.w32), _p(a.w16), _p(ws), _p(dout), _p(a.grads()), 0, 0, _stream(a.device)),
+                  "cc_mapper_bwd_range")
+            on_layers_done(0, a.n)
 
 
 class Gpt2Engine:
@@ -202,6 +228,11 @@ class Gpt2Engine:
 
     views = MapperEngine.views
     to = MapperEngine.to
+
+    def layer_span(self, l: int) -> Tuple[int, int]:
+        lo = self.offsets[2 + 12 * l]
+        hi = self.offsets[2 + 12 * (l + 1)]      # the entry after the last layer is ln_f.weight
+        return lo, hi
 
     def shape(self, B: int, L: int, T: int, cap: int, mode: int) -> Gpt2Shape:
         return Gpt2Shape(B, L, T, cap, mode)
@@ -248,12 +279,16 @@ class ClipCapEngine:
         self.train_lm = train_lm
         self.stats: Optional[torch.Tensor] = None
 
-    def forward_backward(self, tokens: torch.Tensor, embeds: torch.Tensor, reduce_stats=None, backward: bool = True) -> torch.Tensor:
+    def forward_backward(self, tokens: torch.Tensor, embeds: torch.Tensor, reduce_stats=None, backward: bool = True,
+                         on_grads_ready=None) -> torch.Tensor:
         """tokens int64 (B,cap) padded with -1; embeds fp32 (B,E)/(B,W,E).
 
         Returns the mean loss over kept targets (device scalar).  Gradients are ACCUMULATED into the arenas' g32.
         ``reduce_stats(stats)``: optional in-place all-reduce of the 2-float [loss_sum, kept_count] tensor, so the divisor is the
         global kept-token count (N-rank == 1-rank gradients).
+        ``on_grads_ready(arena_index, lo, hi)``: optional; called as soon as the kernels producing gradient elements [lo, hi) of
+        arena 0 (mapper) / 1 (GPT-2) are enqueued, in the order backward finishes them (GPT-2 top layers first, mapper last), so
+        the caller can launch the all-reduce of that slice underneath the remaining backward kernels.
         """
         l = _lib.lib()
         g, m = self.gpt2, self.mapper
@@ -283,8 +318,19 @@ class ClipCapEngine:
             denom = stats[1:2]
             check(l.cc_lmhead_ce_bwd(C.byref(g.cfg), C.byref(shp), _p(ga.w32), _p(ga.w16), _p(ws), _p(denom), _p(g32), st), "cc_lmhead_ce_bwd")
             dprefix = torch.empty_like(prefix)
-            check(l.cc_gpt2_bwd(C.byref(g.cfg), C.byref(shp), _p(ga.w32), _p(ga.w16), _p(ws), _p(tokens), _p(dprefix), _p(g32), st), "cc_gpt2_bwd")
-            m.backward(dprefix)
+            if on_grads_ready is None or not self.train_lm:
+                check(l.cc_gpt2_bwd(C.byref(g.cfg), C.byref(shp), _p(ga.w32), _p(ga.w16), _p(ws), _p(tokens), _p(dprefix), _p(g32), st), "cc_gpt2_bwd")
+            else:
+                NL, grp = g.dims["NL"], 2
+                on_grads_ready(1, g.layer_span(NL - 1)[1], ga.n)                    # ln_f (from cc_lmhead_ce_bwd)
+                hi = NL
+                while hi > 0:
+                    lo = max(0, hi - grp)
+                    check(l.cc_gpt2_bwd_range(C.byref(g.cfg), C.byref(shp), _p(ga.w32), _p(ga.w16), _p(ws), _p(tokens), _p(dprefix), _p(g32),
+                                              hi, lo, st), "cc_gpt2_bwd_range")
+                    on_grads_ready(1, g.layer_span(lo)[0] if lo > 0 else 0, g.layer_span(hi - 1)[1])   # lo == 0: + wte / wpe
+                    hi = lo
+            m.backward(dprefix, on_layers_done=(None if on_grads_ready is None else (lambda lo, hi: on_grads_ready(0, lo, hi))))
         return stats[0] / stats[1].clamp_min(1.0)
 
     def zero_grad(self):

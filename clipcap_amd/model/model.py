@@ -87,9 +87,12 @@ class ClipCapModel(nn.Module):
         tokens, embeds = batch
         eng = self.engine
         eng.zero_grad()
-        loss = eng.forward_backward(tokens, embeds, reduce_stats=(reducer.reduce_stats if reducer is not None else None))
         if reducer is not None:
-            reducer.all_reduce()
+            reducer.begin()
+            loss = eng.forward_backward(tokens, embeds, reduce_stats=reducer.reduce_stats, on_grads_ready=reducer.on_grads_ready)
+            reducer.finish()
+        else:
+            loss = eng.forward_backward(tokens, embeds)
         self._opt_step += 1
         self.transformer_mapper.engine.arena.adamw_step(lr, self._opt_step)
         if self._train_lm:

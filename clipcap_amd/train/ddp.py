@@ -46,6 +46,29 @@ class GradReducer:
         dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.group)
 
     def all_reduce(self) -> None:
+        """Non-overlapped form: everything at once, after backward."""
         works = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for b in self.buckets]
         for w in works:
             w.wait()
+
+    # ---- overlapped form: slices are reduced as backward finishes them ------------------------------------------
+    def begin(self) -> None:
+        self._works = []
+        self._covered = [0] * len(self.flats)
+
+    def on_grads_ready(self, arena: int, lo: int, hi: int) -> None:
+        """Backward has enqueued every kernel that writes flats[arena][lo:hi]: start its all-reduce now.  The collective is
+        ordered after those kernels (ProcessGroupNCCL waits on the current stream) and runs on RCCL's own stream, i.e. under
+        the backward kernels of the layers below."""
+        if hi <= lo:
+            return
+        self._works.append(dist.all_reduce(self.flats[arena][lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._covered[arena] += hi - lo
+
+    def finish(self) -> None:
+        """Blocks the current stream until every slice is reduced; checks that the slices tiled each arena exactly once."""
+        for w in self._works:
+            w.wait()
+        for f, c in zip(self.flats, self._covered):
+            assert c == f.numel(), f"overlapped all-reduce covered {c} of {f.numel()} gradient elements"
+        self._works = []

@@ -78,6 +78,11 @@ int cc_mapper_fwd(const cc_mapper_cfg* cfg, int32_t B, const float* w32, const u
  * g32 (flat, same offsets as w32) is ACCUMULATED into.  Requires the workspace of a save=1 forward. */
 int cc_mapper_bwd(const cc_mapper_cfg* cfg, int32_t B, const float* w32, const uint16_t* w16, void* ws, const float* dout,
                   float* g32, void* stream);
+/* the same, one slice of layers [l_lo, l_hi) at a time, called with descending ranges (first l_hi == N seeds from dout, the call
+ * with l_lo == 0 also produces the linear / prefix_const / pos_embeddings gradients).  Lets the caller start the RCCL
+ * all-reduce of a layer's gradient slice while the layers below it are still in backward. */
+int cc_mapper_bwd_range(const cc_mapper_cfg* cfg, int32_t B, const float* w32, const uint16_t* w16, void* ws, const float* dout,
+                        float* g32, int32_t l_hi, int32_t l_lo, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * GPT-2: transformers GPT2LMHeadModel as called by model.py:56 / inference/base.py:81 with inputs_embeds
@@ -140,6 +145,9 @@ int cc_lmhead_ce_bwd(const cc_gpt2_cfg* cfg, const cc_gpt2_shape* shp, const flo
  * mode 2 additionally accumulates all GPT-2 weight gradients (incl. wte/wpe) into g32. */
 int cc_gpt2_bwd(const cc_gpt2_cfg* cfg, const cc_gpt2_shape* shp, const float* w32, const uint16_t* w16, void* ws,
                 const int64_t* tokens, float* dprefix, float* g32, void* stream);
+/* blocks [l_lo, l_hi) only, descending ranges; the call with l_lo == 0 also writes dprefix (and wte/wpe gradients in mode 2) */
+int cc_gpt2_bwd_range(const cc_gpt2_cfg* cfg, const cc_gpt2_shape* shp, const float* w32, const uint16_t* w16, void* ws,
+                      const int64_t* tokens, float* dprefix, float* g32, int32_t l_hi, int32_t l_lo, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * KV-cached decode (replaces the full re-forward of inference/base.py:81 per step).

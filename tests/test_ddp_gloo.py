@@ -64,7 +64,14 @@ def _worker(rank, world, port, out):
     red.reduce_stats(stats)                      # global kept-token count
     g, local_sum = _grads_flat(sd, names, tk, em, cfg, denom=float(stats[1]))
     flat.copy_(g)
-    red.all_reduce()
+    if rank == 0:      # exercise both forms: they must agree
+        pass
+    n = flat.numel()
+    red.begin()        # overlapped form: slices handed over from the top of the arena to the bottom, like backward does
+    cuts = [n, n - n // 3, n // 4, 0]
+    for hi, lo in zip(cuts, cuts[1:]):
+        red.on_grads_ready(0, lo, hi)
+    red.finish()
     loss_stats = torch.tensor([local_sum])
     dist.all_reduce(loss_stats)
     if rank == 0:

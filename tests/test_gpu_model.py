@@ -160,3 +160,32 @@ def test_gpt2_small_width_logits_vs_oracle():
           f"{floor:.3e}]; vs fp32 oracle {e2:.3e}; bf16-points oracle vs fp32 oracle {drift:.3e}")
     assert e1 <= max(1e-3, 4.0 * floor) and e1 <= 3e-2
     assert e2 <= 1.5 * drift + 1e-3
+
+
+@pytest.mark.parametrize("mode", ["prefix_only", "full"])
+def test_layer_range_backward_equals_full_backward(mode):
+    """The sliced backward used for all-reduce overlap (cc_*_bwd_range + on_grads_ready) produces the same gradients as the
+    single-call backward, and its ready-ranges tile each gradient arena exactly once, top layers first."""
+    from clipcap_amd.engine import ClipCapEngine
+    g = load_golden(f"train_{mode}")
+    E, D, P, L, H, N, n_head, n_layer, V, npos = [int(v) for v in g["cfg"]]
+    sd = sd_of(g)
+    msd = {k[len("transformer_mapper."):]: v for k, v in sd.items() if k.startswith("transformer_mapper.")}
+    gsd = {k[len("language_model."):]: v for k, v in sd.items() if k.startswith("language_model.") and "lm_head" not in k}
+    tokens, embeds = torch.from_numpy(g["in.tokens"]).cuda(), torch.from_numpy(g["in.embeds"]).cuda()
+    grads = []
+    for sliced in (False, True):
+        me, ge = _mapper_engine(msd, E, D, P, L, H, N), _gpt2_engine(gsd, D, n_layer, n_head, V, npos)
+        eng = ClipCapEngine(me, ge, train_lm=(mode == "full"))
+        spans = []
+        eng.forward_backward(tokens, embeds, on_grads_ready=(lambda a, lo, hi: spans.append((a, lo, hi))) if sliced else None)
+        grads.append((me.arena.g32.clone(), ge.arena.g32.clone() if mode == "full" else None))
+        if sliced:
+            for arena, n in ((0, me.arena.n),) + (((1, ge.arena.n),) if mode == "full" else ()):
+                mine = sorted((lo, hi) for a, lo, hi in spans if a == arena)
+                assert mine[0][0] == 0 and mine[-1][1] == n and all(x[1] == y[0] for x, y in zip(mine, mine[1:])), mine
+            order = [a for a, _, _ in spans]
+            assert order == sorted(order, reverse=True)     # GPT-2 slices (arena 1) are ready before the mapper's (arena 0)
+    assert torch.allclose(grads[0][0], grads[1][0], rtol=1e-4, atol=1e-7)
+    if mode == "full":
+        assert torch.allclose(grads[0][1], grads[1][1], rtol=1e-4, atol=1e-7)
