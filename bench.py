@@ -130,8 +130,44 @@ def cpu_baseline(c, max_seconds=25.0):
             "sample": f"oracle fp32 torch-CPU training step (fwd+bwd+AdamW), same model, batch {Bc}, {len(times)} steps, median of steady steps"}
 
 
+def decode_bench(args, device):
+    """BASELINE configs[4]: beam-search (beam=5) caption decode, GPT-2-medium, KV-cached HIP kernels, 64 prefixes per step.
+    A "step" = decoding the whole batch (prefill of the 10-row prefix + up to 67 generated tokens per beam)."""
+    from types import SimpleNamespace
+    from clipcap_amd.inference.base import generate_beam_tokens
+    from clipcap_amd.model.gpt2 import GPT2LM
+    torch.manual_seed(1234)
+    lm = GPT2LM(n_embd=1024, n_layer=24, n_head=16, vocab_size=50257, n_positions=1024).to(device)
+    model = SimpleNamespace(language_model=lm)
+    S, L, beam, entry = args.batch or 64, 10, 5, 67
+    prefix = torch.randn(S, L, 1024, device=device) * 0.5
+    gen = 0
+    for _ in range(max(1, args.warmup)):
+        generate_beam_tokens(model, prefix, beam, entry, 1.0, 50256)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        toks, scores, lens = generate_beam_tokens(model, prefix, beam, entry, 1.0, 50256)
+        best = scores.argmax(dim=1)
+        gen += int(lens.gather(1, best[:, None]).sum())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    steps_per_decode = toks.shape[2]
+    wbytes = 2.0 * (lm.engine.arena.n - (lm.engine.dims["NPOS"] * 1024))     # bf16 weights read once per decode step
+    return {"metric": "decode tok/s (beam=5, GPT-2-medium, KV cache)", "value": round(gen / dt, 1), "unit": "tokens/s", "n_gpus": 1,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4]: beam=5 decode, GPT-2-medium random init, 64 prefixes x 10 rows, 67 new tokens",
+                       "prefixes": S, "beam": beam, "entry_length": entry, "generated_steps": steps_per_decode},
+            "beam_tokens_per_s": round(gen * beam / dt, 1),
+            "roofline": {"bound": "hbm", "kernel": "whole decode step (weights once per generated position)",
+                         "achieved": round(wbytes * steps_per_decode * args.steps / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(wbytes * steps_per_decode * args.steps / dt / 8e12, 4), "traffic": None}}
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", default="train", choices=["train", "decode"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
@@ -151,6 +187,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)   # "nccl" is RCCL on ROCm
+    if args.mode == "decode":
+        if rank == 0:
+            print(json.dumps(decode_bench(args, device)))
+        return
     c = dict(CONFIGS[args.config])
     if args.batch:
         c["B"] = args.batch

@@ -61,7 +61,7 @@ SIGNATURES = {
     "cc_lmhead_ce_bwd": (_I, [_GC, _GS, _P, _P, _P, _P, _P, _P]),
     "cc_gpt2_bwd": (_I, [_GC, _GS, _P, _P, _P, _P, _P, _P, _P]),
     "cc_decode_ws_bytes": (_L, [_GC, _I, _I]),
-    "cc_decode_fwd": (_I, [_GC, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "cc_decode_fwd": (_I, [_GC, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     "cc_decode_reorder": (_I, [_GC, _I, _I, _I, _I, _P, _P, _P, _P]),
     "cc_beam_step": (_I, [_I, _I, _I, _P, _L, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "cc_beam_ws_bytes": (_L, [_I, _I, _I]),

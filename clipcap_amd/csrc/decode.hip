@@ -46,8 +46,8 @@ __global__ void k_kv_append(const bf16_t* __restrict__ qkv, bf16_t* __restrict__
 
 // attention of the Tn new queries of every row against the cache (ctx = pos0 + Tn, causal): one wave per (r,h,t)
 __global__ __launch_bounds__(256) void k_decode_attn(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ kc,
-                                                     const bf16_t* __restrict__ vc, bf16_t* __restrict__ out, int R, int Tn, int H, int hd,
-                                                     int pos0, int ctx_max, float scale) {
+                                                     const bf16_t* __restrict__ vc, const int* __restrict__ row_map, bf16_t* __restrict__ out,
+                                                     int R, int Tn, int H, int hd, int pos0, int ctx_max, float scale) {
     extern __shared__ float psm[];  // [4][ctx_max]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gid = blockIdx.x * 4 + wave;
@@ -56,15 +56,19 @@ __global__ __launch_bounds__(256) void k_decode_attn(const bf16_t* __restrict__ 
     const int D = H * hd, nkeys = pos0 + t + 1;
     float* p = psm + wave * ctx_max;
     const bf16_t* q = qkv + ((size_t)r * Tn + t) * 3 * D + h * hd;
-    const bf16_t* kb = kc + (size_t)r * ctx_max * D + h * hd;
-    const bf16_t* vb = vc + (size_t)r * ctx_max * D + h * hd;
+    // position j of row r lives in cache row row_map[j*R + r] (beam ancestry table; identity when null)
+    const bf16_t* kb = kc + h * hd;
+    const bf16_t* vb = vc + h * hd;
+    int* srow = reinterpret_cast<int*>(psm + 4 * ctx_max) + wave * ctx_max;
+    for (int j = lane; j < nkeys; j += 64) srow[j] = row_map ? row_map[(size_t)j * R + r] : r;
     float m = -INFINITY;
     for (int j = lane; j < nkeys; j += 64) {
         float s = 0.f;
+        const bf16_t* krow = kb + ((size_t)srow[j] * ctx_max + j) * D;
         for (int d = 0; d < hd; d += 8) {
             float a[8], b[8];
             unpack8(*reinterpret_cast<const uint4*>(q + d), a);
-            unpack8(*reinterpret_cast<const uint4*>(kb + (size_t)j * D + d), b);
+            unpack8(*reinterpret_cast<const uint4*>(krow + d), b);
 #pragma unroll
             for (int e = 0; e < 8; e++) s += a[e] * b[e];
         }
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(256) void k_decode_attn(const bf16_t* __restrict__ 
     // wave-private LDS: same-wave writes above are visible to the reads below (in-order DS queue)
     for (int d = lane; d < hd; d += 64) {
         float o = 0.f;
-        for (int j = 0; j < nkeys; j++) o += p[j] * bf2f(vb[(size_t)j * D + d]);
+        for (int j = 0; j < nkeys; j++) o += p[j] * bf2f(vb[((size_t)srow[j] * ctx_max + j) * D + d]);
         out[((size_t)r * Tn + t) * D + h * hd + d] = f2bf(o * inv);
     }
 }
@@ -280,11 +284,11 @@ int64_t cc_decode_ws_bytes(const cc_gpt2_cfg* cfg, int32_t R, int32_t Tnew) {
 }
 
 int cc_decode_fwd(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int32_t ctx_max, const float* w32, const uint16_t* w16,
-                  const float* x, uint16_t* kv, void* ws, float* logits, int64_t ldl, void* stream) {
+                  const float* x, uint16_t* kv, const int32_t* row_map, void* ws, float* logits, int64_t ldl, void* stream) {
     if (!cfg_ok(c) || R <= 0 || Tn <= 0 || pos0 < 0 || !w32 || !w16 || !x || !kv || !ws || !logits) return CC_ERR_ARG;
     const int Ns = std::min(c->Vp, (c->V + 7) / 8 * 8);
     if (pos0 + Tn > ctx_max || pos0 + Tn > c->NPOS || ldl < Ns || (ldl & 3) || ldl > 0x7fffffff) return CC_ERR_SHAPE;
-    if ((size_t)4 * ctx_max * sizeof(float) > 64 * 1024) return CC_ERR_SHAPE;
+    if ((size_t)8 * ctx_max * sizeof(float) > 64 * 1024) return CC_ERR_SHAPE;
     hipStream_t st = S_(stream);
     DecWS w;
     dec_carve(c, R, Tn, ws, w);
@@ -323,8 +327,8 @@ int cc_decode_fwd(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int
             hipLaunchKernelGGL(k_kv_append, dim3((int)std::min<size_t>((total + 255) / 256, 2048)), dim3(256), 0, st, w.qkv, kc, vc, R, Tn, D, pos0,
                                ctx_max);
             const int nw = R * H * Tn;
-            hipLaunchKernelGGL(k_decode_attn, dim3((nw + 3) / 4), dim3(256), (size_t)4 * ctx_max * sizeof(float), st, w.qkv, kc, vc, w.att, R, Tn, H,
-                               hd, pos0, ctx_max, scale);
+            hipLaunchKernelGGL(k_decode_attn, dim3((nw + 3) / 4), dim3(256), (size_t)8 * ctx_max * sizeof(float), st, w.qkv, kc, vc, row_map, w.att, R,
+                               Tn, H, hd, pos0, ctx_max, scale);
         }
         CC_TRY(gemm_resid(0, 0, w.att, D, w16t + pw, D, M, D, D, w.x1, w.x, D, w32 + pb, st));
         CC_TRY(ln_fwd(w.x1, D, nullptr, w32 + l2w, w32 + l2b, w.xn, nullptr, nullptr, nullptr, M, D, st));

@@ -341,9 +341,9 @@ class ClipCapEngine:
 
 
 class DecodeSession:
-    """KV-cached GPT-2 decode state for R independent rows (replaces the per-step full re-forward of the reference's
-    inference/base.py:81).  The cache is bf16 [n_layer][2][R][ctx_max][D], owned here; rows can be re-gathered after a
-    beam step (base.py:93,113) with ``reorder``."""
+    """KV-cached GPT-2 decode state for R rows (replaces the per-step full re-forward of the reference's inference/base.py:81).
+    The cache is bf16 [n_layer][2][R][ctx_max][D], owned here.  A beam reorder (base.py:93,113) does not move cache data: a small
+    int32 ancestry table ``row_map[j][r]`` names the cache row that holds position j of logical row r, and ``reorder`` permutes it."""
 
     def __init__(self, gpt2: Gpt2Engine, rows: int, ctx_max: int):
         _require_cuda(gpt2.arena.w32, "DecodeSession")
@@ -352,8 +352,11 @@ class DecodeSession:
         self.ctx_max = min(ctx_max, gpt2.dims["NPOS"])
         self.pos = 0
         d = gpt2.dims
-        self.kv = torch.empty(d["NL"] * 2 * rows * self.ctx_max * d["D"], dtype=torch.bfloat16, device=gpt2.arena.device)
+        dev = gpt2.arena.device
+        self.kv = torch.empty(d["NL"] * 2 * rows * self.ctx_max * d["D"], dtype=torch.bfloat16, device=dev)
+        self.row_map = torch.arange(rows, dtype=torch.int32, device=dev).repeat(self.ctx_max, 1).contiguous()
         self._ws: Dict[int, torch.Tensor] = {}
+        self._logits: Optional[torch.Tensor] = None
 
     def _workspace(self, tn: int) -> torch.Tensor:
         ws = self._ws.get(tn)
@@ -364,28 +367,41 @@ class DecodeSession:
             self._ws[tn] = ws
         return ws
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        """x fp32 (R, Tnew, D) input embeddings (no positional term) -> fp32 logits of the last new position (R, V)."""
+    def forward(self, x: torch.Tensor, rows: Optional[int] = None) -> torch.Tensor:
+        """x fp32 (R', Tnew, D) input embeddings (no positional term), R' <= R active rows -> fp32 logits of the last new
+        position (R', V).  Valid until the next forward()."""
         g = self.g
         x = x.to(device=g.arena.device, dtype=torch.float32).contiguous()
-        R, tn, D = x.shape
-        assert R == self.R and D == g.dims["D"]
+        Ra, tn, D = x.shape
+        assert Ra <= self.R and D == g.dims["D"]
         if self.pos + tn > self.ctx_max:
             raise RuntimeError(f"decode context overflow: {self.pos}+{tn} > {self.ctx_max}")
         g.arena.sync_bf16()
         Vp = g.dims["Vp"]
-        logits = torch.empty(R, Vp, dtype=torch.float32, device=g.arena.device)
-        check(_lib.lib().cc_decode_fwd(C.byref(g.cfg), R, tn, self.pos, self.ctx_max, _p(g.arena.w32), _p(g.arena.w16), _p(x), _p(self.kv),
-                                      _p(self._workspace(tn)), _p(logits), Vp, _stream(g.arena.device)), "cc_decode_fwd")
+        if self._logits is None:
+            self._logits = torch.empty(self.R, Vp, dtype=torch.float32, device=g.arena.device)
+        logits = self._logits[:Ra]
+        if Ra != self.R:   # fewer active rows (prefill with one row per sample): the cache row stride is still R rows
+            raise RuntimeError("partial-row forward is expressed through a narrower session; use expand()")
+        check(_lib.lib().cc_decode_fwd(C.byref(g.cfg), Ra, tn, self.pos, self.ctx_max, _p(g.arena.w32), _p(g.arena.w16), _p(x), _p(self.kv),
+                                      _p(self.row_map), _p(self._workspace(tn)), _p(logits), Vp, _stream(g.arena.device)), "cc_decode_fwd")
         self.pos += tn
         return logits[:, : g.dims["V"]]
 
-    def reorder(self, src_rows: torch.Tensor, rows_out: Optional[int] = None) -> "DecodeSession":
-        """Returns a session whose row r holds the history of this session's row src_rows[r] (int32 device tensor)."""
-        rows_out = int(src_rows.numel()) if rows_out is None else rows_out
+    def reorder(self, src_rows: torch.Tensor) -> "DecodeSession":
+        """Logical row r continues the history of logical row src_rows[r] (same row count): permutes the ancestry table in place."""
+        src = src_rows.to(device=self.g.arena.device, dtype=torch.int64)
+        if self.pos > 0:
+            self.row_map[: self.pos] = self.row_map[: self.pos].index_select(1, src)
+        return self
+
+    def expand(self, src_rows: torch.Tensor, rows_out: int) -> "DecodeSession":
+        """A wider session (rows_out rows) whose row r starts from this session's row src_rows[r] (beam fan-out after the prefill,
+        base.py:93).  The prefix K/V are copied once (cc_decode_reorder)."""
         out = DecodeSession(self.g, rows_out, self.ctx_max)
         out.pos = self.pos
-        src = src_rows.to(device=self.g.arena.device, dtype=torch.int32).contiguous()
+        src = self.row_map[0].index_select(0, src_rows.to(device=self.g.arena.device, dtype=torch.int64)).to(torch.int32).contiguous() \
+            if self.pos > 0 else src_rows.to(device=self.g.arena.device, dtype=torch.int32).contiguous()
         check(_lib.lib().cc_decode_reorder(C.byref(self.g.cfg), self.R, rows_out, self.pos, self.ctx_max, _p(self.kv), _p(out.kv), _p(src),
                                           _stream(self.g.arena.device)), "cc_decode_reorder")
         return out

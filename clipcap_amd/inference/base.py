@@ -50,16 +50,19 @@ def generate_beam_tokens(model, embeds: torch.Tensor, beam_size: int = 5, entry_
     lg = torch.empty(R, V, dtype=torch.float32, device=dev)
     lg[::beam_size] = logits0                                                   # row 0 of every beam set
     next_tok, src = beam_step(lg, S, beam_size, temperature, True, stop_token, scores, seq_lengths, has_stopped)
-    sess = sess.reorder((base // beam_size).to(torch.int32), R)
+    sess = sess.expand((base // beam_size).to(torch.int32), R)
     tokens = next_tok.to(torch.int64).view(R, 1)
-    for _ in range(1, entry_length):
-        if bool(has_stopped.all()):                                             # base.py:120-121
+    for step in range(1, entry_length):
+        # base.py:120-121 breaks as soon as every beam has stopped.  Steps taken after that point only append token 0 to frozen
+        # beams (scores, lengths and the truncated outputs are unchanged), so polling the flag every 4th step — one host sync
+        # instead of four — cannot change the result.
+        if step % 4 == 1 and bool(has_stopped.all()):
             break
         x = wte[next_tok.to(torch.int64)].view(R, 1, D)                         # base.py:117
         logits = sess.forward(x)
         next_tok, src = beam_step(logits, S, beam_size, temperature, False, stop_token, scores, seq_lengths, has_stopped)
         gsrc = base + src
-        sess = sess.reorder(gsrc, R)
+        sess = sess.reorder(gsrc)
         tokens = torch.cat((tokens[gsrc.to(torch.int64)], next_tok.to(torch.int64).view(R, 1)), dim=1)
     final = scores / seq_lengths                                                # base.py:123
     return tokens.view(S, beam_size, -1), final.view(S, beam_size), seq_lengths.view(S, beam_size)

@@ -107,9 +107,21 @@ def test_kv_cached_decode_equals_full_forward():
     for t in range(4, 9):
         lt = sess.forward(x[:, t:t + 1])
         assert (lt - full[:, t]).abs().max().item() <= 2e-3, t
-    # reorder / fan-out keeps histories
-    s2 = sess.reorder(torch.tensor([2, 2, 0, 1], dtype=torch.int32, device="cuda"))
+    # fan-out (copy) then in-place ancestry reorder keep every row's history
+    src = torch.tensor([2, 2, 0, 1], dtype=torch.int32, device="cuda")
+    s2 = sess.expand(src, 4)
     assert s2.R == 4 and s2.pos == 9
+    x2 = torch.randn(4, 2, 64, device="cuda") * 0.5
+    l9 = s2.forward(x2[:, :1]).clone()   # the logits buffer is reused by the next forward()
+    perm = torch.tensor([1, 0, 3, 3], dtype=torch.int32, device="cuda")
+    s2.reorder(perm)
+    l10 = s2.forward(x2[:, 1:2])
+    for r in range(4):
+        hist = torch.cat((x[int(src[r])], x2[r, :1]))[None]
+        assert (l9[r] - eng.logits(hist)[0, -1]).abs().max().item() <= 2e-3
+        pr = int(perm[r])
+        hist2 = torch.cat((x[int(src[pr])], x2[pr, :1], x2[r, 1:2]))[None]
+        assert (l10[r] - eng.logits(hist2)[0, -1]).abs().max().item() <= 2e-3, r
 
 
 def test_generate_beam_matches_reference_tokens():
