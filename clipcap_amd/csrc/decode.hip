@@ -124,81 +124,53 @@ __global__ void k_embed_tokens(const float* __restrict__ wte, const int* __restr
     }
 }
 
-// ---- beam step: one block per sample ------------------------------------------------------------------------
+// ---- beam step (base.py:84-119) in three small kernels so that all CUs take part --------------------------------
+//   k_beam_rowstats : one block per (sample, beam row): max and sum(exp) of logits/temperature
+//   k_beam_partial  : grid (sample, chunk): top-`beam` of the length-normalised candidate scores inside one slice of the
+//                     flattened beam*V candidate space (thread-local insertion lists + block-wide selection)
+//   k_beam_final    : one block per sample merges the chunk winners, then gathers / updates scores, lengths, stopped flags
+// Ties resolve to the lowest flat index b*V + v.
 constexpr int BEAM_MAX = 16;
+constexpr int BEAM_CHUNKS = 16;
 
 __device__ __forceinline__ bool cand_better(float a, int ia, float b, int ib) { return a > b || (a == b && ia < ib); }
 
-__global__ __launch_bounds__(256) void k_beam_step(const float* __restrict__ logits, size_t ldl, int beam, int V, float inv_temp, int first,
-                                                   int stop_token, float* __restrict__ scores, float* __restrict__ seq_len,
-                                                   unsigned char* __restrict__ stopped, int* __restrict__ next_tok, int* __restrict__ src_row) {
+__global__ __launch_bounds__(256) void k_beam_rowstats(const float* __restrict__ logits, size_t ldl, int V, float inv_temp, float* __restrict__ rs) {
     __shared__ float red[256];
-    __shared__ int redi[256];
-    __shared__ float row_m[BEAM_MAX], row_s[BEAM_MAX];
-    __shared__ float cval[256 * BEAM_MAX];
-    __shared__ int cidx[256 * BEAM_MAX];
-    __shared__ float sel_v[BEAM_MAX];
-    __shared__ int sel_i[BEAM_MAX];
-    const int s = blockIdx.x, tid = threadIdx.x;
-    const int nrows = first ? 1 : beam;
-    const float* lg = logits + (size_t)s * beam * ldl;
-    // per-row softmax statistics (base.py:83-84: logits/temperature -> softmax -> log)
-    for (int b = 0; b < nrows; b++) {
-        float m = -INFINITY;
-        for (int v = tid; v < V; v += 256) m = fmaxf(m, lg[(size_t)b * ldl + v] * inv_temp);
-        red[tid] = m;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]);
-            __syncthreads();
-        }
-        m = red[0];
-        __syncthreads();
-        float sum = 0.f;
-        for (int v = tid; v < V; v += 256) sum += expf(lg[(size_t)b * ldl + v] * inv_temp - m);
-        red[tid] = sum;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if (tid < o) red[tid] += red[tid + o];
-            __syncthreads();
-        }
-        if (tid == 0) { row_m[b] = m; row_s[b] = red[0]; }
-        __syncthreads();
-    }
-    // thread-local top-`beam` of the length-normalised candidate scores
-    float lv[BEAM_MAX];
-    int li[BEAM_MAX];
-#pragma unroll
-    for (int k = 0; k < BEAM_MAX; k++) { lv[k] = -INFINITY; li[k] = 0x7fffffff; }
-    for (int b = 0; b < nrows; b++) {
-        const bool st = !first && stopped[s * beam + b];
-        const float sc = first ? 0.f : scores[s * beam + b];
-        const float len = first ? 1.f : seq_len[s * beam + b] + (st ? 0.f : 1.f);
-        for (int v = tid; v < V; v += 256) {
-            float lp;
-            if (st) lp = (v == 0) ? 0.f : -INFINITY;                                              // base.py:96-97
-            else lp = logf(expf(lg[(size_t)b * ldl + v] * inv_temp - row_m[b]) / row_s[b]);       // softmax().log()
-            const float val = first ? lp : (sc + lp) / len;                                       // base.py:99-101
-            const int idx = b * V + v;
-            if (cand_better(val, idx, lv[beam - 1], li[beam - 1])) {
-                int k = beam - 1;
-                while (k > 0 && cand_better(val, idx, lv[k - 1], li[k - 1])) { lv[k] = lv[k - 1]; li[k] = li[k - 1]; k--; }
-                lv[k] = val; li[k] = idx;
-            }
-        }
-    }
-    for (int k = 0; k < beam; k++) { cval[tid * beam + k] = lv[k]; cidx[tid * beam + k] = li[k]; }
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const float* lg = logits + (size_t)row * ldl;
+    float m = -INFINITY;
+    for (int v = tid; v < V; v += 256) m = fmaxf(m, lg[v] * inv_temp);
+    red[tid] = m;
     __syncthreads();
-    // `beam` rounds of block-wide arg-best over the 256*beam candidates
-    const int ncand = 256 * beam;
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]);
+        __syncthreads();
+    }
+    m = red[0];
+    __syncthreads();
+    float sum = 0.f;
+    for (int v = tid; v < V; v += 256) sum += expf(lg[v] * inv_temp - m);
+    red[tid] = sum;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) { rs[2 * row] = m; rs[2 * row + 1] = red[0]; }
+}
+
+// block-wide selection of the `beam` best of ncand (value, index) candidates held in LDS; results in sel_v / sel_i
+__device__ __forceinline__ void select_top(float* cval, int* cidx, int ncand, int beam, float* red, int* redi, float* sel_v, int* sel_i, int tid,
+                                           int nthreads) {
     for (int k = 0; k < beam; k++) {
         float bv = -INFINITY;
         int bi = 0x7fffffff, bp = -1;
-        for (int c = tid; c < ncand; c += 256)
+        for (int c = tid; c < ncand; c += nthreads)
             if (cidx[c] != 0x7fffffff && (bp < 0 || cand_better(cval[c], cidx[c], bv, bi))) { bv = cval[c]; bi = cidx[c]; bp = c; }
         red[tid] = bv; redi[tid] = bp;
         __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
+        for (int o = nthreads >> 1; o > 0; o >>= 1) {
             if (tid < o) {
                 const int pa = redi[tid], pb = redi[tid + o];
                 if (pb >= 0 && (pa < 0 || cand_better(red[tid + o], cidx[pb], red[tid], cidx[pa]))) { red[tid] = red[tid + o]; redi[tid] = pb; }
@@ -207,33 +179,90 @@ __global__ __launch_bounds__(256) void k_beam_step(const float* __restrict__ log
         }
         if (tid == 0) {
             const int pos = redi[0];
-            sel_v[k] = cval[pos]; sel_i[k] = cidx[pos];
-            cidx[pos] = 0x7fffffff;  // consumed
+            if (pos >= 0) { sel_v[k] = cval[pos]; sel_i[k] = cidx[pos]; cidx[pos] = 0x7fffffff; }
+            else { sel_v[k] = -INFINITY; sel_i[k] = 0x7fffffff; }
         }
         __syncthreads();
     }
-    // gather / update state (base.py:86-119)
+}
+
+__global__ __launch_bounds__(256) void k_beam_partial(const float* __restrict__ logits, size_t ldl, int beam, int V, float inv_temp, int first,
+                                                      const float* __restrict__ rs, const float* __restrict__ scores,
+                                                      const float* __restrict__ seq_len, const unsigned char* __restrict__ stopped,
+                                                      float* __restrict__ pval, int* __restrict__ pidx) {
+    __shared__ float red[256];
+    __shared__ int redi[256];
+    __shared__ float cval[256 * BEAM_MAX];
+    __shared__ int cidx[256 * BEAM_MAX];
+    __shared__ float sel_v[BEAM_MAX];
+    __shared__ int sel_i[BEAM_MAX];
+    const int s = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
+    const int nrows = first ? 1 : beam;
+    const int total = nrows * V;
+    const int per = (total + BEAM_CHUNKS - 1) / BEAM_CHUNKS;
+    const int lo = ch * per, hi = min(total, lo + per);
+    const float* lg = logits + (size_t)s * beam * ldl;
+    float lv[BEAM_MAX];
+    int li[BEAM_MAX];
+#pragma unroll
+    for (int k = 0; k < BEAM_MAX; k++) { lv[k] = -INFINITY; li[k] = 0x7fffffff; }
+    for (int idx = lo + tid; idx < hi; idx += 256) {
+        const int b = idx / V, v = idx - b * V;
+        const bool st = !first && stopped[s * beam + b];
+        float lp;
+        if (st) lp = (v == 0) ? 0.f : -INFINITY;                                                          // base.py:96-97
+        else lp = logf(expf(lg[(size_t)b * ldl + v] * inv_temp - rs[2 * (s * beam + b)]) / rs[2 * (s * beam + b) + 1]);   // softmax().log()
+        const float val = first ? lp : (scores[s * beam + b] + lp) / (seq_len[s * beam + b] + (st ? 0.f : 1.f));    // base.py:99-101
+        if (cand_better(val, idx, lv[beam - 1], li[beam - 1])) {
+            int k = beam - 1;
+            while (k > 0 && cand_better(val, idx, lv[k - 1], li[k - 1])) { lv[k] = lv[k - 1]; li[k] = li[k - 1]; k--; }
+            lv[k] = val; li[k] = idx;
+        }
+    }
+    for (int k = 0; k < beam; k++) { cval[tid * beam + k] = lv[k]; cidx[tid * beam + k] = li[k]; }
+    __syncthreads();
+    select_top(cval, cidx, 256 * beam, beam, red, redi, sel_v, sel_i, tid, 256);
     if (tid < beam) {
+        pval[((size_t)s * BEAM_CHUNKS + ch) * beam + tid] = sel_v[tid];
+        pidx[((size_t)s * BEAM_CHUNKS + ch) * beam + tid] = sel_i[tid];
+    }
+}
+
+__global__ __launch_bounds__(64) void k_beam_final(int beam, int V, int first, int stop_token, const float* __restrict__ pval,
+                                                   const int* __restrict__ pidx, float* __restrict__ scores, float* __restrict__ seq_len,
+                                                   unsigned char* __restrict__ stopped, int* __restrict__ next_tok, int* __restrict__ src_row) {
+    __shared__ float red[64];
+    __shared__ int redi[64];
+    __shared__ float cval[BEAM_CHUNKS * BEAM_MAX];
+    __shared__ int cidx[BEAM_CHUNKS * BEAM_MAX];
+    __shared__ float sel_v[BEAM_MAX];
+    __shared__ int sel_i[BEAM_MAX];
+    __shared__ float ns_[BEAM_MAX], nl_[BEAM_MAX];
+    __shared__ int hs_[BEAM_MAX];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int ncand = BEAM_CHUNKS * beam;
+    for (int c = tid; c < ncand; c += 64) { cval[c] = pval[(size_t)s * ncand + c]; cidx[c] = pidx[(size_t)s * ncand + c]; }
+    __syncthreads();
+    select_top(cval, cidx, ncand, beam, red, redi, sel_v, sel_i, tid, 64);
+    if (tid < beam) {      // gather / update state (base.py:86-119)
         const int idx = sel_i[tid];
         const int b = idx / V, v = idx % V;
-        float nl, ns;
-        unsigned char hs;
-        if (first) { nl = 1.f; ns = sel_v[tid]; hs = 0; }
+        if (first) { nl_[tid] = 1.f; ns_[tid] = sel_v[tid]; hs_[tid] = 0; }
         else {
             const bool st = stopped[s * beam + b];
-            nl = seq_len[s * beam + b] + (st ? 0.f : 1.f);
-            ns = sel_v[tid] * nl;      // scores = scores_sum_average * seq_lengths (base.py:114)
-            hs = st;
+            nl_[tid] = seq_len[s * beam + b] + (st ? 0.f : 1.f);
+            ns_[tid] = sel_v[tid] * nl_[tid];      // scores = scores_sum_average * seq_lengths (base.py:114)
+            hs_[tid] = st;
         }
-        red[tid] = ns; red[32 + tid] = nl; redi[tid] = (int)hs | ((v == stop_token) ? 1 : 0);
+        hs_[tid] |= (v == stop_token) ? 1 : 0;
         next_tok[s * beam + tid] = v;
         src_row[s * beam + tid] = b;
     }
     __syncthreads();
     if (tid < beam) {
-        scores[s * beam + tid] = red[tid];
-        seq_len[s * beam + tid] = red[32 + tid];
-        stopped[s * beam + tid] = (unsigned char)redi[tid];
+        scores[s * beam + tid] = ns_[tid];
+        seq_len[s * beam + tid] = nl_[tid];
+        stopped[s * beam + tid] = (unsigned char)hs_[tid];
     }
 }
 
@@ -353,18 +382,27 @@ int cc_decode_reorder(const cc_gpt2_cfg* c, int32_t R_src, int32_t R_dst, int32_
 }
 
 int64_t cc_beam_ws_bytes(int32_t S, int32_t beam, int32_t V) {
-    (void)S; (void)beam; (void)V;
-    return 256;  // the update runs entirely in LDS; a token workspace keeps the call shape stable
+    (void)V;
+    if (S <= 0 || beam <= 0 || beam > BEAM_MAX) return CC_ERR_SHAPE;
+    return (int64_t)S * beam * 2 * sizeof(float) + (int64_t)S * BEAM_CHUNKS * beam * (sizeof(float) + sizeof(int)) + 512;
 }
 
 int cc_beam_step(int32_t S, int32_t beam, int32_t V, const float* logits, int64_t ldl, float temperature, int32_t first, int32_t stop_token,
                  float* scores, float* seq_lengths, uint8_t* has_stopped, int32_t* next_tokens, int32_t* src_rows, void* ws, void* stream) {
-    (void)ws;
-    if (S <= 0 || beam <= 0 || beam > BEAM_MAX || V <= 0 || !logits || ldl < V || !scores || !seq_lengths || !has_stopped || !next_tokens || !src_rows)
+    if (S <= 0 || beam <= 0 || beam > BEAM_MAX || V <= 0 || !logits || ldl < V || !scores || !seq_lengths || !has_stopped || !next_tokens ||
+        !src_rows || !ws)
         return CC_ERR_ARG;
+    hipStream_t st = S_(stream);
     const float inv_temp = 1.0f / (temperature > 0.f ? temperature : 1.0f);   // base.py:83
-    hipLaunchKernelGGL(k_beam_step, dim3(S), dim3(256), 0, S_(stream), logits, (size_t)ldl, beam, V, inv_temp, first, stop_token, scores,
-                       seq_lengths, has_stopped, next_tokens, src_rows);
+    float* rs = static_cast<float*>(ws);
+    float* pval = rs + (size_t)S * beam * 2;
+    int* pidx = reinterpret_cast<int*>(pval + (size_t)S * BEAM_CHUNKS * beam);
+    // step 0 reads only row 0 of every sample's block of `beam` rows, but computing all rows' statistics is harmless and uniform
+    hipLaunchKernelGGL(k_beam_rowstats, dim3(S * beam), dim3(256), 0, st, logits, (size_t)ldl, V, inv_temp, rs);
+    hipLaunchKernelGGL(k_beam_partial, dim3(S, BEAM_CHUNKS), dim3(256), 0, st, logits, (size_t)ldl, beam, V, inv_temp, first, rs, scores,
+                       seq_lengths, has_stopped, pval, pidx);
+    hipLaunchKernelGGL(k_beam_final, dim3(S), dim3(64), 0, st, beam, V, first, stop_token, pval, pidx, scores, seq_lengths, has_stopped, next_tokens,
+                       src_rows);
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
 

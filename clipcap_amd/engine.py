@@ -417,6 +417,7 @@ def beam_step(logits: torch.Tensor, samples: int, beam: int, temperature: float,
     ldl = logits.stride(0)
     nt = torch.empty(samples * beam, dtype=torch.int32, device=dev)
     sr = torch.empty(samples * beam, dtype=torch.int32, device=dev)
+    ws = torch.empty(_lib.lib().cc_beam_ws_bytes(samples, beam, V), dtype=torch.uint8, device=dev)
     check(_lib.lib().cc_beam_step(samples, beam, V, _p(logits), ldl, float(temperature), int(first), int(stop_token), _p(scores), _p(seq_lengths),
-                                 _p(has_stopped), _p(nt), _p(sr), None, _stream(dev)), "cc_beam_step")
+                                 _p(has_stopped), _p(nt), _p(sr), _p(ws), _stream(dev)), "cc_beam_step")
     return nt, sr
