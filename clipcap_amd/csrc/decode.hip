@@ -271,6 +271,8 @@ struct DecWS {
     bf16_t *xn, *qkv, *att, *hact, *hf;
     float *meanf, *rstdf;
     int* last;
+    float* scratch;
+    size_t scratch_bytes;
     size_t bytes;
 };
 void dec_carve(const cc_gpt2_cfg* c, int R, int Tn, void* ws, DecWS& w) {
@@ -293,6 +295,8 @@ void dec_carve(const cc_gpt2_cfg* c, int R, int Tn, void* ws, DecWS& w) {
     w.meanf = (float*)take((size_t)R * 4);
     w.rstdf = (float*)take((size_t)R * 4);
     w.last = (int*)take((size_t)R * 4);
+    w.scratch_bytes = (size_t)8 * M * 4 * D * 4;   // up to 8 K-slices of the widest (4D) output
+    w.scratch = (float*)take(w.scratch_bytes);
     w.bytes = (off + 255) & ~size_t(255);
 }
 
@@ -350,7 +354,7 @@ int cc_decode_fwd(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int
         bf16_t* kc = kv + (size_t)l * cache_layer;
         bf16_t* vc = kc + (size_t)R * ctx_max * D;
         CC_TRY(ln_fwd(w.x, D, nullptr, w32 + l1w, w32 + l1b, w.xn, nullptr, nullptr, nullptr, M, D, st));
-        CC_TRY(gemm_bf16out(0, 0, w.xn, D, w16t + aw, D, M, 3 * D, D, w.qkv, 3 * D, w32 + ab, 0, nullptr, st));
+        CC_TRY(gemm_nt_skinny(w.xn, D, w16t + aw, D, M, 3 * D, D, w32 + ab, 0, nullptr, nullptr, w.qkv, 3 * D, w.scratch, w.scratch_bytes, st));
         {
             const size_t total = (size_t)M * (D >> 3);
             hipLaunchKernelGGL(k_kv_append, dim3((int)std::min<size_t>((total + 255) / 256, 2048)), dim3(256), 0, st, w.qkv, kc, vc, R, Tn, D, pos0,
@@ -359,10 +363,10 @@ int cc_decode_fwd(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int
             hipLaunchKernelGGL(k_decode_attn, dim3((nw + 3) / 4), dim3(256), (size_t)8 * ctx_max * sizeof(float), st, w.qkv, kc, vc, row_map, w.att, R,
                                Tn, H, hd, pos0, ctx_max, scale);
         }
-        CC_TRY(gemm_resid(0, 0, w.att, D, w16t + pw, D, M, D, D, w.x1, w.x, D, w32 + pb, st));
+        CC_TRY(gemm_nt_skinny(w.att, D, w16t + pw, D, M, D, D, w32 + pb, 0, w.x, w.x1, nullptr, D, w.scratch, w.scratch_bytes, st));
         CC_TRY(ln_fwd(w.x1, D, nullptr, w32 + l2w, w32 + l2b, w.xn, nullptr, nullptr, nullptr, M, D, st));
-        CC_TRY(gemm_bf16out(0, 0, w.xn, D, w16t + fw, D, M, 4 * D, D, w.hact, 4 * D, w32 + fb, 2, nullptr, st));
-        CC_TRY(gemm_resid(0, 0, w.hact, 4 * D, w16t + p2w, 4 * D, M, D, 4 * D, w.x, w.x1, D, w32 + p2b, st));
+        CC_TRY(gemm_nt_skinny(w.xn, D, w16t + fw, D, M, 4 * D, D, w32 + fb, 2, nullptr, nullptr, w.hact, 4 * D, w.scratch, w.scratch_bytes, st));
+        CC_TRY(gemm_nt_skinny(w.hact, 4 * D, w16t + p2w, 4 * D, M, D, 4 * D, w32 + p2b, 0, w.x1, w.x, nullptr, D, w.scratch, w.scratch_bytes, st));
     }
     const int64_t lnf_w = p, lnf_b = p + D;
     hipLaunchKernelGGL(k_last_rows, dim3((R + 255) / 256), dim3(256), 0, st, w.last, R, Tn);

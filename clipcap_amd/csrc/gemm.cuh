@@ -259,7 +259,8 @@ __global__ __launch_bounds__(G_THREADS, 2) void gemm_nt_glds_kernel(const bf16_t
     int tm, tn;
     tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, g.group_m, tm, tn);
     const int m0 = tm * G_BM, n0 = tn * G_BN;
-    const int nk = g.K / G_BK;
+    const int kbeg = blockIdx.z * g.k_chunk;                  // split-K slice (k_chunk is a multiple of 64)
+    const int nk = (min(g.K, kbeg + g.k_chunk) - kbeg) / G_BK;
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -267,8 +268,8 @@ __global__ __launch_bounds__(G_THREADS, 2) void gemm_nt_glds_kernel(const bf16_t
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    glds_tile(A, g.lda, g.M, m0, 0, smem, wave, lane);
-    glds_tile(B, g.ldb, g.N, n0, 0, smem + G_TILE_BYTES, wave, lane);
+    glds_tile(A, g.lda, g.M, m0, kbeg, smem, wave, lane);
+    glds_tile(B, g.ldb, g.N, n0, kbeg, smem + G_TILE_BYTES, wave, lane);
     const int frow = lane & 15, fchunk = lane >> 4;
     for (int kt = 0; kt < nk; kt++) {
         char* cur = smem + (kt & 1) * 2 * G_TILE_BYTES;
@@ -276,8 +277,8 @@ __global__ __launch_bounds__(G_THREADS, 2) void gemm_nt_glds_kernel(const bf16_t
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (kt + 1 < nk) {
-            glds_tile(A, g.lda, g.M, m0, (kt + 1) * G_BK, nxt, wave, lane);
-            glds_tile(B, g.ldb, g.N, n0, (kt + 1) * G_BK, nxt + G_TILE_BYTES, wave, lane);
+            glds_tile(A, g.lda, g.M, m0, kbeg + (kt + 1) * G_BK, nxt, wave, lane);
+            glds_tile(B, g.ldb, g.N, n0, kbeg + (kt + 1) * G_BK, nxt + G_TILE_BYTES, wave, lane);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
@@ -465,7 +466,7 @@ inline int launch_gemm(int al, int bl, const bf16_t* A, int lda, const bf16_t* B
     ksplit = (kt + per - 1) / per;
     g.k_chunk = per * G_BK;
     dim3 grid(((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN), 1, ksplit);
-    if (al == 0 && bl == 0 && (K % G_BK) == 0 && ksplit == 1)
+    if (al == 0 && bl == 0 && (K % G_BK) == 0)
         hipLaunchKernelGGL((gemm_nt_glds_kernel<Epi>), grid, dim3(G_THREADS), 0, st, A, B, g, epi);
     else if (al == 0 && bl == 0)
         hipLaunchKernelGGL((gemm_bf16_kernel<0, 0, Epi>), grid, dim3(G_THREADS), 0, st, A, B, g, epi);

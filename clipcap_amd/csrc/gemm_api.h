@@ -21,4 +21,9 @@ int gemm_lmhead(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int V
 constexpr size_t WGRAD_SCRATCH_BYTES = size_t(48) << 20;
 int gemm_wgrad(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int Mw, int Nw, int K, float* dW, int ldw, float* scratch,
                hipStream_t st);
+// Skinny-M NT GEMMs (KV-cached decode: M = beams x samples, a handful of 128x128 tiles): split K over blockIdx.z so every CU
+// streams a distinct slice of the weights, fp32 slabs in `scratch`, then ONE finishing kernel sums the slabs and applies the
+// epilogue (bias, gelu_new, fp32 residual, bf16 / fp32 stores).  Falls back to the single-pass GEMM when the grid is already wide.
+int gemm_nt_skinny(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const float* bias, int act, const float* res,
+                   float* out32, bf16_t* out16, int ldo, float* scratch, size_t scratch_bytes, hipStream_t st);
 }  // namespace cc

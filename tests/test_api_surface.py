@@ -220,3 +220,26 @@ def test_checkpoint_files_follow_reference_naming_and_load(tmp_path):
     assert isinstance(m2, ClipCapModelPrefixOnly) and not m2.training and m2.config.training_config is None
     for k, v in m.state_dict().items():
         assert torch.equal(v, m2.state_dict()[k]), k
+
+
+def test_sampling_filters_match_reference_outputs():
+    """clipcap_amd.inference.utils vs the reference's filter outputs captured in tests/golden/filters.npz."""
+    from clipcap_amd.inference import utils as U
+    g = load_golden("filters")
+    lg = torch.from_numpy(g["in.logits"])
+    toks = torch.from_numpy(g["in.tokens"])
+    assert np.array_equal(U.top_k_top_p_filtering(lg, top_k=5).numpy(), g["topk5"])
+    assert np.array_equal(U.top_k_top_p_filtering(lg, top_p=0.8).numpy(), g["topp08"])
+    assert np.array_equal(U.top_k_top_p_filtering(lg, top_k=10, top_p=0.5).numpy(), g["topk10_topp05"])
+    assert np.allclose(U.repetition_penalty_apply(lg, toks, 1.2).numpy(), g["rep12"], atol=1e-6)
+    assert np.allclose(U.sentence_length_penalty_apply(torch.from_numpy(g["in.logits2"]), toks, 11, 4, 50, 1.0).numpy(), g["lenpen"], atol=1e-6)
+    # batched use (the reference is 1-D only): rows are filtered independently
+    two = torch.stack((lg, lg.flip(0)))
+    out = U.top_k_top_p_filtering(two, top_k=5)
+    assert np.array_equal(out[0].numpy(), g["topk5"]) and (out[1] > -float("inf")).sum() == 5
+    # nucleus distribution vs the captured final_p (logits recomputed by the oracle from the same tiny GPT-2)
+    from oracle import clipcap_oracle as O
+    b = load_golden("beam_tiny")
+    D, n_layer, n_head, V, npos = [int(v) for v in b["cfg"]]
+    logits = O.gpt2_logits(sd_of(b), torch.from_numpy(g["nucleus.prefix"]), n_head, n_layer)[:, -1, :]
+    assert np.allclose(U.nucleus_distribution(logits, top_p=0.8).numpy(), g["nucleus.final_p"], atol=1e-6)

@@ -199,3 +199,25 @@ def test_train_driver_end_to_end(tmp_path):
     prefix = model.transformer_mapper(torch.randn(1, 24, device="cuda"))
     text = generate_beam(model, tok, prefix, beam_size=3, entry_length=6)
     assert isinstance(text, list) and len(text) == 1 and isinstance(text[0], str)
+
+
+def test_kv_cached_decode_split_k_path_equals_full_forward():
+    """Wider model (D=256: K = 256 / 1024) so that the skinny split-K GEMMs + finishing kernel of the decode path are exercised."""
+    from clipcap_amd.engine import DecodeSession
+    from clipcap_amd.model.gpt2 import GPT2LM
+    torch.manual_seed(3)
+    lm = GPT2LM(n_embd=256, n_layer=2, n_head=4, vocab_size=1000, n_positions=32).to("cuda")
+    with torch.no_grad():
+        for n, p in lm.named_parameters():
+            if n.endswith("bias"):
+                p.normal_(0, 0.02)
+    eng = lm.engine
+    x = torch.randn(12, 7, 256, device="cuda") * 0.5
+    full = eng.logits(x)
+    sess = DecodeSession(eng, 12, 16)
+    l0 = sess.forward(x[:, :3]).clone()
+    scale = full.abs().max().item()
+    assert (l0 - full[:, 2]).abs().max().item() <= 4e-3 * max(1.0, scale)
+    for t in range(3, 7):
+        lt = sess.forward(x[:, t:t + 1])
+        assert (lt - full[:, t]).abs().max().item() <= 4e-3 * max(1.0, scale), t

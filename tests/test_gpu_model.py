@@ -189,3 +189,21 @@ def test_layer_range_backward_equals_full_backward(mode):
     assert torch.allclose(grads[0][0], grads[1][0], rtol=1e-4, atol=1e-7)
     if mode == "full":
         assert torch.allclose(grads[0][1], grads[1][1], rtol=1e-4, atol=1e-7)
+
+
+def test_windowed_mapper_backward_vs_oracle():
+    """TransformerMapperWindowed (mapper.py:133-160) gradients incl. pos_embeddings, sequence W*P+L."""
+    g = load_golden("mapper_windowed")
+    E, D, P, L, H, N, B, W = [int(v) for v in g["dims"]]
+    sd = sd_of(g)
+    eng = _mapper_engine(sd, E, D, P, L, H, N, W=W, use_pos=True)
+    x = torch.from_numpy(g["in.x"])
+    out = eng.forward(x.cuda(), save=True)
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.mapper_forward(sdr, x, projection_length=P, num_heads=H, num_layers=N, window=W, rb=True)
+    ref.square().mean().backward()
+    eng.arena.grads().zero_()
+    eng.backward(2.0 * out / out.numel())
+    gv = eng.views(eng.arena.g32)
+    for k in sd:
+        assert _rel(gv[k].cpu(), sdr[k].grad) <= 3e-2, k
