@@ -1037,26 +1037,28 @@ int ce_rows(const float* pmax, const float* psum, int npart, const int* target, 
 
 __global__ __launch_bounds__(256) void k_ce_dlogits(bf16_t* __restrict__ logits, int ld, int V, const int* __restrict__ target,
                                                     const float* __restrict__ lse, const float* __restrict__ denom, int M) {
-    const int row = blockIdx.y;
     const int col = (blockIdx.x * 256 + threadIdx.x) * 8;
     if (col >= ld) return;
-    const int t = target[row];
-    const float l = lse[row];
-    const float w = (t != 0) ? 1.0f / fmaxf(denom[0], 1.0f) : 0.f;
-    bf16_t* p = logits + (size_t)row * ld + col;
-    float f[8];
-    unpack8(*reinterpret_cast<const uint4*>(p), f);
+    const float inv = 1.0f / fmaxf(denom[0], 1.0f);
+    for (int row = blockIdx.y; row < M; row += gridDim.y) {
+        const int t = target[row];
+        const float l = lse[row];
+        const float w = (t != 0) ? inv : 0.f;
+        bf16_t* p = logits + (size_t)row * ld + col;
+        float f[8];
+        unpack8(*reinterpret_cast<const uint4*>(p), f);
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
-        const int c = col + e;
-        f[e] = (c < V) ? (__expf(f[e] - l) - (c == t ? 1.f : 0.f)) * w : 0.f;
+        for (int e = 0; e < 8; e++) {
+            const int c = col + e;
+            f[e] = (c < V) ? (__expf(f[e] - l) - (c == t ? 1.f : 0.f)) * w : 0.f;
+        }
+        *reinterpret_cast<uint4*>(p) = pack8(f);
     }
-    *reinterpret_cast<uint4*>(p) = pack8(f);
 }
 int ce_dlogits(bf16_t* logits, int ld, int V, const int* target, const float* lse, const float* denom, int M, hipStream_t st) {
     if (ld & 7) return CC_ERR_SHAPE;
     if (M <= 0) return CC_OK;
-    hipLaunchKernelGGL(k_ce_dlogits, dim3((ld / 8 + 255) / 256, M), dim3(256), 0, st, logits, ld, V, target, lse, denom, M);
+    hipLaunchKernelGGL(k_ce_dlogits, dim3((ld / 8 + 255) / 256, std::min(M, 32768)), dim3(256), 0, st, logits, ld, V, target, lse, denom, M);
     return CC_OK;
 }
 

@@ -221,3 +221,55 @@ def test_kv_cached_decode_split_k_path_equals_full_forward():
     for t in range(3, 7):
         lt = sess.forward(x[:, t:t + 1])
         assert (lt - full[:, t]).abs().max().item() <= 4e-3 * max(1.0, scale), t
+
+
+def test_sampling_decoders_run_on_kv_cache_and_match_first_step_distribution():
+    """generate_nucleus_sampling / generate_no_beam / generate: the GPT-2 steps run on the KV-cached HIP path; the pre-sampling
+    distribution of the first step equals the reference's (tests/golden/filters.npz, captured from base.py:165-181)."""
+    from types import SimpleNamespace
+    from clipcap_amd.engine import DecodeSession
+    from clipcap_amd.inference import generate_no_beam, generate_nucleus_sampling
+    from clipcap_amd.inference.utils import nucleus_distribution
+    from clipcap_amd.model.gpt2 import GPT2LM
+    f = load_golden("filters")
+    g = load_golden("beam_tiny")
+    D, n_layer, n_head, V, npos = [int(v) for v in g["cfg"]]
+    lm = GPT2LM(n_embd=D, n_layer=n_layer, n_head=n_head, vocab_size=V, n_positions=npos)
+    lm.load_state_dict(sd_of(g), strict=False)
+    model = SimpleNamespace(language_model=lm.to("cuda"))
+    pref = torch.from_numpy(f["nucleus.prefix"]).cuda()
+    logits = DecodeSession(lm.engine, 1, 16).forward(pref)
+    p = nucleus_distribution(logits, top_p=0.8).cpu().numpy()
+    assert np.abs(p - f["nucleus.final_p"]).max() <= 2e-2 and abs(p.sum() - 1.0) <= 1e-5
+    assert set(np.nonzero(p[0])[0]) == set(np.nonzero(f["nucleus.final_p"][0])[0]) or np.abs(p - f["nucleus.final_p"]).max() <= 2e-2
+    tok = FakeTokenizer(V, 96)
+    torch.manual_seed(0)
+    a = generate_nucleus_sampling(model, tok, pref, number_to_generate=2, entry_length=6, top_p=0.8)
+    torch.manual_seed(0)
+    b = generate_nucleus_sampling(model, tok, pref, number_to_generate=2, entry_length=6, top_p=0.8)
+    assert a == b and len(a) == 2 and all(isinstance(t, str) for t in a)
+    c = generate_no_beam(model, tok, pref, entry_length=5, sweep=False, top_p=0.9)
+    assert len(c) == 1 and len(c[0].split()) <= 5
+    assert len(generate_no_beam(model, tok, pref, entry_length=2)) == 33          # the reference's 11 x 3 sweep (base.py:229-230)
+
+
+def test_checkpoint_resume_restores_optimizer_state(tmp_path):
+    """Training state written by CheckpointSaver resumes bit-exactly (weights, AdamW moments, step counter) — the reference has
+    no resume path; the next step after resume equals the next step of the uninterrupted run."""
+    from clipcap_amd.train.callback import CheckpointSaver, resume
+    m, g = _model_from_train_fixture()
+    m.train()
+    tokens, embeds = torch.from_numpy(g["in.tokens"]).cuda(), torch.from_numpy(g["in.embeds"]).cuda()
+    for _ in range(2):
+        m.fused_step((tokens.clone(), embeds), lr=1e-3)
+    CheckpointSaver(str(tmp_path), "r").save_final_checkpoint(m)
+    l3 = float(m.fused_step((tokens.clone(), embeds), lr=1e-3))
+    after3 = {k: v.clone() for k, v in m.transformer_mapper.state_dict().items()}
+    m2, _ = _model_from_train_fixture()
+    m2.train()
+    resume(m2, str(tmp_path / "r_final.ckpt"))
+    assert m2._opt_step == 2
+    l3b = float(m2.fused_step((tokens.clone(), embeds), lr=1e-3))
+    assert abs(l3 - l3b) <= 1e-6
+    for k, v in m2.transformer_mapper.state_dict().items():
+        assert torch.allclose(v, after3[k], atol=1e-7, rtol=0), k
