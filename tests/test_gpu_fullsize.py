@@ -1,0 +1,70 @@
+"""Full BASELINE size (configs[1]: E=512, TransformerMapper 8 layers P=L=10 H=8, GPT-2-small, B=256, 40 tokens) — the CPU oracle is
+far too slow here, so parity is checked through size-independent properties of the training step:
+  * batch-permutation invariance of the loss and of the (summed) gradients,
+  * additivity: the global-batch gradient equals the kept-token-weighted combination of two half-batch gradients,
+  * gradient scale linearity through the loss divisor, determinism of the loss, finite values everywhere,
+  * decode: KV-cached logits == full re-forward logits at GPT-2-small size."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def big():
+    import bench
+    c = dict(bench.CONFIGS["2"])
+    me, ge, eng = bench.init_engines(c, torch.device("cuda", 0))
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    embeds = torch.randn(c["B"], c["E"], generator=gen, device="cuda")
+    tokens = torch.randint(1, c["V"], (c["B"], c["cap"]), generator=gen, device="cuda")
+    tokens[::7, 30:] = -1            # ragged captions
+    tokens[3, 5] = 0                 # an explicit id-0 target (ignored, model.py:109)
+    return c, me, ge, eng, tokens, embeds
+
+
+def _grads(eng, tokens, embeds):
+    eng.zero_grad()
+    loss = eng.forward_backward(tokens, embeds)
+    torch.cuda.synchronize()
+    return float(loss), eng.mapper.arena.g32.clone(), float(eng.stats[1])
+
+
+def _rel(a, b):
+    return ((a - b).norm() / b.norm()).item()
+
+
+def test_full_size_step_properties(big):
+    c, me, ge, eng, tokens, embeds = big
+    l0, g0, n0 = _grads(eng, tokens, embeds)
+    assert torch.isfinite(g0).all() and abs(l0) < 20 and n0 == float((tokens > 0).sum())
+    # determinism of the loss (no atomics on its path)
+    l0b, g0b, _ = _grads(eng, tokens, embeds)
+    assert l0b == l0 and _rel(g0b, g0) <= 1e-5        # gradients: fp32 atomics in LN / bias reductions only reorder sums
+    # permutation invariance
+    perm = torch.randperm(c["B"], device="cuda")
+    l1, g1, n1 = _grads(eng, tokens[perm], embeds[perm])
+    assert n1 == n0 and abs(l1 - l0) <= 2e-5 * abs(l0) and _rel(g1, g0) <= 2e-3
+    # additivity over a split of the batch, weighted by kept-target counts
+    h = c["B"] // 2
+    la, ga, na = _grads(eng, tokens[:h], embeds[:h])
+    lb, gb, nb = _grads(eng, tokens[h:], embeds[h:])
+    assert na + nb == n0
+    assert abs((la * na + lb * nb) / n0 - l0) <= 2e-5 * abs(l0)
+    # the halves scale dlogits by 1/na, 1/nb instead of 1/n0 before the bf16 rounding: bf16-level, not fp32-level, agreement
+    assert _rel((ga * na + gb * nb) / n0, g0) <= 2e-2
+
+
+def test_full_size_kv_cache_equals_reforward(big):
+    from clipcap_amd.engine import DecodeSession
+    c, me, ge, eng, tokens, embeds = big
+    torch.manual_seed(1)
+    x = torch.randn(4, 14, c["D"], device="cuda") * 0.3
+    full = ge.logits(x)
+    sess = DecodeSession(ge, 4, 32)
+    l = sess.forward(x[:, :10]).clone()
+    scale = full.abs().max().item()
+    assert (l - full[:, 9]).abs().max().item() <= 5e-3 * max(1.0, scale)
+    for t in range(10, 14):
+        l = sess.forward(x[:, t:t + 1])
+        assert (l - full[:, t]).abs().max().item() <= 5e-3 * max(1.0, scale), t
