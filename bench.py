@@ -165,9 +165,41 @@ def decode_bench(args, device):
                          "frac": round(wbytes * steps_per_decode * args.steps / dt / 8e12, 4), "traffic": None}}
 
 
+def mapper_bench(args, device):
+    """north_star sub-target: mapping-transformer forward+backward alone at batch 256 as a fraction of the bf16 MFMA peak
+    (algorithmic FLOPs: 3 x 1.5276 GFLOP per sample)."""
+    c = dict(CONFIGS[args.config])
+    if args.batch:
+        c["B"] = args.batch
+    me, ge, eng = init_engines(c, device)
+    B = c["B"]
+    emb = torch.randn(B, c["E"], device=device)
+    dout = torch.randn(B, c["L"], c["D"], device=device) * 1e-3
+
+    def it():
+        me.arena.grads().zero_()
+        me.forward(emb, save=True)
+        me.backward(dout)
+
+    for _ in range(max(1, args.warmup)):
+        it()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        it()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    tf = 3 * mapper_flops_fwd(c) * B / dt / 1e12
+    return {"metric": "mapping-transformer fwd+bwd (batch 256)", "value": round(B / dt, 1), "unit": "samples/s", "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic", "config": {"workload": f"mapper of {c['name']}", "per_gpu_batch": B},
+            "roofline": {"bound": "mfma", "kernel": "whole mapper fwd+bwd chain", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": None}}
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", default="train", choices=["train", "decode"])
+    ap.add_argument("--mode", default="train", choices=["train", "decode", "mapper"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
@@ -187,9 +219,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)   # "nccl" is RCCL on ROCm
-    if args.mode == "decode":
+    if args.mode in ("decode", "mapper"):
         if rank == 0:
-            print(json.dumps(decode_bench(args, device)))
+            print(json.dumps(decode_bench(args, device) if args.mode == "decode" else mapper_bench(args, device)))
         return
     c = dict(CONFIGS[args.config])
     if args.batch:

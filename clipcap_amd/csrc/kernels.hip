@@ -279,7 +279,9 @@ int ln_bwd(const bf16_t* dy, const float* x, int ldx, const int* row_map, const 
            hipStream_t st) {
     if (D > LN_MAXV * 256 || (D & 3) || (ldx & 3)) return CC_ERR_SHAPE;
     if (rows <= 0) return CC_OK;
-    const int grid = std::min((rows + 3) / 4, 1024);
+    // with parameter gradients every block ends with 2*D fp32 atomics: keep the block count low (one per CU) so that the
+    // atomic tail (measured: it dominated at 1024 blocks) stays ~0.4 M atomics per launch
+    const int grid = std::min((rows + 3) / 4, dgamma ? 256 : 1024);
     const size_t sh = dgamma ? (size_t)8 * D * sizeof(float) : 0;
     hipLaunchKernelGGL(k_ln_bwd, dim3(grid), dim3(256), sh, st, dy, x, ldx, row_map, mean, rstd, gamma, dres, dx32, dx16, dgamma,
                        dbeta, rows, D);
