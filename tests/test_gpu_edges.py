@@ -1,0 +1,108 @@
+"""Edge cases of the hot path on the GPU: smallest batches / sequence lengths, ragged and fully-padded captions, odd (but legal)
+widths, error codes for illegal shapes — each checked against the CPU oracle with the kernels' bf16 rounding points."""
+import ctypes as C
+
+import pytest
+import torch
+
+from oracle import clipcap_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(E, D, P, L, H, N, n_head, n_layer, V, npos, seed=0):
+    from clipcap_amd.engine import ClipCapEngine, Gpt2Engine, MapperEngine
+    torch.manual_seed(seed)
+    me = MapperEngine(E, D, L, P, H, N, device="cuda")
+    ge = Gpt2Engine(D, n_head, n_layer, V, npos, device="cuda")
+    sd = {}
+    for pre, eng in (("transformer_mapper.", me), ("language_model.", ge)):
+        for k, v in eng.views(eng.arena.w32).items():
+            if ("norm" in k or "ln_" in k) and k.endswith("weight"):
+                t = 1.0 + 0.05 * torch.randn(v.shape)
+            elif k.endswith(".bias"):
+                t = 0.02 * torch.randn(v.shape)
+            elif "prefix_const" in k:
+                t = torch.randn(v.shape)
+            else:
+                t = torch.randn(v.shape) * (0.1 if ("wte" in k or "wpe" in k) else 0.5 / v.shape[-1] ** 0.5)
+            sd[pre + k] = t
+            v.copy_(t)
+    cfg = dict(projection_length=P, prefix_length=L, heads=H, layers=N, n_head=n_head, n_layer=n_layer)
+    return ClipCapEngine(me, ge, train_lm=False), sd, cfg
+
+
+def _check(eng, sd, cfg, tokens, embeds, tol=2e-3):
+    loss = eng.forward_backward(tokens.cuda(), embeds.cuda())
+    sdr = {k: v.clone().requires_grad_(k.startswith("transformer_mapper.")) for k, v in sd.items()}
+    kept = int((tokens > 0).sum())
+    if kept == 0:
+        assert float(loss) == 0.0 and float(eng.stats[1]) == 0.0
+        assert torch.count_nonzero(eng.mapper.arena.g32) == 0
+        return
+    ref = O.clipcap_loss(sdr, tokens, embeds, cfg=cfg, rb=True)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) <= tol, (float(loss), float(ref))
+    gv = eng.mapper.views(eng.mapper.arena.g32)
+    for k, v in gv.items():
+        r = sdr["transformer_mapper." + k].grad
+        assert ((v.cpu() - r).norm() / r.norm().clamp_min(1e-12)).item() <= 6e-2, k
+
+
+@pytest.mark.parametrize("B,cap,P,L", [(1, 1, 1, 1), (1, 5, 2, 3), (3, 2, 4, 1), (2, 9, 1, 6)])
+def test_smallest_shapes(B, cap, P, L):
+    eng, sd, cfg = _build(16, 64, P, L, 4, 1, 4, 1, 97, 32)
+    torch.manual_seed(B * 10 + cap)
+    _check(eng, sd, cfg, torch.randint(1, 97, (B, cap)), torch.randn(B, 16))
+
+
+def test_ragged_pads_zero_ids_and_fully_padded_rows():
+    eng, sd, cfg = _build(24, 64, 2, 3, 4, 2, 4, 2, 157, 40)
+    torch.manual_seed(4)
+    tokens = torch.randint(1, 157, (5, 8))
+    tokens[0, 3:] = -1
+    tokens[1, :] = -1              # a caption that is all padding: contributes nothing
+    tokens[2, 0] = 0               # id 0 is ignored by the loss (model.py:109)
+    tokens[4, 7:] = -1
+    _check(eng, sd, cfg, tokens, torch.randn(5, 24))
+    eng.zero_grad()
+    _check(eng, sd, cfg, torch.full((2, 4), -1), torch.randn(2, 24))      # nothing kept at all: loss 0, zero gradients
+
+
+def test_widths_that_are_multiples_of_8_but_not_of_64():
+    # D = 40*... : K of the GEMMs not a multiple of 64 -> generic register-staged kernel instead of the direct-to-LDS one
+    eng, sd, cfg = _build(40, 96, 3, 2, 4, 1, 4, 1, 203, 24)      # hd = 24, Hm = 192, E = 40
+    torch.manual_seed(9)
+    _check(eng, sd, cfg, torch.randint(1, 203, (3, 6)), torch.randn(3, 40), tol=3e-3)
+
+
+def test_illegal_shapes_are_reported_not_miscomputed():
+    from clipcap_amd import _lib
+    from clipcap_amd.engine import MapperEngine
+    with pytest.raises(_lib.CCError):
+        MapperEngine(30, 64, 2, 2, 4, 1)           # E not a multiple of 8
+    with pytest.raises(_lib.CCError):
+        MapperEngine(32, 60, 2, 2, 4, 1)           # D % 8 != 0
+    with pytest.raises(_lib.CCError):
+        MapperEngine(32, 96, 2, 2, 8, 1)           # head dim 12: not a multiple of 8
+    l = _lib.lib()
+    cfg = _lib.Gpt2Cfg(64, 4, 1, 97, 128, 16)
+    shp = _lib.Gpt2Shape(2, 3, 40, 37, 1)          # T > n_positions
+    assert l.cc_gpt2_ws_bytes(C.byref(cfg), C.byref(shp)) == -2
+    assert l.cc_mapper_fwd(None, 1, None, None, None, None, None, 0, None) == -1
+
+
+def test_context_overflow_and_beam_limits():
+    from types import SimpleNamespace
+    from clipcap_amd.engine import DecodeSession
+    from clipcap_amd.inference import generate_beam_tokens
+    from clipcap_amd.model.gpt2 import GPT2LM
+    lm = GPT2LM(n_embd=64, n_layer=1, n_head=4, vocab_size=97, n_positions=12).to("cuda")
+    sess = DecodeSession(lm.engine, 2, 64)         # clamped to n_positions
+    assert sess.ctx_max == 12
+    sess.forward(torch.randn(2, 10, 64, device="cuda"))
+    with pytest.raises(RuntimeError, match="overflow"):
+        sess.forward(torch.randn(2, 3, 64, device="cuda"))
+    toks, scores, lens = generate_beam_tokens(SimpleNamespace(language_model=lm), torch.randn(2, 4, 64, device="cuda"), beam_size=1,
+                                              entry_length=5, stop_token=96)
+    assert toks.shape[:2] == (2, 1) and toks.shape[2] <= 5 and torch.isfinite(scores).all()
