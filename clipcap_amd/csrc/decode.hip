@@ -87,9 +87,16 @@ __global__ __launch_bounds__(256) void k_decode_attn(const bf16_t* __restrict__ 
     const float inv = 1.f / sum;
     // wave-private LDS: same-wave writes above are visible to the reads below (in-order DS queue)
     for (int d = lane; d < hd; d += 64) {
-        float o = 0.f;
-        for (int j = 0; j < nkeys; j++) o += p[j] * bf2f(vb[((size_t)srow[j] * ctx_max + j) * D + d]);
-        out[((size_t)r * Tn + t) * D + h * hd + d] = f2bf(o * inv);
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;      // 4 independent chains keep 4 V loads in flight
+        int j = 0;
+        for (; j + 3 < nkeys; j += 4) {
+            o0 += p[j] * bf2f(vb[((size_t)srow[j] * ctx_max + j) * D + d]);
+            o1 += p[j + 1] * bf2f(vb[((size_t)srow[j + 1] * ctx_max + j + 1) * D + d]);
+            o2 += p[j + 2] * bf2f(vb[((size_t)srow[j + 2] * ctx_max + j + 2) * D + d]);
+            o3 += p[j + 3] * bf2f(vb[((size_t)srow[j + 3] * ctx_max + j + 3) * D + d]);
+        }
+        for (; j < nkeys; j++) o0 += p[j] * bf2f(vb[((size_t)srow[j] * ctx_max + j) * D + d]);
+        out[((size_t)r * Tn + t) * D + h * hd + d] = f2bf((o0 + o1 + o2 + o3) * inv);
     }
 }
 
@@ -338,6 +345,7 @@ int cc_decode_fwd(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int
     const int64_t total = (int64_t)c->Vp * D + (int64_t)c->NPOS * D + (int64_t)c->NL * (12 * (int64_t)D * D + 13 * (int64_t)D) + 2 * D;
     const uint16_t* w16t = w16 + total;   // transposed Conv1D weights (cc_gpt2_sync_weights): forward GEMMs are NT
     const float scale = 1.0f / sqrtf((float)hd);
+    bool xn_ready = false;
     for (int l = 0; l < c->NL; l++) {
         const int64_t l1w = p; p += D;
         const int64_t l1b = p; p += D;
@@ -353,20 +361,38 @@ int cc_decode_fwd(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int
         const int64_t p2b = p; p += D;
         bf16_t* kc = kv + (size_t)l * cache_layer;
         bf16_t* vc = kc + (size_t)R * ctx_max * D;
-        CC_TRY(ln_fwd(w.x, D, nullptr, w32 + l1w, w32 + l1b, w.xn, nullptr, nullptr, nullptr, M, D, st));
-        CC_TRY(gemm_nt_skinny(w.xn, D, w16t + aw, D, M, 3 * D, D, w32 + ab, 0, nullptr, nullptr, w.qkv, 3 * D, w.scratch, w.scratch_bytes, st));
+        // xn = ln_1(x): produced by the previous layer's fused finish when possible
+        if (!xn_ready) CC_TRY(ln_fwd(w.x, D, nullptr, w32 + l1w, w32 + l1b, w.xn, nullptr, nullptr, nullptr, M, D, st));
+        // c_attn (+ fused KV append into the cache)
+        const bool f_qkv = gemm_nt_skinny_can_fuse(M, 3 * D, D, w.scratch_bytes);
+        SkinnyFuse fq;
+        fq.kcache = kc; fq.vcache = vc; fq.Tn = Tn; fq.pos0 = pos0; fq.ctx_max = ctx_max;
+        CC_TRY(gemm_nt_skinny(w.xn, D, w16t + aw, D, M, 3 * D, D, w32 + ab, 0, nullptr, nullptr, w.qkv, 3 * D, w.scratch, w.scratch_bytes, st,
+                              f_qkv ? &fq : nullptr));
         {
-            const size_t total = (size_t)M * (D >> 3);
-            hipLaunchKernelGGL(k_kv_append, dim3((int)std::min<size_t>((total + 255) / 256, 2048)), dim3(256), 0, st, w.qkv, kc, vc, R, Tn, D, pos0,
-                               ctx_max);
+            if (!f_qkv) {
+                const size_t total = (size_t)M * (D >> 3);
+                hipLaunchKernelGGL(k_kv_append, dim3((int)std::min<size_t>((total + 255) / 256, 2048)), dim3(256), 0, st, w.qkv, kc, vc, R, Tn, D, pos0,
+                                   ctx_max);
+            }
             const int nw = R * H * Tn;
             hipLaunchKernelGGL(k_decode_attn, dim3((nw + 3) / 4), dim3(256), (size_t)8 * ctx_max * sizeof(float), st, w.qkv, kc, vc, row_map, w.att, R,
                                Tn, H, hd, pos0, ctx_max, scale);
         }
-        CC_TRY(gemm_nt_skinny(w.att, D, w16t + pw, D, M, D, D, w32 + pb, 0, w.x, w.x1, nullptr, D, w.scratch, w.scratch_bytes, st));
-        CC_TRY(ln_fwd(w.x1, D, nullptr, w32 + l2w, w32 + l2b, w.xn, nullptr, nullptr, nullptr, M, D, st));
+        // attn.c_proj + residual (+ fused ln_2)
+        const bool f_d = gemm_nt_skinny_can_fuse(M, D, D, w.scratch_bytes) && gemm_nt_skinny_can_fuse(M, D, 4 * D, w.scratch_bytes);
+        SkinnyFuse f2;
+        f2.ln_gamma = w32 + l2w; f2.ln_beta = w32 + l2b; f2.ln_out16 = w.xn;
+        CC_TRY(gemm_nt_skinny(w.att, D, w16t + pw, D, M, D, D, w32 + pb, 0, w.x, w.x1, nullptr, D, w.scratch, w.scratch_bytes, st, f_d ? &f2 : nullptr));
+        if (!f_d) CC_TRY(ln_fwd(w.x1, D, nullptr, w32 + l2w, w32 + l2b, w.xn, nullptr, nullptr, nullptr, M, D, st));
         CC_TRY(gemm_nt_skinny(w.xn, D, w16t + fw, D, M, 4 * D, D, w32 + fb, 2, nullptr, nullptr, w.hact, 4 * D, w.scratch, w.scratch_bytes, st));
-        CC_TRY(gemm_nt_skinny(w.hact, 4 * D, w16t + p2w, 4 * D, M, D, 4 * D, w32 + p2b, 0, w.x1, w.x, nullptr, D, w.scratch, w.scratch_bytes, st));
+        // mlp.c_proj + residual (+ fused ln_1 of the next layer: its parameters sit right behind this layer's in the arena)
+        const bool f_next = f_d && l + 1 < c->NL;
+        SkinnyFuse f1;
+        f1.ln_gamma = w32 + p; f1.ln_beta = w32 + p + D; f1.ln_out16 = w.xn;       // p now points at layer l+1's ln_1.weight
+        CC_TRY(gemm_nt_skinny(w.hact, 4 * D, w16t + p2w, 4 * D, M, D, 4 * D, w32 + p2b, 0, w.x1, w.x, nullptr, D, w.scratch, w.scratch_bytes, st,
+                              f_next ? &f1 : nullptr));
+        xn_ready = f_next;
     }
     const int64_t lnf_w = p, lnf_b = p + D;
     hipLaunchKernelGGL(k_last_rows, dim3((R + 255) / 256), dim3(256), 0, st, w.last, R, Tn);

@@ -24,6 +24,19 @@ int gemm_wgrad(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int Mw, int N
 // Skinny-M NT GEMMs (KV-cached decode: M = beams x samples, a handful of 128x128 tiles): split K over blockIdx.z so every CU
 // streams a distinct slice of the weights, fp32 slabs in `scratch`, then ONE finishing kernel sums the slabs and applies the
 // epilogue (bias, gelu_new, fp32 residual, bf16 / fp32 stores).  Falls back to the single-pass GEMM when the grid is already wide.
+// Optional fused tails of the finishing kernel (decode): LayerNorm of the finished fp32 row (N == row width) -> bf16, and the
+// append of the K / V thirds of a finished qkv row to the KV cache.
+struct SkinnyFuse {
+    const float* ln_gamma = nullptr;   // LayerNorm over the N columns of (acc + bias + res): out -> ln_out16 [M, N]
+    const float* ln_beta = nullptr;
+    bf16_t* ln_out16 = nullptr;
+    bf16_t* kcache = nullptr;          // qkv rows (N == 3*D): columns [D,2D) -> kcache, [2D,3D) -> vcache at (r*ctx_max + pos0 + t)*D
+    bf16_t* vcache = nullptr;
+    int Tn = 1, pos0 = 0, ctx_max = 0;
+};
 int gemm_nt_skinny(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const float* bias, int act, const float* res,
-                   float* out32, bf16_t* out16, int ldo, float* scratch, size_t scratch_bytes, hipStream_t st);
+                   float* out32, bf16_t* out16, int ldo, float* scratch, size_t scratch_bytes, hipStream_t st,
+                   const SkinnyFuse* fuse = nullptr);
+// whether gemm_nt_skinny will take the slab + row-finish path for this problem (the only path that supports SkinnyFuse)
+bool gemm_nt_skinny_can_fuse(int M, int N, int K, size_t scratch_bytes);
 }  // namespace cc

@@ -84,16 +84,93 @@ __global__ __launch_bounds__(256) void k_splitk_finish(const float* __restrict__
     }
 }
 
+// one 256-thread block per finished row (M is small here, so rows are the only parallelism): slabs -> (+bias, act, +residual) ->
+// fp32 / bf16 stores -> optional KV append -> optional LayerNorm (block reduction) -> bf16
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float t = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    return t;
+}
+
+__global__ __launch_bounds__(256) void k_splitk_finish_row(const float* __restrict__ slabs, size_t slab_elems, int ks, int M, int N,
+                                                           const float* __restrict__ bias, int act, const float* __restrict__ res,
+                                                           float* __restrict__ out32, bf16_t* __restrict__ out16, int ldo, SkinnyFuse f) {
+    __shared__ float red[4];
+    const int row = blockIdx.x;
+    constexpr int MAXV = 3;                // float4 per thread -> N <= 3072
+    float4 v[MAXV];
+    float s1 = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXV; it++) {
+        const int c = threadIdx.x * 4 + it * 1024;
+        if (c < N) {
+            float4 a = make_float4(0, 0, 0, 0);
+            for (int s = 0; s < ks; s++) {
+                const float4 p = *reinterpret_cast<const float4*>(slabs + s * slab_elems + (size_t)row * N + c);
+                a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+            }
+            if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + c); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+            if (act == 2) { a.x = gelu_new_f(a.x); a.y = gelu_new_f(a.y); a.z = gelu_new_f(a.z); a.w = gelu_new_f(a.w); }
+            else if (act == 1) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+            const size_t o = (size_t)row * ldo + c;
+            if (res) { const float4 r = *reinterpret_cast<const float4*>(res + o); a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w; }
+            if (out32) *reinterpret_cast<float4*>(out32 + o) = a;
+            const uint2 pk = make_uint2(pack2bf(a.x, a.y), pack2bf(a.z, a.w));
+            if (out16) *reinterpret_cast<uint2*>(out16 + o) = pk;
+            if (f.kcache) {                   // N == 3*D
+                const int D = N / 3, which = c / D, cc_ = c - which * D;
+                if (which > 0) {
+                    const int r = row / f.Tn, t = row - r * f.Tn;
+                    bf16_t* dst = (which == 1 ? f.kcache : f.vcache) + ((size_t)r * f.ctx_max + f.pos0 + t) * D + cc_;
+                    *reinterpret_cast<uint2*>(dst) = pk;
+                }
+            }
+            v[it] = a;
+            s1 += a.x + a.y + a.z + a.w;
+        }
+    }
+    if (!f.ln_out16) return;               // block-uniform
+    const float mu = block_sum256(s1, red) / N;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXV; it++) {
+        const int c = threadIdx.x * 4 + it * 1024;
+        if (c < N) { const float a = v[it].x - mu, b = v[it].y - mu, c2 = v[it].z - mu, d = v[it].w - mu; q += a * a + b * b + c2 * c2 + d * d; }
+    }
+    const float rs = rsqrtf(block_sum256(q, red) / N + 1e-5f);
+#pragma unroll
+    for (int it = 0; it < MAXV; it++) {
+        const int c = threadIdx.x * 4 + it * 1024;
+        if (c < N) {
+            const float4 g = *reinterpret_cast<const float4*>(f.ln_gamma + c), b = *reinterpret_cast<const float4*>(f.ln_beta + c);
+            *reinterpret_cast<uint2*>(f.ln_out16 + (size_t)row * N + c) =
+                make_uint2(pack2bf((v[it].x - mu) * rs * g.x + b.x, (v[it].y - mu) * rs * g.y + b.y),
+                           pack2bf((v[it].z - mu) * rs * g.z + b.z, (v[it].w - mu) * rs * g.w + b.w));
+        }
+    }
+}
+
+bool gemm_nt_skinny_can_fuse(int M, int N, int K, size_t scratch_bytes) {
+    return M > 0 && N > 0 && (N & 7) == 0 && N <= 3072 && (K % G_BK) == 0 && scratch_bytes >= (size_t)M * N * sizeof(float);
+}
+
 int gemm_nt_skinny(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const float* bias, int act, const float* res,
-                   float* out32, bf16_t* out16, int ldo, float* scratch, size_t scratch_bytes, hipStream_t st) {
+                   float* out32, bf16_t* out16, int ldo, float* scratch, size_t scratch_bytes, hipStream_t st, const SkinnyFuse* fuse) {
     if ((N & 7) || (ldo & 7)) return CC_ERR_SHAPE;
     const int tiles = ((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
     int ks = 384 / (tiles > 0 ? tiles : 1);
     const int kmax = K / (2 * G_BK);                       // at least 2 K-steps per slice
     if (ks > kmax) ks = kmax;
+    if (ks < 1) ks = 1;
     const size_t slab = (size_t)M * N;
-    if (scratch && slab && (K % G_BK) == 0) { const size_t fit = scratch_bytes / (slab * sizeof(float)); if ((size_t)ks > fit) ks = (int)fit; } else ks = 1;
-    if (ks <= 1) {
+    const bool can_slab = scratch && slab && (K % G_BK) == 0 && scratch_bytes >= slab * sizeof(float);
+    if (can_slab) { const size_t fit = scratch_bytes / (slab * sizeof(float)); if ((size_t)ks > fit) ks = (int)fit; }
+    const bool fused = fuse && (fuse->ln_out16 || fuse->kcache);
+    if (!can_slab || (ks <= 1 && !fused)) {
+        if (fused) return CC_ERR_SHAPE;                    // callers only request fusion when the slab path is available
         if (res) { EpiResid e{out32, res, bias, ldo, M, N}; return launch_gemm(0, 0, A, lda, B, ldb, M, N, K, 1, e, st); }
         if (out16) { EpiBF16 e{out16, nullptr, bias, ldo, M, N, act}; return launch_gemm(0, 0, A, lda, B, ldb, M, N, K, 1, e, st); }
         EpiF32 e{out32, bias, ldo, M, N, 0, 1.0f};
@@ -104,9 +181,15 @@ int gemm_nt_skinny(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, in
     int rc = launch_gemm(0, 0, A, lda, B, ldb, M, N, K, ks, e, st);
     if (rc != CC_OK) return rc;
     const int kt = K / G_BK, per = (kt + ks - 1) / ks, ks_eff = (kt + per - 1) / per;
-    const size_t n8 = (size_t)M * (N >> 3);
-    hipLaunchKernelGGL(k_splitk_finish, dim3((int)std::min<size_t>((n8 + 255) / 256, 2048)), dim3(256), 0, st, scratch, slab, ks_eff, M, N, bias, act,
-                       res, out32, out16, ldo);
+    if (N <= 3072 && (N & 3) == 0) {
+        SkinnyFuse f = fuse ? *fuse : SkinnyFuse{};
+        hipLaunchKernelGGL(k_splitk_finish_row, dim3(M), dim3(256), 0, st, scratch, slab, ks_eff, M, N, bias, act, res, out32, out16, ldo, f);
+    } else {
+        if (fused) return CC_ERR_SHAPE;
+        const size_t n8 = (size_t)M * (N >> 3);
+        hipLaunchKernelGGL(k_splitk_finish, dim3((int)std::min<size_t>((n8 + 255) / 256, 2048)), dim3(256), 0, st, scratch, slab, ks_eff, M, N, bias,
+                           act, res, out32, out16, ldo);
+    }
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
 }  // namespace cc
