@@ -44,22 +44,26 @@ __global__ void k_kv_append(const bf16_t* __restrict__ qkv, bf16_t* __restrict__
     }
 }
 
-// attention of the Tn new queries of every row against the cache (ctx = pos0 + Tn, causal): one wave per (r,h,t)
+// attention of the Tn new queries of every row against the cache (ctx = pos0 + Tn, causal): one wave per (r,h,t).
+// scores: one key per lane (K row = hd contiguous bf16, 16-B loads).  PV: lane = (key group kg, 8-wide d chunk dc): every V load
+// is a 16-B vector, the key loop is 64/(hd/8) times shorter than one-d-per-lane, partial sums meet in wave-private LDS.
 __global__ __launch_bounds__(256) void k_decode_attn(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ kc,
                                                      const bf16_t* __restrict__ vc, const int* __restrict__ row_map, bf16_t* __restrict__ out,
                                                      int R, int Tn, int H, int hd, int pos0, int ctx_max, float scale) {
-    extern __shared__ float psm[];  // [4][ctx_max]
+    extern __shared__ float psm[];  // per wave: p[ctx_max] | srow[ctx_max] | red[8][hd]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gid = blockIdx.x * 4 + wave;
     if (gid >= R * H * Tn) return;
     const int t = gid % Tn, h = (gid / Tn) % H, r = gid / (Tn * H);
     const int D = H * hd, nkeys = pos0 + t + 1;
-    float* p = psm + wave * ctx_max;
+    const int per_wave = 2 * ctx_max + 8 * hd;
+    float* p = psm + wave * per_wave;
+    int* srow = reinterpret_cast<int*>(p + ctx_max);
+    float* red = p + 2 * ctx_max;
     const bf16_t* q = qkv + ((size_t)r * Tn + t) * 3 * D + h * hd;
     // position j of row r lives in cache row row_map[j*R + r] (beam ancestry table; identity when null)
     const bf16_t* kb = kc + h * hd;
     const bf16_t* vb = vc + h * hd;
-    int* srow = reinterpret_cast<int*>(psm + 4 * ctx_max) + wave * ctx_max;
     for (int j = lane; j < nkeys; j += 64) srow[j] = row_map ? row_map[(size_t)j * R + r] : r;
     float m = -INFINITY;
     for (int j = lane; j < nkeys; j += 64) {
@@ -86,17 +90,24 @@ __global__ __launch_bounds__(256) void k_decode_attn(const bf16_t* __restrict__ 
     sum = wave_sum(sum);
     const float inv = 1.f / sum;
     // wave-private LDS: same-wave writes above are visible to the reads below (in-order DS queue)
-    for (int d = lane; d < hd; d += 64) {
-        float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;      // 4 independent chains keep 4 V loads in flight
-        int j = 0;
-        for (; j + 3 < nkeys; j += 4) {
-            o0 += p[j] * bf2f(vb[((size_t)srow[j] * ctx_max + j) * D + d]);
-            o1 += p[j + 1] * bf2f(vb[((size_t)srow[j + 1] * ctx_max + j + 1) * D + d]);
-            o2 += p[j + 2] * bf2f(vb[((size_t)srow[j + 2] * ctx_max + j + 2) * D + d]);
-            o3 += p[j + 3] * bf2f(vb[((size_t)srow[j + 3] * ctx_max + j + 3) * D + d]);
+    const int nchunk = hd >> 3, kgroups = min(8, 64 / nchunk);
+    const int kg = lane / nchunk, dc = lane - kg * nchunk;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (kg < kgroups) {
+        for (int j = kg; j < nkeys; j += kgroups) {
+            float v[8];
+            unpack8(*reinterpret_cast<const uint4*>(vb + ((size_t)srow[j] * ctx_max + j) * D + dc * 8), v);
+            const float pj = p[j];
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc[e] += pj * v[e];
         }
-        for (; j < nkeys; j++) o0 += p[j] * bf2f(vb[((size_t)srow[j] * ctx_max + j) * D + d]);
-        out[((size_t)r * Tn + t) * D + h * hd + d] = f2bf((o0 + o1 + o2 + o3) * inv);
+#pragma unroll
+        for (int e = 0; e < 8; e++) red[kg * hd + dc * 8 + e] = acc[e];
+    }
+    for (int d = lane; d < hd; d += 64) {
+        float o = 0.f;
+        for (int g = 0; g < kgroups; g++) o += red[g * hd + d];
+        out[((size_t)r * Tn + t) * D + h * hd + d] = f2bf(o * inv);
     }
 }
 
@@ -328,7 +339,7 @@ int cc_decode_fwd(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int
     if (!cfg_ok(c) || R <= 0 || Tn <= 0 || pos0 < 0 || !w32 || !w16 || !x || !kv || !ws || !logits) return CC_ERR_ARG;
     const int Ns = std::min(c->Vp, (c->V + 7) / 8 * 8);
     if (pos0 + Tn > ctx_max || pos0 + Tn > c->NPOS || ldl < Ns || (ldl & 3) || ldl > 0x7fffffff) return CC_ERR_SHAPE;
-    if ((size_t)8 * ctx_max * sizeof(float) > 64 * 1024) return CC_ERR_SHAPE;
+    if ((size_t)4 * (2 * ctx_max + 8 * (c->D / c->H)) * sizeof(float) > 64 * 1024) return CC_ERR_SHAPE;
     hipStream_t st = S_(stream);
     DecWS w;
     dec_carve(c, R, Tn, ws, w);
@@ -376,7 +387,7 @@ int cc_decode_fwd(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int
                                    ctx_max);
             }
             const int nw = R * H * Tn;
-            hipLaunchKernelGGL(k_decode_attn, dim3((nw + 3) / 4), dim3(256), (size_t)8 * ctx_max * sizeof(float), st, w.qkv, kc, vc, row_map, w.att, R,
+            hipLaunchKernelGGL(k_decode_attn, dim3((nw + 3) / 4), dim3(256), (size_t)4 * (2 * ctx_max + 8 * hd) * sizeof(float), st, w.qkv, kc, vc, row_map, w.att, R,
                                Tn, H, hd, pos0, ctx_max, scale);
         }
         // attn.c_proj + residual (+ fused ln_2)
