@@ -248,7 +248,9 @@ __device__ __forceinline__ void glds_tile(const bf16_t* __restrict__ base, int l
     }
 }
 
-template <class Epi>
+// ABL: ablation bits for tools/gemm_bench.py (0 in every product instantiation): 1 = no loads in the K loop, 2 = no MFMAs,
+// 4 = no fragment reads (results are then meaningless; timing only)
+template <class Epi, int ABL = 0>
 __global__ __launch_bounds__(G_THREADS, 2) void gemm_nt_glds_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                                      GemmShape g, Epi epi) {
     __shared__ __attribute__((aligned(1024))) char smem[4 * G_TILE_BYTES];
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void gemm_nt_glds_kernel(const bf16_t
         char* nxt = smem + ((kt + 1) & 1) * 2 * G_TILE_BYTES;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kt + 1 < nk) {
+        if (kt + 1 < nk && !(ABL & 1)) {
             glds_tile(A, g.lda, g.M, m0, kbeg + (kt + 1) * G_BK, nxt, wave, lane);
             glds_tile(B, g.ldb, g.N, n0, kbeg + (kt + 1) * G_BK, nxt + G_TILE_BYTES, wave, lane);
         }
@@ -284,16 +286,25 @@ __global__ __launch_bounds__(G_THREADS, 2) void gemm_nt_glds_kernel(const bf16_t
         for (int ks = 0; ks < 2; ks++) {
             bf16x8 af[4], bfr[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-                af[i] = *reinterpret_cast<const bf16x8*>(cur + g_lds_off(wm * 64 + i * 16 + frow, ks * 4 + fchunk));
+            for (int i = 0; i < 4; i++) {
+                if (!(ABL & 4) || kt == 0) af[i] = *reinterpret_cast<const bf16x8*>(cur + g_lds_off(wm * 64 + i * 16 + frow, ks * 4 + fchunk));
+                else asm volatile("" : "=v"(af[i]));
+            }
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                bfr[j] = *reinterpret_cast<const bf16x8*>(cur + G_TILE_BYTES + g_lds_off(wn * 64 + j * 16 + frow, ks * 4 + fchunk));
+            for (int j = 0; j < 4; j++) {
+                if (!(ABL & 4) || kt == 0) bfr[j] = *reinterpret_cast<const bf16x8*>(cur + G_TILE_BYTES + g_lds_off(wn * 64 + j * 16 + frow, ks * 4 + fchunk));
+                else asm volatile("" : "=v"(bfr[j]));
+            }
+            if (ABL & 2) {
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+                for (int i = 0; i < 4; i++) asm volatile("" ::"v"(af[i]), "v"(bfr[i]));
+            } else {
 #pragma unroll
-                for (int j = 0; j < 4; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
         }
     }
     __syncthreads();
@@ -466,6 +477,15 @@ inline int launch_gemm(int al, int bl, const bf16_t* A, int lda, const bf16_t* B
     ksplit = (kt + per - 1) / per;
     g.k_chunk = per * G_BK;
     dim3 grid(((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN), 1, ksplit);
+#ifdef CC_GEMM_ABLATION
+    static const int abl = []() { const char* e = getenv("CC_GEMM_ABL"); return e ? atoi(e) : 0; }();
+    if (al == 0 && bl == 0 && (K % G_BK) == 0 && abl == 1) { hipLaunchKernelGGL((gemm_nt_glds_kernel<Epi, 1>), grid, dim3(G_THREADS), 0, st, A, B, g, epi); }
+    else if (al == 0 && bl == 0 && (K % G_BK) == 0 && abl == 2) { hipLaunchKernelGGL((gemm_nt_glds_kernel<Epi, 2>), grid, dim3(G_THREADS), 0, st, A, B, g, epi); }
+    else if (al == 0 && bl == 0 && (K % G_BK) == 0 && abl == 4) { hipLaunchKernelGGL((gemm_nt_glds_kernel<Epi, 4>), grid, dim3(G_THREADS), 0, st, A, B, g, epi); }
+    else if (al == 0 && bl == 0 && (K % G_BK) == 0 && abl == 5) { hipLaunchKernelGGL((gemm_nt_glds_kernel<Epi, 5>), grid, dim3(G_THREADS), 0, st, A, B, g, epi); }
+    else if (al == 0 && bl == 0 && (K % G_BK) == 0 && abl == 6) { hipLaunchKernelGGL((gemm_nt_glds_kernel<Epi, 6>), grid, dim3(G_THREADS), 0, st, A, B, g, epi); }
+    else
+#endif
     if (al == 0 && bl == 0 && (K % G_BK) == 0)
         hipLaunchKernelGGL((gemm_nt_glds_kernel<Epi>), grid, dim3(G_THREADS), 0, st, A, B, g, epi);
     else if (al == 0 && bl == 0)

@@ -1,3 +1,5 @@
+// Built with `make ABLATION=1` this TU also carries the timing-only ablation variants of the NT kernel (CC_GEMM_ABL=1|2|4|5|6 at
+// run time, tools/gemm_bench.py); the default build has none, so product code generation is not perturbed by sibling variants.
 #include "gemm.cuh"
 #include <algorithm>
 #include "gemm_api.h"
