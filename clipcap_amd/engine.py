@@ -208,8 +208,7 @@ class Gpt2Engine:
         offs = (C.c_int64 * (2 + 12 * n_layer + 2))()
         check(l.cc_gpt2_param_offsets(C.byref(self.cfg), offs))
         self.offsets = list(offs)
-        self._ws: Dict[Tuple[int, int, int, int, int], torch.Tensor] = {}
-        self._dec_ws: Dict[Tuple[int, int], torch.Tensor] = {}
+        self._ws: Dict[int, torch.Tensor] = {}
 
     def _sync(self, w32, w16, st):
         return _lib.lib().cc_gpt2_sync_weights(C.byref(self.cfg), w32, w16, st)
@@ -238,16 +237,15 @@ class Gpt2Engine:
         return Gpt2Shape(B, L, T, cap, mode)
 
     def workspace(self, shp: Gpt2Shape) -> torch.Tensor:
-        key = (shp.B, shp.L, shp.T, shp.cap, shp.mode)
-        ws = self._ws.get(key)
-        if ws is None:
-            nbytes = _lib.lib().cc_gpt2_ws_bytes(C.byref(self.cfg), C.byref(shp))
-            check(nbytes, "cc_gpt2_ws_bytes")
-            # one live workspace per mode keeps memory bounded when batch shapes vary
-            for k in [k for k in self._ws if k[4] == shp.mode]:
-                del self._ws[k]
+        """One buffer per mode, grown on demand: the library carves its layout from the base pointer on every call, so a buffer
+        sized for the largest shape seen serves all smaller ones (caption length varies from batch to batch in real training)."""
+        nbytes = _lib.lib().cc_gpt2_ws_bytes(C.byref(self.cfg), C.byref(shp))
+        check(nbytes, "cc_gpt2_ws_bytes")
+        ws = self._ws.get(shp.mode)
+        if ws is None or ws.numel() < nbytes or ws.device != self.arena.device:
+            self._ws.pop(shp.mode, None)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=self.arena.device)
-            self._ws[key] = ws
+            self._ws[shp.mode] = ws
         return ws
 
     # -- inference-style forward: logits for all rows (ClipCapModel.forward / language_model(inputs_embeds=...)) --

@@ -107,11 +107,25 @@ def get_dataloader(data_path: str = "./dataset/", language_model: str = "gpt2-xl
     return ds, ds.encoder_embedding_size
 
 
-class DevicePrefetcher:
-    """Uploads batch i+1 (pinned staging + non_blocking copy on a side stream) while batch i is being consumed."""
+def trim_padding(tokens: torch.Tensor, multiple: int = 8) -> torch.Tensor:
+    """Drops the all-padding tail columns of a right-padded (-1) token batch (kept length rounded up to `multiple`).
+    Exact: a dropped column has no kept target (model.py:103-109), and under the causal mask no kept row attends to it, so
+    loss and gradients are unchanged while GPT-2 runs on L + longest_caption rows instead of L + max_token_length."""
+    if tokens.numel() == 0:
+        return tokens
+    lengths = tokens.ge(0).sum(dim=1)
+    keep = int(lengths.max())
+    keep = min(tokens.shape[1], max(multiple, (keep + multiple - 1) // multiple * multiple))
+    return tokens[:, :keep].contiguous()
 
-    def __init__(self, it, device):
+
+class DevicePrefetcher:
+    """Uploads batch i+1 (pinned staging + non_blocking copy on a side stream) while batch i is being consumed; trims the
+    all-padding tail of the token batch on the host first (``trim_padding``)."""
+
+    def __init__(self, it, device, trim: bool = True):
         self.it = iter(it)
+        self.trim = trim
         self.device = torch.device(device)
         self.stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
         self._next = self._load()
@@ -121,6 +135,8 @@ class DevicePrefetcher:
             tokens, emb = next(self.it)
         except StopIteration:
             return None
+        if self.trim:
+            tokens = trim_padding(tokens)
         if self.stream is None:
             return tokens, emb
         with torch.cuda.stream(self.stream):
