@@ -213,12 +213,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    # test hooks (single-GPU boxes): CC_BENCH_DEVICE pins every rank to one device, CC_BENCH_BACKEND=gloo replaces RCCL, so the
+    # whole multi-rank flow of this file can be exercised where only one GPU exists.  Never set by the driver.
+    dev_index = int(os.environ.get("CC_BENCH_DEVICE", local))
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)   # "nccl" is RCCL on ROCm
+        backend = os.environ.get("CC_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     if args.mode in ("decode", "mapper"):
         if rank == 0:
             print(json.dumps(decode_bench(args, device) if args.mode == "decode" else mapper_bench(args, device)))
