@@ -312,6 +312,141 @@ __global__ __launch_bounds__(G_THREADS, 2) void gemm_nt_glds_kernel(const bf16_t
 }
 
 // ------------------------------------------------------------------------------------------------
+// NT 256 x 256 kernel for large outputs ("stag256"): 8 waves, wave tile 128 x 64 (8 x 4 MFMA tiles), K-tile 32, FOUR LDS stages
+// of 32 KiB.  Per FLOP it moves half the L2->LDS bytes and 3/4 of the fragment reads of the 128 x 128 kernel — the two
+// resources the ablation shows saturated there.  One block per CU means no second block to hide a barrier stall, so the two
+// wave groups (rows 0-127 / 128-255; one wave of each per SIMD) are locked one segment apart by the block barrier; a segment
+// is either the 12 fragment reads of a K-tile or its 32 MFMAs:   2t: g0 L(t) | g1 M(t-1)      2t+1: g0 M(t) | g1 L(t)
+// Tile t+3 is issued (global_load_lds) at the start of segment 2t — its buffer's last reader finished in segment 2t-1 — and
+// tile t+1 is awaited with a COUNTED vmcnt(8) before the barrier ending segment 2t+1: two tiles stay in flight across the
+// barriers (raw s_barrier; a __syncthreads() would drain the DMA queue).  With a single tile in flight the same structure ran
+// 1129 TFLOP/s at 8192^3 and 1789 with the loads ablated: latency, not bandwidth, was the limiter.  The two groups run
+// separate code paths (one loop with per-segment role branches made hipcc spill 90 registers).
+// LDS image [row][32 k] (64-B rows), chunk' = chunk ^ ((row>>2)&3): conflict-free ds_read_b128 fragment reads.
+// ------------------------------------------------------------------------------------------------
+constexpr int H_BM = 256, H_BN = 256, H_BK = 32, H_NS = 4, H_STAGE = (H_BM + H_BN) * H_BK * 2;   // 32 KiB per stage, 128 KiB total
+// 64-B rows, 4 chunks of 16 B.  ds_read_b128 is serviced in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (guide, LDS
+// table): with lane = (row & 15) + 16 * chunk a group holds rows 0-3 and 12-15 at chunk c and rows 4-11 at chunk c^1, so the XOR
+// key has to be 0,0,3,3 for row>>2 = 0..3 (not 0,1,2,3) for the 16 lanes to land on 16 different 16-B bank groups.
+__device__ __forceinline__ int h_swz(int row) { return (row & 8) ? 3 : 0; }
+__device__ __forceinline__ int h_lds_off(int row, int chunk) { return row * 64 + ((chunk ^ h_swz(row)) << 4); }
+// DMA issue is done by the group that is in its fragment-read segment (never ahead of a group's MFMAs: 4 DMA instructions cost
+// ~600 issue cycles): group 0 streams the A tile, group 1 the B tile; wave w of a group takes 1-KiB segments w, w+4, w+8, w+12.
+#define H_SRC_EXPR(IS_A) const bf16_t* src = (IS_A) ? A + (size_t)min(m0 + row, g.M - 1) * g.lda + k0_ + chunk * 8 : B + (size_t)min(n0 + row, g.N - 1) * g.ldb + k0_ + chunk * 8;
+#define H_ISSUE(T, IS_A)                                                                                                 \
+    {                                                                                                                    \
+        char* st_ = smem + ((T) & (H_NS - 1)) * H_STAGE + ((IS_A) ? 0 : H_BM * H_BK * 2);                                \
+        const int k0_ = (T)*H_BK;                                                                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) {                                                               \
+            const int seg = wn + 4 * i_;                        /* 16 segments of 16 rows x 64 B per operand tile */      \
+            const int row = seg * 16 + (lane >> 2);                                                                      \
+            const int chunk = (lane & 3) ^ h_swz(row);                                                             \
+            H_SRC_EXPR(IS_A)                                                                                                \
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(st_ + seg * 1024), 16, 0, 0);                         \
+        }                                                                                                                \
+    }
+#define H_LOADF(T)                                                                                                       \
+    {                                                                                                                    \
+        const char* ca_ = smem + ((T) & (H_NS - 1)) * H_STAGE;                                                           \
+        const char* cb_ = ca_ + H_BM * H_BK * 2;                                                                         \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) af[i_] = *reinterpret_cast<const bf16x8*>(ca_ + h_lds_off(arow + i_ * 16 + frow, fchunk)); \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; j_++) bfr[j_] = *reinterpret_cast<const bf16x8*>(cb_ + h_lds_off(bcol + j_ * 16 + frow, fchunk)); \
+    }
+#define H_MFMA()                                                                                                         \
+    {                                                                                                                    \
+        __builtin_amdgcn_s_setprio(1);                                                                                   \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) _Pragma("unroll") for (int j_ = 0; j_ < 4; j_++)                 \
+            acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i_], bfr[j_], acc[i_][j_], 0, 0, 0);                \
+        __builtin_amdgcn_s_setprio(0);                                                                                   \
+    }
+#define H_SEGEND()                                                                                                       \
+    {                                                                                                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        __builtin_amdgcn_s_barrier();                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+    }
+// tile t+1 must have landed; tiles t+2 and t+3 (4 DMA instructions per wave each) may stay in flight
+#define H_WAIT(T)                                                                                                        \
+    {                                                                                                                    \
+        const int rem_ = min(nk - 1, (T) + 3) - ((T) + 1);                                                               \
+        if (rem_ >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                  \
+        else if (rem_ == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                             \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                            \
+    }
+template <class Epi>
+__global__ __launch_bounds__(512, 1) void gemm_nt_stag256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, GemmShape g, Epi epi) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wn = wave & 3;
+    const int arow = grp * 128, bcol = wn * 64;
+    const int tiles_n = (g.N + H_BN - 1) / H_BN, tiles_m = (g.M + H_BM - 1) / H_BM;
+    int tm, tn;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, g.group_m, tm, tn);
+    const int m0 = tm * H_BM, n0 = tn * H_BN;
+    const int nk = g.K / H_BK;
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[8], bfr[4];
+    const int frow = lane & 15, fchunk = lane >> 4;
+    if (grp == 0) {
+        H_ISSUE(0, true);
+        if (nk > 1) H_ISSUE(1, true);
+        if (nk > 2) H_ISSUE(2, true);
+        H_WAIT(-1);
+        H_SEGEND();
+        for (int t = 0; t < nk; t++) {
+            if (t + 3 < nk) H_ISSUE(t + 3, true);      // buffer (t+3)&3 was last read (by group 1) in segment 2t-1
+            H_LOADF(t); H_SEGEND();
+            H_MFMA(); H_WAIT(t); H_SEGEND();
+        }
+        H_SEGEND();
+    } else {
+        H_ISSUE(0, false);
+        if (nk > 1) H_ISSUE(1, false);
+        if (nk > 2) H_ISSUE(2, false);
+        H_WAIT(-1);
+        H_SEGEND();
+        for (int t = 0; t < nk; t++) {
+            if (t >= 1) H_MFMA();
+            H_SEGEND();
+            if (t + 3 < nk) H_ISSUE(t + 3, false);     // one segment after group 0's half of the same tile
+            H_LOADF(t); H_WAIT(t); H_SEGEND();
+        }
+        H_MFMA(); H_SEGEND();
+    }
+    __syncthreads();
+    float* strip = reinterpret_cast<float*>(smem) + wave * (16 * G_EPI_LD);
+    const int er = (lane >> 4) * 4, ec = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) strip[(er + r) * G_EPI_LD + j * 16 + ec] = acc[i][j][r];
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const int q = lane + 64 * s;
+            const int lr = q >> 3, c8 = q & 7;
+            float v[8];
+            const float4 a = *reinterpret_cast<const float4*>(strip + lr * G_EPI_LD + c8 * 8);
+            const float4 b = *reinterpret_cast<const float4*>(strip + lr * G_EPI_LD + c8 * 8 + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            epi(m0 + arow + i * 16 + lr, n0 + bcol + c8 * 8, v);
+        }
+    }
+}
+#undef H_ISSUE
+#undef H_LOADF
+#undef H_MFMA
+#undef H_SEGEND
+#undef H_WAIT
+
+// ------------------------------------------------------------------------------------------------
 // Epilogues.  operator()(row, col, v[8]) is called by EVERY lane (wave-uniform call site): lanes q..q+7 of
 // a wave hold the 64 consecutive columns [col&~63, +64) of one row, so row-wise reductions are 3 shuffles.
 // ------------------------------------------------------------------------------------------------
@@ -477,6 +612,25 @@ inline int launch_gemm(int al, int bl, const bf16_t* A, int lda, const bf16_t* B
     ksplit = (kt + per - 1) / per;
     g.k_chunk = per * G_BK;
     dim3 grid(((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN), 1, ksplit);
+    // Tile choice for NT launches: the 256 x 256 kernel moves half the L2->LDS bytes per flop (about 1.2x the 128 x 128 kernel's
+    // rate on full waves) but has 1 block per CU, so it only wins when its wave quantisation is not much worse (measured table in
+    // DESIGN.md 4.1).  CC_GEMM_S256=0 / 1 forces the choice for tools/gemm_bench.py.
+    static const int s256 = []() { const char* e = getenv("CC_GEMM_S256"); return e ? atoi(e) : -1; }();
+    bool big = false;
+    if (al == 0 && bl == 0 && (K % H_BK) == 0 && ksplit == 1 && s256 != 0) {
+        const long t256 = (long)((M + H_BM - 1) / H_BM) * ((N + H_BN - 1) / H_BN), t128 = (long)grid.x;
+        const double e256 = (double)t256 / (double)(((t256 + 255) / 256) * 256), e128 = (double)t128 / (double)(((t128 + 511) / 512) * 512);
+        big = s256 == 1 || 1.2 * e256 > 1.02 * e128;
+    }
+    if (big) {
+        constexpr size_t sh = (size_t)H_NS * H_STAGE;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)gemm_nt_stag256_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((gemm_nt_stag256_kernel<Epi>), dim3(((M + H_BM - 1) / H_BM) * ((N + H_BN - 1) / H_BN)), dim3(512), sh, st, A, B, g, epi);
+    } else
 #ifdef CC_GEMM_ABLATION
     static const int abl = []() { const char* e = getenv("CC_GEMM_ABL"); return e ? atoi(e) : 0; }();
     if (al == 0 && bl == 0 && (K % G_BK) == 0 && abl == 1) { hipLaunchKernelGGL((gemm_nt_glds_kernel<Epi, 1>), grid, dim3(G_THREADS), 0, st, A, B, g, epi); }
