@@ -689,6 +689,12 @@ int cc_gemm_bf16_f32(int32_t al, int32_t bl, const uint16_t* A, int32_t lda, con
     return gemm_f32out(al, bl, A, lda, B, ldb, M, N, K, C, ldc, ksplit > 1 ? nullptr : bias, ksplit > 1 ? 2 : 0, 1.0f, ksplit, S_(stream));
 }
 
+int cc_gemm_tile_mode(int32_t mode) {
+    const int old = g_gemm_tile_mode;
+    g_gemm_tile_mode = mode;
+    return old;
+}
+
 int cc_layernorm_fwd(const float* x, const float* gamma, const float* beta, uint16_t* y, float* mean, float* rstd, int32_t rows, int32_t D,
                      void* stream) {
     if (!x || !gamma || !beta || !y) return CC_ERR_ARG;

@@ -10,13 +10,15 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN stays NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// fp32 -> bf16 on the gfx950 converter (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN) — one instruction per PAIR; the
+// integer-arithmetic rounding it replaces cost ~7 VALU instructions and a divergent NaN branch per element and made every
+// bf16-storing epilogue instruction-bound.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_hw;
+typedef __attribute__((ext_vector_type(2))) float f32x2_hw;
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_hw{lo, hi}, bf16x2_hw));
 }
-__device__ __forceinline__ unsigned pack2bf(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f) & 0xffffu); }
 __device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
     f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
     f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);

@@ -19,7 +19,9 @@
 // multiples of 8 elements, base pointers 16-B aligned.  M, N (row counts) and K of a K-strided operand are free.
 #pragma once
 #include <cstdlib>
+#include <type_traits>
 #include "common.cuh"
+#include "gemm_api.h"
 
 namespace cc {
 
@@ -325,6 +327,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void gemm_nt_glds_kernel(const bf16_t
 // LDS image [row][32 k] (64-B rows), chunk' = chunk ^ ((row>>2)&3): conflict-free ds_read_b128 fragment reads.
 // ------------------------------------------------------------------------------------------------
 constexpr int H_BM = 256, H_BN = 256, H_BK = 32, H_NS = 4, H_STAGE = (H_BM + H_BN) * H_BK * 2;   // 32 KiB per stage, 128 KiB total
+// The B tile may be narrower: NJ MFMA column tiles per wave -> block tile 256 x (64 NJ); NJ = 3 gives 256 x 192 for N = 768-like widths.
 // 64-B rows, 4 chunks of 16 B.  ds_read_b128 is serviced in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (guide, LDS
 // table): with lane = (row & 15) + 16 * chunk a group holds rows 0-3 and 12-15 at chunk c and rows 4-11 at chunk c^1, so the XOR
 // key has to be 0,0,3,3 for row>>2 = 0..3 (not 0,1,2,3) for the 16 lanes to land on 16 different 16-B bank groups.
@@ -337,8 +340,8 @@ __device__ __forceinline__ int h_lds_off(int row, int chunk) { return row * 64 +
     {                                                                                                                    \
         char* st_ = smem + ((T) & (H_NS - 1)) * H_STAGE + ((IS_A) ? 0 : H_BM * H_BK * 2);                                \
         const int k0_ = (T)*H_BK;                                                                                        \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) {                                                               \
-            const int seg = wn + 4 * i_;                        /* 16 segments of 16 rows x 64 B per operand tile */      \
+        _Pragma("unroll") for (int i_ = 0; i_ < ((IS_A) ? 4 : NJ); i_++) {                                              \
+            const int seg = wn + 4 * i_;                        /* 16 (A) or 4 NJ (B) segments of 16 rows x 64 B */       \
             const int row = seg * 16 + (lane >> 2);                                                                      \
             const int chunk = (lane & 3) ^ h_swz(row);                                                             \
             H_SRC_EXPR(IS_A)                                                                                                \
@@ -350,13 +353,13 @@ __device__ __forceinline__ int h_lds_off(int row, int chunk) { return row * 64 +
         const char* ca_ = smem + ((T) & (H_NS - 1)) * H_STAGE;                                                           \
         const char* cb_ = ca_ + H_BM * H_BK * 2;                                                                         \
         _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) af[i_] = *reinterpret_cast<const bf16x8*>(ca_ + h_lds_off(arow + i_ * 16 + frow, fchunk)); \
-        _Pragma("unroll") for (int j_ = 0; j_ < 4; j_++) bfr[j_] = *reinterpret_cast<const bf16x8*>(cb_ + h_lds_off(bcol + j_ * 16 + frow, fchunk)); \
+        _Pragma("unroll") for (int j_ = 0; j_ < NJ; j_++) bfr[j_] = *reinterpret_cast<const bf16x8*>(cb_ + h_lds_off(bcol + j_ * 16 + frow, fchunk)); \
     }
 #define H_MFMA()                                                                                                         \
     {                                                                                                                    \
         __builtin_amdgcn_s_setprio(1);                                                                                   \
-        _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) _Pragma("unroll") for (int j_ = 0; j_ < 4; j_++)                 \
-            acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i_], bfr[j_], acc[i_][j_], 0, 0, 0);                \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) _Pragma("unroll") for (int j_ = 0; j_ < NJ; j_++)                \
+            acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j_], af[i_], acc[i_][j_], 0, 0, 0);                \
         __builtin_amdgcn_s_setprio(0);                                                                                   \
     }
 #define H_SEGEND()                                                                                                       \
@@ -366,85 +369,126 @@ __device__ __forceinline__ int h_lds_off(int row, int chunk) { return row * 64 +
         __builtin_amdgcn_s_barrier();                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
     }
-// tile t+1 must have landed; tiles t+2 and t+3 (4 DMA instructions per wave each) may stay in flight
-#define H_WAIT(T)                                                                                                        \
+// tile t+1 must have landed; tiles t+2 and t+3 (CNT DMA instructions per wave each: 4 in group 0, NJ in group 1) may stay in flight
+#define H_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+#define H_WAIT(T, CNT)                                                                                                   \
     {                                                                                                                    \
         const int rem_ = min(nk - 1, (T) + 3) - ((T) + 1);                                                               \
-        if (rem_ >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                  \
-        else if (rem_ == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                             \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                            \
+        if (rem_ >= 2) { if ((CNT) == 4) H_VMCNT(8); else if ((CNT) == 3) H_VMCNT(6); else H_VMCNT(4); }                 \
+        else if (rem_ == 1) { if ((CNT) == 4) H_VMCNT(4); else if ((CNT) == 3) H_VMCNT(3); else H_VMCNT(2); }            \
+        else H_VMCNT(0);                                                                                                 \
     }
-template <class Epi>
+// epilogue functors that reduce along a row (lm_head softmax partials) take the wave's whole 64-column strip: Epi::strip()
+template <class E> struct epi_row_strip { static constexpr bool value = false; };
+template <class Epi, int NJ>
 __global__ __launch_bounds__(512, 1) void gemm_nt_stag256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, GemmShape g, Epi epi) {
+    static_assert(NJ >= 2 && NJ <= 4, "wave tile is 128 x (16 NJ)");
+    constexpr int BN = 64 * NJ;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wn = wave & 3;
-    const int arow = grp * 128, bcol = wn * 64;
-    const int tiles_n = (g.N + H_BN - 1) / H_BN, tiles_m = (g.M + H_BM - 1) / H_BM;
+    const int arow = grp * 128, bcol = wn * (16 * NJ);
+    const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + H_BM - 1) / H_BM;
     int tm, tn;
     tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, g.group_m, tm, tn);
-    const int m0 = tm * H_BM, n0 = tn * H_BN;
+    const int m0 = tm * H_BM, n0 = tn * BN;
     const int nk = g.K / H_BK;
-    f32x4 acc[8][4];
+    f32x4 acc[8][NJ];
 #pragma unroll
     for (int i = 0; i < 8; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 af[8], bfr[4];
+        for (int j = 0; j < NJ; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[8], bfr[NJ];
     const int frow = lane & 15, fchunk = lane >> 4;
     if (grp == 0) {
         H_ISSUE(0, true);
         if (nk > 1) H_ISSUE(1, true);
         if (nk > 2) H_ISSUE(2, true);
-        H_WAIT(-1);
+        H_WAIT(-1, 4);
         H_SEGEND();
         for (int t = 0; t < nk; t++) {
             if (t + 3 < nk) H_ISSUE(t + 3, true);      // buffer (t+3)&3 was last read (by group 1) in segment 2t-1
             H_LOADF(t); H_SEGEND();
-            H_MFMA(); H_WAIT(t); H_SEGEND();
+            H_MFMA(); H_WAIT(t, 4); H_SEGEND();
         }
         H_SEGEND();
     } else {
         H_ISSUE(0, false);
         if (nk > 1) H_ISSUE(1, false);
         if (nk > 2) H_ISSUE(2, false);
-        H_WAIT(-1);
+        H_WAIT(-1, NJ);
         H_SEGEND();
         for (int t = 0; t < nk; t++) {
             if (t >= 1) H_MFMA();
             H_SEGEND();
             if (t + 3 < nk) H_ISSUE(t + 3, false);     // one segment after group 0's half of the same tile
-            H_LOADF(t); H_WAIT(t); H_SEGEND();
+            H_LOADF(t); H_WAIT(t, NJ); H_SEGEND();
         }
         H_MFMA(); H_SEGEND();
     }
-    __syncthreads();
-    float* strip = reinterpret_cast<float*>(smem) + wave * (16 * G_EPI_LD);
-    const int er = (lane >> 4) * 4, ec = lane & 15;
+    // Epilogue without LDS.  The MFMAs ran with the operands swapped (B fragment first), so a lane holds C[row = lane & 15]
+    // [cols 4 q .. 4 q + 3] of each 16 x 16 tile (q = lane >> 4): four CONSECUTIVE columns of one row.  v_permlane16_swap on the
+    // accumulators of two tiles X, Y hands the odd 16-lane rows of X to Y and the even rows of Y to X; afterwards lane q holds
+    // eight consecutive columns 8 (q >> 1) .. + 7 of tile (q & 1 ? Y : X): the functors' (row, col, v[8]) contract, straight from
+    // registers.  Tiles pair along j; a leftover column tile (odd NJ) pairs along i.
+    const int q = lane >> 4, rl = lane & 15;
+#define H_PAIR(X, Y, V)                                                                                                  \
+    _Pragma("unroll") for (int r_ = 0; r_ < 4; r_++) {                                                                   \
+        const auto s_ = __builtin_amdgcn_permlane16_swap(__float_as_uint((X)[r_]), __float_as_uint((Y)[r_]), false, false); \
+        (V)[r_] = __uint_as_float(s_[0]);                                                                                \
+        (V)[4 + r_] = __uint_as_float(s_[1]);                                                                            \
+    }
+    if constexpr (epi_row_strip<Epi>::value) {
+        static_assert(!epi_row_strip<Epi>::value || NJ == 4, "row-strip epilogues need the 64-column wave strip");
+        int tg[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+        for (int i = 0; i < 8; i++) tg[i] = epi.load_target(m0 + arow + i * 16 + rl);      // all loads before the first store
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int i = 0; i < 8; i++) {
+            float va[8], vb[8];
+            H_PAIR(acc[i][0], acc[i][1], va);
+            H_PAIR(acc[i][NJ - 2], acc[i][NJ - 1], vb);
+            const int cb = n0 + bcol + (q & 1) * 16 + (q >> 1) * 8;
+            epi.strip(m0 + arow + i * 16 + rl, cb, cb + 32, va, vb, tg[i]);
+        }
+    } else {
+        if constexpr (Epi::kPre) {                         // loads (residual / aux / C) folded into the accumulators first
 #pragma unroll
-            for (int r = 0; r < 4; r++) strip[(er + r) * G_EPI_LD + j * 16 + ec] = acc[i][j][r];
+            for (int i = 0; i < 8; i++)
 #pragma unroll
-        for (int s = 0; s < 2; s++) {
-            const int q = lane + 64 * s;
-            const int lr = q >> 3, c8 = q & 7;
-            float v[8];
-            const float4 a = *reinterpret_cast<const float4*>(strip + lr * G_EPI_LD + c8 * 8);
-            const float4 b = *reinterpret_cast<const float4*>(strip + lr * G_EPI_LD + c8 * 8 + 4);
-            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-            epi(m0 + arow + i * 16 + lr, n0 + bcol + c8 * 8, v);
+                for (int j = 0; j < NJ; j++) epi.pre4(m0 + arow + i * 16 + rl, n0 + bcol + j * 16 + q * 4, acc[i][j]);
+        }
+        float bias[(NJ + 1) / 2][8];
+#pragma unroll
+        for (int jp = 0; jp < NJ / 2; jp++) epi.bias8(n0 + bcol + (2 * jp + (q & 1)) * 16 + (q >> 1) * 8, bias[jp]);
+        if constexpr (NJ & 1) epi.bias8(n0 + bcol + (NJ - 1) * 16 + (q >> 1) * 8, bias[NJ / 2]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+#pragma unroll
+            for (int jp = 0; jp < NJ / 2; jp++) {
+                float v[8];
+                H_PAIR(acc[i][2 * jp], acc[i][2 * jp + 1], v);
+                epi.fin(m0 + arow + i * 16 + rl, n0 + bcol + (2 * jp + (q & 1)) * 16 + (q >> 1) * 8, v, bias[jp]);
+            }
+            if constexpr (NJ & 1) {
+                if (i & 1) {
+                    float v[8];
+                    H_PAIR(acc[i - 1][NJ - 1], acc[i][NJ - 1], v);
+                    epi.fin(m0 + arow + (i - 1 + (q & 1)) * 16 + rl, n0 + bcol + (NJ - 1) * 16 + (q >> 1) * 8, v, bias[NJ / 2]);
+                }
+            }
         }
     }
+#undef H_PAIR
 }
 #undef H_ISSUE
 #undef H_LOADF
 #undef H_MFMA
 #undef H_SEGEND
 #undef H_WAIT
+#undef H_VMCNT
 
 // ------------------------------------------------------------------------------------------------
 // Epilogues.  operator()(row, col, v[8]) is called by EVERY lane (wave-uniform call site): lanes q..q+7 of
@@ -452,6 +496,16 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_stag256_kernel(const bf16_t* _
 // ------------------------------------------------------------------------------------------------
 
 // C(bf16) = act(acc + bias); optionally also stores the pre-activation (needed by gelu backward).
+__device__ __forceinline__ void load_bias8(const float* bias, int col, int Ns, float (&b)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; e++) b[e] = 0.f;
+    if (bias && col < Ns) {
+        const float4 b0 = *reinterpret_cast<const float4*>(bias + col);
+        const float4 b1 = *reinterpret_cast<const float4*>(bias + col + 4);
+        b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
+    }
+}
+
 struct EpiBF16 {
     bf16_t* C;
     bf16_t* pre;        // nullable
@@ -465,6 +519,27 @@ struct EpiBF16 {
             const float4 b1 = *reinterpret_cast<const float4*>(bias + col + 4);
             v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
         }
+        if (pre) *reinterpret_cast<uint4*>(pre + (size_t)row * ldc + col) = pack8(v);
+        if (act == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
+        } else if (act == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = gelu_new_f(v[e]);
+        }
+        *reinterpret_cast<uint4*>(C + (size_t)row * ldc + col) = pack8(v);
+    }
+    // Split form for the 256-row kernels (see gemm_nt_stag256_kernel): every global LOAD of the epilogue happens before its first
+    // STORE — with loads and stores both pending on the one vmcnt counter the compiler must wait vmcnt(0), i.e. drain the store
+    // queue, before using any loaded value.  pre4(): per 16x16 tile in accumulator layout (4 consecutive columns of one row);
+    // bias8(): the lane's 8 bias values for a column group; fin(): math + stores only.
+    static constexpr bool kPre = false;
+    __device__ __forceinline__ void pre4(int, int, f32x4&) const {}
+    __device__ __forceinline__ void bias8(int col, float (&b)[8]) const { load_bias8(bias, col, Ns, b); }
+    __device__ __forceinline__ void fin(int row, int col, float (&v)[8], const float (&b)[8]) const {
+        if (row >= M || col >= Ns) return;
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] += b[e];
         if (pre) *reinterpret_cast<uint4*>(pre + (size_t)row * ldc + col) = pack8(v);
         if (act == 1) {
 #pragma unroll
@@ -495,6 +570,19 @@ struct EpiResid {
         }
         *reinterpret_cast<float4*>(out + o) = make_float4(r0.x + v[0] + b0.x, r0.y + v[1] + b0.y, r0.z + v[2] + b0.z, r0.w + v[3] + b0.w);
         *reinterpret_cast<float4*>(out + o + 4) = make_float4(r1.x + v[4] + b1.x, r1.y + v[5] + b1.y, r1.z + v[6] + b1.z, r1.w + v[7] + b1.w);
+    }
+    static constexpr bool kPre = true;
+    __device__ __forceinline__ void pre4(int row, int col, f32x4& a) const {        // acc += residual
+        if (row >= M || col >= Ns) return;
+        const float4 r = *reinterpret_cast<const float4*>(res + (size_t)row * ld + col);
+        a[0] += r.x; a[1] += r.y; a[2] += r.z; a[3] += r.w;
+    }
+    __device__ __forceinline__ void bias8(int col, float (&b)[8]) const { load_bias8(bias, col, Ns, b); }
+    __device__ __forceinline__ void fin(int row, int col, float (&v)[8], const float (&b)[8]) const {
+        if (row >= M || col >= Ns) return;
+        const size_t o = (size_t)row * ld + col;
+        *reinterpret_cast<float4*>(out + o) = make_float4(v[0] + b[0], v[1] + b[1], v[2] + b[2], v[3] + b[3]);
+        *reinterpret_cast<float4*>(out + o + 4) = make_float4(v[4] + b[4], v[5] + b[5], v[6] + b[6], v[7] + b[7]);
     }
 };
 
@@ -529,6 +617,25 @@ struct EpiF32 {
         *reinterpret_cast<float4*>(p) = o0;
         *reinterpret_cast<float4*>(p + 4) = o1;
     }
+    static constexpr bool kPre = true;
+    __device__ __forceinline__ void pre4(int row, int col, f32x4& a) const {        // acc = alpha * acc (+ C for mode 1)
+        a[0] *= alpha; a[1] *= alpha; a[2] *= alpha; a[3] *= alpha;
+        if (mode != 1 || row >= M || col >= Ns) return;
+        const float4 c = *reinterpret_cast<const float4*>(C + (size_t)row * ldc + col);
+        a[0] += c.x; a[1] += c.y; a[2] += c.z; a[3] += c.w;
+    }
+    __device__ __forceinline__ void bias8(int col, float (&b)[8]) const { load_bias8(mode == 0 ? bias : nullptr, col, Ns, b); }
+    __device__ __forceinline__ void fin(int row, int col, float (&v)[8], const float (&b)[8]) const {
+        if (row >= M || col >= Ns) return;
+        float* p = C + (size_t)row * ldc + col + (mode == 3 ? blockIdx.z * zstride : 0);
+        if (mode == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) __hip_atomic_fetch_add(p + e, v[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        *reinterpret_cast<float4*>(p) = make_float4(v[0] + b[0], v[1] + b[1], v[2] + b[2], v[3] + b[3]);
+        *reinterpret_cast<float4*>(p + 4) = make_float4(v[4] + b[4], v[5] + b[5], v[6] + b[6], v[7] + b[7]);
+    }
 };
 
 // C(bf16) = acc * act'(aux)   (dgrad through relu: aux = post-activation h; through gelu_new: aux = pre-activation u)
@@ -550,6 +657,22 @@ struct EpiDAct {
             for (int e = 0; e < 8; e++) v[e] *= gelu_new_grad(a[e]);
         }
         *reinterpret_cast<uint4*>(C + o) = pack8(v);
+    }
+    static constexpr bool kPre = true;
+    __device__ __forceinline__ void pre4(int row, int col, f32x4& a) const {        // acc *= act'(aux)
+        if (row >= M || col >= Ns) return;
+        const uint2 u = *reinterpret_cast<const uint2*>(aux + (size_t)row * ldc + col);
+        const float x[4] = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+#pragma unroll
+        for (int e = 0; e < 4; e++) a[e] = act == 1 ? (x[e] > 0.f ? a[e] : 0.f) : a[e] * gelu_new_grad(x[e]);
+    }
+    __device__ __forceinline__ void bias8(int, float (&b)[8]) const {
+#pragma unroll
+        for (int e = 0; e < 8; e++) b[e] = 0.f;
+    }
+    __device__ __forceinline__ void fin(int row, int col, float (&v)[8], const float (&)[8]) const {
+        if (row >= M || col >= Ns) return;
+        *reinterpret_cast<uint4*>(C + (size_t)row * ldc + col) = pack8(v);
     }
 };
 
@@ -588,7 +711,54 @@ struct EpiLMHead {
         if (t >= 0 && t < 8) tgt_logit[row] = v[t];
         *reinterpret_cast<uint4*>(C + (size_t)row * ldc + col) = pack8(v);
     }
+    // 256-row kernels: the lane holds columns ca..ca+7 and cb..cb+7 of `row`; lanes l, l^16, l^32, l^48 together hold the row's
+    // aligned 64-column block (all lanes of the wave must call this).
+    __device__ __forceinline__ int load_target(int row) const { return row < M ? target[row] : -1; }
+    __device__ __forceinline__ void strip(int row, int ca, int cb, float (&va)[8], float (&vb)[8], int t) const {
+        constexpr float L2E = 1.4426950408889634f;
+        float m, s = 0.f;
+        if (__builtin_amdgcn_readfirstlane(ca | 63) < V) {          // the whole 64-column block is inside the vocabulary (wave-uniform)
+            m = fmaxf(fmaxf(fmaxf(va[0], va[1]), fmaxf(va[2], va[3])), fmaxf(fmaxf(va[4], va[5]), fmaxf(va[6], va[7])));
+            m = fmaxf(m, fmaxf(fmaxf(fmaxf(vb[0], vb[1]), fmaxf(vb[2], vb[3])), fmaxf(fmaxf(vb[4], vb[5]), fmaxf(vb[6], vb[7]))));
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            const float ml = -m * L2E;
+#pragma unroll
+            for (int e = 0; e < 8; e++) s += __builtin_amdgcn_exp2f(fmaf(va[e], L2E, ml)) + __builtin_amdgcn_exp2f(fmaf(vb[e], L2E, ml));
+        } else {
+            m = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                if (ca + e >= V) va[e] = 0.f; else m = fmaxf(m, va[e]);
+                if (cb + e >= V) vb[e] = 0.f; else m = fmaxf(m, vb[e]);
+            }
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                if (ca + e < V) s += __expf(va[e] - m);
+                if (cb + e < V) s += __expf(vb[e] - m);
+            }
+        }
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (row >= M) return;
+        if ((ca & 63) == 0 && ca < ldc) {
+            const int blk = ca >> 6;
+            pmax[(size_t)row * npart + blk] = m;
+            psum[(size_t)row * npart + blk] = (m == -INFINITY) ? 0.f : s;
+        }
+        if (ca < ldc) {
+            if (t >= ca && t < ca + 8) tgt_logit[row] = va[t - ca];
+            *reinterpret_cast<uint4*>(C + (size_t)row * ldc + ca) = pack8(va);
+        }
+        if (cb < ldc) {
+            if (t >= cb && t < cb + 8) tgt_logit[row] = vb[t - cb];
+            *reinterpret_cast<uint4*>(C + (size_t)row * ldc + cb) = pack8(vb);
+        }
+    }
 };
+template <> struct epi_row_strip<EpiLMHead> { static constexpr bool value = true; };
 
 // ------------------------------------------------------------------------------------------------
 // Host launcher
@@ -612,24 +782,33 @@ inline int launch_gemm(int al, int bl, const bf16_t* A, int lda, const bf16_t* B
     ksplit = (kt + per - 1) / per;
     g.k_chunk = per * G_BK;
     dim3 grid(((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN), 1, ksplit);
-    // Tile choice for NT launches: the 256 x 256 kernel moves half the L2->LDS bytes per flop (about 1.2x the 128 x 128 kernel's
-    // rate on full waves) but has 1 block per CU, so it only wins when its wave quantisation is not much worse (measured table in
-    // DESIGN.md 4.1).  CC_GEMM_S256=0 / 1 forces the choice for tools/gemm_bench.py.
-    static const int s256 = []() { const char* e = getenv("CC_GEMM_S256"); return e ? atoi(e) : -1; }();
-    bool big = false;
+    // Tile choice for NT launches.  The 256-row kernel moves 1/2 (256 wide) or 2/3 (192 wide) of the 128 x 128 kernel's L2->LDS
+    // bytes per flop and runs ~1.2x / ~1.15x its rate on full waves, but holds one block per CU, so wave quantisation decides:
+    // cost = rounds x tile area / rate, the 128 x 128 kernel counted with 2 co-resident blocks per CU (measured table: DESIGN.md 4.1).
+    // g_gemm_tile_mode (cc_gemm_tile_mode / CC_GEMM_S256) = 0 (never) / 3 / 4 (force) overrides it for tests and tools/gemm_bench.py.
+    const int s256 = g_gemm_tile_mode;
+    int nj = 0;
     if (al == 0 && bl == 0 && (K % H_BK) == 0 && ksplit == 1 && s256 != 0) {
-        const long t256 = (long)((M + H_BM - 1) / H_BM) * ((N + H_BN - 1) / H_BN), t128 = (long)grid.x;
-        const double e256 = (double)t256 / (double)(((t256 + 255) / 256) * 256), e128 = (double)t128 / (double)(((t128 + 511) / 512) * 512);
-        big = s256 == 1 || 1.2 * e256 > 1.02 * e128;
+        const long tm = (M + H_BM - 1) / H_BM, t128 = (long)grid.x;
+        const long t256 = tm * ((N + 255) / 256), t192 = tm * ((N + 191) / 192);
+        const double c128 = t128 <= 256 ? 16384.0 / 0.75 : (double)((t128 + 511) / 512) * 32768.0;
+        const double c256 = (double)((t256 + 255) / 256) * 65536.0 / 1.2, c192 = (double)((t192 + 255) / 256) * 49152.0 / 1.15;
+        constexpr bool can192 = !std::is_same<Epi, EpiLMHead>::value;   // its partials assume 64-column wave strips
+        if (s256 == 4 || (s256 < 0 && c256 < 0.98 * c128 && (!can192 || c256 <= c192))) nj = 4;
+        else if (can192 && (s256 == 3 || (s256 < 0 && c192 < 0.98 * c128))) nj = 3;
     }
-    if (big) {
+    if (nj) {
         constexpr size_t sh = (size_t)H_NS * H_STAGE;
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)gemm_nt_stag256_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-            attr_set = true;
+        const dim3 gr((unsigned)(((M + H_BM - 1) / H_BM) * ((N + 64 * nj - 1) / (64 * nj))));
+        if (nj == 4) {
+            static bool attr4 = false;
+            if (!attr4) { (void)hipFuncSetAttribute((const void*)gemm_nt_stag256_kernel<Epi, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr4 = true; }
+            hipLaunchKernelGGL((gemm_nt_stag256_kernel<Epi, 4>), gr, dim3(512), sh, st, A, B, g, epi);
+        } else if constexpr (!std::is_same<Epi, EpiLMHead>::value) {
+            static bool attr3 = false;
+            if (!attr3) { (void)hipFuncSetAttribute((const void*)gemm_nt_stag256_kernel<Epi, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr3 = true; }
+            hipLaunchKernelGGL((gemm_nt_stag256_kernel<Epi, 3>), gr, dim3(512), sh, st, A, B, g, epi);
         }
-        hipLaunchKernelGGL((gemm_nt_stag256_kernel<Epi>), dim3(((M + H_BM - 1) / H_BM) * ((N + H_BN - 1) / H_BN)), dim3(512), sh, st, A, B, g, epi);
     } else
 #ifdef CC_GEMM_ABLATION
     static const int abl = []() { const char* e = getenv("CC_GEMM_ABL"); return e ? atoi(e) : 0; }();

@@ -3,6 +3,9 @@
 #include "common.cuh"
 
 namespace cc {
+// NT tile choice: -1 chooser (default; CC_GEMM_S256 in the environment presets it), 0 = 128 x 128 only, 3 / 4 = force the
+// 256 x 192 / 256 x 256 kernel wherever it is legal.  Test / microbenchmark hook (cc_gemm_tile_mode).
+extern int g_gemm_tile_mode;
 // al/bl: 0 = K-contiguous operand ([rows][K]), 1 = K-strided operand ([K][rows]).  See gemm.cuh.
 int gemm_bf16out(int al, int bl, const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, bf16_t* C, int ldc,
                  const float* bias, int act, bf16_t* pre, hipStream_t st);

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include "gemm_api.h"
 namespace cc {
+int g_gemm_tile_mode = []() { const char* e = getenv("CC_GEMM_S256"); return e ? atoi(e) : -1; }();
 int gemm_f32out(int al, int bl, const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, float* C, int ldc,
                 const float* bias, int mode, float alpha, int ksplit, hipStream_t st) {
     if ((ldc & 3) || (N & 7)) return CC_ERR_SHAPE;

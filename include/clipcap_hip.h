@@ -189,6 +189,9 @@ int cc_cast_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
  * ------------------------------------------------------------------------------------------------------------ */
 int cc_gemm_bf16_f32(int32_t al, int32_t bl, const uint16_t* A, int32_t lda, const uint16_t* B, int32_t ldb, int32_t M, int32_t N,
                      int32_t K, float* C, int32_t ldc, const float* bias, int32_t ksplit, void* stream);
+/* NT GEMM tile choice: -1 = cost-model chooser (default), 0 = 128x128 kernel only, 3 / 4 = force the 256x192 / 256x256 kernel
+ * wherever it is legal.  Process-global; returns the previous mode.  For tests and tools/gemm_bench.py only. */
+int cc_gemm_tile_mode(int32_t mode);
 int cc_layernorm_fwd(const float* x, const float* gamma, const float* beta, uint16_t* y, float* mean, float* rstd, int32_t rows,
                      int32_t D, void* stream);
 int cc_attention_fwd(const uint16_t* qkv, int32_t B, int32_t S, int32_t H, int32_t hd, int32_t causal, uint16_t* out, float* lse,

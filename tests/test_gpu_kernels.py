@@ -45,6 +45,29 @@ def test_gemm_layouts(al, bl, M, N, K):
     assert torch.isnan(Cm[:, N:]).all()   # nothing written outside the N columns
 
 
+@pytest.mark.parametrize("mode", [3, 4])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 32), (8, 8, 32), (520, 200, 96), (1000, 392, 1024), (300, 776, 160)])
+def test_gemm_nt_256_row_tiles(mode, M, N, K):
+    """the 256 x 192 / 256 x 256 group-staggered NT kernels (forced: the chooser would pick 128 x 128 at these sizes)"""
+    torch.manual_seed(M + N + K + mode)
+    dev = "cuda"
+    A = _bf(torch.randn(M, K, device=dev))
+    Bt = _bf(torch.randn(N, K, device=dev) * 0.5 + 0.1)
+    bias = torch.randn(N, device=dev)
+    ref = A.float() @ Bt.float().t() + bias
+    Cm = torch.full((M, N + 8), float("nan"), device=dev)
+    old = _lib().cc_gemm_tile_mode(mode)
+    try:
+        rc = _lib().cc_gemm_bf16_f32(0, 0, _p(A), K, _p(Bt), K, M, N, K, _p(Cm), N + 8, _p(bias), 1, _st())
+        torch.cuda.synchronize()
+    finally:
+        _lib().cc_gemm_tile_mode(old)
+    assert rc == 0
+    err = (Cm[:, :N] - ref).abs().max().item()
+    assert err <= 2e-3 * max(1.0, ref.abs().max().item() / 10), err
+    assert torch.isnan(Cm[:, N:]).all()
+
+
 @pytest.mark.parametrize("ksplit", [2, 5, 16])
 def test_gemm_wgrad_split_k_atomic(ksplit):
     torch.manual_seed(ksplit)
