@@ -150,6 +150,78 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[4][4], char* smem, in
     }
 }
 
+// epilogue functors that reduce along a row (lm_head softmax partials) take the wave's whole 64-column strip: Epi::strip()
+template <class E> struct epi_row_strip { static constexpr bool value = false; };
+
+// ---- epilogue straight from registers (no LDS) for the 256-row kernels (8 waves, one block per CU: nothing else on the CU hides
+// an LDS round trip and its barrier; with the 128 x 128 kernels' two co-resident blocks the strip epilogue above measured 1.5 %
+// faster on the training step).  The kernel issues its MFMAs with the operands SWAPPED (B fragment first), so
+// a lane holds C[row = lane & 15][cols 4 q .. 4 q + 3] of each 16 x 16 tile (q = lane >> 4): four CONSECUTIVE columns of one row.
+// v_permlane16_swap on the accumulators of two tiles X, Y hands the odd 16-lane rows of X to Y and the even rows of Y to X;
+// afterwards lane q holds eight consecutive columns 8 (q >> 1) .. + 7 of tile (q & 1 ? Y : X) — the functors' (row, col, v[8])
+// unit.  Tiles pair along j; a leftover column tile (odd NJ) pairs along i.
+// Order: every global LOAD of the epilogue (residual / activation input / bias / targets) is issued before its first STORE: with
+// loads and stores both pending on the single vmcnt counter the compiler has to wait vmcnt(0) — drain the store queue — before
+// it may use a loaded value, which serialised the old load-store-load-store epilogue on the HBM write latency.
+//   Epi::pre4(row, col, acc4)        loads folded into one tile's accumulators (accumulator layout), kPre only
+//   Epi::bias8(col, b[8])            the lane's bias values for a column group
+//   Epi::fin(row, col, v[8], b[8])   math + stores only
+//   Epi::strip(...)                  row-strip functors (NJ == 4): both column groups of the row at once
+template <class Epi, int NI, int NJ>
+__device__ __forceinline__ void gemm_epilogue_regs(f32x4 (&acc)[NI][NJ], int lane, int row0, int col0, const Epi& epi) {
+    static_assert(NI % 2 == 0, "leftover column tiles pair along i");
+    const int q = lane >> 4, rl = lane & 15;
+#define G_PAIR(X, Y, V)                                                                                                  \
+    _Pragma("unroll") for (int r_ = 0; r_ < 4; r_++) {                                                                   \
+        const auto s_ = __builtin_amdgcn_permlane16_swap(__float_as_uint((X)[r_]), __float_as_uint((Y)[r_]), false, false); \
+        (V)[r_] = __uint_as_float(s_[0]);                                                                                \
+        (V)[4 + r_] = __uint_as_float(s_[1]);                                                                            \
+    }
+    if constexpr (epi_row_strip<Epi>::value) {
+        static_assert(!epi_row_strip<Epi>::value || NJ == 4, "row-strip epilogues need a 64-column wave strip");
+        int tg[NI];
+#pragma unroll
+        for (int i = 0; i < NI; i++) tg[i] = epi.load_target(row0 + i * 16 + rl);
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            float va[8], vb[8];
+            G_PAIR(acc[i][0], acc[i][1], va);
+            G_PAIR(acc[i][NJ - 2], acc[i][NJ - 1], vb);
+            const int cb = col0 + (q & 1) * 16 + (q >> 1) * 8;
+            epi.strip(row0 + i * 16 + rl, cb, cb + 32, va, vb, tg[i]);
+        }
+    } else {
+        if constexpr (Epi::kPre) {
+#pragma unroll
+            for (int i = 0; i < NI; i++)
+#pragma unroll
+                for (int j = 0; j < NJ; j++) epi.pre4(row0 + i * 16 + rl, col0 + j * 16 + q * 4, acc[i][j]);
+        }
+        float bias[(NJ + 1) / 2][8];
+#pragma unroll
+        for (int jp = 0; jp < NJ / 2; jp++) epi.bias8(col0 + (2 * jp + (q & 1)) * 16 + (q >> 1) * 8, bias[jp]);
+        if constexpr (NJ & 1) epi.bias8(col0 + (NJ - 1) * 16 + (q >> 1) * 8, bias[NJ / 2]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+#pragma unroll
+            for (int jp = 0; jp < NJ / 2; jp++) {
+                float v[8];
+                G_PAIR(acc[i][2 * jp], acc[i][2 * jp + 1], v);
+                epi.fin(row0 + i * 16 + rl, col0 + (2 * jp + (q & 1)) * 16 + (q >> 1) * 8, v, bias[jp]);
+            }
+            if constexpr (NJ & 1) {
+                if (i & 1) {
+                    float v[8];
+                    G_PAIR(acc[i - 1][NJ - 1], acc[i][NJ - 1], v);
+                    epi.fin(row0 + (i - 1 + (q & 1)) * 16 + rl, col0 + (NJ - 1) * 16 + (q >> 1) * 8, v, bias[NJ / 2]);
+                }
+            }
+        }
+    }
+#undef G_PAIR
+}
+
 // tile id -> (m-tile, n-tile): ids walk GROUP_M m-tiles down, then one n-tile across (column-major inside a band of
 // GROUP_M m-tiles).  With the XCD remap above, the ~64 blocks resident on one XCD cover an 8x8 patch of tiles, whose
 // A and B panels (16 x 128 x K bf16) fit that XCD's 4 MiB L2 instead of streaming B once per m-tile.
@@ -378,8 +450,6 @@ __device__ __forceinline__ int h_lds_off(int row, int chunk) { return row * 64 +
         else if (rem_ == 1) { if ((CNT) == 4) H_VMCNT(4); else if ((CNT) == 3) H_VMCNT(3); else H_VMCNT(2); }            \
         else H_VMCNT(0);                                                                                                 \
     }
-// epilogue functors that reduce along a row (lm_head softmax partials) take the wave's whole 64-column strip: Epi::strip()
-template <class E> struct epi_row_strip { static constexpr bool value = false; };
 template <class Epi, int NJ>
 __global__ __launch_bounds__(512, 1) void gemm_nt_stag256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, GemmShape g, Epi epi) {
     static_assert(NJ >= 2 && NJ <= 4, "wave tile is 128 x (16 NJ)");
@@ -427,61 +497,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_stag256_kernel(const bf16_t* _
         }
         H_MFMA(); H_SEGEND();
     }
-    // Epilogue without LDS.  The MFMAs ran with the operands swapped (B fragment first), so a lane holds C[row = lane & 15]
-    // [cols 4 q .. 4 q + 3] of each 16 x 16 tile (q = lane >> 4): four CONSECUTIVE columns of one row.  v_permlane16_swap on the
-    // accumulators of two tiles X, Y hands the odd 16-lane rows of X to Y and the even rows of Y to X; afterwards lane q holds
-    // eight consecutive columns 8 (q >> 1) .. + 7 of tile (q & 1 ? Y : X): the functors' (row, col, v[8]) contract, straight from
-    // registers.  Tiles pair along j; a leftover column tile (odd NJ) pairs along i.
-    const int q = lane >> 4, rl = lane & 15;
-#define H_PAIR(X, Y, V)                                                                                                  \
-    _Pragma("unroll") for (int r_ = 0; r_ < 4; r_++) {                                                                   \
-        const auto s_ = __builtin_amdgcn_permlane16_swap(__float_as_uint((X)[r_]), __float_as_uint((Y)[r_]), false, false); \
-        (V)[r_] = __uint_as_float(s_[0]);                                                                                \
-        (V)[4 + r_] = __uint_as_float(s_[1]);                                                                            \
-    }
-    if constexpr (epi_row_strip<Epi>::value) {
-        static_assert(!epi_row_strip<Epi>::value || NJ == 4, "row-strip epilogues need the 64-column wave strip");
-        int tg[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) tg[i] = epi.load_target(m0 + arow + i * 16 + rl);      // all loads before the first store
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            float va[8], vb[8];
-            H_PAIR(acc[i][0], acc[i][1], va);
-            H_PAIR(acc[i][NJ - 2], acc[i][NJ - 1], vb);
-            const int cb = n0 + bcol + (q & 1) * 16 + (q >> 1) * 8;
-            epi.strip(m0 + arow + i * 16 + rl, cb, cb + 32, va, vb, tg[i]);
-        }
-    } else {
-        if constexpr (Epi::kPre) {                         // loads (residual / aux / C) folded into the accumulators first
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-#pragma unroll
-                for (int j = 0; j < NJ; j++) epi.pre4(m0 + arow + i * 16 + rl, n0 + bcol + j * 16 + q * 4, acc[i][j]);
-        }
-        float bias[(NJ + 1) / 2][8];
-#pragma unroll
-        for (int jp = 0; jp < NJ / 2; jp++) epi.bias8(n0 + bcol + (2 * jp + (q & 1)) * 16 + (q >> 1) * 8, bias[jp]);
-        if constexpr (NJ & 1) epi.bias8(n0 + bcol + (NJ - 1) * 16 + (q >> 1) * 8, bias[NJ / 2]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-#pragma unroll
-            for (int jp = 0; jp < NJ / 2; jp++) {
-                float v[8];
-                H_PAIR(acc[i][2 * jp], acc[i][2 * jp + 1], v);
-                epi.fin(m0 + arow + i * 16 + rl, n0 + bcol + (2 * jp + (q & 1)) * 16 + (q >> 1) * 8, v, bias[jp]);
-            }
-            if constexpr (NJ & 1) {
-                if (i & 1) {
-                    float v[8];
-                    H_PAIR(acc[i - 1][NJ - 1], acc[i][NJ - 1], v);
-                    epi.fin(m0 + arow + (i - 1 + (q & 1)) * 16 + rl, n0 + bcol + (NJ - 1) * 16 + (q >> 1) * 8, v, bias[NJ / 2]);
-                }
-            }
-        }
-    }
-#undef H_PAIR
+    gemm_epilogue_regs<Epi, 8, NJ>(acc, lane, m0 + arow, n0 + bcol, epi);
 }
 #undef H_ISSUE
 #undef H_LOADF
