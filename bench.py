@@ -309,11 +309,11 @@ def main():
                    "parallelism": f"dp{world}", "final_loss": round(float(loss.item()), 4)},
         "step_algorithmic_tflops": round(step_tflops, 1),
         "step_frac_of_bf16_peak": round(step_tflops / (PEAK_BF16_TFLOPS * world), 4),
-        "roofline": {"bound": "mfma", "kernel": f"gemm_bf16_kernel @ {args.site}", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
+        "roofline": {"bound": "mfma", "kernel": ("gemm_nt_stag256_kernel<EpiLMHead,4>" if args.site == "lmhead_fwd" else "NT GEMM") + f" @ {args.site}", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "avg_launch_ms": round(avg_ms, 4), "launches": n.value,
-                     # fabric bytes per launch from the PMC passes in profiles/r01_d_pmc_fetch_write.md (FETCH_SIZE x2 gfx950
+                     # fabric bytes per launch from the PMC passes in profiles/r01_i_pmc_fetch_write.md (FETCH_SIZE x2 gfx950
                      # correction + WRITE_SIZE, calibrated 1.0 on k_ce_dlogits); only measured for the default site/config
-                     "traffic": (2 * 644175 + 1117070) * 1024 if (args.site == "lmhead_fwd" and args.config == "2" and not args.batch) else None,
+                     "traffic": (2 * 604061 + 1097837) * 1024 if (args.site == "lmhead_fwd" and args.config == "2" and not args.batch) else None,
                      "algorithmic_bytes": int(2 * (Mc * D + c["V"] * D + Mc * ((c["V"] + 127) // 128 * 128)) + 8 * Mc * ((c["V"] + 127) // 128 * 2))
                      if args.site == "lmhead_fwd" else None},
     }
