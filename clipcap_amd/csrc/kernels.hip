@@ -147,6 +147,7 @@ int transpose_bf16(const bf16_t* src, bf16_t* dst, int R, int C, hipStream_t st)
 // ------------------------------------------------------------------------------------------------------------
 constexpr int LN_MAXV = 8;  // float4 per lane -> D <= 2048
 
+template <int NV>   // float4 per lane actually used: D <= 256 NV (a run-time bound of 8 kept 8 x 4 registers live per array)
 __global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ x, int ldx, const int* __restrict__ row_map,
                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                 bf16_t* __restrict__ y, float* __restrict__ y32, float* __restrict__ mean,
@@ -155,10 +156,10 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ x, int
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + (size_t)(row_map ? row_map[row] : row) * ldx;
-    float4 v[LN_MAXV];
+    float4 v[NV];
     float s = 0.f;
 #pragma unroll
-    for (int it = 0; it < LN_MAXV; it++) {
+    for (int it = 0; it < NV; it++) {
         const int c = lane * 4 + it * 256;
         if (c < D) {
             v[it] = *reinterpret_cast<const float4*>(xr + c);
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ x, int
     const float mu = wave_sum(s) / D;
     float q = 0.f;
 #pragma unroll
-    for (int it = 0; it < LN_MAXV; it++) {
+    for (int it = 0; it < NV; it++) {
         const int c = lane * 4 + it * 256;
         if (c < D) {
             const float a = v[it].x - mu, b = v[it].y - mu, cc_ = v[it].z - mu, d = v[it].w - mu;
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ x, int
         if (rstd) rstd[row] = rs;
     }
 #pragma unroll
-    for (int it = 0; it < LN_MAXV; it++) {
+    for (int it = 0; it < NV; it++) {
         const int c = lane * 4 + it * 256;
         if (c < D) {
             const float4 g = *reinterpret_cast<const float4*>(gamma + c), b = *reinterpret_cast<const float4*>(beta + c);
@@ -196,13 +197,17 @@ int ln_fwd(const float* x, int ldx, const int* row_map, const float* gamma, cons
            float* mean, float* rstd, int rows, int D, hipStream_t st) {
     if (D > LN_MAXV * 256 || (D & 3) || (ldx & 3)) return CC_ERR_SHAPE;
     if (rows <= 0) return CC_OK;
-    hipLaunchKernelGGL(k_ln_fwd, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, row_map, gamma, beta, y, y32, mean, rstd, rows, D, 1e-5f);
+    const dim3 gr((rows + 3) / 4);
+#define LN_FWD(NV) hipLaunchKernelGGL(k_ln_fwd<NV>, gr, dim3(256), 0, st, x, ldx, row_map, gamma, beta, y, y32, mean, rstd, rows, D, 1e-5f)
+    if (D <= 256) LN_FWD(1); else if (D <= 512) LN_FWD(2); else if (D <= 768) LN_FWD(3); else if (D <= 1024) LN_FWD(4); else LN_FWD(LN_MAXV);
+#undef LN_FWD
     return CC_OK;
 }
 
 // LayerNorm backward.  dy(bf16)[r]; x[map(r)]; mean/rstd[r].  dx_out[map(r)] = (dres ? dres[map(r)] : 0) + dLN ; also a
 // bf16 copy of dx_out for the next dgrad GEMM.  Optional dgamma/dbeta (atomic fp32 accumulation, one atomic per
 // column per block).  Each wave walks rows  row = blockIdx*4 + wave + k*gridDim*4.
+template <int NV, bool DG>   // NV as in k_ln_fwd; DG: accumulate dgamma / dbeta
 __global__ __launch_bounds__(256) void k_ln_bwd(const bf16_t* __restrict__ dy, const float* __restrict__ x, int ldx,
                                                 const int* __restrict__ row_map, const float* __restrict__ mean,
                                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
@@ -211,16 +216,16 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const bf16_t* __restrict__ dy, c
                                                 int rows, int D) {
     extern __shared__ __attribute__((aligned(16))) float ln_red[];  // [2][4][D] when dgamma
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float4 pg[LN_MAXV], pb[LN_MAXV];
+    float4 pg[DG ? NV : 1], pb[DG ? NV : 1];
 #pragma unroll
-    for (int it = 0; it < LN_MAXV; it++) pg[it] = pb[it] = make_float4(0, 0, 0, 0);
+    for (int it = 0; it < (DG ? NV : 1); it++) pg[it] = pb[it] = make_float4(0, 0, 0, 0);
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
         const size_t xr = (size_t)(row_map ? row_map[row] : row) * ldx;
         const float mu = mean[row], rs = rstd[row];
-        float4 g[LN_MAXV], xh[LN_MAXV];
+        float4 g[NV], xh[NV], rr[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int it = 0; it < LN_MAXV; it++) {
+        for (int it = 0; it < NV; it++) {
             const int c = lane * 4 + it * 256;
             if (c < D) {
                 const uint2 d = *reinterpret_cast<const uint2*>(dy + (size_t)row * D + c);
@@ -228,11 +233,12 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const bf16_t* __restrict__ dy, c
                 const float d2 = __uint_as_float(d.y << 16), d3 = __uint_as_float(d.y & 0xffff0000u);
                 const float4 xv = *reinterpret_cast<const float4*>(x + xr + c);
                 const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
+                rr[it] = dres ? *reinterpret_cast<const float4*>(dres + xr + c) : make_float4(0, 0, 0, 0);   // fetched with the row, not after the reductions
                 xh[it] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
                 g[it] = make_float4(d0 * gm.x, d1 * gm.y, d2 * gm.z, d3 * gm.w);
                 s1 += g[it].x + g[it].y + g[it].z + g[it].w;
                 s2 += g[it].x * xh[it].x + g[it].y * xh[it].y + g[it].z * xh[it].z + g[it].w * xh[it].w;
-                if (dgamma) {
+                if constexpr (DG) {
                     pg[it].x += d0 * xh[it].x; pg[it].y += d1 * xh[it].y; pg[it].z += d2 * xh[it].z; pg[it].w += d3 * xh[it].w;
                     pb[it].x += d0; pb[it].y += d1; pb[it].z += d2; pb[it].w += d3;
                 }
@@ -240,25 +246,22 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const bf16_t* __restrict__ dy, c
         }
         const float m1 = wave_sum(s1) / D, m2 = wave_sum(s2) / D;
 #pragma unroll
-        for (int it = 0; it < LN_MAXV; it++) {
+        for (int it = 0; it < NV; it++) {
             const int c = lane * 4 + it * 256;
             if (c < D) {
                 float4 o = make_float4(rs * (g[it].x - m1 - xh[it].x * m2), rs * (g[it].y - m1 - xh[it].y * m2),
                                        rs * (g[it].z - m1 - xh[it].z * m2), rs * (g[it].w - m1 - xh[it].w * m2));
-                if (dres) {
-                    const float4 r = *reinterpret_cast<const float4*>(dres + xr + c);
-                    o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-                }
+                o.x += rr[it].x; o.y += rr[it].y; o.z += rr[it].z; o.w += rr[it].w;
                 *reinterpret_cast<float4*>(dx32 + xr + c) = o;
                 if (dx16) *reinterpret_cast<uint2*>(dx16 + xr + c) = make_uint2(pack2bf(o.x, o.y), pack2bf(o.z, o.w));
             }
         }
     }
-    if (dgamma) {
+    if constexpr (DG) {
         float* rg = ln_red;
         float* rb = ln_red + 4 * D;
 #pragma unroll
-        for (int it = 0; it < LN_MAXV; it++) {
+        for (int it = 0; it < NV; it++) {
             const int c = lane * 4 + it * 256;
             if (c < D) {
                 *reinterpret_cast<float4*>(rg + wave * D + c) = pg[it];
@@ -281,10 +284,13 @@ int ln_bwd(const bf16_t* dy, const float* x, int ldx, const int* row_map, const 
     if (rows <= 0) return CC_OK;
     // with parameter gradients every block ends with 2*D fp32 atomics: keep the block count low (one per CU) so that the
     // atomic tail (measured: it dominated at 1024 blocks) stays ~0.4 M atomics per launch
-    const int grid = std::min((rows + 3) / 4, dgamma ? 256 : 1024);
+    const int grid = std::min((rows + 3) / 4, dgamma ? 256 : 8192);
     const size_t sh = dgamma ? (size_t)8 * D * sizeof(float) : 0;
-    hipLaunchKernelGGL(k_ln_bwd, dim3(grid), dim3(256), sh, st, dy, x, ldx, row_map, mean, rstd, gamma, dres, dx32, dx16, dgamma,
-                       dbeta, rows, D);
+#define LN_BWD(NV, DG) hipLaunchKernelGGL((k_ln_bwd<NV, DG>), dim3(grid), dim3(256), sh, st, dy, x, ldx, row_map, mean, rstd, gamma, dres, dx32, dx16, dgamma, dbeta, rows, D)
+#define LN_BWD_D(DG) { if (D <= 256) LN_BWD(1, DG); else if (D <= 512) LN_BWD(2, DG); else if (D <= 768) LN_BWD(3, DG); else if (D <= 1024) LN_BWD(4, DG); else LN_BWD(LN_MAXV, DG); }
+    if (dgamma) LN_BWD_D(true) else LN_BWD_D(false)
+#undef LN_BWD_D
+#undef LN_BWD
     return CC_OK;
 }
 
