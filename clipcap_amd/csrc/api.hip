@@ -689,6 +689,14 @@ int cc_gemm_bf16_f32(int32_t al, int32_t bl, const uint16_t* A, int32_t lda, con
     return gemm_f32out(al, bl, A, lda, B, ldb, M, N, K, C, ldc, ksplit > 1 ? nullptr : bias, ksplit > 1 ? 2 : 0, 1.0f, ksplit, S_(stream));
 }
 
+int cc_sample_step(const float* logits, int32_t R, int32_t V, int32_t ld, float temperature, int32_t top_k, float top_p, int32_t mode,
+                   const int64_t* history, int32_t hist_len, int32_t hist_ld, float repetition_penalty, const float* u, int32_t* next_token,
+                   float* probs_out, void* stream) {
+    if (!logits || !u || !next_token || R < 0) return CC_ERR_ARG;
+    return sample_rows(logits, R, V, ld, temperature, top_k, top_p, mode, reinterpret_cast<const long long*>(history), hist_len, hist_ld,
+                       repetition_penalty, u, next_token, probs_out, S_(stream));
+}
+
 int cc_gemm_tile_mode(int32_t mode) {
     const int old = g_gemm_tile_mode;
     g_gemm_tile_mode = mode;

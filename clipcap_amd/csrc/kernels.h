@@ -34,6 +34,9 @@ int embed_bwd(const float* dx0, const long long* tokens, int cap, float* dwte, f
 int ce_rows(const float* pmax, const float* psum, int npart, const int* target, const float* tgt_logit, float* lse, float* row_loss,
             float* stats, int M, hipStream_t st);
 int ce_dlogits(bf16_t* logits, int ld, int V, const int* target, const float* lse, const float* denom, int M, hipStream_t st);
+// sample.hip: one sampling step per row (temperature, repetition penalty, top-k, top-p, inverse-CDF draw at u[row])
+int sample_rows(const float* logits, int R, int V, int ld, float temperature, int top_k, float top_p, int mode, const long long* hist,
+                int hist_len, int hist_ld, float rep_pen, const float* u, int* next_token, float* probs_out, hipStream_t st);
 int ce_targets(const long long* tokens, int* target, int* row_map, int B, int cap, int L, int T, hipStream_t st);
 
 int adamw(float* p, const float* g, float* m, float* v, bf16_t* p16, size_t n, float lr, float b1, float b2, float eps, float wd,

@@ -419,3 +419,22 @@ def beam_step(logits: torch.Tensor, samples: int, beam: int, temperature: float,
     check(_lib.lib().cc_beam_step(samples, beam, V, _p(logits), ldl, float(temperature), int(first), int(stop_token), _p(scores), _p(seq_lengths),
                                  _p(has_stopped), _p(nt), _p(sr), _p(ws), _stream(dev)), "cc_beam_step")
     return nt, sr
+
+
+def sample_step(logits: torch.Tensor, u: torch.Tensor, temperature: float = 1.0, top_k: int = 0, top_p: float = 0.0, mode: int = 0,
+                history: torch.Tensor = None, hist_len: int = 0, repetition_penalty: float = 1.0, return_probs: bool = False):
+    """One device-side sampling step for every row of fp32 ``logits`` (R, V) (reference inference/base.py:159-184 for mode 0 =
+    generate_nucleus_sampling, :245-262 + utils.py:5-37 for mode 1 = top_k_top_p_filtering + softmax).  ``u`` (R,) uniforms in
+    [0, 1) drive the inverse-CDF draw; ``history`` int64 (R, >= hist_len) feeds the repetition penalty.
+    Returns next_tokens int32 (R,) [, probs fp32 (R, V) — the pre-sampling distribution]."""
+    dev = logits.device
+    R, V = logits.shape
+    nt = torch.empty(R, dtype=torch.int32, device=dev)
+    probs = torch.empty(R, V, dtype=torch.float32, device=dev) if return_probs else None
+    if history is not None:
+        assert history.dtype == torch.int64 and history.shape[0] == R and history.stride(1) == 1
+    check(_lib.lib().cc_sample_step(_p(logits), R, V, logits.stride(0), float(temperature), int(top_k or 0), float(top_p or 0.0), int(mode),
+                                   _p(history) if history is not None else None, int(hist_len), history.stride(0) if history is not None else 0,
+                                   float(repetition_penalty), _p(u), _p(nt), _p(probs) if probs is not None else None, _stream(dev)),
+          "cc_sample_step")
+    return (nt, probs) if return_probs else nt

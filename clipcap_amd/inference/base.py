@@ -11,7 +11,7 @@ from typing import Callable, List, Optional, Tuple, Union
 
 import torch
 
-from clipcap_amd.engine import DecodeSession, beam_step
+from clipcap_amd.engine import DecodeSession, beam_step, sample_step
 from clipcap_amd.inference.utils import (nucleus_distribution, repetition_penalty_apply, sentence_length_penalty_apply,  # noqa: F401
                                          top_k_top_p_filtering)
 
@@ -86,58 +86,77 @@ def generate_beam(model, tokenizer: Callable, embeds: torch.Tensor, number_to_ge
 
 
 @torch.no_grad()
+def sample_tokens(model, embeds: torch.Tensor, entry_length: int = 67, stop_token: int = 50256, *, mode: int = 0, top_p: float = 0.8,
+                  top_k: Optional[int] = None, temperature: float = 1.0, repetition_penalty: float = 1.0,
+                  generator: Optional[torch.Generator] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """KV-cached sampling for a batch of prefixes, every step on the device (cc_decode_fwd + cc_sample_step, no host sync except
+    an all-rows-stopped poll every 4th step).  embeds fp32 (R, L, D).  mode 0 = the nucleus rule of generate_nucleus_sampling
+    (base.py:165-181), mode 1 = top_k_top_p_filtering + softmax (base.py:245-262).
+    Returns (tokens int64 (R, n), stop_pos int64 (R,)): stop_pos[r] = index of the first stop token of row r (n if none)."""
+    lm = model.language_model
+    g = lm.engine
+    dev = g.arena.device
+    embeds = embeds.to(dev, torch.float32)
+    R, L0, D = embeds.shape
+    wte = lm.get_input_embeddings().weight.detach()
+    sess = DecodeSession(g, R, L0 + entry_length)
+    toks = torch.zeros(R, entry_length, dtype=torch.int64, device=dev)
+    done = torch.zeros(R, dtype=torch.bool, device=dev)
+    stop_pos = torch.full((R,), entry_length, dtype=torch.int64, device=dev)
+    x = embeds
+    n = 0
+    for step in range(entry_length):
+        logits = sess.forward(x)                                                     # (R, V) fp32
+        u = torch.rand(R, device=dev, generator=generator)
+        nxt = sample_step(logits, u, temperature=temperature, top_k=top_k or 0, top_p=top_p, mode=mode, history=toks, hist_len=step,
+                          repetition_penalty=repetition_penalty).to(torch.int64)
+        toks[:, step] = nxt
+        hit = (nxt == stop_token) & ~done
+        stop_pos = torch.where(hit, torch.full_like(stop_pos, step), stop_pos)
+        done |= hit
+        n = step + 1
+        if step % 4 == 3 and bool(done.all()):
+            break
+        x = wte[nxt].view(R, 1, D)
+    return toks[:, :n], stop_pos.clamp(max=n)
+
+
+def _rows_for(embeds: torch.Tensor, number_to_generate: int) -> torch.Tensor:
+    return embeds.repeat_interleave(max(1, number_to_generate), dim=0) if number_to_generate > 1 else embeds
+
+
 def generate_nucleus_sampling(model, tokenizer: Callable, embeds: torch.Tensor, number_to_generate: int = 1,
                               text_prefix_tokens: Optional[torch.Tensor] = None, entry_length: int = 67, top_p: float = 0.8, top_k=None,
-                              temperature: float = 1.0) -> List[str]:
-    """base.py:135-201 with a KV cache.  One sample per call row; stops on EOS."""
-    lm = model.language_model
+                              temperature: float = 1.0, generator: Optional[torch.Generator] = None) -> List[str]:
+    """base.py:135-201 with a KV cache and the sampling step on the device.  The reference is batch-1 and loops number_to_generate
+    times; here every (prefix row, repetition) is one row of a single batched decode.  The returned text of a row includes its
+    stop token, as the reference's does (it appends before breaking, base.py:186-195)."""
     stop = _stop_id(tokenizer)
     embeds = _with_text_prefix(model, embeds, text_prefix_tokens)
-    wte = lm.get_input_embeddings().weight.detach()
-    gens = []
-    for _ in range(number_to_generate):
-        sess = DecodeSession(lm.engine, 1, embeds.shape[1] + entry_length)
-        x = embeds[:1]
-        toks = [] if text_prefix_tokens is None else [int(t) for t in text_prefix_tokens.flatten()]
-        for _ in range(entry_length):
-            logits = sess.forward(x) / (temperature if temperature > 0 else 1.0)
-            nxt = torch.multinomial(nucleus_distribution(logits, top_p, top_k), num_samples=1)
-            toks.append(int(nxt))
-            if toks[-1] == stop:
-                break
-            x = wte[nxt].view(1, 1, -1)
-        gens.append(tokenizer.decode(toks))
-    return gens
+    toks, stop_pos = sample_tokens(model, _rows_for(embeds, number_to_generate), entry_length, stop, mode=0, top_p=top_p, top_k=top_k,
+                                   temperature=temperature, generator=generator)
+    head = [] if text_prefix_tokens is None else [int(t) for t in text_prefix_tokens.flatten()]
+    toks, stop_pos = toks.cpu(), stop_pos.cpu()
+    return [tokenizer.decode(head + toks[r, :min(int(stop_pos[r]) + 1, toks.shape[1])].tolist()) for r in range(toks.shape[0])]
 
 
-@torch.no_grad()
 def generate_no_beam(model, tokenizer: Callable, embeds: torch.Tensor, text_prefix_tokens: Optional[torch.Tensor] = None,
                      top_p: float = 0.9, top_k: float = 0.0, entry_length: int = 67, temperature: float = 1.0,
                      repetition_penalty: float = 1.2, desired_sentence_length: int = 50, sentence_length_factor: float = 1.0,
-                     sweep: bool = True) -> List[str]:
+                     sweep: bool = True, generator: Optional[torch.Generator] = None) -> List[str]:
     """base.py:204-279: the reference's debugging sweep over top_p x temperature (sweep=True reproduces it; sweep=False samples
-    once with the given top_p / temperature)."""
-    lm = model.language_model
+    once with the given top_p / temperature).  Like the reference, ``repetition_penalty`` is accepted but not applied (its call is
+    commented out, base.py:236-239), and the sentence-length penalty (base.py:248-254) is omitted: it multiplies logits whose
+    VALUE equals the stop token id (utils.py:45 compares values, not ids), which never happens for real logits.  The text of a
+    row excludes its stop token (the reference breaks before appending, base.py:261-262)."""
     stop = _stop_id(tokenizer)
     embeds = _with_text_prefix(model, embeds, text_prefix_tokens)
-    wte = lm.get_input_embeddings().weight.detach()
     grid = [(p, t) for p in (0.5, 0.55, 0.6, 0.65, 0.7, 0.75, 0.8, 0.85, 0.9, 0.95, 1.0) for t in (0.9, 0.95, 1.0)] if sweep \
         else [(top_p, temperature)]
+    head = [] if text_prefix_tokens is None else [int(v) for v in text_prefix_tokens.flatten()]
     gens = []
     for p, t in grid:
-        sess = DecodeSession(lm.engine, 1, embeds.shape[1] + entry_length)
-        x = embeds[:1]
-        toks: List[int] = [] if text_prefix_tokens is None else [int(v) for v in text_prefix_tokens.flatten()]
-        for _ in range(entry_length):
-            logits = sess.forward(x)[0] / (t if t > 0 else 1.0)
-            logits = top_k_top_p_filtering(logits, top_k=int(top_k), top_p=p)
-            if toks:
-                tk = torch.tensor(toks, device=logits.device)
-                logits = sentence_length_penalty_apply(logits, tk, stop, len(toks), desired_sentence_length, sentence_length_factor)
-            nxt = torch.multinomial(torch.softmax(logits, dim=-1), 1)
-            if int(nxt) == stop:
-                break
-            toks.append(int(nxt))
-            x = wte[nxt].view(1, 1, -1)
-        gens.append(tokenizer.decode(toks))
+        toks, stop_pos = sample_tokens(model, embeds, entry_length, stop, mode=1, top_p=p, top_k=int(top_k), temperature=t, generator=generator)
+        toks, stop_pos = toks.cpu(), stop_pos.cpu()
+        gens.extend(tokenizer.decode(head + toks[r, :int(stop_pos[r])].tolist()) for r in range(toks.shape[0]))
     return gens

@@ -184,6 +184,22 @@ int cc_adamw_step(float* p32, const float* g32, float* m, float* v, uint16_t* p1
 int cc_cast_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Sampling decoders (replaces the per-step torch ops of clipcap/inference/base.py:159-184 generate_nucleus_sampling and
+ * :233-262 generate_no_beam + utils.py:5-37): one step for R rows of fp32 logits [R][ld].
+ *   x = logits (history tokens first scaled by the repetition penalty, utils.py:33-37) / temperature (<= 0 -> 1, base.py:163)
+ *   mode 0 (nucleus): p = softmax(x); the top_k largest (<= 0 or >= V: all); minimal descending prefix with cumulative p >= top_p
+ *                     (mass relative to the FULL softmax, base.py:170-176); renormalised
+ *   mode 1 (filter):  keep x >= the top_k-th largest (ties kept, utils.py:14-17), then the minimal descending prefix whose softmax
+ *                     mass over that set is > top_p (utils.py:19-29; top_p <= 0: off); softmax of the rest
+ *   next_token[r] = inverse CDF, in token-id order, of that distribution at u[r] in [0,1).  probs_out (nullable, [R][V]) receives
+ *   the distribution itself.  history: int64 [R][hist_ld], first hist_len entries per row (nullable; penalty 1.0 = off).
+ * No sort, no host sync; deterministic for given (logits, u).
+ * ------------------------------------------------------------------------------------------------------------ */
+int cc_sample_step(const float* logits, int32_t R, int32_t V, int32_t ld, float temperature, int32_t top_k, float top_p, int32_t mode,
+                   const int64_t* history, int32_t hist_len, int32_t hist_ld, float repetition_penalty, const float* u, int32_t* next_token,
+                   float* probs_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Unit-test hook: one bf16 MFMA GEMM C = A·B (+bias) with fp32 output, any of the three operand layouts
  * (al/bl: 0 = [rows][K], 1 = [K][rows]); ksplit>1 accumulates atomically into C (caller zeroes C).
  * ------------------------------------------------------------------------------------------------------------ */

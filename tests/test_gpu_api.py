@@ -242,6 +242,11 @@ def test_sampling_decoders_run_on_kv_cache_and_match_first_step_distribution():
     p = nucleus_distribution(logits, top_p=0.8).cpu().numpy()
     assert np.abs(p - f["nucleus.final_p"]).max() <= 2e-2 and abs(p.sum() - 1.0) <= 1e-5
     assert set(np.nonzero(p[0])[0]) == set(np.nonzero(f["nucleus.final_p"][0])[0]) or np.abs(p - f["nucleus.final_p"]).max() <= 2e-2
+    # the product path: cc_sample_step on the same logits gives the same distribution as the torch restatement above
+    from clipcap_amd.engine import sample_step
+    _, pk = sample_step(logits, torch.rand(1, device="cuda"), top_p=0.8, mode=0, return_probs=True)
+    assert np.abs(pk.cpu().numpy() - p).max() <= 2e-6
+    assert np.abs(pk.cpu().numpy() - f["nucleus.final_p"]).max() <= 2e-2
     tok = FakeTokenizer(V, 96)
     torch.manual_seed(0)
     a = generate_nucleus_sampling(model, tok, pref, number_to_generate=2, entry_length=6, top_p=0.8)
@@ -251,6 +256,12 @@ def test_sampling_decoders_run_on_kv_cache_and_match_first_step_distribution():
     c = generate_no_beam(model, tok, pref, entry_length=5, sweep=False, top_p=0.9)
     assert len(c) == 1 and len(c[0].split()) <= 5
     assert len(generate_no_beam(model, tok, pref, entry_length=2)) == 33          # the reference's 11 x 3 sweep (base.py:229-230)
+    # batched prefixes (the reference is batch-1): every row is decoded in the same device loop
+    from clipcap_amd.inference.base import sample_tokens
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    toks, stop_pos = sample_tokens(model, pref.repeat(5, 1, 1), entry_length=7, stop_token=96, mode=0, top_p=0.8, generator=gen)
+    assert toks.shape[0] == 5 and toks.shape[1] <= 7 and int(toks.max()) < V and int(toks.min()) >= 0
+    assert all(int(stop_pos[r]) == toks.shape[1] or int(toks[r, int(stop_pos[r])]) == 96 for r in range(5))
 
 
 def test_checkpoint_resume_restores_optimizer_state(tmp_path):

@@ -1,0 +1,120 @@
+"""cc_sample_step (on-device temperature / repetition penalty / top-k / top-p / multinomial) against the oracle restatements of the
+reference's helpers (oracle.nucleus_final_p = inference/base.py:165-181, oracle.top_k_top_p_filtering = utils.py:5-30,
+oracle.repetition_penalty_apply = utils.py:33-37, each pinned to the reference by tests/golden/filters.npz in test_oracle_golden)."""
+import pytest
+import torch
+
+from oracle import clipcap_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _eng():
+    from clipcap_amd import engine
+    return engine
+
+
+def _margin_ok(probs_sorted_cum: torch.Tensor, top_p: float, tol: float = 2e-5) -> bool:
+    """the reference's own fp32 cumsum decides the cut; skip rows where the crossing is within rounding of top_p"""
+    return bool(((probs_sorted_cum - top_p).abs() > tol).all())
+
+
+@pytest.mark.parametrize("V,scale", [(97, 3.0), (1000, 4.0), (50257, 6.0)])
+@pytest.mark.parametrize("top_p,top_k,temperature", [(0.8, None, 1.0), (0.5, 40, 0.7), (0.95, 300, 1.3), (1.0, None, 1.0), (0.05, None, 1.0)])
+def test_nucleus_distribution_matches_reference_semantics(V, scale, top_p, top_k, temperature):
+    torch.manual_seed(V + int(top_p * 100))
+    R = 7
+    top_k = min(top_k, V) if top_k else None          # the reference's topk() raises beyond V; the kernel treats >= V as "all"
+    logits = (torch.randn(R, V) * scale).cuda()
+    u = torch.rand(R, device="cuda")
+    nt, probs = _eng().sample_step(logits, u, temperature=temperature, top_k=top_k or 0, top_p=top_p, mode=0, return_probs=True)
+    x = logits.cpu() / temperature
+    ref = oracle.nucleus_final_p(x, top_p=top_p, top_k=top_k)
+    p_sorted = torch.softmax(x, -1).sort(-1, descending=True).values
+    if top_k:
+        p_sorted = p_sorted[:, :top_k]
+    cum = p_sorted.cumsum(-1)
+    probs = probs.cpu()
+    checked = 0
+    for r in range(R):
+        if top_p < 1.0 and not _margin_ok(cum[r], top_p):
+            continue
+        checked += 1
+        assert torch.allclose(probs[r], ref[r], atol=2e-6, rtol=1e-4), (r, (probs[r] - ref[r]).abs().max())
+        if top_p < 1.0:     # at 1.0 the reference's cut is wherever its fp32 cumsum first rounds up to 1: only ~1e-7 tails differ
+            assert (probs[r] > 0).sum() == (ref[r] > 0).sum()
+    assert checked >= R - 2
+    assert torch.allclose(probs.sum(-1), torch.ones(R), atol=1e-5)
+    # the drawn token is the inverse CDF (token-id order) of that distribution at u
+    cdf = probs.double().cumsum(-1)
+    for r in range(R):
+        t = int(nt[r])
+        lo = float(cdf[r, t - 1]) if t > 0 else 0.0
+        hi = float(cdf[r, t])
+        assert probs[r, t] > 0
+        assert lo - 1e-6 <= float(u[r]) <= hi + 1e-6
+
+
+@pytest.mark.parametrize("V", [97, 50257])
+@pytest.mark.parametrize("top_p,top_k,temperature", [(0.9, 0, 1.0), (0.5, 10, 0.9), (0.0, 5, 1.0), (1.0, 0, 0.95)])
+def test_filter_mode_matches_top_k_top_p_filtering(V, top_p, top_k, temperature):
+    torch.manual_seed(V + top_k)
+    R = 5
+    logits = (torch.randn(R, V) * 5.0).cuda()
+    u = torch.rand(R, device="cuda")
+    nt, probs = _eng().sample_step(logits, u, temperature=temperature, top_k=top_k, top_p=top_p, mode=1, return_probs=True)
+    probs = probs.cpu()
+    checked = 0
+    for r in range(R):
+        x = logits[r].cpu() / temperature
+        ref = torch.softmax(oracle.top_k_top_p_filtering(x.clone(), top_k=top_k, top_p=top_p), -1)
+        xs = x.clone()
+        if top_k > 0:
+            xs[xs < xs.topk(top_k).values[-1]] = -float("inf")
+        cum = torch.softmax(xs.sort(descending=True).values, -1).cumsum(-1)
+        if 0 < top_p < 1.0 and not _margin_ok(cum, top_p):
+            continue
+        checked += 1
+        assert torch.allclose(probs[r], ref, atol=2e-6, rtol=1e-4), (r, (probs[r] - ref).abs().max())
+        if top_p < 1.0:
+            assert (probs[r] > 0).sum() == (ref > 0).sum()
+    assert checked >= R - 2
+
+
+def test_repetition_penalty_and_history():
+    torch.manual_seed(3)
+    R, V = 4, 211
+    logits = (torch.randn(R, V) * 2.0).cuda()
+    hist = torch.randint(0, V, (R, 9), device="cuda")
+    hist[:, 3] = hist[:, 1]                         # duplicates are penalised once
+    u = torch.rand(R, device="cuda")
+    _, probs = _eng().sample_step(logits, u, top_p=1.0, mode=0, history=hist, hist_len=6, repetition_penalty=1.2, return_probs=True)
+    for r in range(R):
+        x = oracle.repetition_penalty_apply(logits[r].cpu().clone(), hist[r, :6].cpu().unique(), 1.2)
+        assert torch.allclose(probs[r].cpu(), torch.softmax(x, -1), atol=2e-6, rtol=1e-4)
+
+
+def test_ties_at_the_threshold_are_kept_in_index_order():
+    V = 64
+    x = torch.zeros(1, V)
+    x[0, 5] = 2.0
+    x[0, [9, 20, 33, 47]] = 1.0                     # four equal runners-up
+    u = torch.tensor([0.5], device="cuda")
+    # nucleus, exactly k = 3: the top-1 plus the first two ties by index
+    _, probs = _eng().sample_step(x.cuda(), u, top_k=3, top_p=1.0, mode=0, return_probs=True)
+    assert sorted(torch.nonzero(probs[0].cpu()).flatten().tolist()) == [5, 9, 20]
+    # filter mode keeps every tie of the k-th value (utils.py: logits < kth are removed)
+    _, probs = _eng().sample_step(x.cuda(), u, top_k=3, top_p=0.0, mode=1, return_probs=True)
+    assert sorted(torch.nonzero(probs[0].cpu()).flatten().tolist()) == [5, 9, 20, 33, 47]
+
+
+def test_draws_follow_the_distribution():
+    torch.manual_seed(11)
+    V, N = 50, 4096
+    row = torch.randn(V) * 2.0
+    logits = row.expand(N, V).contiguous().cuda()
+    u = torch.rand(N, device="cuda")
+    nt, probs = _eng().sample_step(logits, u, top_p=0.9, mode=0, return_probs=True)
+    freq = torch.bincount(nt.cpu().long(), minlength=V).double() / N
+    assert (freq - probs[0].cpu().double()).abs().max() < 0.03
+    assert freq[probs[0].cpu() == 0].sum() == 0
