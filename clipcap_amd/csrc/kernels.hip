@@ -207,19 +207,19 @@ int ln_fwd(const float* x, int ldx, const int* row_map, const float* gamma, cons
 // LayerNorm backward.  dy(bf16)[r]; x[map(r)]; mean/rstd[r].  dx_out[map(r)] = (dres ? dres[map(r)] : 0) + dLN ; also a
 // bf16 copy of dx_out for the next dgrad GEMM.  Optional dgamma/dbeta (atomic fp32 accumulation, one atomic per
 // column per block).  Each wave walks rows  row = blockIdx*4 + wave + k*gridDim*4.
-template <int NV, bool DG>   // NV as in k_ln_fwd; DG: accumulate dgamma / dbeta
-__global__ __launch_bounds__(256) void k_ln_bwd(const bf16_t* __restrict__ dy, const float* __restrict__ x, int ldx,
+template <int NV, bool DG, int NW>   // NV as in k_ln_fwd; DG: accumulate dgamma / dbeta; NW waves per block
+__global__ __launch_bounds__(NW * 64) void k_ln_bwd(const bf16_t* __restrict__ dy, const float* __restrict__ x, int ldx,
                                                 const int* __restrict__ row_map, const float* __restrict__ mean,
                                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                 const float* __restrict__ dres, float* __restrict__ dx32,
                                                 bf16_t* __restrict__ dx16, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                 int rows, int D) {
-    extern __shared__ __attribute__((aligned(16))) float ln_red[];  // [2][4][D] when dgamma
+    extern __shared__ __attribute__((aligned(16))) float ln_red[];  // [2][NW][D] when dgamma
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float4 pg[DG ? NV : 1], pb[DG ? NV : 1];
 #pragma unroll
     for (int it = 0; it < (DG ? NV : 1); it++) pg[it] = pb[it] = make_float4(0, 0, 0, 0);
-    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    for (int row = blockIdx.x * NW + wave; row < rows; row += gridDim.x * NW) {
         const size_t xr = (size_t)(row_map ? row_map[row] : row) * ldx;
         const float mu = mean[row], rs = rstd[row];
         float4 g[NV], xh[NV], rr[NV];
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const bf16_t* __restrict__ dy, c
     }
     if constexpr (DG) {
         float* rg = ln_red;
-        float* rb = ln_red + 4 * D;
+        float* rb = ln_red + NW * D;
 #pragma unroll
         for (int it = 0; it < NV; it++) {
             const int c = lane * 4 + it * 256;
@@ -269,9 +269,10 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const bf16_t* __restrict__ dy, c
             }
         }
         __syncthreads();
-        for (int c = threadIdx.x; c < D; c += 256) {
-            const float sg = rg[c] + rg[D + c] + rg[2 * D + c] + rg[3 * D + c];
-            const float sb = rb[c] + rb[D + c] + rb[2 * D + c] + rb[3 * D + c];
+        for (int c = threadIdx.x; c < D; c += NW * 64) {
+            float sg = 0.f, sb = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; w++) { sg += rg[w * D + c]; sb += rb[w * D + c]; }
             __hip_atomic_fetch_add(dgamma + c, sg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_add(dbeta + c, sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -283,12 +284,13 @@ int ln_bwd(const bf16_t* dy, const float* x, int ldx, const int* row_map, const 
     if (D > LN_MAXV * 256 || (D & 3) || (ldx & 3)) return CC_ERR_SHAPE;
     if (rows <= 0) return CC_OK;
     // with parameter gradients every block ends with 2*D fp32 atomics: keep the block count low (one per CU) so that the
-    // atomic tail (measured: it dominated at 1024 blocks) stays ~0.4 M atomics per launch
-    const int grid = std::min((rows + 3) / 4, dgamma ? 256 : 8192);
-    const size_t sh = dgamma ? (size_t)8 * D * sizeof(float) : 0;
-#define LN_BWD(NV, DG) hipLaunchKernelGGL((k_ln_bwd<NV, DG>), dim3(grid), dim3(256), sh, st, dy, x, ldx, row_map, mean, rstd, gamma, dres, dx32, dx16, dgamma, dbeta, rows, D)
-#define LN_BWD_D(DG) { if (D <= 256) LN_BWD(1, DG); else if (D <= 512) LN_BWD(2, DG); else if (D <= 768) LN_BWD(3, DG); else if (D <= 1024) LN_BWD(4, DG); else LN_BWD(LN_MAXV, DG); }
-    if (dgamma) LN_BWD_D(true) else LN_BWD_D(false)
+    // atomic tail (measured: it dominated at 1024 blocks) stays ~0.4 M atomics per launch, and give those blocks 8 waves
+    const int nw = (dgamma && (size_t)16 * D * sizeof(float) <= 65536) ? 8 : 4;      // 8-wave reduction buffer within the 64 KiB default
+    const int grid = std::min((rows + nw - 1) / nw, dgamma ? 256 : 8192);
+    const size_t sh = dgamma ? (size_t)2 * nw * D * sizeof(float) : 0;
+#define LN_BWD(NV, DG, NW) hipLaunchKernelGGL((k_ln_bwd<NV, DG, NW>), dim3(grid), dim3(NW * 64), sh, st, dy, x, ldx, row_map, mean, rstd, gamma, dres, dx32, dx16, dgamma, dbeta, rows, D)
+#define LN_BWD_D(DG, NW) { if (D <= 256) LN_BWD(1, DG, NW); else if (D <= 512) LN_BWD(2, DG, NW); else if (D <= 768) LN_BWD(3, DG, NW); else if (D <= 1024) LN_BWD(4, DG, NW); else LN_BWD(LN_MAXV, DG, NW); }
+    if (dgamma && nw == 8) LN_BWD_D(true, 8) else if (dgamma) LN_BWD_D(true, 4) else LN_BWD_D(false, 4)
 #undef LN_BWD_D
 #undef LN_BWD
     return CC_OK;
