@@ -69,6 +69,8 @@ SIGNATURES = {
     "cc_adamw_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P]),
     "cc_cast_bf16": (_I, [_P, _P, _L, _P]),
     "cc_sample_step": (_I, [_P, _I, _I, _I, _F, _I, _F, _I, _P, _I, _I, _F, _P, _P, _P, _P]),
+    "cc_wgrad_scratch_bytes": (_L, []),
+    "cc_gemm_wgrad": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _P]),
     "cc_gemm_tile_mode": (_I, [_I]),
     "cc_gemm_bf16_f32": (_I, [_I, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P]),
     "cc_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),

@@ -697,6 +697,14 @@ int cc_sample_step(const float* logits, int32_t R, int32_t V, int32_t ld, float 
                        repetition_penalty, u, next_token, probs_out, S_(stream));
 }
 
+int64_t cc_wgrad_scratch_bytes(void) { return (int64_t)WGRAD_SCRATCH_BYTES; }
+
+int cc_gemm_wgrad(const uint16_t* X, int32_t ldx, const uint16_t* Y, int32_t ldy, int32_t Mw, int32_t Nw, int32_t K, float* dW, int32_t ldw,
+                  float* scratch, void* stream) {
+    if (!X || !Y || !dW) return CC_ERR_ARG;
+    return gemm_wgrad(X, ldx, Y, ldy, Mw, Nw, K, dW, ldw, scratch, S_(stream));
+}
+
 int cc_gemm_tile_mode(int32_t mode) {
     const int old = g_gemm_tile_mode;
     g_gemm_tile_mode = mode;

@@ -407,28 +407,70 @@ __device__ __forceinline__ int h_swz(int row) { return (row & 8) ? 3 : 0; }
 __device__ __forceinline__ int h_lds_off(int row, int chunk) { return row * 64 + ((chunk ^ h_swz(row)) << 4); }
 // DMA issue is done by the group that is in its fragment-read segment (never ahead of a group's MFMAs: 4 DMA instructions cost
 // ~600 issue cycles): group 0 streams the A tile, group 1 the B tile; wave w of a group takes 1-KiB segments w, w+4, w+8, w+12.
-#define H_SRC_EXPR(IS_A) const bf16_t* src = (IS_A) ? A + (size_t)min(m0 + row, g.M - 1) * g.lda + k0_ + chunk * 8 : B + (size_t)min(n0 + row, g.N - 1) * g.ldb + k0_ + chunk * 8;
+// TT (both operands K-strided: A is [K][M], B is [K][N] — the weight-gradient GEMM): the LDS image of a stage is [32 k][256 cols]
+// (512-B rows), filled by the same 16 DMA instructions per operand (2 k-rows each), and the fragments are read with
+// ds_read_b64_tr_b16: a 16-lane group fetches a [4 k][16 col] block, 8 B per lane at row k0 + (lane>>2), column 4 (lane&3), and
+// lane j receives column j's four k values — the MFMA operand layout without any register transpose (probed on MI355X).
+// A 32-lane half of that read touches 8 rows x 32 B; rows are 512 B apart, so the 32-B slot index inside each 256-B window is
+// XORed with g(k) = (k & 3) | ((k >> 3 & 1) << 2), distinct for the 8 rows of a half: conflict-free.
+__device__ __forceinline__ int h_tt_g(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
 #define H_ISSUE(T, IS_A)                                                                                                 \
     {                                                                                                                    \
         char* st_ = smem + ((T) & (H_NS - 1)) * H_STAGE + ((IS_A) ? 0 : H_BM * H_BK * 2);                                \
-        const int k0_ = (T)*H_BK;                                                                                        \
+        const int k0_ = kbeg + (T)*H_BK;                                                                                 \
         _Pragma("unroll") for (int i_ = 0; i_ < ((IS_A) ? 4 : NJ); i_++) {                                              \
-            const int seg = wn + 4 * i_;                        /* 16 (A) or 4 NJ (B) segments of 16 rows x 64 B */       \
-            const int row = seg * 16 + (lane >> 2);                                                                      \
-            const int chunk = (lane & 3) ^ h_swz(row);                                                             \
-            H_SRC_EXPR(IS_A)                                                                                                \
+            const int seg = wn + 4 * i_;                        /* 16 (A) or 4 NJ (B) segments of 1 KiB */                \
+            const bf16_t* src;                                                                                           \
+            if constexpr (TT) {                                                                                          \
+                const int kr = seg * 2 + (lane >> 5);           /* 2 k-rows of 512 B per segment */                       \
+                const int c = (lane & 31) ^ (h_tt_g(kr) << 1);                                                            \
+                src = (IS_A) ? A + (size_t)(k0_ + kr) * g.lda + min(m0 + c * 8, g.M - 8)                                  \
+                             : B + (size_t)(k0_ + kr) * g.ldb + min(n0 + c * 8, g.N - 8);                                 \
+            } else {                                                                                                     \
+                const int row = seg * 16 + (lane >> 2);         /* 16 rows x 64 B per segment */                          \
+                const int chunk = (lane & 3) ^ h_swz(row);                                                               \
+                src = (IS_A) ? A + (size_t)min(m0 + row, g.M - 1) * g.lda + k0_ + chunk * 8                               \
+                             : B + (size_t)min(n0 + row, g.N - 1) * g.ldb + k0_ + chunk * 8;                              \
+            }                                                                                                            \
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(st_ + seg * 1024), 16, 0, 0);                         \
         }                                                                                                                \
     }
+// The transpose reads are issued as inline asm: through the builtin the compiler cannot prove they do not alias the pending
+// global_load_lds writes and puts an s_waitcnt vmcnt(0) in front of every fragment-read segment (measured: 468 instead of ~900
+// TFLOP/s).  The asm results are only combined into MFMA operands (H_TT_OPER) after the segment's own s_waitcnt lgkmcnt(0).
+typedef __attribute__((ext_vector_type(2))) int h_i32x2;
+struct HTTFrag { h_i32x2 lo, hi; };          // k = 8 kg + 0..3 and 8 kg + 4..7 of one column
+__device__ __forceinline__ HTTFrag h_tt_read(const char* tile, int lane_base, int xoff) {
+    typedef __attribute__((address_space(3))) const char* lp_t;
+    const unsigned a = (unsigned)(size_t)(lp_t)(tile + lane_base + xoff);
+    HTTFrag f;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(a) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(f.hi) : "v"(a) : "memory");
+    return f;
+}
+__device__ __forceinline__ bf16x8 h_tt_oper(const HTTFrag& f) {
+    typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+    const i32x4_t v = {f.lo[0], f.lo[1], f.hi[0], f.hi[1]};
+    return __builtin_bit_cast(bf16x8, v);
+}
 #define H_LOADF(T)                                                                                                       \
     {                                                                                                                    \
         const char* ca_ = smem + ((T) & (H_NS - 1)) * H_STAGE;                                                           \
         const char* cb_ = ca_ + H_BM * H_BK * 2;                                                                         \
-        _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) af[i_] = *reinterpret_cast<const bf16x8*>(ca_ + h_lds_off(arow + i_ * 16 + frow, fchunk)); \
-        _Pragma("unroll") for (int j_ = 0; j_ < NJ; j_++) bfr[j_] = *reinterpret_cast<const bf16x8*>(cb_ + h_lds_off(bcol + j_ * 16 + frow, fchunk)); \
+        if constexpr (TT) {                                                                                              \
+            _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) taf[i_] = h_tt_read(ca_, tt_base, ((grp * 16 + 2 * i_) ^ tt_gx) << 4);  \
+            _Pragma("unroll") for (int j_ = 0; j_ < NJ; j_++) tbf[j_] = h_tt_read(cb_, tt_base, ((wn * 8 + 2 * j_) ^ tt_gx) << 4);  \
+        } else {                                                                                                         \
+            _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) af[i_] = *reinterpret_cast<const bf16x8*>(ca_ + h_lds_off(arow + i_ * 16 + frow, fchunk)); \
+            _Pragma("unroll") for (int j_ = 0; j_ < NJ; j_++) bfr[j_] = *reinterpret_cast<const bf16x8*>(cb_ + h_lds_off(bcol + j_ * 16 + frow, fchunk)); \
+        }                                                                                                                \
     }
 #define H_MFMA()                                                                                                         \
-    {                                                                                                                    \
+    {                                                                                                      \
+        if constexpr (TT) {                                                                                              \
+            _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) af[i_] = h_tt_oper(taf[i_]);                                 \
+            _Pragma("unroll") for (int j_ = 0; j_ < NJ; j_++) bfr[j_] = h_tt_oper(tbf[j_]);                               \
+        }                                                                                                                \
         __builtin_amdgcn_s_setprio(1);                                                                                   \
         _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) _Pragma("unroll") for (int j_ = 0; j_ < NJ; j_++)                \
             acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j_], af[i_], acc[i_][j_], 0, 0, 0);                \
@@ -450,9 +492,10 @@ __device__ __forceinline__ int h_lds_off(int row, int chunk) { return row * 64 +
         else if (rem_ == 1) { if ((CNT) == 4) H_VMCNT(4); else if ((CNT) == 3) H_VMCNT(3); else H_VMCNT(2); }            \
         else H_VMCNT(0);                                                                                                 \
     }
-template <class Epi, int NJ>
+template <class Epi, int NJ, bool TT = false>
 __global__ __launch_bounds__(512, 1) void gemm_nt_stag256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, GemmShape g, Epi epi) {
     static_assert(NJ >= 2 && NJ <= 4, "wave tile is 128 x (16 NJ)");
+    static_assert(!TT || NJ == 4, "the K-strided image is laid out for 256-column tiles");
     constexpr int BN = 64 * NJ;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -463,14 +506,21 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_stag256_kernel(const bf16_t* _
     int tm, tn;
     tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, g.group_m, tm, tn);
     const int m0 = tm * H_BM, n0 = tn * BN;
-    const int nk = g.K / H_BK;
+    const int kbeg = blockIdx.z * g.k_chunk;                  // split-K slice (k_chunk is a multiple of 64)
+    const int nk = (min(g.K, kbeg + g.k_chunk) - kbeg) / H_BK;
     f32x4 acc[8][NJ];
 #pragma unroll
     for (int i = 0; i < 8; i++)
 #pragma unroll
         for (int j = 0; j < NJ; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 af[8], bfr[NJ];
+    HTTFrag taf[TT ? 8 : 1], tbf[TT ? NJ : 1];
+    (void)taf; (void)tbf;
     const int frow = lane & 15, fchunk = lane >> 4;
+    // TT fragment addressing: k row 8 fchunk + (frow >> 2), byte 16 ((frow & 3) >> 1) + 8 (frow & 1) inside the 32-B slot
+    const int tt_base = (8 * fchunk + (frow >> 2)) * 512 + ((frow & 3) >> 1) * 16 + (frow & 1) * 8;
+    const int tt_gx = h_tt_g(8 * fchunk + (frow >> 2)) << 1;
+    (void)tt_base; (void)tt_gx;
     if (grp == 0) {
         H_ISSUE(0, true);
         if (nk > 1) H_ISSUE(1, true);
@@ -845,6 +895,30 @@ inline int launch_gemm(int al, int bl, const bf16_t* A, int lda, const bf16_t* B
         hipLaunchKernelGGL((gemm_bf16_kernel<1, 1, Epi>), grid, dim3(G_THREADS), 0, st, A, B, g, epi);
     else
         return CC_ERR_ARG;
+    return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+}
+
+// Weight-gradient form C[M][N] = sum_k A[k][M] B[k][N] (both operands K-strided) on the 256 x 256 kernel with direct-to-LDS staging
+// and transpose reads; K is split over blockIdx.z (epi must be an EpiF32 in slab mode when ksplit > 1).  K % 32 == 0, M % 8 == 0,
+// N % 8 == 0.  Returns the effective slice count through *ks_eff.
+template <class Epi>
+inline int launch_gemm_tt256(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, int ksplit, const Epi& epi, int* ks_eff,
+                             hipStream_t st) {
+    if ((K % H_BK) || (M & 7) || (N & 7) || (lda & 7) || (ldb & 7) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return CC_ERR_SHAPE;
+    GemmShape g;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
+    g.group_m = 8;
+    if (ksplit < 1) ksplit = 1;
+    const int kt = (K + G_BK - 1) / G_BK;
+    const int per = (kt + ksplit - 1) / ksplit;
+    ksplit = (kt + per - 1) / per;
+    g.k_chunk = per * G_BK;
+    if (ks_eff) *ks_eff = ksplit;
+    constexpr size_t sh = (size_t)H_NS * H_STAGE;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_stag256_kernel<Epi, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr = true; }
+    const dim3 gr((unsigned)(((M + H_BM - 1) / H_BM) * ((N + H_BN - 1) / H_BN)), 1, (unsigned)ksplit);
+    hipLaunchKernelGGL((gemm_nt_stag256_kernel<Epi, 4, true>), gr, dim3(512), sh, st, A, B, g, epi);
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
 

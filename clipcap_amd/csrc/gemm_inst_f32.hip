@@ -30,12 +30,34 @@ __global__ __launch_bounds__(256) void k_slab_reduce(const float* __restrict__ s
 int gemm_wgrad(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int Mw, int Nw, int K, float* dW, int ldw, float* scratch,
                hipStream_t st) {
     if ((Nw & 7) || (ldw & 3)) return CC_ERR_SHAPE;
+    const size_t slab = (size_t)Mw * Nw;
+    const size_t fit = scratch ? WGRAD_SCRATCH_BYTES / (slab * sizeof(float)) : 1;
+    // 256 x 256 kernel with DMA staging + transpose reads (one block per CU; slices sized to fill the CUs once).  It wins from
+    // about 30 GFLOP per launch (GPT-2 weight gradients: +10...17 %); below that the 128 x 128 register-staged kernel's finer
+    // tiles and fewer, smaller slabs win (mapper weight gradients, K = 5120) — tools/wgrad_bench.py.
+    if (g_gemm_tile_mode != 0 && (K % H_BK) == 0 && (Mw & 7) == 0 && (g_gemm_tile_mode == 4 || 2.0 * Mw * Nw * (double)K >= 3e10)) {
+        const int tiles = ((Mw + H_BM - 1) / H_BM) * ((Nw + H_BN - 1) / H_BN);
+        int ks = std::max(1, 256 / tiles);
+        ks = std::min(ks, std::max(1, K / 512));          // at least 16 K-tiles per slice
+        if ((size_t)ks > fit) ks = (int)std::max<size_t>(fit, 1);
+        if (ks == 1) {                                    // wide outputs (lm_head): accumulate straight into dW
+            EpiF32 e{dW, nullptr, ldw, Mw, Nw, 1, 1.0f};
+            return launch_gemm_tt256(X, ldx, Y, ldy, Mw, Nw, K, 1, e, nullptr, st);
+        }
+        EpiF32 e{scratch, nullptr, Nw, Mw, Nw, 3, 1.0f};
+        e.zstride = slab;
+        int ks_eff = 1;
+        const int rc = launch_gemm_tt256(X, ldx, Y, ldy, Mw, Nw, K, ks, e, &ks_eff, st);
+        if (rc != CC_OK) return rc;
+        const size_t n4 = slab / 4;
+        hipLaunchKernelGGL(k_slab_reduce, dim3((int)std::min<size_t>((n4 + 255) / 256, 2048)), dim3(256), 0, st, scratch, slab, ks_eff, Nw, dW, ldw, n4);
+        return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+    }
     const int tiles = ((Mw + G_BM - 1) / G_BM) * ((Nw + G_BN - 1) / G_BN);
     int ks = 512 / (tiles > 0 ? tiles : 1);
     const int kmax = (K + 255) / 256;  // at least 4 K-steps per slice
     if (ks > kmax) ks = kmax;
-    const size_t slab = (size_t)Mw * Nw;
-    if (scratch) { const size_t fit = WGRAD_SCRATCH_BYTES / (slab * sizeof(float)); if ((size_t)ks > fit) ks = (int)fit; } else ks = 1;
+    if (scratch) { if ((size_t)ks > fit) ks = (int)fit; } else ks = 1;
     if (ks <= 1) return gemm_f32out(1, 1, X, ldx, Y, ldy, Mw, Nw, K, dW, ldw, nullptr, 1, 1.0f, 1, st);
     // slices z write slab z (EpiF32 store mode; C pointer advanced per z inside the kernel via blockIdx.z * slab)
     EpiF32 e{scratch, nullptr, Nw, Mw, Nw, 3, 1.0f};

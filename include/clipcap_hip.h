@@ -205,8 +205,13 @@ int cc_sample_step(const float* logits, int32_t R, int32_t V, int32_t ld, float 
  * ------------------------------------------------------------------------------------------------------------ */
 int cc_gemm_bf16_f32(int32_t al, int32_t bl, const uint16_t* A, int32_t lda, const uint16_t* B, int32_t ldb, int32_t M, int32_t N,
                      int32_t K, float* C, int32_t ldc, const float* bias, int32_t ksplit, void* stream);
-/* NT GEMM tile choice: -1 = cost-model chooser (default), 0 = 128x128 kernel only, 3 / 4 = force the 256x192 / 256x256 kernel
- * wherever it is legal.  Process-global; returns the previous mode.  For tests and tools/gemm_bench.py only. */
+/* Weight-gradient GEMM as the backward passes run it: dW[Mw][Nw] += X^T Y with X stored [K][Mw], Y stored [K][Nw] (bf16), fp32
+ * accumulation into dW; K is split into slices whose partial sums go through `scratch` (cc_wgrad_scratch_bytes() bytes, device). */
+int64_t cc_wgrad_scratch_bytes(void);
+int cc_gemm_wgrad(const uint16_t* X, int32_t ldx, const uint16_t* Y, int32_t ldy, int32_t Mw, int32_t Nw, int32_t K, float* dW, int32_t ldw,
+                  float* scratch, void* stream);
+/* NT GEMM tile choice: -1 = cost-model chooser (default), 0 = 128x128 kernels only (also for cc_gemm_wgrad), 3 / 4 = force the 256x192 / 256x256
+ * kernel wherever it is legal.  Process-global; returns the previous mode.  For tests and tools/gemm_bench.py only. */
 int cc_gemm_tile_mode(int32_t mode);
 int cc_layernorm_fwd(const float* x, const float* gamma, const float* beta, uint16_t* y, float* mean, float* rstd, int32_t rows,
                      int32_t D, void* stream);

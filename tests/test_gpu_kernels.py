@@ -68,6 +68,31 @@ def test_gemm_nt_256_row_tiles(mode, M, N, K):
     assert torch.isnan(Cm[:, N:]).all()
 
 
+@pytest.mark.parametrize("mode", [4, 0, -1])
+@pytest.mark.parametrize("K,Mw,Nw", [(5120, 768, 1536), (1024, 264, 200), (96, 8, 8), (2080, 520, 776), (12800, 768, 768), (1237, 192, 264)])
+def test_gemm_wgrad_kernels(mode, K, Mw, Nw):
+    """dW += X^T Y through cc_gemm_wgrad: the 256 x 256 DMA + transpose-read kernel (mode 4 forces it wherever K % 32 == 0; mode -1 picks it from
+    ~30 GFLOP) and the register-staged 128 x 128 kernel (mode 0, and any K); accumulation into a non-zero dW with a padded leading dimension."""
+    torch.manual_seed(K + Mw + Nw)
+    dev = "cuda"
+    X = _bf(torch.randn(K, Mw, device=dev))
+    Y = _bf(torch.randn(K, Nw, device=dev) * 0.5)
+    dW0 = torch.randn(Mw, Nw + 4, device=dev)
+    dW = dW0.clone()
+    ref = dW0[:, :Nw] + X.float().t() @ Y.float()
+    scratch = torch.empty(_lib().cc_wgrad_scratch_bytes(), dtype=torch.uint8, device=dev)
+    old = _lib().cc_gemm_tile_mode(mode)
+    try:
+        rc = _lib().cc_gemm_wgrad(_p(X), Mw, _p(Y), Nw, Mw, Nw, K, _p(dW), Nw + 4, _p(scratch), _st())
+        torch.cuda.synchronize()
+    finally:
+        _lib().cc_gemm_tile_mode(old)
+    assert rc == 0
+    err = (dW[:, :Nw] - ref).abs().max().item()
+    assert err <= 2e-3 * max(1.0, ref.abs().max().item() / 10), err
+    assert torch.equal(dW[:, Nw:], dW0[:, Nw:])
+
+
 @pytest.mark.parametrize("ksplit", [2, 5, 16])
 def test_gemm_wgrad_split_k_atomic(ksplit):
     torch.manual_seed(ksplit)
