@@ -464,8 +464,8 @@ __global__ __launch_bounds__(256) void k_attn_fwd_mfma(const bf16_t* __restrict_
     bf16x8 qf[KK];
 #pragma unroll
     for (int kk = 0; kk < KK; kk++) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (q < S) v = *reinterpret_cast<const uint4*>(base + (size_t)q * rs + kk * 16 + half * 8);
+        uint4 v = *reinterpret_cast<const uint4*>(base + (size_t)min(q, S - 1) * rs + kk * 16 + half * 8);
+        if (q >= S) v = make_uint4(0, 0, 0, 0);
         qf[kk] = __builtin_bit_cast(bf16x8, v);
     }
     f32x16 o[NB];
@@ -482,8 +482,8 @@ __global__ __launch_bounds__(256) void k_attn_fwd_mfma(const bf16_t* __restrict_
         for (int r = 0; r < 16; r++) s[r] = 0.f;
 #pragma unroll
         for (int kk = 0; kk < KK; kk++) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (key < S) v = *reinterpret_cast<const uint4*>(base + D + (size_t)key * rs + kk * 16 + half * 8);
+            uint4 v = *reinterpret_cast<const uint4*>(base + D + (size_t)min(key, S - 1) * rs + kk * 16 + half * 8);
+            if (key >= S) v = make_uint4(0, 0, 0, 0);
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v), qf[kk], s, 0, 0, 0);
         }
         // V block -> wave-private LDS, row-major [32 keys][HD]
@@ -491,8 +491,8 @@ __global__ __launch_bounds__(256) void k_attn_fwd_mfma(const bf16_t* __restrict_
         for (int c = 0; c < HD / 16; c++) {
             const int idx = lane + 64 * c;
             const int vk = idx / C8, vc = idx % C8;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (kb * 32 + vk < S) v = *reinterpret_cast<const uint4*>(base + 2 * D + (size_t)(kb * 32 + vk) * rs + vc * 8);
+            uint4 v = *reinterpret_cast<const uint4*>(base + 2 * D + (size_t)min(kb * 32 + vk, S - 1) * rs + vc * 8);
+            if (kb * 32 + vk >= S) v = make_uint4(0, 0, 0, 0);
             *reinterpret_cast<uint4*>(vs + vk * HD + vc * 8) = v;
         }
         float mx = -INFINITY;
@@ -606,8 +606,8 @@ __device__ __forceinline__ void stage_block(bf16_t* dst, const bf16_t* src, size
     for (int c = 0; c < HD / 16; c++) {
         const int idx = lane + 64 * c;
         const int r = idx / C8, cc = idx % C8;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (row0 + r < S) v = *reinterpret_cast<const uint4*>(src + (size_t)(row0 + r) * row_stride + cc * 8);
+        uint4 v = *reinterpret_cast<const uint4*>(src + (size_t)min(row0 + r, S - 1) * row_stride + cc * 8);
+        if (row0 + r >= S) v = make_uint4(0, 0, 0, 0);
         *reinterpret_cast<uint4*>(dst + r * HD + cc * 8) = v;
     }
 }
@@ -627,9 +627,11 @@ __device__ __forceinline__ bf16x8 gather_col(const bf16_t* blk, int d, int t, in
 __device__ __forceinline__ bf16x8 pack_frag(const float* p) {
     return __builtin_bit_cast(bf16x8, make_uint4(pack2bf(p[0], p[1]), pack2bf(p[2], p[3]), pack2bf(p[4], p[5]), pack2bf(p[6], p[7])));
 }
+// Row loads are branch-free: the caller clamps the row index into range and the value is zeroed by a select.  A predicated
+// load (`if (ok) v = *p`) puts every load in its own basic block — 43 branches in the dkv loop — and the loads stop overlapping.
 __device__ __forceinline__ bf16x8 load_frag(const bf16_t* row_ptr, bool ok) {
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (ok) v = *reinterpret_cast<const uint4*>(row_ptr);
+    uint4 v = *reinterpret_cast<const uint4*>(row_ptr);
+    if (!ok) v = make_uint4(0, 0, 0, 0);
     return __builtin_bit_cast(bf16x8, v);
 }
 
@@ -640,6 +642,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const bf16_t* __restrict__
     constexpr int KK = HD / 16, NB = HD / 32;
     __shared__ __attribute__((aligned(16))) bf16_t qsm[4][32 * HD];
     __shared__ __attribute__((aligned(16))) bf16_t dsm[4][32 * HD];
+    __shared__ __attribute__((aligned(16))) float ldsm[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nblk = (S + 31) >> 5;
     const int item = blockIdx.x * 4 + wave;
@@ -655,8 +658,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const bf16_t* __restrict__
     bf16x8 kf[KK], vf[KK];
 #pragma unroll
     for (int kk = 0; kk < KK; kk++) {
-        kf[kk] = load_frag(base + D + (size_t)key * rs + kk * 16 + half * 8, key < S);
-        vf[kk] = load_frag(base + 2 * D + (size_t)key * rs + kk * 16 + half * 8, key < S);
+        kf[kk] = load_frag(base + D + (size_t)min(key, S - 1) * rs + kk * 16 + half * 8, key < S);
+        vf[kk] = load_frag(base + 2 * D + (size_t)min(key, S - 1) * rs + kk * 16 + half * 8, key < S);
     }
     f32x16 dk[NB], dv[NB];
 #pragma unroll
@@ -670,19 +673,32 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const bf16_t* __restrict__
         for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
         for (int kk = 0; kk < KK; kk++) {
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_frag(base + (size_t)qa * rs + kk * 16 + half * 8, qa < S), kf[kk], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_frag(dbase + (size_t)qa * D + kk * 16 + half * 8, qa < S), vf[kk], dp, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_frag(base + (size_t)min(qa, S - 1) * rs + kk * 16 + half * 8, qa < S), kf[kk], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_frag(dbase + (size_t)min(qa, S - 1) * D + kk * 16 + half * 8, qa < S), vf[kk], dp, 0, 0, 0);
         }
         stage_block<HD>(qsm[wave], base, rs, i * 32, S, lane);
         stage_block<HD>(dsm[wave], dbase, (size_t)D, i * 32, S, lane);
+        // log-sum-exp and delta of the block's 32 queries: one coalesced load each into a wave-private LDS row, read back as
+        // 4 x float4 per lane (queries 4 half + 8 g + 0..3) instead of 32 scalar global loads per iteration
+        {
+            const int qq = min(i * 32 + (lane & 31), S - 1);
+            ldsm[wave][lane] = half ? drow[qq] : lrow[qq];          // [0,32): lse, [32,64): delta
+        }
+        float lq[16], dq_[16];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) {
+            const float4 a = *reinterpret_cast<const float4*>(&ldsm[wave][4 * half + 8 * g4]);
+            const float4 b = *reinterpret_cast<const float4*>(&ldsm[wave][32 + 4 * half + 8 * g4]);
+            lq[g4 * 4 + 0] = a.x; lq[g4 * 4 + 1] = a.y; lq[g4 * 4 + 2] = a.z; lq[g4 * 4 + 3] = a.w;
+            dq_[g4 * 4 + 0] = b.x; dq_[g4 * 4 + 1] = b.y; dq_[g4 * 4 + 2] = b.z; dq_[g4 * 4 + 3] = b.w;
+        }
         float p[16], ds[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int qr = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             const bool ok = qr < S && key < S && (!CAUSAL || key <= qr);
-            const int qc = min(qr, S - 1);
-            p[r] = ok ? __expf(s[r] * scale - lrow[qc]) : 0.f;
-            ds[r] = p[r] * (dp[r] - drow[qc]) * scale;
+            p[r] = ok ? __expf(s[r] * scale - lq[r]) : 0.f;
+            ds[r] = p[r] * (dp[r] - dq_[r]) * scale;
         }
         const bf16x8 pf[2] = {pack_frag(p), pack_frag(p + 8)};
         const bf16x8 dsf[2] = {pack_frag(ds), pack_frag(ds + 8)};
@@ -732,8 +748,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const bf16_t* __restrict__ 
     bf16x8 qf[KK], dof[KK];
 #pragma unroll
     for (int kk = 0; kk < KK; kk++) {
-        qf[kk] = load_frag(base + (size_t)q * rs + kk * 16 + half * 8, q < S);
-        dof[kk] = load_frag(dbase + (size_t)q * D + kk * 16 + half * 8, q < S);
+        qf[kk] = load_frag(base + (size_t)min(q, S - 1) * rs + kk * 16 + half * 8, q < S);
+        dof[kk] = load_frag(dbase + (size_t)min(q, S - 1) * D + kk * 16 + half * 8, q < S);
     }
     f32x16 dq[NB];
 #pragma unroll
@@ -748,8 +764,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const bf16_t* __restrict__ 
         for (int r = 0; r < 16; r++) { st[r] = 0.f; dpt[r] = 0.f; }
 #pragma unroll
         for (int kk = 0; kk < KK; kk++) {
-            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_frag(base + D + (size_t)key * rs + kk * 16 + half * 8, key < S), qf[kk], st, 0, 0, 0);
-            dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_frag(base + 2 * D + (size_t)key * rs + kk * 16 + half * 8, key < S), dof[kk], dpt, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_frag(base + D + (size_t)min(key, S - 1) * rs + kk * 16 + half * 8, key < S), qf[kk], st, 0, 0, 0);
+            dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_frag(base + 2 * D + (size_t)min(key, S - 1) * rs + kk * 16 + half * 8, key < S), dof[kk], dpt, 0, 0, 0);
         }
         stage_block<HD>(ksm[wave], base + D, rs, j * 32, S, lane);
         float ds[16];
