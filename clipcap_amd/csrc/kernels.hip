@@ -445,11 +445,31 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const bf16_t* __restrict__ qkv
 // ------------------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+// Wave-private LDS copy of a [32 rows][HD] block, rows ATT_LD(HD) elements apart (192 B for HD 64 / 96, 320 B for 128: the four
+// rows a 32-lane half of a transpose read touches fall into four different 64-B bank slots), and the A fragment of k-step t
+// read from it with ds_read_b64_tr_b16: lane (row d = 32 nb + (lane & 31), half) needs rows {16 t + 4 half + 0..3} and
+// {16 t + 8 + 4 half + 0..3} of column d — the k-slot order the accumulator layout gives P / dS — i.e. two [4 row][16 col]
+// transpose reads per 16-lane group instead of 8 ds_read_u16 + 4 packs.
+template <int HD> struct AttLd { static constexpr int v = HD == 128 ? 160 : 96; };
+template <int HD>
+__device__ __forceinline__ bf16x8 frag_tr(const bf16_t* blk, int nb, int t, int lane) {
+    typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+    typedef __attribute__((address_space(3))) s16x4_t* lp_t;
+    constexpr int LD = AttLd<HD>::v;
+    const int half = lane >> 5, j = lane & 15, dsub = (lane >> 4) & 1;
+    const bf16_t* p = blk + (16 * t + 4 * half + (j >> 2)) * LD + nb * 32 + 16 * dsub + 4 * (j & 3);
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)p);
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(p + 8 * LD));
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
 template <int HD, bool CAUSAL>
 __global__ __launch_bounds__(256) void k_attn_fwd_mfma(const bf16_t* __restrict__ qkv, int B, int S, int H, float scale,
                                                        bf16_t* __restrict__ out, float* __restrict__ lse_out) {
     constexpr int KK = HD / 16, NB = HD / 32, C8 = HD / 8;
-    __shared__ __attribute__((aligned(16))) bf16_t vsm[4][32 * HD];
+    __shared__ __attribute__((aligned(16))) bf16_t vsm[4][32 * AttLd<HD>::v];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nqb = (S + 31) >> 5;
     const int item = blockIdx.x * 4 + wave;
@@ -475,25 +495,37 @@ __global__ __launch_bounds__(256) void k_attn_fwd_mfma(const bf16_t* __restrict_
         for (int r = 0; r < 16; r++) o[nb][r] = 0.f;
     float m = -INFINITY, l = 0.f;
     const int nkb = CAUSAL ? qb + 1 : nqb;
-    for (int kb = 0; kb < nkb; kb++) {
+    // K fragments and the V block's 16-B chunks are loaded one key block ahead of their use
+    uint4 kq[KK], vq[HD / 16];
+    auto fetch = [&](int kb, uint4 (&kd)[KK], uint4 (&vd)[HD / 16]) {
         const int key = kb * 32 + (lane & 31);
-        f32x16 s;
-#pragma unroll
-        for (int r = 0; r < 16; r++) s[r] = 0.f;
 #pragma unroll
         for (int kk = 0; kk < KK; kk++) {
-            uint4 v = *reinterpret_cast<const uint4*>(base + D + (size_t)min(key, S - 1) * rs + kk * 16 + half * 8);
-            if (key >= S) v = make_uint4(0, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v), qf[kk], s, 0, 0, 0);
+            kd[kk] = *reinterpret_cast<const uint4*>(base + D + (size_t)min(key, S - 1) * rs + kk * 16 + half * 8);
+            if (key >= S) kd[kk] = make_uint4(0, 0, 0, 0);
         }
-        // V block -> wave-private LDS, row-major [32 keys][HD]
 #pragma unroll
         for (int c = 0; c < HD / 16; c++) {
             const int idx = lane + 64 * c;
             const int vk = idx / C8, vc = idx % C8;
-            uint4 v = *reinterpret_cast<const uint4*>(base + 2 * D + (size_t)min(kb * 32 + vk, S - 1) * rs + vc * 8);
-            if (kb * 32 + vk >= S) v = make_uint4(0, 0, 0, 0);
-            *reinterpret_cast<uint4*>(vs + vk * HD + vc * 8) = v;
+            vd[c] = *reinterpret_cast<const uint4*>(base + 2 * D + (size_t)min(kb * 32 + vk, S - 1) * rs + vc * 8);
+            if (kb * 32 + vk >= S) vd[c] = make_uint4(0, 0, 0, 0);
+        }
+    };
+    fetch(0, kq, vq);
+    for (int kb = 0; kb < nkb; kb++) {
+        uint4 kn[KK], vn[HD / 16];
+        fetch(kb + 1, kn, vn);
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; r++) s[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kq[kk]), qf[kk], s, 0, 0, 0);
+        // V block -> wave-private LDS, row-major [32 keys][ATT_LD]
+#pragma unroll
+        for (int c = 0; c < HD / 16; c++) {
+            const int idx = lane + 64 * c;
+            *reinterpret_cast<uint4*>(vs + (idx / C8) * AttLd<HD>::v + (idx % C8) * 8) = vq[c];
         }
         float mx = -INFINITY;
 #pragma unroll
@@ -527,22 +559,13 @@ __global__ __launch_bounds__(256) void k_attn_fwd_mfma(const bf16_t* __restrict_
             pf[t] = __builtin_bit_cast(bf16x8, v);
         }
 #pragma unroll
-        for (int nb = 0; nb < NB; nb++) {
-            const int d = nb * 32 + (lane & 31);
+        for (int nb = 0; nb < NB; nb++)
 #pragma unroll
-            for (int t = 0; t < 2; t++) {
-                unsigned w[4];
+            for (int t = 0; t < 2; t++) o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<HD>(vs, nb, t, lane), pf[t], o[nb], 0, 0, 0);
 #pragma unroll
-                for (int e2 = 0; e2 < 4; e2++) {
-                    const int e0 = 2 * e2, e1 = 2 * e2 + 1;
-                    const int k0 = (e0 & 3) + 8 * (2 * t + (e0 >> 2)) + 4 * half;
-                    const int k1 = (e1 & 3) + 8 * (2 * t + (e1 >> 2)) + 4 * half;
-                    w[e2] = (unsigned)vs[k0 * HD + d] | ((unsigned)vs[k1 * HD + d] << 16);
-                }
-                const uint4 av = make_uint4(w[0], w[1], w[2], w[3]);
-                o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), pf[t], o[nb], 0, 0, 0);
-            }
-        }
+        for (int kk = 0; kk < KK; kk++) kq[kk] = kn[kk];
+#pragma unroll
+        for (int c = 0; c < HD / 16; c++) vq[c] = vn[c];
     }
     if (q < S) {
         const float inv = l > 0.f ? 1.f / l : 0.f;
@@ -599,31 +622,6 @@ __global__ __launch_bounds__(256) void k_attn_delta(const bf16_t* __restrict__ d
     delta[((size_t)b * H + h) * S + q] = acc;
 }
 
-template <int HD>
-__device__ __forceinline__ void stage_block(bf16_t* dst, const bf16_t* src, size_t row_stride, int row0, int S, int lane) {
-    constexpr int C8 = HD / 8;
-#pragma unroll
-    for (int c = 0; c < HD / 16; c++) {
-        const int idx = lane + 64 * c;
-        const int r = idx / C8, cc = idx % C8;
-        uint4 v = *reinterpret_cast<const uint4*>(src + (size_t)min(row0 + r, S - 1) * row_stride + cc * 8);
-        if (row0 + r >= S) v = make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<uint4*>(dst + r * HD + cc * 8) = v;
-    }
-}
-// A fragment of k-step t: 8 rows {(e&3) + 8(2t + (e>>2)) + 4*half} of column d of a row-major [32][HD] LDS block
-template <int HD>
-__device__ __forceinline__ bf16x8 gather_col(const bf16_t* blk, int d, int t, int half) {
-    unsigned w[4];
-#pragma unroll
-    for (int e2 = 0; e2 < 4; e2++) {
-        const int e0 = 2 * e2, e1 = 2 * e2 + 1;
-        const int r0 = (e0 & 3) + 8 * (2 * t + (e0 >> 2)) + 4 * half;
-        const int r1 = (e1 & 3) + 8 * (2 * t + (e1 >> 2)) + 4 * half;
-        w[e2] = (unsigned)blk[r0 * HD + d] | ((unsigned)blk[r1 * HD + d] << 16);
-    }
-    return __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
-}
 __device__ __forceinline__ bf16x8 pack_frag(const float* p) {
     return __builtin_bit_cast(bf16x8, make_uint4(pack2bf(p[0], p[1]), pack2bf(p[2], p[3]), pack2bf(p[4], p[5]), pack2bf(p[6], p[7])));
 }
@@ -640,8 +638,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const bf16_t* __restrict__
                                                       const float* __restrict__ lse, const float* __restrict__ delta, int B, int S, int H,
                                                       float scale, bf16_t* __restrict__ dqkv) {
     constexpr int KK = HD / 16, NB = HD / 32;
-    __shared__ __attribute__((aligned(16))) bf16_t qsm[4][32 * HD];
-    __shared__ __attribute__((aligned(16))) bf16_t dsm[4][32 * HD];
+    __shared__ __attribute__((aligned(16))) bf16_t qsm[4][32 * AttLd<HD>::v];
+    __shared__ __attribute__((aligned(16))) bf16_t dsm[4][32 * AttLd<HD>::v];
     __shared__ __attribute__((aligned(16))) float ldsm[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nblk = (S + 31) >> 5;
@@ -666,18 +664,39 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const bf16_t* __restrict__
     for (int nb = 0; nb < NB; nb++)
 #pragma unroll
         for (int r = 0; r < 16; r++) { dk[nb][r] = 0.f; dv[nb][r] = 0.f; }
-    for (int i = CAUSAL ? j : 0; i < nblk; i++) {
-        const int qa = i * 32 + (lane & 31);
+    // The Q / dO fragments of query block i are loaded one iteration ahead (the loop is a chain of dependent global round trips
+    // otherwise) and the row-major LDS copies the dK / dV products need are written from those same registers: the lanes'
+    // fragments (row lane & 31, columns 16 kk + 8 half .. + 7) tile the block exactly.
+    const int i0 = CAUSAL ? j : 0;
+    bf16x8 qf[KK], df[KK];
+    {
+        const int qa = i0 * 32 + (lane & 31);
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++) {
+            qf[kk] = load_frag(base + (size_t)min(qa, S - 1) * rs + kk * 16 + half * 8, qa < S);
+            df[kk] = load_frag(dbase + (size_t)min(qa, S - 1) * D + kk * 16 + half * 8, qa < S);
+        }
+    }
+    for (int i = i0; i < nblk; i++) {
+        bf16x8 qn[KK], dn[KK];
+        {
+            const int qa = (i + 1) * 32 + (lane & 31);      // block i + 1 (clamped rows; unused after the last iteration)
+#pragma unroll
+            for (int kk = 0; kk < KK; kk++) {
+                qn[kk] = load_frag(base + (size_t)min(qa, S - 1) * rs + kk * 16 + half * 8, qa < S);
+                dn[kk] = load_frag(dbase + (size_t)min(qa, S - 1) * D + kk * 16 + half * 8, qa < S);
+            }
+        }
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
         for (int kk = 0; kk < KK; kk++) {
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_frag(base + (size_t)min(qa, S - 1) * rs + kk * 16 + half * 8, qa < S), kf[kk], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_frag(dbase + (size_t)min(qa, S - 1) * D + kk * 16 + half * 8, qa < S), vf[kk], dp, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[kk], kf[kk], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[kk], vf[kk], dp, 0, 0, 0);
+            *reinterpret_cast<bf16x8*>(qsm[wave] + (lane & 31) * AttLd<HD>::v + kk * 16 + half * 8) = qf[kk];
+            *reinterpret_cast<bf16x8*>(dsm[wave] + (lane & 31) * AttLd<HD>::v + kk * 16 + half * 8) = df[kk];
         }
-        stage_block<HD>(qsm[wave], base, rs, i * 32, S, lane);
-        stage_block<HD>(dsm[wave], dbase, (size_t)D, i * 32, S, lane);
         // log-sum-exp and delta of the block's 32 queries: one coalesced load each into a wave-private LDS row, read back as
         // 4 x float4 per lane (queries 4 half + 8 g + 0..3) instead of 32 scalar global loads per iteration
         {
@@ -703,14 +722,14 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const bf16_t* __restrict__
         const bf16x8 pf[2] = {pack_frag(p), pack_frag(p + 8)};
         const bf16x8 dsf[2] = {pack_frag(ds), pack_frag(ds + 8)};
 #pragma unroll
-        for (int nb = 0; nb < NB; nb++) {
-            const int d = nb * 32 + (lane & 31);
+        for (int nb = 0; nb < NB; nb++)
 #pragma unroll
             for (int t = 0; t < 2; t++) {
-                dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gather_col<HD>(dsm[wave], d, t, half), pf[t], dv[nb], 0, 0, 0);
-                dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gather_col<HD>(qsm[wave], d, t, half), dsf[t], dk[nb], 0, 0, 0);
+                dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<HD>(dsm[wave], nb, t, lane), pf[t], dv[nb], 0, 0, 0);
+                dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<HD>(qsm[wave], nb, t, lane), dsf[t], dk[nb], 0, 0, 0);
             }
-        }
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++) { qf[kk] = qn[kk]; df[kk] = dn[kk]; }
     }
     if (key < S) {
         bf16_t* orow = dqkv + ((size_t)b * S + key) * rs + h * HD;
@@ -732,7 +751,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const bf16_t* __restrict__ 
                                                      const float* __restrict__ lse, const float* __restrict__ delta, int B, int S, int H,
                                                      float scale, bf16_t* __restrict__ dqkv) {
     constexpr int KK = HD / 16, NB = HD / 32;
-    __shared__ __attribute__((aligned(16))) bf16_t ksm[4][32 * HD];
+    __shared__ __attribute__((aligned(16))) bf16_t ksm[4][32 * AttLd<HD>::v];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nblk = (S + 31) >> 5;
     const int item = blockIdx.x * 4 + wave;
@@ -757,17 +776,35 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const bf16_t* __restrict__ 
 #pragma unroll
         for (int r = 0; r < 16; r++) dq[nb][r] = 0.f;
     const int jend = CAUSAL ? i + 1 : nblk;
+    // K / V fragments one key block ahead; the row-major K copy for dQ^T += K^T dS^T is written from the K fragment registers
+    bf16x8 kf[KK], vf[KK];
+    {
+        const int key = lane & 31;
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++) {
+            kf[kk] = load_frag(base + D + (size_t)min(key, S - 1) * rs + kk * 16 + half * 8, key < S);
+            vf[kk] = load_frag(base + 2 * D + (size_t)min(key, S - 1) * rs + kk * 16 + half * 8, key < S);
+        }
+    }
     for (int j = 0; j < jend; j++) {
-        const int key = j * 32 + (lane & 31);
+        bf16x8 kn[KK], vn[KK];
+        {
+            const int key = (j + 1) * 32 + (lane & 31);
+#pragma unroll
+            for (int kk = 0; kk < KK; kk++) {
+                kn[kk] = load_frag(base + D + (size_t)min(key, S - 1) * rs + kk * 16 + half * 8, key < S);
+                vn[kk] = load_frag(base + 2 * D + (size_t)min(key, S - 1) * rs + kk * 16 + half * 8, key < S);
+            }
+        }
         f32x16 st, dpt;
 #pragma unroll
         for (int r = 0; r < 16; r++) { st[r] = 0.f; dpt[r] = 0.f; }
 #pragma unroll
         for (int kk = 0; kk < KK; kk++) {
-            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_frag(base + D + (size_t)min(key, S - 1) * rs + kk * 16 + half * 8, key < S), qf[kk], st, 0, 0, 0);
-            dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_frag(base + 2 * D + (size_t)min(key, S - 1) * rs + kk * 16 + half * 8, key < S), dof[kk], dpt, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[kk], st, 0, 0, 0);
+            dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kk], dof[kk], dpt, 0, 0, 0);
+            *reinterpret_cast<bf16x8*>(ksm[wave] + (lane & 31) * AttLd<HD>::v + kk * 16 + half * 8) = kf[kk];
         }
-        stage_block<HD>(ksm[wave], base + D, rs, j * 32, S, lane);
         float ds[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) {
@@ -778,12 +815,12 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const bf16_t* __restrict__ 
         }
         const bf16x8 dsf[2] = {pack_frag(ds), pack_frag(ds + 8)};
 #pragma unroll
-        for (int nb = 0; nb < NB; nb++) {
-            const int d = nb * 32 + (lane & 31);
+        for (int nb = 0; nb < NB; nb++)
 #pragma unroll
             for (int t = 0; t < 2; t++)
-                dq[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gather_col<HD>(ksm[wave], d, t, half), dsf[t], dq[nb], 0, 0, 0);
-        }
+                dq[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<HD>(ksm[wave], nb, t, lane), dsf[t], dq[nb], 0, 0, 0);
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++) { kf[kk] = kn[kk]; vf[kk] = vn[kk]; }
     }
     if (q < S) {
         bf16_t* orow = dqkv + ((size_t)b * S + q) * rs + h * HD;
