@@ -124,6 +124,15 @@ __device__ __forceinline__ int xcd_remap(int b, int nb) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
+// Functors whose epilogue reads a second tensor (dgrad-through-activation: the activation input) can hand it over in the strip
+// layout before the first store: Epi::StripAux / load_aux(row, col) / operator()(row, col, v, aux).  Otherwise every such load sits
+// between two stores, and with loads and stores on the one vmcnt counter the compiler waits vmcnt(0) for it — a store-queue drain
+// per 16-row strip.
+// epilogue functors that reduce along a row (lm_head softmax partials) take the wave's whole 64-column strip: Epi::strip()
+template <class E> struct epi_row_strip { static constexpr bool value = false; };
+template <class E, class = void> struct epi_strip_aux { static constexpr bool value = false; };
+template <class E> struct epi_strip_aux<E, decltype((void)sizeof(typename E::StripAux))> { static constexpr bool value = true; };
+
 // ---- epilogue: wave-private LDS strip [16][68] fp32; C layout of 16x16x32: col = lane&15, row = (lane>>4)*4 + reg.
 // Every lane ends up with 8 consecutive columns of one row -> vector epilogue.  Caller must have passed a barrier
 // after the last LDS read of the main loop.
@@ -131,6 +140,35 @@ template <class Epi>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[4][4], char* smem, int wave, int lane, int row0, int col0, const Epi& epi) {
     float* strip = reinterpret_cast<float*>(smem) + wave * (16 * G_EPI_LD);
     const int er = (lane >> 4) * 4, ec = lane & 15;
+    if constexpr (epi_strip_aux<Epi>::value) {
+        typename Epi::StripAux aux[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const int q = lane + 64 * s;
+                aux[i][s] = epi.load_aux(row0 + i * 16 + (q >> 3), col0 + (q & 7) * 8);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) strip[(er + r) * G_EPI_LD + j * 16 + ec] = acc[i][j][r];
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const int q = lane + 64 * s;
+                const int lr = q >> 3, c8 = q & 7;
+                float v[8];
+                const float4 a = *reinterpret_cast<const float4*>(strip + lr * G_EPI_LD + c8 * 8);
+                const float4 b = *reinterpret_cast<const float4*>(strip + lr * G_EPI_LD + c8 * 8 + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+                epi(row0 + i * 16 + lr, col0 + c8 * 8, v, aux[i][s]);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
 #pragma unroll
@@ -149,9 +187,6 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[4][4], char* smem, in
         }
     }
 }
-
-// epilogue functors that reduce along a row (lm_head softmax partials) take the wave's whole 64-column strip: Epi::strip()
-template <class E> struct epi_row_strip { static constexpr bool value = false; };
 
 // ---- epilogue straight from registers (no LDS) for the 256-row kernels (8 waves, one block per CU: nothing else on the CU hides
 // an LDS round trip and its barrier; with the 128 x 128 kernels' two co-resident blocks the strip epilogue above measured 1.5 %
@@ -723,6 +758,23 @@ struct EpiDAct {
             for (int e = 0; e < 8; e++) v[e] *= gelu_new_grad(a[e]);
         }
         *reinterpret_cast<uint4*>(C + o) = pack8(v);
+    }
+    typedef uint4 StripAux;                                                           // 128 x 128 strip epilogue: aux fetched up front
+    __device__ __forceinline__ uint4 load_aux(int row, int col) const {
+        return (row < M && col < Ns) ? *reinterpret_cast<const uint4*>(aux + (size_t)row * ldc + col) : make_uint4(0, 0, 0, 0);
+    }
+    __device__ __forceinline__ void operator()(int row, int col, float (&v)[8], const uint4& ax) const {
+        if (row >= M || col >= Ns) return;
+        float a[8];
+        unpack8(ax, a);
+        if (act == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = a[e] > 0.f ? v[e] : 0.f;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] *= gelu_new_grad(a[e]);
+        }
+        *reinterpret_cast<uint4*>(C + (size_t)row * ldc + col) = pack8(v);
     }
     static constexpr bool kPre = true;
     __device__ __forceinline__ void pre4(int row, int col, f32x4& a) const {        // acc *= act'(aux)
