@@ -420,6 +420,66 @@ __global__ __launch_bounds__(G_THREADS, 2) void gemm_nt_glds_kernel(const bf16_t
     gemm_epilogue(acc, smem, wave, lane, m0 + wm * 64, n0 + wn * 64, epi);
 }
 
+// Small grids (<= one 128 x 128 tile per CU): the same kernel with FOUR LDS stages (128 KiB, one block per CU by construction) and
+// three K-tiles of DMA in flight behind a counted vmcnt.  With a single block per CU the 2-stage kernel above exposes a full
+// L2/HBM round trip per K-step (s_waitcnt vmcnt(0) with nothing else on the CU to run): mapper GEMMs (M = 5120) ran 12-24 K-steps
+// at ~0.85 us each.  On grids that fill the CUs twice the 2-stage kernel with two co-resident blocks stays better (measured -30 %
+// for this variant there), so launch_gemm only picks it when tiles <= CUs.
+template <class Epi>
+__global__ __launch_bounds__(G_THREADS, 1) void gemm_nt_glds4_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                                      GemmShape g, Epi epi) {
+    extern __shared__ __attribute__((aligned(1024))) char smem4[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (g.N + G_BN - 1) / G_BN, tiles_m = (g.M + G_BM - 1) / G_BM;
+    int tm, tn;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, g.group_m, tm, tn);
+    const int m0 = tm * G_BM, n0 = tn * G_BN;
+    const int kbeg = blockIdx.z * g.k_chunk;
+    const int nk = (min(g.K, kbeg + g.k_chunk) - kbeg) / G_BK;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define G4_ISSUE(T)                                                                                                      \
+    {                                                                                                                    \
+        char* st_ = smem4 + ((T) & 3) * 2 * G_TILE_BYTES;                                                                \
+        glds_tile(A, g.lda, g.M, m0, kbeg + (T)*G_BK, st_, wave, lane);                                                  \
+        glds_tile(B, g.ldb, g.N, n0, kbeg + (T)*G_BK, st_ + G_TILE_BYTES, wave, lane);                                   \
+    }
+    G4_ISSUE(0);
+    if (nk > 1) G4_ISSUE(1);
+    if (nk > 2) G4_ISSUE(2);
+    const int frow = lane & 15, fchunk = lane >> 4;
+    for (int kt = 0; kt < nk; kt++) {
+        // tile kt must have landed; tiles kt+1, kt+2 (8 DMA instructions per wave each) may stay in flight
+        const int rem = min(nk - 1, kt + 2) - kt;
+        if (rem >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // raw barrier: __syncthreads() would drain the DMA queue
+        if (kt + 3 < nk) G4_ISSUE(kt + 3);             // buffer (kt+3)&3 held tile kt-1, which every wave finished before this barrier
+        const char* cur = smem4 + (kt & 3) * 2 * G_TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) af[i] = *reinterpret_cast<const bf16x8*>(cur + g_lds_off(wm * 64 + i * 16 + frow, ks * 4 + fchunk));
+#pragma unroll
+            for (int j = 0; j < 4; j++) bfr[j] = *reinterpret_cast<const bf16x8*>(cur + G_TILE_BYTES + g_lds_off(wn * 64 + j * 16 + frow, ks * 4 + fchunk));
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+#undef G4_ISSUE
+    __syncthreads();
+    gemm_epilogue(acc, smem4, wave, lane, m0 + wm * 64, n0 + wn * 64, epi);
+}
+
 // ------------------------------------------------------------------------------------------------
 // NT 256 x 256 kernel for large outputs ("stag256"): 8 waves, wave tile 128 x 64 (8 x 4 MFMA tiles), K-tile 32, FOUR LDS stages
 // of 32 KiB.  Per FLOP it moves half the L2->LDS bytes and 3/4 of the fragment reads of the 128 x 128 kernel — the two
@@ -937,7 +997,13 @@ inline int launch_gemm(int al, int bl, const bf16_t* A, int lda, const bf16_t* B
     else if (al == 0 && bl == 0 && (K % G_BK) == 0 && abl == 6) { hipLaunchKernelGGL((gemm_nt_glds_kernel<Epi, 6>), grid, dim3(G_THREADS), 0, st, A, B, g, epi); }
     else
 #endif
-    if (al == 0 && bl == 0 && (K % G_BK) == 0)
+    if (al == 0 && bl == 0 && (K % G_BK) == 0 && (long)grid.x * grid.z <= 256 && g_gemm_tile_mode != 0 && K / (int)grid.z >= 4 * G_BK) {
+        // at most one block per CU: nothing co-resident to hide the 2-stage kernel's per-K-step round trip -> 4-stage variant
+        constexpr size_t sh4 = (size_t)8 * G_TILE_BYTES;
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_glds4_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh4); attr = true; }
+        hipLaunchKernelGGL((gemm_nt_glds4_kernel<Epi>), grid, dim3(G_THREADS), sh4, st, A, B, g, epi);
+    } else if (al == 0 && bl == 0 && (K % G_BK) == 0)
         hipLaunchKernelGGL((gemm_nt_glds_kernel<Epi>), grid, dim3(G_THREADS), 0, st, A, B, g, epi);
     else if (al == 0 && bl == 0)
         hipLaunchKernelGGL((gemm_bf16_kernel<0, 0, Epi>), grid, dim3(G_THREADS), 0, st, A, B, g, epi);
