@@ -153,29 +153,39 @@ constexpr int BEAM_CHUNKS = 16;
 
 __device__ __forceinline__ bool cand_better(float a, int ia, float b, int ib) { return a > b || (a == b && ia < ib); }
 
-__global__ __launch_bounds__(256) void k_beam_rowstats(const float* __restrict__ logits, size_t ldl, int V, float inv_temp, float* __restrict__ rs) {
-    __shared__ float red[256];
+template <bool VEC>   // VEC: rows are 16-B aligned (ldl % 4 == 0, aligned base) -> float4 loads
+__global__ __launch_bounds__(512) void k_beam_rowstats(const float* __restrict__ logits, size_t ldl, int V, float inv_temp, float* __restrict__ rs) {
+    __shared__ float red[8];
     const int row = blockIdx.x, tid = threadIdx.x;
     const float* lg = logits + (size_t)row * ldl;
+    const int V4 = VEC ? (V >> 2) : 0;
     float m = -INFINITY;
-    for (int v = tid; v < V; v += 256) m = fmaxf(m, lg[v] * inv_temp);
-    red[tid] = m;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]);
-        __syncthreads();
+    for (int v = tid; v < V4; v += 512) {
+        const float4 x = reinterpret_cast<const float4*>(lg)[v];
+        m = fmaxf(fmaxf(m, fmaxf(x.x, x.y) * inv_temp), fmaxf(x.z, x.w) * inv_temp);      // inv_temp > 0: max(x) t == max(x t)
     }
+    for (int v = V4 * 4 + tid; v < V; v += 512) m = fmaxf(m, lg[v] * inv_temp);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
     m = red[0];
+    for (int i = 1; i < 8; i++) m = fmaxf(m, red[i]);
     __syncthreads();
     float sum = 0.f;
-    for (int v = tid; v < V; v += 256) sum += expf(lg[v] * inv_temp - m);
-    red[tid] = sum;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) red[tid] += red[tid + o];
-        __syncthreads();
+    for (int v = tid; v < V4; v += 512) {
+        const float4 x = reinterpret_cast<const float4*>(lg)[v];
+        sum += expf(x.x * inv_temp - m) + expf(x.y * inv_temp - m) + expf(x.z * inv_temp - m) + expf(x.w * inv_temp - m);
     }
-    if (tid == 0) { rs[2 * row] = m; rs[2 * row + 1] = red[0]; }
+    for (int v = V4 * 4 + tid; v < V; v += 512) sum += expf(lg[v] * inv_temp - m);
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.f;
+        for (int i = 0; i < 8; i++) t += red[i];
+        rs[2 * row] = m;
+        rs[2 * row + 1] = t;
+    }
 }
 
 // block-wide selection of the `beam` best of ncand (value, index) candidates held in LDS; results in sel_v / sel_i
@@ -204,7 +214,12 @@ __device__ __forceinline__ void select_top(float* cval, int* cidx, int ncand, in
     }
 }
 
-__global__ __launch_bounds__(256) void k_beam_partial(const float* __restrict__ logits, size_t ldl, int beam, int V, float inv_temp, int first,
+// TB = compile-time beam width (0: run-time width, lists in scratch memory — the slow fallback for beam > 8).
+// Each candidate's exact value needs expf + divide + logf (the reference's softmax().log() arithmetic); almost all of the 250 k
+// candidates lose against the thread's current worst kept value, so a cheap bound (x t - m - log(sum), equal up to ~1e-6) with a
+// 1e-3 margin decides whether the exact value is evaluated at all.
+template <int TB>
+__global__ __launch_bounds__(256) void k_beam_partial(const float* __restrict__ logits, size_t ldl, int beam_rt, int V, float inv_temp, int first,
                                                       const float* __restrict__ rs, const float* __restrict__ scores,
                                                       const float* __restrict__ seq_len, const unsigned char* __restrict__ stopped,
                                                       float* __restrict__ pval, int* __restrict__ pidx) {
@@ -214,30 +229,67 @@ __global__ __launch_bounds__(256) void k_beam_partial(const float* __restrict__ 
     __shared__ int cidx[256 * BEAM_MAX];
     __shared__ float sel_v[BEAM_MAX];
     __shared__ int sel_i[BEAM_MAX];
+    constexpr int LB = TB > 0 ? TB : BEAM_MAX;
+    const int beam = TB > 0 ? TB : beam_rt;
     const int s = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
     const int nrows = first ? 1 : beam;
     const int total = nrows * V;
     const int per = (total + BEAM_CHUNKS - 1) / BEAM_CHUNKS;
     const int lo = ch * per, hi = min(total, lo + per);
     const float* lg = logits + (size_t)s * beam * ldl;
-    float lv[BEAM_MAX];
-    int li[BEAM_MAX];
+    float lv[LB];
+    int li[LB];
 #pragma unroll
-    for (int k = 0; k < BEAM_MAX; k++) { lv[k] = -INFINITY; li[k] = 0x7fffffff; }
-    for (int idx = lo + tid; idx < hi; idx += 256) {
-        const int b = idx / V, v = idx - b * V;
+    for (int k = 0; k < LB; k++) { lv[k] = -INFINITY; li[k] = 0x7fffffff; }
+    // a chunk (total / 16 candidates) spans at most two beam rows when V >= per; handled generally by walking row segments
+    for (int b = lo / V; b < nrows && b * V < hi; b++) {
+        const int seg_lo = max(lo, b * V), seg_hi = min(hi, (b + 1) * V);
         const bool st = !first && stopped[s * beam + b];
-        float lp;
-        if (st) lp = (v == 0) ? 0.f : -INFINITY;                                                          // base.py:96-97
-        else lp = logf(expf(lg[(size_t)b * ldl + v] * inv_temp - rs[2 * (s * beam + b)]) / rs[2 * (s * beam + b) + 1]);   // softmax().log()
-        const float val = first ? lp : (scores[s * beam + b] + lp) / (seq_len[s * beam + b] + (st ? 0.f : 1.f));    // base.py:99-101
-        if (cand_better(val, idx, lv[beam - 1], li[beam - 1])) {
-            int k = beam - 1;
-            while (k > 0 && cand_better(val, idx, lv[k - 1], li[k - 1])) { lv[k] = lv[k - 1]; li[k] = li[k - 1]; k--; }
-            lv[k] = val; li[k] = idx;
+        const float m = rs[2 * (s * beam + b)], sum = rs[2 * (s * beam + b) + 1];
+        const float lsum = logf(sum);
+        const float sc = first ? 0.f : scores[s * beam + b];
+        const float inv_len = first ? 1.f : 1.0f / (seq_len[s * beam + b] + (st ? 0.f : 1.f));
+        const float len = first ? 1.f : (seq_len[s * beam + b] + (st ? 0.f : 1.f));
+        const float* row = lg + (size_t)b * ldl - (size_t)b * V;      // row[idx] = lg[b * ldl + (idx - b V)]
+        for (int idx = seg_lo + tid; idx < seg_hi; idx += 256) {
+            const int v = idx - b * V;
+            float val;
+            if (st) {
+                val = (v == 0) ? (first ? 0.f : (sc + 0.f) / len) : -INFINITY;                               // base.py:96-101
+            } else {
+                const float x = row[idx] * inv_temp - m;
+                const float bound = first ? (x - lsum) : (sc + (x - lsum)) * inv_len;
+                const float worst = TB > 0 ? lv[LB - 1] : lv[beam - 1];
+                if (bound + 1e-3f < worst) continue;
+                const float lp = logf(expf(x) / sum);                                                        // softmax().log()
+                val = first ? lp : (sc + lp) / len;                                                          // base.py:99-101
+            }
+            if constexpr (TB > 0) {
+                if (cand_better(val, idx, lv[LB - 1], li[LB - 1])) {
+                    lv[LB - 1] = val; li[LB - 1] = idx;
+#pragma unroll
+                    for (int k = LB - 1; k > 0; k--) {
+                        if (cand_better(lv[k], li[k], lv[k - 1], li[k - 1])) {
+                            const float tv = lv[k]; lv[k] = lv[k - 1]; lv[k - 1] = tv;
+                            const int ti = li[k]; li[k] = li[k - 1]; li[k - 1] = ti;
+                        }
+                    }
+                }
+            } else {
+                if (cand_better(val, idx, lv[beam - 1], li[beam - 1])) {
+                    int k = beam - 1;
+                    while (k > 0 && cand_better(val, idx, lv[k - 1], li[k - 1])) { lv[k] = lv[k - 1]; li[k] = li[k - 1]; k--; }
+                    lv[k] = val; li[k] = idx;
+                }
+            }
         }
     }
-    for (int k = 0; k < beam; k++) { cval[tid * beam + k] = lv[k]; cidx[tid * beam + k] = li[k]; }
+    if constexpr (TB > 0) {
+#pragma unroll
+        for (int k = 0; k < LB; k++) { cval[tid * LB + k] = lv[k]; cidx[tid * LB + k] = li[k]; }
+    } else {
+        for (int k = 0; k < beam; k++) { cval[tid * beam + k] = lv[k]; cidx[tid * beam + k] = li[k]; }
+    }
     __syncthreads();
     select_top(cval, cidx, 256 * beam, beam, red, redi, sel_v, sel_i, tid, 256);
     if (tid < beam) {
@@ -439,9 +491,21 @@ int cc_beam_step(int32_t S, int32_t beam, int32_t V, const float* logits, int64_
     float* pval = rs + (size_t)S * beam * 2;
     int* pidx = reinterpret_cast<int*>(pval + (size_t)S * BEAM_CHUNKS * beam);
     // step 0 reads only row 0 of every sample's block of `beam` rows, but computing all rows' statistics is harmless and uniform
-    hipLaunchKernelGGL(k_beam_rowstats, dim3(S * beam), dim3(256), 0, st, logits, (size_t)ldl, V, inv_temp, rs);
-    hipLaunchKernelGGL(k_beam_partial, dim3(S, BEAM_CHUNKS), dim3(256), 0, st, logits, (size_t)ldl, beam, V, inv_temp, first, rs, scores,
-                       seq_lengths, has_stopped, pval, pidx);
+    if ((ldl & 3) || ((uintptr_t)logits & 15))
+        hipLaunchKernelGGL(k_beam_rowstats<false>, dim3(S * beam), dim3(512), 0, st, logits, (size_t)ldl, V, inv_temp, rs);
+    else
+        hipLaunchKernelGGL(k_beam_rowstats<true>, dim3(S * beam), dim3(512), 0, st, logits, (size_t)ldl, V, inv_temp, rs);
+#define BEAM_PARTIAL(TB) hipLaunchKernelGGL(k_beam_partial<TB>, dim3(S, BEAM_CHUNKS), dim3(256), 0, st, logits, (size_t)ldl, beam, V, inv_temp, first, rs, scores, seq_lengths, has_stopped, pval, pidx)
+    switch (beam) {
+        case 1: BEAM_PARTIAL(1); break;
+        case 2: BEAM_PARTIAL(2); break;
+        case 3: BEAM_PARTIAL(3); break;
+        case 4: BEAM_PARTIAL(4); break;
+        case 5: BEAM_PARTIAL(5); break;
+        case 8: BEAM_PARTIAL(8); break;
+        default: BEAM_PARTIAL(0); break;
+    }
+#undef BEAM_PARTIAL
     hipLaunchKernelGGL(k_beam_final, dim3(S), dim3(64), 0, st, beam, V, first, stop_token, pval, pidx, scores, seq_lengths, has_stopped, next_tokens,
                        src_rows);
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
