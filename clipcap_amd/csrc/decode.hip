@@ -427,7 +427,8 @@ int cc_decode_fwd(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int
         // xn = ln_1(x): produced by the previous layer's fused finish when possible
         if (!xn_ready) CC_TRY(ln_fwd(w.x, D, nullptr, w32 + l1w, w32 + l1b, w.xn, nullptr, nullptr, nullptr, M, D, st));
         // c_attn (+ fused KV append into the cache)
-        const bool f_qkv = gemm_nt_skinny_can_fuse(M, 3 * D, D, w.scratch_bytes);
+        const bool f_qkv = gemm_nt_skinny_can_fuse(M, 3 * D, D, w.scratch_bytes) &&
+                           ((M + 127) / 128) * ((3 * D + 127) / 128) < skinny_single_min_tiles();
         SkinnyFuse fq;
         fq.kcache = kc; fq.vcache = vc; fq.Tn = Tn; fq.pos0 = pos0; fq.ctx_max = ctx_max;
         CC_TRY(gemm_nt_skinny(w.xn, D, w16t + aw, D, M, 3 * D, D, w32 + ab, 0, nullptr, nullptr, w.qkv, 3 * D, w.scratch, w.scratch_bytes, st,

@@ -40,6 +40,7 @@ struct SkinnyFuse {
 int gemm_nt_skinny(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const float* bias, int act, const float* res,
                    float* out32, bf16_t* out16, int ldo, float* scratch, size_t scratch_bytes, hipStream_t st,
                    const SkinnyFuse* fuse = nullptr);
+int skinny_single_min_tiles();   // grids of at least this many 128 x 128 tiles skip split-K (CC_SKINNY_SINGLE; tuning knob)
 // whether gemm_nt_skinny will take the slab + row-finish path for this problem (the only path that supports SkinnyFuse)
 bool gemm_nt_skinny_can_fuse(int M, int N, int K, size_t scratch_bytes);
 }  // namespace cc

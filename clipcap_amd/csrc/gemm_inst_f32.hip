@@ -178,6 +178,10 @@ __global__ __launch_bounds__(256) void k_splitk_finish_row(const float* __restri
     }
 }
 
+int skinny_single_min_tiles() {
+    static const int v = []() { const char* e = getenv("CC_SKINNY_SINGLE"); return e ? atoi(e) : 60; }();   // measured on config 5: 171 (never) / 165 (90) / 159 (60) / 160 (20) ms per decode batch
+    return v;
+}
 bool gemm_nt_skinny_can_fuse(int M, int N, int K, size_t scratch_bytes) {
     return M > 0 && N > 0 && (N & 7) == 0 && N <= 3072 && (K % G_BK) == 0 && scratch_bytes >= (size_t)M * N * sizeof(float);
 }
@@ -194,6 +198,8 @@ int gemm_nt_skinny(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, in
     const bool can_slab = scratch && slab && (K % G_BK) == 0 && scratch_bytes >= slab * sizeof(float);
     if (can_slab) { const size_t fit = scratch_bytes / (slab * sizeof(float)); if ((size_t)ks > fit) ks = (int)fit; }
     const bool fused = fuse && (fuse->ln_out16 || fuse->kcache);
+    // wide-enough grids go single-pass with the epilogue fused into the GEMM (4-stage small-grid kernel): one launch instead of two
+    if (!fused && tiles >= skinny_single_min_tiles()) ks = 1;
     if (!can_slab || (ks <= 1 && !fused)) {
         if (fused) return CC_ERR_SHAPE;                    // callers only request fusion when the slab path is available
         if (res) { EpiResid e{out32, res, bias, ldo, M, N}; return launch_gemm(0, 0, A, lda, B, ldb, M, N, K, 1, e, st); }
