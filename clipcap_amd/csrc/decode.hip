@@ -30,25 +30,14 @@ __global__ void k_add_wpe(const float* __restrict__ xin, const float* __restrict
     }
 }
 
-// append the new K / V rows of qkv [R*Tn, 3D] to the cache [2][R][ctx_max][D] of one layer
-__global__ void k_kv_append(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ kc, bf16_t* __restrict__ vc, int R, int Tn, int D, int pos0,
-                            int ctx_max) {
-    const int d8n = D >> 3;
-    const size_t total = (size_t)R * Tn * d8n;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % d8n), t = (int)((i / d8n) % Tn), r = (int)(i / ((size_t)d8n * Tn));
-        const bf16_t* src = qkv + ((size_t)r * Tn + t) * 3 * D + c * 8;
-        const size_t dst = ((size_t)r * ctx_max + pos0 + t) * D + c * 8;
-        *reinterpret_cast<uint4*>(kc + dst) = *reinterpret_cast<const uint4*>(src + D);
-        *reinterpret_cast<uint4*>(vc + dst) = *reinterpret_cast<const uint4*>(src + 2 * D);
-    }
-}
-
 // attention of the Tn new queries of every row against the cache (ctx = pos0 + Tn, causal): one wave per (r,h,t).
 // scores: one key per lane (K row = hd contiguous bf16, 16-B loads).  PV: lane = (key group kg, 8-wide d chunk dc): every V load
 // is a 16-B vector, the key loop is 64/(hd/8) times shorter than one-d-per-lane, partial sums meet in wave-private LDS.
-__global__ __launch_bounds__(256) void k_decode_attn(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ kc,
-                                                     const bf16_t* __restrict__ vc, const int* __restrict__ row_map, bf16_t* __restrict__ out,
+// APPEND: the wave also writes its own (row, head, new position) K / V slice into the cache (instead of a separate append launch)
+// and reads the keys / values of the NEW positions straight from qkv — other waves' cache writes are not ordered with its reads.
+template <bool APPEND>
+__global__ __launch_bounds__(256) void k_decode_attn(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ kc,
+                                                     bf16_t* __restrict__ vc, const int* __restrict__ row_map, bf16_t* __restrict__ out,
                                                      int R, int Tn, int H, int hd, int pos0, int ctx_max, float scale) {
     extern __shared__ float psm[];  // per wave: p[ctx_max] | srow[ctx_max] | red[8][hd]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -64,11 +53,21 @@ __global__ __launch_bounds__(256) void k_decode_attn(const bf16_t* __restrict__ 
     // position j of row r lives in cache row row_map[j*R + r] (beam ancestry table; identity when null)
     const bf16_t* kb = kc + h * hd;
     const bf16_t* vb = vc + h * hd;
+    if (APPEND) {
+        const int c8 = hd >> 3;                            // 16-B chunks per head slice
+        if (lane < 2 * c8) {
+            const int which = lane / c8, c = lane - which * c8;
+            const uint4 v = *reinterpret_cast<const uint4*>(q + (which + 1) * D + c * 8);
+            bf16_t* dst = (which ? vc : kc) + ((size_t)r * ctx_max + pos0 + t) * D + h * hd + c * 8;
+            *reinterpret_cast<uint4*>(dst) = v;
+        }
+    }
+    const bf16_t* knew = qkv + (size_t)r * Tn * 3 * D + D + h * hd;        // K of new position u: knew + u * 3D  (V: + D)
     for (int j = lane; j < nkeys; j += 64) srow[j] = row_map ? row_map[(size_t)j * R + r] : r;
     float m = -INFINITY;
     for (int j = lane; j < nkeys; j += 64) {
         float s = 0.f;
-        const bf16_t* krow = kb + ((size_t)srow[j] * ctx_max + j) * D;
+        const bf16_t* krow = (APPEND && j >= pos0) ? knew + (size_t)(j - pos0) * 3 * D : kb + ((size_t)srow[j] * ctx_max + j) * D;
         for (int d = 0; d < hd; d += 8) {
             float a[8], b[8];
             unpack8(*reinterpret_cast<const uint4*>(q + d), a);
@@ -96,7 +95,8 @@ __global__ __launch_bounds__(256) void k_decode_attn(const bf16_t* __restrict__ 
     if (kg < kgroups) {
         for (int j = kg; j < nkeys; j += kgroups) {
             float v[8];
-            unpack8(*reinterpret_cast<const uint4*>(vb + ((size_t)srow[j] * ctx_max + j) * D + dc * 8), v);
+            const bf16_t* vrow = (APPEND && j >= pos0) ? knew + D + (size_t)(j - pos0) * 3 * D : vb + ((size_t)srow[j] * ctx_max + j) * D;
+            unpack8(*reinterpret_cast<const uint4*>(vrow + dc * 8), v);
             const float pj = p[j];
 #pragma unroll
             for (int e = 0; e < 8; e++) acc[e] += pj * v[e];
@@ -434,14 +434,12 @@ int cc_decode_fwd(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int
         CC_TRY(gemm_nt_skinny(w.xn, D, w16t + aw, D, M, 3 * D, D, w32 + ab, 0, nullptr, nullptr, w.qkv, 3 * D, w.scratch, w.scratch_bytes, st,
                               f_qkv ? &fq : nullptr));
         {
-            if (!f_qkv) {
-                const size_t total = (size_t)M * (D >> 3);
-                hipLaunchKernelGGL(k_kv_append, dim3((int)std::min<size_t>((total + 255) / 256, 2048)), dim3(256), 0, st, w.qkv, kc, vc, R, Tn, D, pos0,
-                                   ctx_max);
-            }
             const int nw = R * H * Tn;
-            hipLaunchKernelGGL(k_decode_attn, dim3((nw + 3) / 4), dim3(256), (size_t)4 * (2 * ctx_max + 8 * hd) * sizeof(float), st, w.qkv, kc, vc, row_map, w.att, R,
-                               Tn, H, hd, pos0, ctx_max, scale);
+            const size_t shm = (size_t)4 * (2 * ctx_max + 8 * hd) * sizeof(float);
+            if (f_qkv)
+                hipLaunchKernelGGL(k_decode_attn<false>, dim3((nw + 3) / 4), dim3(256), shm, st, w.qkv, kc, vc, row_map, w.att, R, Tn, H, hd, pos0, ctx_max, scale);
+            else
+                hipLaunchKernelGGL(k_decode_attn<true>, dim3((nw + 3) / 4), dim3(256), shm, st, w.qkv, kc, vc, row_map, w.att, R, Tn, H, hd, pos0, ctx_max, scale);
         }
         // attn.c_proj + residual (+ fused ln_2)
         const bool f_d = gemm_nt_skinny_can_fuse(M, D, D, w.scratch_bytes) && gemm_nt_skinny_can_fuse(M, D, 4 * D, w.scratch_bytes);
