@@ -652,6 +652,100 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_stag256_kernel(const bf16_t* _
 #undef H_VMCNT
 
 // ------------------------------------------------------------------------------------------------
+// TT 128 x 128 kernel (both operands K-strided, weight gradients below the 256-row kernel's break-even): the 4-stage small-grid
+// pipeline above with the K-strided staging and transpose reads of the 256-row TT kernel.  LDS stage = A [64 k][128 cols] |
+// B [64 k][128 cols] (256-B rows, 16 KiB each); one DMA instruction = 4 k-rows; the 32-B slot XOR g(k) covers the whole row.
+// Fragment reads are software-pipelined one 32-deep K-step ahead (a wave is alone on its SIMD: nothing else hides the LDS latency).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ HTTFrag g_tt_read(const char* tile, int lane_base, int xoff) {
+    typedef __attribute__((address_space(3))) const char* lp_t;
+    const unsigned a = (unsigned)(size_t)(lp_t)(tile + lane_base + xoff);
+    HTTFrag f;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(a) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(f.hi) : "v"(a) : "memory");      // + 4 k-rows of 256 B
+    return f;
+}
+__device__ __forceinline__ void glds_tile_tt(const bf16_t* __restrict__ base, int ld, int cols, int c0, int k0, char* lds, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int seg = wave + 4 * i;                      // 16 segments of 1 KiB = 4 k-rows x 256 B
+        const int kr = seg * 4 + (lane >> 4);
+        const int c = (lane & 15) ^ (h_tt_g(kr) << 1);
+        const bf16_t* src = base + (size_t)(k0 + kr) * ld + min(c0 + c * 8, cols - 8);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + seg * 1024), 16, 0, 0);
+    }
+}
+template <class Epi>
+__global__ __launch_bounds__(G_THREADS, 1) void gemm_tt_glds4_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                                      GemmShape g, Epi epi) {
+    extern __shared__ __attribute__((aligned(1024))) char smemt[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (g.N + G_BN - 1) / G_BN, tiles_m = (g.M + G_BM - 1) / G_BM;
+    int tm, tn;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, g.group_m, tm, tn);
+    const int m0 = tm * G_BM, n0 = tn * G_BN;
+    const int kbeg = blockIdx.z * g.k_chunk;
+    const int nk = (min(g.K, kbeg + g.k_chunk) - kbeg) / G_BK;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define GT_ISSUE(T)                                                                                                      \
+    {                                                                                                                    \
+        char* st_ = smemt + ((T) & 3) * 2 * G_TILE_BYTES;                                                                \
+        glds_tile_tt(A, g.lda, g.M, m0, kbeg + (T)*G_BK, st_, wave, lane);                                               \
+        glds_tile_tt(B, g.ldb, g.N, n0, kbeg + (T)*G_BK, st_ + G_TILE_BYTES, wave, lane);                                \
+    }
+    GT_ISSUE(0);
+    if (nk > 1) GT_ISSUE(1);
+    if (nk > 2) GT_ISSUE(2);
+    const int frow = lane & 15, fchunk = lane >> 4;
+    const int tt_base = (8 * fchunk + (frow >> 2)) * 256 + ((frow & 3) >> 1) * 16 + (frow & 1) * 8;
+    const int tt_gx = h_tt_g(8 * fchunk + (frow >> 2)) << 1;
+    HTTFrag fa[2][4], fb[2][4];
+#define GT_READ(SET, CUR, KS)                                                                                            \
+    {                                                                                                                    \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) fa[SET][i_] = g_tt_read((CUR) + (KS)*32 * 256, tt_base, ((wm * 8 + 2 * i_) ^ tt_gx) << 4);                 \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; j_++) fb[SET][j_] = g_tt_read((CUR) + G_TILE_BYTES + (KS)*32 * 256, tt_base, ((wn * 8 + 2 * j_) ^ tt_gx) << 4);  \
+    }
+#define GT_MFMA(SET)                                                                                                     \
+    {                                                                                                                    \
+        bf16x8 af[4], bfr[4];                                                                                            \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) af[i_] = h_tt_oper(fa[SET][i_]);                                 \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; j_++) bfr[j_] = h_tt_oper(fb[SET][j_]);                                \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) _Pragma("unroll") for (int j_ = 0; j_ < 4; j_++)                 \
+            acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i_], bfr[j_], acc[i_][j_], 0, 0, 0);                \
+    }
+#define GT_LGKM0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+    for (int kt = 0; kt < nk; kt++) {
+        const int rem = min(nk - 1, kt + 2) - kt;
+        if (rem >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 3 < nk) GT_ISSUE(kt + 3);
+        const char* cur = smemt + (kt & 3) * 2 * G_TILE_BYTES;
+        GT_READ(0, cur, 0);
+        GT_LGKM0();
+        GT_READ(1, cur, 1);                    // K-step 1 fragments in flight under K-step 0's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        GT_MFMA(0);
+        GT_LGKM0();
+        GT_MFMA(1);
+    }
+#undef GT_ISSUE
+#undef GT_READ
+#undef GT_MFMA
+#undef GT_LGKM0
+    __syncthreads();
+    gemm_epilogue(acc, smemt, wave, lane, m0 + wm * 64, n0 + wn * 64, epi);
+}
+
+
+// ------------------------------------------------------------------------------------------------
 // Epilogues.  operator()(row, col, v[8]) is called by EVERY lane (wave-uniform call site): lanes q..q+7 of
 // a wave hold the 64 consecutive columns [col&~63, +64) of one row, so row-wise reductions are 3 shuffles.
 // ------------------------------------------------------------------------------------------------
@@ -1037,6 +1131,28 @@ inline int launch_gemm_tt256(const bf16_t* A, int lda, const bf16_t* B, int ldb,
     if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_stag256_kernel<Epi, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr = true; }
     const dim3 gr((unsigned)(((M + H_BM - 1) / H_BM) * ((N + H_BN - 1) / H_BN)), 1, (unsigned)ksplit);
     hipLaunchKernelGGL((gemm_nt_stag256_kernel<Epi, 4, true>), gr, dim3(512), sh, st, A, B, g, epi);
+    return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+}
+
+// TT 128 x 128 launcher (see gemm_tt_glds4_kernel): K % 64 == 0, M % 8 == 0, N % 8 == 0; slices over blockIdx.z.
+template <class Epi>
+inline int launch_gemm_tt128(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, int ksplit, const Epi& epi, int* ks_eff,
+                             hipStream_t st) {
+    if ((K % G_BK) || (M & 7) || (N & 7) || (lda & 7) || (ldb & 7) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return CC_ERR_SHAPE;
+    GemmShape g;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
+    g.group_m = 8;
+    if (ksplit < 1) ksplit = 1;
+    const int kt = K / G_BK;
+    const int per = (kt + ksplit - 1) / ksplit;
+    ksplit = (kt + per - 1) / per;
+    g.k_chunk = per * G_BK;
+    if (ks_eff) *ks_eff = ksplit;
+    constexpr size_t sh = (size_t)8 * G_TILE_BYTES;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tt_glds4_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr = true; }
+    const dim3 gr((unsigned)(((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN)), 1, (unsigned)ksplit);
+    hipLaunchKernelGGL((gemm_tt_glds4_kernel<Epi>), gr, dim3(G_THREADS), sh, st, A, B, g, epi);
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
 

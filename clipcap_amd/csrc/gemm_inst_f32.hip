@@ -54,6 +54,22 @@ int gemm_wgrad(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int Mw, int N
         return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
     }
     const int tiles = ((Mw + G_BM - 1) / G_BM) * ((Nw + G_BN - 1) / G_BN);
+    // small weight gradients (mapper, K = 5120): 128 x 128 TT kernel, 4-stage DMA pipeline + transpose reads, one block per CU
+    if (g_gemm_tile_mode != 0 && (K % G_BK) == 0 && K >= 1024 && (Mw & 7) == 0 && tiles <= 256 && scratch) {
+        int ks = std::max(1, 256 / tiles);
+        ks = std::min(ks, std::max(1, K / (4 * G_BK)));
+        if ((size_t)ks > fit) ks = (int)std::max<size_t>(fit, 1);
+        if (fit >= 1) {
+            EpiF32 e{scratch, nullptr, Nw, Mw, Nw, 3, 1.0f};
+            e.zstride = slab;
+            int ks_eff = 1;
+            const int rc = launch_gemm_tt128(X, ldx, Y, ldy, Mw, Nw, K, ks, e, &ks_eff, st);
+            if (rc != CC_OK) return rc;
+            const size_t n4 = slab / 4;
+            hipLaunchKernelGGL(k_slab_reduce, dim3((int)std::min<size_t>((n4 + 255) / 256, 2048)), dim3(256), 0, st, scratch, slab, ks_eff, Nw, dW, ldw, n4);
+            return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+        }
+    }
     int ks = 512 / (tiles > 0 ? tiles : 1);
     const int kmax = (K + 255) / 256;  // at least 4 K-steps per slice
     if (ks > kmax) ks = kmax;

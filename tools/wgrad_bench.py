@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Weight-gradient GEMM (dW += X^T Y, both operands K-strided) through cc_gemm_wgrad: the 256x256 DMA + transpose-read kernel
-(tile mode 4 = forced) against the register-staged 128x128 kernel (tile mode 0) and the chooser (-1), interleaved, best of 3."""
+(tile mode 4 = forced) against the register-staged 128x128 kernel (tile mode 0) and the chooser (-1: 256x256 from ~30 GFLOP, else the
+128x128 DMA + transpose-read kernel), interleaved, best of 3."""
 import ctypes as C
 import sys
 import os
