@@ -423,28 +423,30 @@ int cc_mapper_bwd_range(const cc_mapper_cfg* c, int32_t B, const float* w32, con
         CC_TRY(copy_rows(dout, (size_t)c->L * D, w.dx32 + (size_t)PP * D, (size_t)S * D, c->L * D, B, st));
         CC_TRY(f32_to_bf16(w.dx32, w.dx16, (size_t)M * D, st));
     }
+    WgradBatch wb;          // one slab-reduce launch per layer for its four weight gradients
     for (int l = l_hi - 1; l >= l_lo; l--) {
         const auto& y = o.layer[l];
         // fc2: y = h W2^T + b2
-        CC_TIMED(CC_SITE_MAPPER_WGRAD_FC2, st, gemm_wgrad(w.dx16, D, w.h[l], Hm, D, Hm, M, g32 + y.w2, Hm, w.wg_scratch, st));
+        CC_TIMED(CC_SITE_MAPPER_WGRAD_FC2, st, gemm_wgrad(w.dx16, D, w.h[l], Hm, D, Hm, M, g32 + y.w2, Hm, w.wg_scratch, st, &wb));
         CC_TRY(colsum_bf16(w.dx16, D, M, D, g32 + y.b2, st));
         CC_TRY(gemm_dact(0, 0, w.dx16, D, w16t + y.w2, D, M, Hm, D, w.dh16, Hm, w.h[l], 1, st));          // W2^T [Hm, D]
         // fc1
-        CC_TRY(gemm_wgrad(w.dh16, Hm, w.xn2[l], D, Hm, D, M, g32 + y.w1, D, w.wg_scratch, st));
+        CC_TRY(gemm_wgrad(w.dh16, Hm, w.xn2[l], D, Hm, D, M, g32 + y.w1, D, w.wg_scratch, st, &wb));
         CC_TRY(colsum_bf16(w.dh16, Hm, M, Hm, g32 + y.b1, st));
         CC_TRY(gemm_bf16out(0, 0, w.dh16, Hm, w16t + y.w1, Hm, M, D, Hm, w.dxn16, D, nullptr, 0, nullptr, st));   // W1^T [D, Hm]
         CC_TRY(ln_bwd(w.dxn16, w.x1[l], D, nullptr, w.mean2[l], w.rstd2[l], w32 + y.n2w, w.dx32, w.dx32, w.dx16, g32 + y.n2w,
                       g32 + y.n2b, M, D, st));
         // project
-        CC_TRY(gemm_wgrad(w.dx16, D, w.att[l], D, D, D, M, g32 + y.wp, D, w.wg_scratch, st));
+        CC_TRY(gemm_wgrad(w.dx16, D, w.att[l], D, D, D, M, g32 + y.wp, D, w.wg_scratch, st, &wb));
         CC_TRY(colsum_bf16(w.dx16, D, M, D, g32 + y.bp, st));
         CC_TRY(gemm_bf16out(0, 0, w.dx16, D, w16t + y.wp, D, M, D, D, w.datt16, D, nullptr, 0, nullptr, st));     // Wp^T
         CC_TRY(attn_bwd(w.qkv[l], w.datt16, w.att[l], w.lse[l], w.adelta, B, S, H, hd, false, w.dqkv16, st));
         // fused q/kv projection (to_queries.weight ++ to_keys_values.weight = [3D, D])
-        CC_TRY(gemm_wgrad(w.dqkv16, 3 * D, w.xn1[l], D, 3 * D, D, M, g32 + y.wq, D, w.wg_scratch, st));
+        CC_TRY(gemm_wgrad(w.dqkv16, 3 * D, w.xn1[l], D, 3 * D, D, M, g32 + y.wq, D, w.wg_scratch, st, &wb));
         CC_TRY(gemm_bf16out(0, 0, w.dqkv16, 3 * D, w16t + y.wq, 3 * D, M, D, 3 * D, w.dxn16, D, nullptr, 0, nullptr, st));  // Wqkv^T [D, 3D]
         CC_TRY(ln_bwd(w.dxn16, w.x[l], D, nullptr, w.mean1[l], w.rstd1[l], w32 + y.n1w, w.dx32, w.dx32, w.dx16, g32 + y.n1w,
                       g32 + y.n1b, M, D, st));
+        CC_TRY(wgrad_flush(wb, st));
     }
     if (l_lo > 0) return CC_OK;
     // prefix_const, pos_embeddings, linear

@@ -21,9 +21,19 @@ int gemm_lmhead(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int V
 // weight gradient dW[Mw][Nw] += X^T Y with X stored [K][Mw], Y stored [K][Nw].  Split-K for occupancy: the K slices
 // write fp32 slabs into `scratch` (plain stores) and a second kernel folds them into dW — fp32 atomics on the same
 // tile from 7-14 concurrent blocks measured 3x slower than the whole GEMM (profiles/r01_b_gemm_microbench.md).
-constexpr size_t WGRAD_SCRATCH_BYTES = size_t(48) << 20;
+constexpr size_t WGRAD_SCRATCH_BYTES = size_t(96) << 20;
+// Several weight gradients of one layer can share one slab-reduce launch: pass a WgradBatch, each gemm_wgrad then parks its slabs
+// in its own part of `scratch` and wgrad_flush() folds all of them into their dW targets (8 launches per mapper backward instead
+// of 32).  A gradient whose slabs do not fit behind the parked ones flushes the batch first.
+struct WgradBatch {
+    struct Item { const float* slabs; size_t slab; int ks, Nw; float* dW; int ldw; size_t n4; };
+    Item it[8];
+    int n = 0;
+    size_t used = 0;      // bytes of scratch already holding parked slabs
+};
+int wgrad_flush(WgradBatch& b, hipStream_t st);
 int gemm_wgrad(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int Mw, int Nw, int K, float* dW, int ldw, float* scratch,
-               hipStream_t st);
+               hipStream_t st, WgradBatch* batch = nullptr);
 // Skinny-M NT GEMMs (KV-cached decode: M = beams x samples, a handful of 128x128 tiles): split K over blockIdx.z so every CU
 // streams a distinct slice of the weights, fp32 slabs in `scratch`, then ONE finishing kernel sums the slabs and applies the
 // epilogue (bias, gelu_new, fp32 residual, bf16 / fp32 stores).  Falls back to the single-pass GEMM when the grid is already wide.

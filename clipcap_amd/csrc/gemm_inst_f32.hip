@@ -27,14 +27,60 @@ __global__ __launch_bounds__(256) void k_slab_reduce(const float* __restrict__ s
     }
 }
 
+struct SlabItems { WgradBatch::Item it[8]; };
+__global__ __launch_bounds__(256) void k_slab_reduce_multi(SlabItems items) {
+    const WgradBatch::Item& q = items.it[blockIdx.y];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < q.n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 a = reinterpret_cast<const float4*>(q.slabs)[i];
+        for (int s = 1; s < q.ks; s++) {
+            const float4 b = reinterpret_cast<const float4*>(q.slabs + s * q.slab)[i];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        const size_t e = i * 4;
+        float* d = q.dW + (e / q.Nw) * q.ldw + (e % q.Nw);
+        const float4 c = *reinterpret_cast<const float4*>(d);
+        *reinterpret_cast<float4*>(d) = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+    }
+}
+int wgrad_flush(WgradBatch& b, hipStream_t st) {
+    if (b.n == 0) return CC_OK;
+    SlabItems items;
+    size_t nmax = 0;
+    for (int i = 0; i < b.n; i++) { items.it[i] = b.it[i]; nmax = std::max(nmax, b.it[i].n4); }
+    hipLaunchKernelGGL(k_slab_reduce_multi, dim3((int)std::min<size_t>((nmax + 255) / 256, 1024), b.n), dim3(256), 0, st, items);
+    b.n = 0;
+    b.used = 0;
+    return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+}
+// folds `ks` slabs at `slabs` into dW: immediately, or parked in the batch
+static int wgrad_reduce(const float* slabs, size_t slab, int ks, int Nw, float* dW, int ldw, WgradBatch* batch, hipStream_t st) {
+    const size_t n4 = slab / 4;
+    if (batch) {
+        batch->it[batch->n++] = WgradBatch::Item{slabs, slab, ks, Nw, dW, ldw, n4};
+        batch->used += (size_t)ks * slab * sizeof(float);
+        batch->used = (batch->used + 255) & ~size_t(255);
+        if (batch->n == 8) return wgrad_flush(*batch, st);
+        return CC_OK;
+    }
+    hipLaunchKernelGGL(k_slab_reduce, dim3((int)std::min<size_t>((n4 + 255) / 256, 2048)), dim3(256), 0, st, slabs, slab, ks, Nw, dW, ldw, n4);
+    return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+}
+
 int gemm_wgrad(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int Mw, int Nw, int K, float* dW, int ldw, float* scratch,
-               hipStream_t st) {
+               hipStream_t st, WgradBatch* batch) {
     if ((Nw & 7) || (ldw & 3)) return CC_ERR_SHAPE;
     const size_t slab = (size_t)Mw * Nw;
-    const size_t fit = scratch ? WGRAD_SCRATCH_BYTES / (slab * sizeof(float)) : 1;
+    // scratch left behind the batch's parked slabs; a gradient that cannot get at least 2 slices there flushes the batch first
+    if (batch && scratch && batch->n > 0 && WGRAD_SCRATCH_BYTES - batch->used < 2 * slab * sizeof(float)) {
+        const int rcf = wgrad_flush(*batch, st);
+        if (rcf != CC_OK) return rcf;
+    }
+    const size_t used = (batch && scratch) ? batch->used : 0;
+    float* sc = scratch ? scratch + used / sizeof(float) : nullptr;
+    const size_t fit = scratch ? (WGRAD_SCRATCH_BYTES - used) / (slab * sizeof(float)) : 1;
     // 256 x 256 kernel with DMA staging + transpose reads (one block per CU; slices sized to fill the CUs once).  It wins from
-    // about 30 GFLOP per launch (GPT-2 weight gradients: +10...17 %); below that the 128 x 128 register-staged kernel's finer
-    // tiles and fewer, smaller slabs win (mapper weight gradients, K = 5120) — tools/wgrad_bench.py.
+    // about 30 GFLOP per launch (GPT-2 weight gradients: +10...17 %); below that the 128 x 128 TT kernel's finer tiles and fewer,
+    // smaller slabs win (mapper weight gradients, K = 5120) — tools/wgrad_bench.py.
     if (g_gemm_tile_mode != 0 && (K % H_BK) == 0 && (Mw & 7) == 0 && (g_gemm_tile_mode == 4 || 2.0 * Mw * Nw * (double)K >= 3e10)) {
         const int tiles = ((Mw + H_BM - 1) / H_BM) * ((Nw + H_BN - 1) / H_BN);
         int ks = std::max(1, 256 / tiles);
@@ -44,31 +90,25 @@ int gemm_wgrad(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int Mw, int N
             EpiF32 e{dW, nullptr, ldw, Mw, Nw, 1, 1.0f};
             return launch_gemm_tt256(X, ldx, Y, ldy, Mw, Nw, K, 1, e, nullptr, st);
         }
-        EpiF32 e{scratch, nullptr, Nw, Mw, Nw, 3, 1.0f};
+        EpiF32 e{sc, nullptr, Nw, Mw, Nw, 3, 1.0f};
         e.zstride = slab;
         int ks_eff = 1;
         const int rc = launch_gemm_tt256(X, ldx, Y, ldy, Mw, Nw, K, ks, e, &ks_eff, st);
         if (rc != CC_OK) return rc;
-        const size_t n4 = slab / 4;
-        hipLaunchKernelGGL(k_slab_reduce, dim3((int)std::min<size_t>((n4 + 255) / 256, 2048)), dim3(256), 0, st, scratch, slab, ks_eff, Nw, dW, ldw, n4);
-        return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+        return wgrad_reduce(sc, slab, ks_eff, Nw, dW, ldw, batch, st);
     }
     const int tiles = ((Mw + G_BM - 1) / G_BM) * ((Nw + G_BN - 1) / G_BN);
     // small weight gradients (mapper, K = 5120): 128 x 128 TT kernel, 4-stage DMA pipeline + transpose reads, one block per CU
-    if (g_gemm_tile_mode != 0 && (K % G_BK) == 0 && K >= 1024 && (Mw & 7) == 0 && tiles <= 256 && scratch) {
+    if (g_gemm_tile_mode != 0 && (K % G_BK) == 0 && K >= 1024 && (Mw & 7) == 0 && tiles <= 256 && scratch && fit >= 1) {
         int ks = std::max(1, 256 / tiles);
         ks = std::min(ks, std::max(1, K / (4 * G_BK)));
-        if ((size_t)ks > fit) ks = (int)std::max<size_t>(fit, 1);
-        if (fit >= 1) {
-            EpiF32 e{scratch, nullptr, Nw, Mw, Nw, 3, 1.0f};
-            e.zstride = slab;
-            int ks_eff = 1;
-            const int rc = launch_gemm_tt128(X, ldx, Y, ldy, Mw, Nw, K, ks, e, &ks_eff, st);
-            if (rc != CC_OK) return rc;
-            const size_t n4 = slab / 4;
-            hipLaunchKernelGGL(k_slab_reduce, dim3((int)std::min<size_t>((n4 + 255) / 256, 2048)), dim3(256), 0, st, scratch, slab, ks_eff, Nw, dW, ldw, n4);
-            return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
-        }
+        if ((size_t)ks > fit) ks = (int)fit;
+        EpiF32 e{sc, nullptr, Nw, Mw, Nw, 3, 1.0f};
+        e.zstride = slab;
+        int ks_eff = 1;
+        const int rc = launch_gemm_tt128(X, ldx, Y, ldy, Mw, Nw, K, ks, e, &ks_eff, st);
+        if (rc != CC_OK) return rc;
+        return wgrad_reduce(sc, slab, ks_eff, Nw, dW, ldw, batch, st);
     }
     int ks = 512 / (tiles > 0 ? tiles : 1);
     const int kmax = (K + 255) / 256;  // at least 4 K-steps per slice
@@ -76,16 +116,14 @@ int gemm_wgrad(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int Mw, int N
     if (scratch) { if ((size_t)ks > fit) ks = (int)fit; } else ks = 1;
     if (ks <= 1) return gemm_f32out(1, 1, X, ldx, Y, ldy, Mw, Nw, K, dW, ldw, nullptr, 1, 1.0f, 1, st);
     // slices z write slab z (EpiF32 store mode; C pointer advanced per z inside the kernel via blockIdx.z * slab)
-    EpiF32 e{scratch, nullptr, Nw, Mw, Nw, 3, 1.0f};
+    EpiF32 e{sc, nullptr, Nw, Mw, Nw, 3, 1.0f};
     e.zstride = slab;
     int rc = launch_gemm(1, 1, X, ldx, Y, ldy, Mw, Nw, K, ks, e, st);
     if (rc != CC_OK) return rc;
     // the launcher may have reduced the slice count (ceil division): recompute it the same way
     const int kt = (K + G_BK - 1) / G_BK, per = (kt + ks - 1) / ks;
     const int ks_eff = (kt + per - 1) / per;
-    const size_t n4 = slab / 4;
-    hipLaunchKernelGGL(k_slab_reduce, dim3((int)std::min<size_t>((n4 + 255) / 256, 2048)), dim3(256), 0, st, scratch, slab, ks_eff, Nw, dW, ldw, n4);
-    return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+    return wgrad_reduce(sc, slab, ks_eff, Nw, dW, ldw, batch, st);
 }
 
 __global__ __launch_bounds__(256) void k_splitk_finish(const float* __restrict__ slabs, size_t slab_elems, int ks, int M, int N,
