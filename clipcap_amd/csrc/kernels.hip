@@ -594,8 +594,8 @@ static int attn_fwd_mfma_launch(const bf16_t* qkv, int B, int S, int H, bool cau
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// MFMA attention backward (head dim 64 / 96 / 128), three kernels, no atomics, no transposes through HBM:
-//   k_attn_delta : delta[b,h,q] = sum_d dO[q,d] O[q,d]
+// MFMA attention backward (head dim 64 / 96 / 128), two kernels, no atomics, no transposes through HBM
+// (delta[b,h,q] = sum_d dO[q,d] O[q,d] is computed and stored by the dQ kernel, which runs first):
 //   k_attn_bwd_dkv (one wave per (b,h,key block j), loops over query blocks): "S orientation" — lane <-> key (col),
 //       registers <-> 16 queries — so bf16(P) and bf16(dS) are directly the B fragments of
 //       dV^T[d][key] += dO^T[d][q] P[q][key]   and   dK^T[d][key] += Q^T[d][q] dS[q][key];
@@ -604,24 +604,6 @@ static int attn_fwd_mfma_launch(const bf16_t* qkv, int B, int S, int H, bool cau
 //       lane <-> query — so bf16(dS^T) is the B fragment of dQ^T[d][q] += K^T[d][key] dS^T[key][q] (K block via LDS).
 // P is recomputed from the saved log-sum-exp; dS = P (dP - delta) * scale.
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_attn_delta(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ o, float* __restrict__ delta,
-                                                    int B, int S, int H, int hd) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= B * S * H) return;
-    const int h = idx % H, row = idx / H;
-    const int b = row / S, q = row % S;
-    const size_t off = (size_t)row * H * hd + (size_t)h * hd;
-    float acc = 0.f;
-    for (int d = 0; d < hd; d += 8) {
-        float x[8], y[8];
-        unpack8(*reinterpret_cast<const uint4*>(dout + off + d), x);
-        unpack8(*reinterpret_cast<const uint4*>(o + off + d), y);
-#pragma unroll
-        for (int e = 0; e < 8; e++) acc += x[e] * y[e];
-    }
-    delta[((size_t)b * H + h) * S + q] = acc;
-}
-
 __device__ __forceinline__ bf16x8 pack_frag(const float* p) {
     return __builtin_bit_cast(bf16x8, make_uint4(pack2bf(p[0], p[1]), pack2bf(p[2], p[3]), pack2bf(p[4], p[5]), pack2bf(p[6], p[7])));
 }
@@ -747,8 +729,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const bf16_t* __restrict__
 }
 
 template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256) void k_attn_bwd_dq(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
-                                                     const float* __restrict__ lse, const float* __restrict__ delta, int B, int S, int H,
+__global__ __launch_bounds__(256) void k_attn_bwd_dq(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const bf16_t* __restrict__ o,
+                                                     const float* __restrict__ lse, float* __restrict__ delta, int B, int S, int H,
                                                      float scale, bf16_t* __restrict__ dqkv) {
     constexpr int KK = HD / 16, NB = HD / 32;
     __shared__ __attribute__((aligned(16))) bf16_t ksm[4][32 * AttLd<HD>::v];
@@ -763,13 +745,24 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const bf16_t* __restrict__ 
     const bf16_t* dbase = dout + (size_t)b * S * D + h * HD;
     const int half = lane >> 5, q = i * 32 + (lane & 31);
     const float my_lse = q < S ? lse[((size_t)b * H + h) * S + q] : 0.f;
-    const float my_delta = q < S ? delta[((size_t)b * H + h) * S + q] : 0.f;
     bf16x8 qf[KK], dof[KK];
+    // delta[q] = sum_d dO[q,d] O[q,d]: in this orientation a lane owns half of its query's row, so the dot product is 4 fragment
+    // products + one cross-half shuffle.  Computed here and stored for the dK/dV kernel, which runs after this one (the separate
+    // k_attn_delta launch is gone).
+    float my_delta = 0.f;
 #pragma unroll
     for (int kk = 0; kk < KK; kk++) {
         qf[kk] = load_frag(base + (size_t)min(q, S - 1) * rs + kk * 16 + half * 8, q < S);
         dof[kk] = load_frag(dbase + (size_t)min(q, S - 1) * D + kk * 16 + half * 8, q < S);
+        const bf16x8 of = load_frag(o + ((size_t)b * S + min(q, S - 1)) * D + h * HD + kk * 16 + half * 8, q < S);
+        float x[8], y[8];
+        unpack8(__builtin_bit_cast(uint4, dof[kk]), x);
+        unpack8(__builtin_bit_cast(uint4, of), y);
+#pragma unroll
+        for (int e = 0; e < 8; e++) my_delta += x[e] * y[e];
     }
+    my_delta += __shfl_xor(my_delta, 32, 64);
+    if (half == 0 && q < S) delta[((size_t)b * H + h) * S + q] = my_delta;
     f32x16 dq[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; nb++)
@@ -840,13 +833,13 @@ static int attn_bwd_mfma_launch(const bf16_t* qkv, const bf16_t* dout, const bf1
                                 bool causal, bf16_t* dqkv, hipStream_t st) {
     const int items = B * H * ((S + 31) / 32);
     const float scale = 1.0f / sqrtf((float)HD);
-    hipLaunchKernelGGL(k_attn_delta, dim3((B * S * H + 255) / 256), dim3(256), 0, st, dout, o, delta, B, S, H, HD);
+    // dQ first: it also produces delta, which the dK/dV kernel reads
     if (causal) {
+        hipLaunchKernelGGL((k_attn_bwd_dq<HD, true>), dim3((items + 3) / 4), dim3(256), 0, st, qkv, dout, o, lse, delta, B, S, H, scale, dqkv);
         hipLaunchKernelGGL((k_attn_bwd_dkv<HD, true>), dim3((items + 3) / 4), dim3(256), 0, st, qkv, dout, lse, delta, B, S, H, scale, dqkv);
-        hipLaunchKernelGGL((k_attn_bwd_dq<HD, true>), dim3((items + 3) / 4), dim3(256), 0, st, qkv, dout, lse, delta, B, S, H, scale, dqkv);
     } else {
+        hipLaunchKernelGGL((k_attn_bwd_dq<HD, false>), dim3((items + 3) / 4), dim3(256), 0, st, qkv, dout, o, lse, delta, B, S, H, scale, dqkv);
         hipLaunchKernelGGL((k_attn_bwd_dkv<HD, false>), dim3((items + 3) / 4), dim3(256), 0, st, qkv, dout, lse, delta, B, S, H, scale, dqkv);
-        hipLaunchKernelGGL((k_attn_bwd_dq<HD, false>), dim3((items + 3) / 4), dim3(256), 0, st, qkv, dout, lse, delta, B, S, H, scale, dqkv);
     }
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
