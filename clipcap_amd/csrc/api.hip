@@ -353,13 +353,16 @@ int cc_mapper_sync_weights(const cc_mapper_cfg* c, const float* w32, uint16_t* w
     CC_TRY(f32_to_bf16(w32, w16, (size_t)o.total, st));
     bf16_t* t = w16 + o.total;
     const int D = c->D, Hm = c->Hm;
+    TransposeBatch tb;                      // 8 layers x 4 matrices: one launch per 32 matrices instead of one each
     for (int l = 0; l < c->N; l++) {
         const auto& y = o.layer[l];
-        CC_TRY(transpose_bf16(w16 + y.wq, t + y.wq, 3 * D, D, st));   // fused [3D, D] -> [D, 3D]
-        CC_TRY(transpose_bf16(w16 + y.wp, t + y.wp, D, D, st));
-        CC_TRY(transpose_bf16(w16 + y.w1, t + y.w1, Hm, D, st));       // [Hm, D] -> [D, Hm]
-        CC_TRY(transpose_bf16(w16 + y.w2, t + y.w2, D, Hm, st));       // [D, Hm] -> [Hm, D]
+        tb.add(w16 + y.wq, t + y.wq, 3 * D, D);   // fused [3D, D] -> [D, 3D]
+        tb.add(w16 + y.wp, t + y.wp, D, D);
+        tb.add(w16 + y.w1, t + y.w1, Hm, D);       // [Hm, D] -> [D, Hm]
+        tb.add(w16 + y.w2, t + y.w2, D, Hm);       // [D, Hm] -> [Hm, D]
+        if (tb.n == 32) { CC_TRY(transpose_bf16_multi(tb, st)); tb.n = 0; }
     }
+    CC_TRY(transpose_bf16_multi(tb, st));
     return CC_OK;
 }
 
@@ -503,13 +506,16 @@ int cc_gpt2_sync_weights(const cc_gpt2_cfg* c, const float* w32, uint16_t* w16, 
     bf16_t* t = w16 + o.total;
     const int D = c->D;
     CC_TRY(transpose_bf16(w16 + o.wte, t + o.wte, c->Vp, D, st));     // [Vp, D] -> [D, Vp]  (lm_head dgrad)
+    TransposeBatch tb;
     for (int l = 0; l < c->NL; l++) {
         const auto& y = o.layer[l];
-        CC_TRY(transpose_bf16(w16 + y.aw, t + y.aw, D, 3 * D, st));    // Conv1D [in,out] -> [out,in]: forward is NT on these
-        CC_TRY(transpose_bf16(w16 + y.pw, t + y.pw, D, D, st));
-        CC_TRY(transpose_bf16(w16 + y.fw, t + y.fw, D, 4 * D, st));
-        CC_TRY(transpose_bf16(w16 + y.p2w, t + y.p2w, 4 * D, D, st));
+        tb.add(w16 + y.aw, t + y.aw, D, 3 * D);    // Conv1D [in,out] -> [out,in]: forward is NT on these
+        tb.add(w16 + y.pw, t + y.pw, D, D);
+        tb.add(w16 + y.fw, t + y.fw, D, 4 * D);
+        tb.add(w16 + y.p2w, t + y.p2w, 4 * D, D);
+        if (tb.n == 32) { CC_TRY(transpose_bf16_multi(tb, st)); tb.n = 0; }
     }
+    CC_TRY(transpose_bf16_multi(tb, st));
     return CC_OK;
 }
 

@@ -15,6 +15,13 @@ int batch_sum(const float* src, size_t src_stride, float* dst, int len, int B, h
 int copy_rows(const float* src, size_t src_stride, float* dst, size_t dst_stride, int len, int B, hipStream_t st);
 
 int transpose_bf16(const bf16_t* src, bf16_t* dst, int R, int C, hipStream_t st);
+struct TransposeBatch {
+    struct Item { const bf16_t* src; bf16_t* dst; int R, C; };
+    Item it[32];
+    int n = 0;
+    void add(const bf16_t* s, bf16_t* d, int R, int C) { it[n++] = Item{s, d, R, C}; }
+};
+int transpose_bf16_multi(const TransposeBatch& b, hipStream_t st);   // up to 32 matrices in one launch
 
 int ln_fwd(const float* x, int ldx, const int* row_map, const float* gamma, const float* beta, bf16_t* y, float* y32, float* mean,
            float* rstd, int rows, int D, hipStream_t st);

@@ -134,6 +134,46 @@ __global__ __launch_bounds__(256) void k_transpose_bf16(const bf16_t* __restrict
         }
     }
 }
+// several matrices in one launch (the per-step weight sync transposes 4 small matrices per layer): blockIdx.z picks the matrix,
+// blocks outside its extents exit
+__global__ __launch_bounds__(256) void k_transpose_bf16_multi(TransposeBatch b) {
+    const TransposeBatch::Item& m = b.it[blockIdx.z];
+    if ((int)blockIdx.x * 64 >= m.C || (int)blockIdx.y * 64 >= m.R) return;
+    __shared__ bf16_t tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, R = m.R, C = m.C;
+    const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const int r = r0 + rl + 32 * p, c = c0 + cg * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r < R && c < C) v = *reinterpret_cast<const uint4*>(m.src + (size_t)r * C + c);
+        const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+#pragma unroll
+        for (int k = 0; k < 8; k++) tile[rl + 32 * p][cg * 8 + k] = e[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const int c = c0 + rl + 32 * p, r = r0 + cg * 8;
+        if (c < C && r < R) {
+            bf16_t e[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) e[k] = tile[cg * 8 + k][rl + 32 * p];
+            *reinterpret_cast<uint4*>(m.dst + (size_t)c * R + r) = *reinterpret_cast<const uint4*>(e);
+        }
+    }
+}
+int transpose_bf16_multi(const TransposeBatch& b, hipStream_t st) {
+    if (b.n <= 0) return CC_OK;
+    int mr = 0, mc = 0;
+    for (int i = 0; i < b.n; i++) {
+        if ((b.it[i].R & 7) || (b.it[i].C & 7)) return CC_ERR_SHAPE;
+        mr = std::max(mr, b.it[i].R);
+        mc = std::max(mc, b.it[i].C);
+    }
+    hipLaunchKernelGGL(k_transpose_bf16_multi, dim3((mc + 63) / 64, (mr + 63) / 64, b.n), dim3(256), 0, st, b);
+    return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+}
 int transpose_bf16(const bf16_t* src, bf16_t* dst, int R, int C, hipStream_t st) {
     if ((R & 7) || (C & 7)) return CC_ERR_SHAPE;
     if (R <= 0 || C <= 0) return CC_OK;
