@@ -165,6 +165,36 @@ def decode_bench(args, device):
                          "frac": round(wbytes * steps_per_decode * args.steps / dt / 8e12, 4), "traffic": None}}
 
 
+def sample_bench(args, device):
+    """nucleus-sampling decode (top_p 0.8), GPT-2-medium, KV cache + cc_sample_step, 320 prefixes per step (the row
+    count of the beam bench: 64 x 5).  A "step" = prefill of the 10-row prefix + 67 sampled tokens per row (no early stop with
+    random-init weights; rows that sample EOS keep running to the common length)."""
+    from types import SimpleNamespace
+    from clipcap_amd.inference.base import sample_tokens
+    from clipcap_amd.model.gpt2 import GPT2LM
+    torch.manual_seed(1234)
+    lm = GPT2LM(n_embd=1024, n_layer=24, n_head=16, vocab_size=50257, n_positions=1024).to(device)
+    model = SimpleNamespace(language_model=lm)
+    R, L, entry = args.batch or 320, 10, 67
+    prefix = torch.randn(R, L, 1024, device=device) * 0.5
+    gen = torch.Generator(device=device).manual_seed(7)
+    for _ in range(max(1, args.warmup)):
+        sample_tokens(model, prefix, entry, 50256, mode=0, top_p=0.8, generator=gen)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 0
+    for _ in range(args.steps):
+        toks, stop_pos = sample_tokens(model, prefix, entry, 50256, mode=0, top_p=0.8, generator=gen)
+        n += int(toks.shape[0] * toks.shape[1])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"metric": "sampling decode tok/s (nucleus top_p=0.8, GPT-2-medium, KV cache)", "value": round(n / dt, 1), "unit": "tokens/s",
+            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "nucleus sampling decode, GPT-2-medium random init, 320 prefixes x 10 rows, 67 new tokens", "rows": R,
+                       "entry_length": entry}}
+
+
 def mapper_bench(args, device):
     """north_star sub-target: mapping-transformer forward+backward alone at batch 256 as a fraction of the bf16 MFMA peak
     (algorithmic FLOPs: 3 x 1.5276 GFLOP per sample)."""
@@ -199,7 +229,7 @@ def mapper_bench(args, device):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", default="train", choices=["train", "decode", "mapper"])
+    ap.add_argument("--mode", default="train", choices=["train", "decode", "mapper", "sample"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
@@ -226,9 +256,10 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
-    if args.mode in ("decode", "mapper"):
+    if args.mode in ("decode", "mapper", "sample"):
         if rank == 0:
-            print(json.dumps(decode_bench(args, device) if args.mode == "decode" else mapper_bench(args, device)))
+            fn = {"decode": decode_bench, "mapper": mapper_bench, "sample": sample_bench}[args.mode]
+            print(json.dumps(fn(args, device)))
         return
     c = dict(CONFIGS[args.config])
     if args.batch:

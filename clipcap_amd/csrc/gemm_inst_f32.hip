@@ -70,6 +70,8 @@ int gemm_wgrad(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int Mw, int N
                hipStream_t st, WgradBatch* batch) {
     if ((Nw & 7) || (ldw & 3)) return CC_ERR_SHAPE;
     const size_t slab = (size_t)Mw * Nw;
+    // the DMA-staged TT kernels need 16-B aligned operands and row strides; anything else takes the register-staged kernel
+    const bool tt_ok = (Mw & 7) == 0 && (ldx & 7) == 0 && (ldy & 7) == 0 && ((uintptr_t)X & 15) == 0 && ((uintptr_t)Y & 15) == 0;
     // scratch left behind the batch's parked slabs; a gradient that cannot get at least 2 slices there flushes the batch first
     if (batch && scratch && batch->n > 0 && WGRAD_SCRATCH_BYTES - batch->used < 2 * slab * sizeof(float)) {
         const int rcf = wgrad_flush(*batch, st);
@@ -81,7 +83,7 @@ int gemm_wgrad(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int Mw, int N
     // 256 x 256 kernel with DMA staging + transpose reads (one block per CU; slices sized to fill the CUs once).  It wins from
     // about 30 GFLOP per launch (GPT-2 weight gradients: +10...17 %); below that the 128 x 128 TT kernel's finer tiles and fewer,
     // smaller slabs win (mapper weight gradients, K = 5120) — tools/wgrad_bench.py.
-    if (g_gemm_tile_mode != 0 && (K % H_BK) == 0 && (Mw & 7) == 0 && (g_gemm_tile_mode == 4 || 2.0 * Mw * Nw * (double)K >= 3e10)) {
+    if (g_gemm_tile_mode != 0 && tt_ok && (K % H_BK) == 0 && (g_gemm_tile_mode == 4 || 2.0 * Mw * Nw * (double)K >= 3e10)) {
         const int tiles = ((Mw + H_BM - 1) / H_BM) * ((Nw + H_BN - 1) / H_BN);
         int ks = std::max(1, 256 / tiles);
         ks = std::min(ks, std::max(1, K / 512));          // at least 16 K-tiles per slice
@@ -99,7 +101,7 @@ int gemm_wgrad(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int Mw, int N
     }
     const int tiles = ((Mw + G_BM - 1) / G_BM) * ((Nw + G_BN - 1) / G_BN);
     // small weight gradients (mapper, K = 5120): 128 x 128 TT kernel, 4-stage DMA pipeline + transpose reads, one block per CU
-    if (g_gemm_tile_mode != 0 && (K % G_BK) == 0 && K >= 1024 && (Mw & 7) == 0 && tiles <= 256 && scratch && fit >= 1) {
+    if (g_gemm_tile_mode != 0 && tt_ok && (K % G_BK) == 0 && K >= 1024 && tiles <= 256 && scratch && fit >= 1) {
         int ks = std::max(1, 256 / tiles);
         ks = std::min(ks, std::max(1, K / (4 * G_BK)));
         if ((size_t)ks > fit) ks = (int)fit;
