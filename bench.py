@@ -237,6 +237,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
     ap.add_argument("--site", default="lmhead_fwd", help="GEMM call site timed for the roofline object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropout", action="store_true", help="configs 3/4: run the full finetune without GPT-2 dropout")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -280,12 +281,15 @@ def main():
 
     def one_step(i):
         eng.zero_grad()
+        # full finetune: GPT-2 train-mode dropout (p = 0.1 on embeddings, attention probabilities and both residual branches, the
+        # GPT2Config defaults the reference runs with), a new mask seed per step and rank
+        drop = (0.1, 0.1, 0.1, 1000003 * (i + 1) + rank) if (c["train_lm"] and not args.no_dropout) else None
         if reducer:   # all-reduce of each layer slice starts as soon as its backward kernels are enqueued
             reducer.begin()
-            loss = eng.forward_backward(tokens, embeds, reduce_stats=reducer.reduce_stats, on_grads_ready=reducer.on_grads_ready)
+            loss = eng.forward_backward(tokens, embeds, reduce_stats=reducer.reduce_stats, on_grads_ready=reducer.on_grads_ready, dropout=drop)
             reducer.finish()
         else:
-            loss = eng.forward_backward(tokens, embeds)
+            loss = eng.forward_backward(tokens, embeds, dropout=drop)
         lr = base_lr * linear_schedule_factor(i, warm, total_steps + 1)
         for a in arenas:
             a.adamw_step(lr, i + 1)

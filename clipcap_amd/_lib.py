@@ -68,6 +68,8 @@ SIGNATURES = {
     "cc_embed_tokens": (_I, [_GC, _I, _P, _P, _P, _P]),
     "cc_adamw_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P]),
     "cc_cast_bf16": (_I, [_P, _P, _L, _P]),
+    "cc_gpt2_set_dropout": (_I, [_F, _F, _F, C.c_uint64]),
+    "cc_dropout_mask": (_I, [C.c_uint64, _I, _I, _F, _L, _P, _P]),
     "cc_sample_step": (_I, [_P, _I, _I, _I, _F, _I, _F, _I, _P, _I, _I, _F, _P, _P, _P, _P]),
     "cc_wgrad_scratch_bytes": (_L, []),
     "cc_gemm_wgrad": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _P]),

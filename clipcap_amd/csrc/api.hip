@@ -519,6 +519,19 @@ int cc_gpt2_sync_weights(const cc_gpt2_cfg* c, const float* w32, uint16_t* w16, 
     return CC_OK;
 }
 
+// GPT-2 dropout (full finetune in train mode).  Process-global like the tile mode: set before a training step's forward, read by
+// cc_gpt2_embed / cc_gpt2_fwd / cc_gpt2_bwd(_range) of that step; all zero (the default) = eval behaviour.
+static struct { float p_embd = 0.f, p_attn = 0.f, p_resid = 0.f; unsigned long long seed = 0; } g_gpt2_drop;
+int cc_gpt2_set_dropout(float p_embd, float p_attn, float p_resid, uint64_t seed) {
+    if (p_embd < 0.f || p_embd >= 1.f || p_attn < 0.f || p_attn >= 1.f || p_resid < 0.f || p_resid >= 1.f) return CC_ERR_ARG;
+    g_gpt2_drop.p_embd = p_embd; g_gpt2_drop.p_attn = p_attn; g_gpt2_drop.p_resid = p_resid; g_gpt2_drop.seed = seed;
+    return CC_OK;
+}
+int cc_dropout_mask(uint64_t seed, int32_t site, int32_t layer, float p, int64_t n, uint8_t* out, void* stream) {
+    if (!out || n < 0 || site < 0 || site > 3 || layer < 0 || layer > 255 || p < 0.f || p >= 1.f) return CC_ERR_ARG;
+    return dropout_mask_u8(out, (size_t)n, make_drop(p, seed, (unsigned)site, (unsigned)layer), S_(stream));
+}
+
 int cc_gpt2_embed(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, const float* prefix, const int64_t* tokens, void* ws,
                   void* stream) {
     if (!gpt2_cfg_ok(c) || !shape_ok(c, s) || !w32 || !ws || (s->L > 0 && !prefix) || (s->T > s->L && !tokens)) return CC_ERR_ARG;
@@ -526,8 +539,10 @@ int cc_gpt2_embed(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32
     gpt2_offsets(c, o);
     Gpt2WS w;
     gpt2_carve(c, s->B, s->T, s->T - s->L, s->mode, ws, w);
-    return embed_concat(prefix, reinterpret_cast<const long long*>(tokens), s->cap, w32 + o.wte, w32 + o.wpe, w.x[0], s->B, s->L, s->T,
-                        c->D, 0, S_(stream));
+    CC_TRY(embed_concat(prefix, reinterpret_cast<const long long*>(tokens), s->cap, w32 + o.wte, w32 + o.wpe, w.x[0], s->B, s->L, s->T,
+                        c->D, 0, S_(stream)));
+    // embd dropout on inputs_embeds + position_embeds (hf GPT2Model.forward: self.drop)
+    return dropout_f32(w.x[0], (size_t)s->B * s->T * c->D, make_drop(g_gpt2_drop.p_embd, g_gpt2_drop.seed, DROP_EMBD, 0), S_(stream));
 }
 
 int cc_gpt2_embed_from(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, const float* inputs_embeds, void* ws,
@@ -554,13 +569,15 @@ int cc_gpt2_fwd(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, 
         // hf :262-310: x1 = x + c_proj(attn(c_attn(ln_1 x)))
         CC_TRY(ln_fwd(w.x[l], D, nullptr, w32 + y.l1w, w32 + y.l1b, w.xn1[l], nullptr, w.mean1[l], w.rstd1[l], M, D, st));
         CC_TRY(gemm_bf16out(0, 0, w.xn1[l], D, w16t + y.aw, D, M, 3 * D, D, w.qkv[l], 3 * D, w32 + y.ab, 0, nullptr, st));
-        CC_TRY(attn_fwd(w.qkv[l], s->B, s->T, H, hd, true, w.att[l], w.lse[l], st));
-        CC_TRY(gemm_resid(0, 0, w.att[l], D, w16t + y.pw, D, M, D, D, w.x1[l], w.x[l], D, w32 + y.pb, st));
+        CC_TRY(attn_fwd(w.qkv[l], s->B, s->T, H, hd, true, w.att[l], w.lse[l], st, make_drop(g_gpt2_drop.p_attn, g_gpt2_drop.seed, DROP_ATTN, l)));
+        CC_TRY(gemm_resid(0, 0, w.att[l], D, w16t + y.pw, D, M, D, D, w.x1[l], w.x[l], D, w32 + y.pb, st,
+                          make_drop(g_gpt2_drop.p_resid, g_gpt2_drop.seed, DROP_RESID_ATTN, l)));
         // x = x1 + c_proj(gelu_new(c_fc(ln_2 x1)))   (hf :229-243)
         CC_TRY(ln_fwd(w.x1[l], D, nullptr, w32 + y.l2w, w32 + y.l2b, w.xn2[l], nullptr, w.mean2[l], w.rstd2[l], M, D, st));
         CC_TIMED(CC_SITE_GPT2_FC_FWD, st, gemm_bf16out(0, 0, w.xn2[l], D, w16t + y.fw, D, M, 4 * D, D, w.hact[l], 4 * D, w32 + y.fb, 2,
                                                         s->mode >= 1 ? w.u[l] : nullptr, st));
-        CC_TIMED(CC_SITE_GPT2_PROJ2_FWD, st, gemm_resid(0, 0, w.hact[l], 4 * D, w16t + y.p2w, 4 * D, M, D, 4 * D, w.x[l + 1], w.x1[l], D, w32 + y.p2b, st));
+        CC_TIMED(CC_SITE_GPT2_PROJ2_FWD, st, gemm_resid(0, 0, w.hact[l], 4 * D, w16t + y.p2w, 4 * D, M, D, 4 * D, w.x[l + 1], w.x1[l], D, w32 + y.p2b, st,
+                                                       make_drop(g_gpt2_drop.p_resid, g_gpt2_drop.seed, DROP_RESID_MLP, l)));
     }
     return CC_OK;
 }
@@ -642,6 +659,9 @@ int cc_gpt2_bwd_range(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float*
     const bool full = s->mode == 2;
     for (int l = l_hi - 1; l >= l_lo; l--) {
         const auto& y = o.layer[l];
+        // residual dropout: the gradient entering a c_proj is the masked residual gradient (its bf16 copy is only read by that
+        // c_proj's backward GEMMs, so it is masked in place; dx32, the residual stream's own gradient, stays unmasked)
+        CC_TRY(dropout_bf16(w.dx16, (size_t)M * D, make_drop(g_gpt2_drop.p_resid, g_gpt2_drop.seed, DROP_RESID_MLP, l), st));
         // mlp.c_proj (Conv1D [4D, D]): y = hact W + b
         if (full) {
             CC_TRY(gemm_wgrad(w.hact[l], D4, w.dx16, D, D4, D, M, g32 + y.p2w, D, w.wg_scratch, st));
@@ -657,12 +677,14 @@ int cc_gpt2_bwd_range(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float*
         CC_TRY(ln_bwd(w.dxn16, w.x1[l], D, nullptr, w.mean2[l], w.rstd2[l], w32 + y.l2w, w.dx32, w.dx32, w.dx16, full ? g32 + y.l2w : nullptr,
                       full ? g32 + y.l2b : nullptr, M, D, st));
         // attn.c_proj (Conv1D [D, D])
+        CC_TRY(dropout_bf16(w.dx16, (size_t)M * D, make_drop(g_gpt2_drop.p_resid, g_gpt2_drop.seed, DROP_RESID_ATTN, l), st));
         if (full) {
             CC_TRY(gemm_wgrad(w.att[l], D, w.dx16, D, D, D, M, g32 + y.pw, D, w.wg_scratch, st));
             CC_TRY(colsum_bf16(w.dx16, D, M, D, g32 + y.pb, st));
         }
         CC_TRY(gemm_bf16out(0, 0, w.dx16, D, w16 + y.pw, D, M, D, D, w.datt16, D, nullptr, 0, nullptr, st));
-        CC_TRY(attn_bwd(w.qkv[l], w.datt16, w.att[l], w.lse[l], w.adelta, s->B, s->T, H, hd, true, w.dqkv16, st));
+        CC_TRY(attn_bwd(w.qkv[l], w.datt16, w.att[l], w.lse[l], w.adelta, s->B, s->T, H, hd, true, w.dqkv16, st,
+                        make_drop(g_gpt2_drop.p_attn, g_gpt2_drop.seed, DROP_ATTN, l)));
         // attn.c_attn (Conv1D [D, 3D])
         if (full) {
             CC_TRY(gemm_wgrad(w.xn1[l], D, w.dqkv16, D3, D, D3, M, g32 + y.aw, D3, w.wg_scratch, st));
@@ -673,6 +695,7 @@ int cc_gpt2_bwd_range(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float*
                       full ? g32 + y.l1b : nullptr, M, D, st));
     }
     if (l_lo > 0) return CC_OK;
+    CC_TRY(dropout_f32(w.dx32, (size_t)M * D, make_drop(g_gpt2_drop.p_embd, g_gpt2_drop.seed, DROP_EMBD, 0), st));   // d(inputs + wpe)
     if (s->L > 0) CC_TRY(copy_rows(w.dx32, (size_t)s->T * D, dprefix, (size_t)s->L * D, s->L * D, s->B, st));
     if (full)
         CC_TRY(embed_bwd(w.dx32, reinterpret_cast<const long long*>(tokens), s->cap, g32 + o.wte, g32 + o.wpe, s->B, s->L, s->T, D, st));

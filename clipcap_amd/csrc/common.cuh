@@ -45,6 +45,36 @@ __device__ __forceinline__ float gelu_new_grad(float x) {
     return 0.5f * (1.0f + t) + 0.5f * x * dt;
 }
 
+// ---- dropout (GPT-2 full finetune in train mode: embd / attention-probability / residual dropout, hf modeling_gpt2.py) --------
+// Counter-based: keep(element) is a hash of (seed, stream = site * 256 + layer, element index), so the backward pass regenerates the
+// forward's mask instead of storing it.  thresh = p * 2^32 (0 = dropout off); kept values are scaled by 1 / (1 - p).
+struct Drop {
+    unsigned thresh = 0, seed_lo = 0, seed_hi = 0, stream = 0;
+    float scale = 1.0f;
+};
+__host__ __device__ __forceinline__ unsigned drop_hash(unsigned seed_lo, unsigned seed_hi, unsigned stream, unsigned idx) {
+    unsigned x = idx ^ seed_lo;
+    x *= 0x9E3779B1u; x ^= x >> 15;
+    x += (stream * 0x85EBCA6Bu) ^ seed_hi;
+    x *= 0xC2B2AE35u; x ^= x >> 13;
+    x *= 0x27D4EB2Fu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ bool drop_keep(const Drop& d, unsigned idx) { return drop_hash(d.seed_lo, d.seed_hi, d.stream, idx) >= d.thresh; }
+// multiplier of element idx: 0 or 1 / (1 - p)
+__device__ __forceinline__ float drop_mul(const Drop& d, unsigned idx) { return drop_keep(d, idx) ? d.scale : 0.f; }
+enum { DROP_EMBD = 0, DROP_ATTN = 1, DROP_RESID_ATTN = 2, DROP_RESID_MLP = 3 };
+inline Drop make_drop(float p, unsigned long long seed, unsigned site, unsigned layer) {
+    Drop d;
+    if (p > 0.f) {
+        const double t = (double)p * 4294967296.0;
+        d.thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+        d.scale = 1.0f / (1.0f - p);
+        d.seed_lo = (unsigned)seed; d.seed_hi = (unsigned)(seed >> 32); d.stream = site * 256u + layer;
+    }
+    return d;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

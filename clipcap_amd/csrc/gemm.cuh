@@ -807,12 +807,13 @@ struct EpiBF16 {
     }
 };
 
-// out(fp32) = res + acc + bias   (residual stream update; out may alias res)
+// out(fp32) = res + drop(acc + bias)   (residual stream update; out may alias res; drop = residual dropout, off unless drop.thresh)
 struct EpiResid {
     float* out;
     const float* res;
     const float* bias;  // nullable
     int ld, M, Ns;
+    Drop drop;
     __device__ __forceinline__ void operator()(int row, int col, float (&v)[8]) const {
         if (row >= M || col >= Ns) return;
         const size_t o = (size_t)row * ld + col;
@@ -823,16 +824,31 @@ struct EpiResid {
             b0 = *reinterpret_cast<const float4*>(bias + col);
             b1 = *reinterpret_cast<const float4*>(bias + col + 4);
         }
-        *reinterpret_cast<float4*>(out + o) = make_float4(r0.x + v[0] + b0.x, r0.y + v[1] + b0.y, r0.z + v[2] + b0.z, r0.w + v[3] + b0.w);
-        *reinterpret_cast<float4*>(out + o + 4) = make_float4(r1.x + v[4] + b1.x, r1.y + v[5] + b1.y, r1.z + v[6] + b1.z, r1.w + v[7] + b1.w);
+        float y[8] = {v[0] + b0.x, v[1] + b0.y, v[2] + b0.z, v[3] + b0.w, v[4] + b1.x, v[5] + b1.y, v[6] + b1.z, v[7] + b1.w};
+        if (drop.thresh) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) y[e] *= drop_mul(drop, (unsigned)o + e);
+        }
+        *reinterpret_cast<float4*>(out + o) = make_float4(r0.x + y[0], r0.y + y[1], r0.z + y[2], r0.w + y[3]);
+        *reinterpret_cast<float4*>(out + o + 4) = make_float4(r1.x + y[4], r1.y + y[5], r1.z + y[6], r1.w + y[7]);
     }
     static constexpr bool kPre = true;
-    __device__ __forceinline__ void pre4(int row, int col, f32x4& a) const {        // acc += residual
+    __device__ __forceinline__ void pre4(int row, int col, f32x4& a) const {        // acc += residual (with dropout: bias and mask too)
         if (row >= M || col >= Ns) return;
-        const float4 r = *reinterpret_cast<const float4*>(res + (size_t)row * ld + col);
+        const size_t o = (size_t)row * ld + col;
+        const float4 r = *reinterpret_cast<const float4*>(res + o);
+        if (drop.thresh) {
+            float4 b = make_float4(0, 0, 0, 0);
+            if (bias) b = *reinterpret_cast<const float4*>(bias + col);
+            a[0] = r.x + drop_mul(drop, (unsigned)o) * (a[0] + b.x);
+            a[1] = r.y + drop_mul(drop, (unsigned)o + 1) * (a[1] + b.y);
+            a[2] = r.z + drop_mul(drop, (unsigned)o + 2) * (a[2] + b.z);
+            a[3] = r.w + drop_mul(drop, (unsigned)o + 3) * (a[3] + b.w);
+            return;
+        }
         a[0] += r.x; a[1] += r.y; a[2] += r.z; a[3] += r.w;
     }
-    __device__ __forceinline__ void bias8(int col, float (&b)[8]) const { load_bias8(bias, col, Ns, b); }
+    __device__ __forceinline__ void bias8(int col, float (&b)[8]) const { load_bias8(drop.thresh ? nullptr : bias, col, Ns, b); }
     __device__ __forceinline__ void fin(int row, int col, float (&v)[8], const float (&b)[8]) const {
         if (row >= M || col >= Ns) return;
         const size_t o = (size_t)row * ld + col;

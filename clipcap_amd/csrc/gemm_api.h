@@ -10,7 +10,7 @@ extern int g_gemm_tile_mode;
 int gemm_bf16out(int al, int bl, const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, bf16_t* C, int ldc,
                  const float* bias, int act, bf16_t* pre, hipStream_t st);
 int gemm_resid(int al, int bl, const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, float* out, const float* res,
-               int ld, const float* bias, hipStream_t st);
+               int ld, const float* bias, hipStream_t st, Drop drop = Drop());
 // mode 0 store (+bias), 1 add, 2 atomic add (required when ksplit > 1)
 int gemm_f32out(int al, int bl, const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, float* C, int ldc,
                 const float* bias, int mode, float alpha, int ksplit, hipStream_t st);

@@ -29,10 +29,14 @@ int ln_bwd(const bf16_t* dy, const float* x, int ldx, const int* row_map, const 
            const float* dres, float* dx32, bf16_t* dx16, float* dgamma, float* dbeta, int rows, int D, hipStream_t st);
 int colsum_bf16(const bf16_t* X, int ld, int M, int N, float* out, hipStream_t st);
 
-int attn_fwd(const bf16_t* qkv, int B, int S, int H, int hd, bool causal, bf16_t* out, float* lse, hipStream_t st);
+int attn_fwd(const bf16_t* qkv, int B, int S, int H, int hd, bool causal, bf16_t* out, float* lse, hipStream_t st, Drop drop = Drop());
 // o: forward output (for delta = rowsum(dO*O)); delta: fp32 scratch [B*H*S].  Both may be null -> VALU kernel.
 int attn_bwd(const bf16_t* qkv, const bf16_t* dout, const bf16_t* o, const float* lse, float* delta, int B, int S, int H, int hd, bool causal,
-             bf16_t* dqkv, hipStream_t st);
+             bf16_t* dqkv, hipStream_t st, Drop drop = Drop());
+// in-place dropout of an fp32 / bf16 buffer of n elements (n % 4 == 0 / n % 8 == 0): x[i] *= keep(i) / (1 - p)
+int dropout_f32(float* x, size_t n, Drop drop, hipStream_t st);
+int dropout_bf16(bf16_t* x, size_t n, Drop drop, hipStream_t st);
+int dropout_mask_u8(unsigned char* out, size_t n, Drop drop, hipStream_t st);   // test hook: out[i] = keep(i)
 
 int embed_concat(const float* prefix, const long long* tokens, int cap, const float* wte, const float* wpe, float* x0, int B, int L,
                  int T, int D, int pos0, hipStream_t st);

@@ -505,9 +505,9 @@ __device__ __forceinline__ bf16x8 frag_tr(const bf16_t* blk, int nb, int t, int 
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int HD, bool CAUSAL>
+template <int HD, bool CAUSAL, bool DROP = false>
 __global__ __launch_bounds__(256) void k_attn_fwd_mfma(const bf16_t* __restrict__ qkv, int B, int S, int H, float scale,
-                                                       bf16_t* __restrict__ out, float* __restrict__ lse_out) {
+                                                       bf16_t* __restrict__ out, float* __restrict__ lse_out, Drop drop = Drop()) {
     constexpr int KK = HD / 16, NB = HD / 32, C8 = HD / 8;
     __shared__ __attribute__((aligned(16))) bf16_t vsm[4][32 * AttLd<HD>::v];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -591,6 +591,11 @@ __global__ __launch_bounds__(256) void k_attn_fwd_mfma(const bf16_t* __restrict_
         for (int nb = 0; nb < NB; nb++)
 #pragma unroll
             for (int r = 0; r < 16; r++) o[nb][r] *= alpha;
+        if (DROP) {     // attention-probability dropout (hf sdpa dropout_p): applied to P for the PV product only, the row sum l stays
+            const unsigned rowbase = ((unsigned)(b * H + h) * S + min(q, S - 1)) * S;
+#pragma unroll
+            for (int r = 0; r < 16; r++) p[r] *= drop_mul(drop, rowbase + min(kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, S - 1));
+        }
         bf16x8 pf[2];
 #pragma unroll
         for (int t = 0; t < 2; t++) {
@@ -623,13 +628,16 @@ __global__ __launch_bounds__(256) void k_attn_fwd_mfma(const bf16_t* __restrict_
 }
 
 template <int HD>
-static int attn_fwd_mfma_launch(const bf16_t* qkv, int B, int S, int H, bool causal, bf16_t* out, float* lse, hipStream_t st) {
+static int attn_fwd_mfma_launch(const bf16_t* qkv, int B, int S, int H, bool causal, bf16_t* out, float* lse, hipStream_t st, Drop drop) {
     const int items = B * H * ((S + 31) / 32);
     const float scale = 1.0f / sqrtf((float)HD);
-    if (causal)
-        hipLaunchKernelGGL((k_attn_fwd_mfma<HD, true>), dim3((items + 3) / 4), dim3(256), 0, st, qkv, B, S, H, scale, out, lse);
+    if (drop.thresh) {
+        if (!causal) return CC_ERR_SHAPE;      // dropout is a GPT-2 (causal) feature
+        hipLaunchKernelGGL((k_attn_fwd_mfma<HD, true, true>), dim3((items + 3) / 4), dim3(256), 0, st, qkv, B, S, H, scale, out, lse, drop);
+    } else if (causal)
+        hipLaunchKernelGGL((k_attn_fwd_mfma<HD, true>), dim3((items + 3) / 4), dim3(256), 0, st, qkv, B, S, H, scale, out, lse, drop);
     else
-        hipLaunchKernelGGL((k_attn_fwd_mfma<HD, false>), dim3((items + 3) / 4), dim3(256), 0, st, qkv, B, S, H, scale, out, lse);
+        hipLaunchKernelGGL((k_attn_fwd_mfma<HD, false>), dim3((items + 3) / 4), dim3(256), 0, st, qkv, B, S, H, scale, out, lse, drop);
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
 
@@ -655,10 +663,10 @@ __device__ __forceinline__ bf16x8 load_frag(const bf16_t* row_ptr, bool ok) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int HD, bool CAUSAL>
+template <int HD, bool CAUSAL, bool DROP = false>
 __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                       const float* __restrict__ lse, const float* __restrict__ delta, int B, int S, int H,
-                                                      float scale, bf16_t* __restrict__ dqkv) {
+                                                      float scale, bf16_t* __restrict__ dqkv, Drop drop = Drop()) {
     constexpr int KK = HD / 16, NB = HD / 32;
     __shared__ __attribute__((aligned(16))) bf16_t qsm[4][32 * AttLd<HD>::v];
     __shared__ __attribute__((aligned(16))) bf16_t dsm[4][32 * AttLd<HD>::v];
@@ -739,7 +747,13 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const bf16_t* __restrict__
             const int qr = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             const bool ok = qr < S && key < S && (!CAUSAL || key <= qr);
             p[r] = ok ? __expf(s[r] * scale - lq[r]) : 0.f;
-            ds[r] = p[r] * (dp[r] - dq_[r]) * scale;
+            if (DROP) {     // A_d = M A / (1-p): dV uses A_d, dA = M dA_d / (1-p), dS = A (dA - delta)  (delta = rowsum(dO O) = rowsum(A_d dA_d))
+                const float mk = drop_mul(drop, ((unsigned)(b * H + h) * S + min(qr, S - 1)) * S + min(key, S - 1));
+                ds[r] = p[r] * (mk * dp[r] - dq_[r]) * scale;
+                p[r] *= mk;
+            } else {
+                ds[r] = p[r] * (dp[r] - dq_[r]) * scale;
+            }
         }
         const bf16x8 pf[2] = {pack_frag(p), pack_frag(p + 8)};
         const bf16x8 dsf[2] = {pack_frag(ds), pack_frag(ds + 8)};
@@ -768,10 +782,10 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const bf16_t* __restrict__
     }
 }
 
-template <int HD, bool CAUSAL>
+template <int HD, bool CAUSAL, bool DROP = false>
 __global__ __launch_bounds__(256) void k_attn_bwd_dq(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const bf16_t* __restrict__ o,
                                                      const float* __restrict__ lse, float* __restrict__ delta, int B, int S, int H,
-                                                     float scale, bf16_t* __restrict__ dqkv) {
+                                                     float scale, bf16_t* __restrict__ dqkv, Drop drop = Drop()) {
     constexpr int KK = HD / 16, NB = HD / 32;
     __shared__ __attribute__((aligned(16))) bf16_t ksm[4][32 * AttLd<HD>::v];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -844,7 +858,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const bf16_t* __restrict__ 
             const int kr = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             const bool ok = kr < S && q < S && (!CAUSAL || kr <= q);
             const float p = ok ? __expf(st[r] * scale - my_lse) : 0.f;
-            ds[r] = p * (dpt[r] - my_delta) * scale;
+            const float mk = DROP ? drop_mul(drop, ((unsigned)(b * H + h) * S + min(q, S - 1)) * S + min(kr, S - 1)) : 1.0f;
+            ds[r] = p * (mk * dpt[r] - my_delta) * scale;
         }
         const bf16x8 dsf[2] = {pack_frag(ds), pack_frag(ds + 8)};
 #pragma unroll
@@ -870,11 +885,15 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const bf16_t* __restrict__ 
 
 template <int HD>
 static int attn_bwd_mfma_launch(const bf16_t* qkv, const bf16_t* dout, const bf16_t* o, const float* lse, float* delta, int B, int S, int H,
-                                bool causal, bf16_t* dqkv, hipStream_t st) {
+                                bool causal, bf16_t* dqkv, hipStream_t st, Drop drop) {
     const int items = B * H * ((S + 31) / 32);
     const float scale = 1.0f / sqrtf((float)HD);
     // dQ first: it also produces delta, which the dK/dV kernel reads
-    if (causal) {
+    if (drop.thresh) {
+        if (!causal) return CC_ERR_SHAPE;
+        hipLaunchKernelGGL((k_attn_bwd_dq<HD, true, true>), dim3((items + 3) / 4), dim3(256), 0, st, qkv, dout, o, lse, delta, B, S, H, scale, dqkv, drop);
+        hipLaunchKernelGGL((k_attn_bwd_dkv<HD, true, true>), dim3((items + 3) / 4), dim3(256), 0, st, qkv, dout, lse, delta, B, S, H, scale, dqkv, drop);
+    } else if (causal) {
         hipLaunchKernelGGL((k_attn_bwd_dq<HD, true>), dim3((items + 3) / 4), dim3(256), 0, st, qkv, dout, o, lse, delta, B, S, H, scale, dqkv);
         hipLaunchKernelGGL((k_attn_bwd_dkv<HD, true>), dim3((items + 3) / 4), dim3(256), 0, st, qkv, dout, lse, delta, B, S, H, scale, dqkv);
     } else {
@@ -887,14 +906,15 @@ static int attn_bwd_mfma_launch(const bf16_t* qkv, const bf16_t* dout, const bf1
 static size_t attn_fwd_lds(int S, int hd) { return ((size_t)3 * S * (hd + 4) + (size_t)S * (S + 1)) * 4; }
 static size_t attn_bwd_lds(int S, int hd) { return ((size_t)4 * S * (hd + 4) + (size_t)2 * S * (S + 1)) * 4; }
 
-int attn_fwd(const bf16_t* qkv, int B, int S, int H, int hd, bool causal, bf16_t* out, float* lse, hipStream_t st) {
+int attn_fwd(const bf16_t* qkv, int B, int S, int H, int hd, bool causal, bf16_t* out, float* lse, hipStream_t st, Drop drop) {
     if ((hd & 7) || S <= 0) return CC_ERR_SHAPE;
     static const bool no_mfma = getenv("CC_ATTN_VALU") != nullptr;   // A/B switch for profiling
-    if (!no_mfma) {
-        if (hd == 64) return attn_fwd_mfma_launch<64>(qkv, B, S, H, causal, out, lse, st);
-        if (hd == 96) return attn_fwd_mfma_launch<96>(qkv, B, S, H, causal, out, lse, st);
-        if (hd == 128) return attn_fwd_mfma_launch<128>(qkv, B, S, H, causal, out, lse, st);
+    if (!no_mfma || drop.thresh) {
+        if (hd == 64) return attn_fwd_mfma_launch<64>(qkv, B, S, H, causal, out, lse, st, drop);
+        if (hd == 96) return attn_fwd_mfma_launch<96>(qkv, B, S, H, causal, out, lse, st, drop);
+        if (hd == 128) return attn_fwd_mfma_launch<128>(qkv, B, S, H, causal, out, lse, st, drop);
     }
+    if (drop.thresh) return CC_ERR_SHAPE;          // the VALU fallback kernels have no dropout
     const size_t sh = attn_fwd_lds(S, hd);
     if (sh > 160 * 1024) return CC_ERR_SHAPE;
     const float scale = 1.0f / sqrtf((float)hd);
@@ -997,14 +1017,15 @@ __global__ __launch_bounds__(256) void k_attn_bwd(const bf16_t* __restrict__ qkv
     }
 }
 int attn_bwd(const bf16_t* qkv, const bf16_t* dout, const bf16_t* o, const float* lse, float* delta, int B, int S, int H, int hd, bool causal,
-             bf16_t* dqkv, hipStream_t st) {
+             bf16_t* dqkv, hipStream_t st, Drop drop) {
     if ((hd & 7) || S <= 0) return CC_ERR_SHAPE;
     static const bool no_mfma = getenv("CC_ATTN_VALU") != nullptr;
-    if (!no_mfma && o && delta) {
-        if (hd == 64) return attn_bwd_mfma_launch<64>(qkv, dout, o, lse, delta, B, S, H, causal, dqkv, st);
-        if (hd == 96) return attn_bwd_mfma_launch<96>(qkv, dout, o, lse, delta, B, S, H, causal, dqkv, st);
-        if (hd == 128) return attn_bwd_mfma_launch<128>(qkv, dout, o, lse, delta, B, S, H, causal, dqkv, st);
+    if ((!no_mfma || drop.thresh) && o && delta) {
+        if (hd == 64) return attn_bwd_mfma_launch<64>(qkv, dout, o, lse, delta, B, S, H, causal, dqkv, st, drop);
+        if (hd == 96) return attn_bwd_mfma_launch<96>(qkv, dout, o, lse, delta, B, S, H, causal, dqkv, st, drop);
+        if (hd == 128) return attn_bwd_mfma_launch<128>(qkv, dout, o, lse, delta, B, S, H, causal, dqkv, st, drop);
     }
+    if (drop.thresh) return CC_ERR_SHAPE;          // the VALU fallback kernel has no dropout
     const size_t sh = attn_bwd_lds(S, hd);
     if (sh > 160 * 1024) return CC_ERR_SHAPE;
     const float scale = 1.0f / sqrtf((float)hd);
@@ -1021,6 +1042,50 @@ int attn_bwd(const bf16_t* qkv, const bf16_t* dout, const bf16_t* o, const float
 // ------------------------------------------------------------------------------------------------------------
 // GPT-2 input assembly: x0[b,t,:] = (t < L ? prefix[b,t,:] : wte[tok[b,t-L],:]) + wpe[pos0 + t,:]   (fp32)
 // (clipcap/model/model.py:45-49 + hf modeling_gpt2.py:571-577).  tokens < 0 (pads) are read as id 0 (model.py:104).
+// ------------------------------------------------------------------------------------------------------------
+// In-place dropout (common.cuh: counter-based mask): embedding dropout on x0 / dx0 (fp32) and the masked bf16 copy of the residual
+// gradient that feeds a c_proj backward.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void k_dropout_f32(float* __restrict__ x, size_t n4, Drop d) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 v = reinterpret_cast<float4*>(x)[i];
+        const unsigned e = (unsigned)(i * 4);
+        v.x *= drop_mul(d, e); v.y *= drop_mul(d, e + 1); v.z *= drop_mul(d, e + 2); v.w *= drop_mul(d, e + 3);
+        reinterpret_cast<float4*>(x)[i] = v;
+    }
+}
+__global__ void k_dropout_bf16(bf16_t* __restrict__ x, size_t n8, Drop d) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        float f[8];
+        unpack8(reinterpret_cast<const uint4*>(x)[i], f);
+        const unsigned e = (unsigned)(i * 8);
+#pragma unroll
+        for (int k = 0; k < 8; k++) f[k] *= drop_mul(d, e + k);
+        reinterpret_cast<uint4*>(x)[i] = pack8(f);
+    }
+}
+__global__ void k_dropout_mask(unsigned char* __restrict__ out, size_t n, Drop d) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = (d.thresh == 0 || drop_keep(d, (unsigned)i)) ? 1 : 0;
+}
+int dropout_f32(float* x, size_t n, Drop d, hipStream_t st) {
+    if (!d.thresh || !n) return CC_OK;
+    if (n & 3) return CC_ERR_SHAPE;
+    hipLaunchKernelGGL(k_dropout_f32, dim3((int)std::min<size_t>((n / 4 + 255) / 256, 4096)), dim3(256), 0, st, x, n / 4, d);
+    return CC_OK;
+}
+int dropout_bf16(bf16_t* x, size_t n, Drop d, hipStream_t st) {
+    if (!d.thresh || !n) return CC_OK;
+    if (n & 7) return CC_ERR_SHAPE;
+    hipLaunchKernelGGL(k_dropout_bf16, dim3((int)std::min<size_t>((n / 8 + 255) / 256, 4096)), dim3(256), 0, st, x, n / 8, d);
+    return CC_OK;
+}
+int dropout_mask_u8(unsigned char* out, size_t n, Drop d, hipStream_t st) {
+    if (!n) return CC_OK;
+    hipLaunchKernelGGL(k_dropout_mask, dim3((int)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, st, out, n, d);
+    return CC_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 __global__ void k_embed_concat(const float* __restrict__ prefix, const long long* __restrict__ tokens, int cap,
                                const float* __restrict__ wte, const float* __restrict__ wpe, float* __restrict__ x0,

@@ -278,7 +278,7 @@ class ClipCapEngine:
         self.stats: Optional[torch.Tensor] = None
 
     def forward_backward(self, tokens: torch.Tensor, embeds: torch.Tensor, reduce_stats=None, backward: bool = True,
-                         on_grads_ready=None) -> torch.Tensor:
+                         on_grads_ready=None, dropout=None) -> torch.Tensor:
         """tokens int64 (B,cap) padded with -1; embeds fp32 (B,E)/(B,W,E).
 
         Returns the mean loss over kept targets (device scalar).  Gradients are ACCUMULATED into the arenas' g32.
@@ -287,6 +287,8 @@ class ClipCapEngine:
         ``on_grads_ready(arena_index, lo, hi)``: optional; called as soon as the kernels producing gradient elements [lo, hi) of
         arena 0 (mapper) / 1 (GPT-2) are enqueued, in the order backward finishes them (GPT-2 top layers first, mapper last), so
         the caller can launch the all-reduce of that slice underneath the remaining backward kernels.
+        ``dropout``: optional (p_embd, p_attn, p_resid, seed) — GPT-2 train-mode dropout for this step (full finetune; the masks
+        are a hash of (seed, site, layer, element) regenerated by the backward kernels, cc_gpt2_set_dropout).
         """
         l = _lib.lib()
         g, m = self.gpt2, self.mapper
@@ -303,6 +305,16 @@ class ClipCapEngine:
         st = _stream(dev)
         ga = g.arena
         prefix = m.forward(embeds, save=True)
+        if dropout is not None:
+            check(l.cc_gpt2_set_dropout(float(dropout[0]), float(dropout[1]), float(dropout[2]), int(dropout[3]) & 0xFFFFFFFFFFFFFFFF),
+                  "cc_gpt2_set_dropout")
+        try:
+            return self._forward_backward(l, g, m, ga, shp, ws, st, prefix, tokens, reduce_stats, backward, on_grads_ready, dev)
+        finally:
+            if dropout is not None:
+                l.cc_gpt2_set_dropout(0.0, 0.0, 0.0, 0)          # the setting is process-global: never leak it into eval / decode
+
+    def _forward_backward(self, l, g, m, ga, shp, ws, st, prefix, tokens, reduce_stats, backward, on_grads_ready, dev):
         check(l.cc_gpt2_embed(C.byref(g.cfg), C.byref(shp), _p(ga.w32), _p(prefix), _p(tokens), _p(ws), st), "cc_gpt2_embed")
         check(l.cc_gpt2_fwd(C.byref(g.cfg), C.byref(shp), _p(ga.w32), _p(ga.w16), _p(ws), st), "cc_gpt2_fwd")
         if self.stats is None or self.stats.device != dev:

@@ -48,10 +48,14 @@ class _TiedHead(nn.Module):
 
 class GPT2LM(ArenaModule):
     def __init__(self, n_embd: int = 768, n_layer: int = 12, n_head: int = 12, vocab_size: int = 50257, n_positions: int = 1024,
-                 initializer_range: float = 0.02, name_or_path: str = ""):
+                 initializer_range: float = 0.02, name_or_path: str = "", embd_pdrop: float = 0.1, attn_pdrop: float = 0.1,
+                 resid_pdrop: float = 0.1):
         super().__init__()
+        # *_pdrop: GPT2Config defaults (0.1); they act only in train mode of a full finetune (ClipCapModel), through the HIP kernels'
+        # counter-based masks (cc_gpt2_set_dropout)
         self.config = SimpleNamespace(n_embd=n_embd, n_layer=n_layer, n_head=n_head, vocab_size=vocab_size, n_positions=n_positions,
-                                      initializer_range=initializer_range, name_or_path=name_or_path)
+                                      initializer_range=initializer_range, name_or_path=name_or_path, embd_pdrop=embd_pdrop,
+                                      attn_pdrop=attn_pdrop, resid_pdrop=resid_pdrop)
         self.engine = Gpt2Engine(n_embd, n_head, n_layer, vocab_size, n_positions)
         self._bind_parameters()
         self.lm_head = _TiedHead(self._arena_params["transformer.wte.weight"])
@@ -78,7 +82,8 @@ class GPT2LM(ArenaModule):
     def from_config_dict(cls, cfg: dict, name: str = "") -> "GPT2LM":
         return cls(n_embd=cfg.get("n_embd", 768), n_layer=cfg.get("n_layer", 12), n_head=cfg.get("n_head", 12),
                    vocab_size=cfg.get("vocab_size", 50257), n_positions=cfg.get("n_positions", 1024),
-                   initializer_range=cfg.get("initializer_range", 0.02), name_or_path=name)
+                   initializer_range=cfg.get("initializer_range", 0.02), name_or_path=name, embd_pdrop=cfg.get("embd_pdrop", 0.1),
+                   attn_pdrop=cfg.get("attn_pdrop", 0.1), resid_pdrop=cfg.get("resid_pdrop", 0.1))
 
     @classmethod
     def from_pretrained(cls, name_or_path: str) -> "GPT2LM":
@@ -105,7 +110,8 @@ class GPT2LM(ArenaModule):
         hf = AutoModelForCausalLM.from_pretrained(name_or_path)
         c = hf.config
         model = cls(n_embd=c.n_embd, n_layer=c.n_layer, n_head=c.n_head, vocab_size=c.vocab_size, n_positions=c.n_positions,
-                    initializer_range=c.initializer_range, name_or_path=name_or_path)
+                    initializer_range=c.initializer_range, name_or_path=name_or_path, embd_pdrop=c.embd_pdrop, attn_pdrop=c.attn_pdrop,
+                    resid_pdrop=c.resid_pdrop)
         model.load_state_dict(hf.state_dict(), strict=False)
         return model
 

@@ -82,6 +82,20 @@ class ClipCapModel(nn.Module):
             self._engine = ClipCapEngine(self.transformer_mapper.engine, self.language_model.engine, train_lm=self._train_lm)
         return self._engine
 
+    def _dropout(self):
+        """(p_embd, p_attn, p_resid, seed) for this step, or None.  The reference's ClipCapModel leaves the HF GPT-2 in train mode
+        during a full finetune (model.py:19; only ClipCapModelPrefixOnly pins it to eval, :120-123), so its embd / attention /
+        residual dropout is active; the seed comes from torch's CPU generator (torch.manual_seed reproduces a run) plus the rank."""
+        lm = self.language_model
+        if not (self._train_lm and lm.training):
+            return None
+        c = lm.config
+        ps = (float(getattr(c, "embd_pdrop", 0.0)), float(getattr(c, "attn_pdrop", 0.0)), float(getattr(c, "resid_pdrop", 0.0)))
+        if max(ps) <= 0.0:
+            return None
+        rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+        return ps + (int(torch.randint(0, 2 ** 48, (1,)).item()) ^ (rank << 50),)
+
     def fused_step(self, batch: Tuple[torch.Tensor, torch.Tensor], lr: float, reducer=None) -> torch.Tensor:
         """One optimizer step: zero grads -> forward+backward kernel chains -> (all-reduce) -> fused AdamW. Returns the loss."""
         tokens, embeds = batch
@@ -89,10 +103,11 @@ class ClipCapModel(nn.Module):
         eng.zero_grad()
         if reducer is not None:
             reducer.begin()
-            loss = eng.forward_backward(tokens, embeds, reduce_stats=reducer.reduce_stats, on_grads_ready=reducer.on_grads_ready)
+            loss = eng.forward_backward(tokens, embeds, reduce_stats=reducer.reduce_stats, on_grads_ready=reducer.on_grads_ready,
+                                        dropout=self._dropout())
             reducer.finish()
         else:
-            loss = eng.forward_backward(tokens, embeds)
+            loss = eng.forward_backward(tokens, embeds, dropout=self._dropout())
         self._opt_step += 1
         self.transformer_mapper.engine.arena.adamw_step(lr, self._opt_step)
         if self._train_lm:
@@ -124,7 +139,7 @@ class ClipCapModel(nn.Module):
         tokens, embeds = batch
         eng = self.engine
         eng.zero_grad()
-        loss = eng.forward_backward(tokens, embeds)
+        loss = eng.forward_backward(tokens, embeds, dropout=self._dropout())
         self.last_loss = loss
         if torch.is_grad_enabled():
             return _StepLoss.apply(self, loss, *[self._lookup(o, n) for o, n in self._param_index])

@@ -184,6 +184,18 @@ int cc_adamw_step(float* p32, const float* g32, float* m, float* v, uint16_t* p1
 int cc_cast_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * GPT-2 dropout for full-finetune training (reference: ClipCapModel in train mode leaves the HF GPT-2 in train mode, model.py:19;
+ * hf modeling_gpt2.py: embd_pdrop on inputs+positions, attn_pdrop on the attention probabilities, resid_pdrop after both c_proj).
+ * Masks are a counter-based hash of (seed, site, layer, element) regenerated in the backward pass — nothing is stored.  The
+ * setting is process-global: call before a step's cc_gpt2_embed; cc_gpt2_fwd / cc_gpt2_bwd(_range) of that step read the same
+ * values.  All-zero probabilities (the default) = eval behaviour (ClipCapModelPrefixOnly keeps GPT-2 in eval, model.py:120-123).
+ * cc_dropout_mask (test hook) writes keep flags of one stream: site 0 embd [B*T*D], 1 attention [B*H*T*T], 2 residual after
+ * attn.c_proj [B*T*D], 3 residual after mlp.c_proj [B*T*D].
+ * ------------------------------------------------------------------------------------------------------------ */
+int cc_gpt2_set_dropout(float p_embd, float p_attn, float p_resid, uint64_t seed);
+int cc_dropout_mask(uint64_t seed, int32_t site, int32_t layer, float p, int64_t n, uint8_t* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Sampling decoders (replaces the per-step torch ops of clipcap/inference/base.py:159-184 generate_nucleus_sampling and
  * :233-262 generate_no_beam + utils.py:5-37): one step for R rows of fp32 logits [R][ld].
  *   x = logits (history tokens first scaled by the repetition penalty, utils.py:33-37) / temperature (<= 0 -> 1, base.py:163)

@@ -117,10 +117,13 @@ def _conv1d(x: Tensor, w: Tensor, b: Tensor, rb: bool) -> Tensor:
     return _r(x, rb) @ _r(w, rb) + b
 
 
-def gpt2_block_forward(p, pre, x, n_head, rb=False, past_kv=None):
+def gpt2_block_forward(p, pre, x, n_head, rb=False, past_kv=None, drop=None, layer=0):
     """GPT2Block.forward (hf :262-310): pre-LN; causal MHA with scale hd^-0.5 (:97-98, :54-72); MLP gelu_new.
 
     past_kv: optional (K,V) each (B,H,ctx,hd) for the KV-cached decode restatement; returns new (K,V).
+    drop: train-mode dropout with EXTERNALLY supplied keep masks (hf attn_pdrop on the attention probabilities inside sdpa,
+    resid_pdrop after both c_proj, :214-226, :241): {"p_attn", "p_resid", "attn": [mask (B,H,T,T)], "resid_attn": [(B,T,D)],
+    "resid_mlp": [(B,T,D)]}; kept entries are scaled by 1/(1-p) like torch.nn.functional.dropout.
     """
     bsz, t, d = x.shape
     hd = d // n_head
@@ -140,15 +143,23 @@ def gpt2_block_forward(p, pre, x, n_head, rb=False, past_kv=None):
     kj = torch.arange(ctx).unsqueeze(0)
     att = att.masked_fill(kj > qi, float("-inf"))
     att = att.softmax(dim=-1)
+    if drop is not None and drop.get("p_attn", 0.0) > 0:
+        att = att * drop["attn"][layer] / (1.0 - drop["p_attn"])
     a = _r((_r(att, rb) @ v).transpose(1, 2).reshape(bsz, t, d), rb)
-    x = x + _conv1d(a, p[pre + "attn.c_proj.weight"], p[pre + "attn.c_proj.bias"], rb)
+    y = _conv1d(a, p[pre + "attn.c_proj.weight"], p[pre + "attn.c_proj.bias"], rb)
+    if drop is not None and drop.get("p_resid", 0.0) > 0:
+        y = y * drop["resid_attn"][layer] / (1.0 - drop["p_resid"])
+    x = x + y
     h = F.layer_norm(x, (d,), p[pre + "ln_2.weight"], p[pre + "ln_2.bias"], 1e-5)
     h = _r(gelu_new(_conv1d(h, p[pre + "mlp.c_fc.weight"], p[pre + "mlp.c_fc.bias"], rb)), rb)
-    x = x + _conv1d(h, p[pre + "mlp.c_proj.weight"], p[pre + "mlp.c_proj.bias"], rb)
+    y = _conv1d(h, p[pre + "mlp.c_proj.weight"], p[pre + "mlp.c_proj.bias"], rb)
+    if drop is not None and drop.get("p_resid", 0.0) > 0:
+        y = y * drop["resid_mlp"][layer] / (1.0 - drop["p_resid"])
+    x = x + y
     return x, (k, v)
 
 
-def gpt2_hidden(p, inputs_embeds, n_head, n_layer, pre="transformer.", rb=False, past=None, pos_offset=0):
+def gpt2_hidden(p, inputs_embeds, n_head, n_layer, pre="transformer.", rb=False, past=None, pos_offset=0, drop=None):
     """GPT2Model.forward with inputs_embeds (hf :514-634): + wpe[arange(T)+past] (:571-577), blocks, ln_f.
 
     Right-padding attention_mask is not restated: it has exactly zero effect on non-pad rows under a
@@ -156,18 +167,20 @@ def gpt2_hidden(p, inputs_embeds, n_head, n_layer, pre="transformer.", rb=False,
     """
     t = inputs_embeds.shape[1]
     x = inputs_embeds + p[pre + "wpe.weight"][pos_offset:pos_offset + t].unsqueeze(0)
+    if drop is not None and drop.get("p_embd", 0.0) > 0:          # hf :586 self.drop(hidden_states)
+        x = x * drop["embd"] / (1.0 - drop["p_embd"])
     new_past = []
     for i in range(n_layer):
-        x, kv = gpt2_block_forward(p, f"{pre}h.{i}.", x, n_head, rb, None if past is None else past[i])
+        x, kv = gpt2_block_forward(p, f"{pre}h.{i}.", x, n_head, rb, None if past is None else past[i], drop, i)
         new_past.append(kv)
     d = x.shape[-1]
     x = F.layer_norm(x, (d,), p[pre + "ln_f.weight"], p[pre + "ln_f.bias"], 1e-5)
     return x, new_past
 
 
-def gpt2_logits(p, inputs_embeds, n_head, n_layer, pre="", rb=False):
+def gpt2_logits(p, inputs_embeds, n_head, n_layer, pre="", rb=False, drop=None):
     """GPT2LMHeadModel.forward (hf :650-725): logits = hidden @ wte^T (tied, :638, :703)."""
-    h, _ = gpt2_hidden(p, inputs_embeds, n_head, n_layer, pre + "transformer.", rb)
+    h, _ = gpt2_hidden(p, inputs_embeds, n_head, n_layer, pre + "transformer.", rb, drop=drop)
     return _r(h, rb) @ _r(p[pre + "transformer.wte.weight"], rb).t()
 
 
@@ -175,17 +188,17 @@ def gpt2_logits(p, inputs_embeds, n_head, n_layer, pre="", rb=False):
 # ClipCapModel  (clipcap/model/model.py:43-58 forward, :94-113 training_step)
 # --------------------------------------------------------------------------------------------------
 
-def clipcap_logits(p, tokens, embeds, *, cfg, rb=False):
+def clipcap_logits(p, tokens, embeds, *, cfg, rb=False, drop=None):
     """ClipCapModel.forward (model.py:43-58): wte(tokens); mapper; cat [prefix; tok]; GPT-2 -> logits (B,T,V)."""
     wte = p["language_model.transformer.wte.weight"]
     tok_emb = wte[tokens]
     prefix = mapper_forward(p, embeds, projection_length=cfg["projection_length"], num_heads=cfg["heads"],
                             num_layers=cfg["layers"], pre="transformer_mapper.", window=cfg.get("window", 1), rb=rb)
     x = torch.cat((prefix, tok_emb), dim=1)
-    return gpt2_logits(p, x, cfg["n_head"], cfg["n_layer"], pre="language_model.", rb=rb)
+    return gpt2_logits(p, x, cfg["n_head"], cfg["n_layer"], pre="language_model.", rb=rb, drop=drop)
 
 
-def clipcap_loss(p, tokens_padded, embeds, *, cfg, rb=False, denom: Optional[float] = None):
+def clipcap_loss(p, tokens_padded, embeds, *, cfg, rb=False, denom: Optional[float] = None, drop=None):
     """ClipCapModel.training_step (model.py:94-113).
 
     mask = tokens>=0; pads -> 0 (:103-104); logits[:, L-1:-1] (:108); cross_entropy(ignore_index=0) mean over
@@ -194,7 +207,7 @@ def clipcap_loss(p, tokens_padded, embeds, *, cfg, rb=False, denom: Optional[flo
     """
     tokens = tokens_padded.clone()
     tokens[tokens < 0] = 0
-    logits = clipcap_logits(p, tokens, embeds, cfg=cfg, rb=rb)
+    logits = clipcap_logits(p, tokens, embeds, cfg=cfg, rb=rb, drop=drop)
     L = cfg["prefix_length"]
     lg = logits[:, L - 1:-1]
     if denom is None:

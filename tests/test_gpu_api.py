@@ -18,7 +18,8 @@ def _model_from_train_fixture(mode="prefix_only"):
     from clipcap_amd.model.gpt2 import GPT2LM
     g = load_golden(f"train_{mode}")
     E, D, P, L, H, N, n_head, n_layer, V, npos = [int(v) for v in g["cfg"]]
-    lm = GPT2LM(n_embd=D, n_layer=n_layer, n_head=n_head, vocab_size=V, n_positions=npos)
+    # the fixtures were captured with resid_pdrop = embd_pdrop = attn_pdrop = 0 (oracle/gen_golden.py)
+    lm = GPT2LM(n_embd=D, n_layer=n_layer, n_head=n_head, vocab_size=V, n_positions=npos, embd_pdrop=0.0, attn_pdrop=0.0, resid_pdrop=0.0)
     cfg = Config(language_model="unused", train_language_model=(mode == "full"), prefix_length=L, projection_length=P, transformer_layers=N,
                  transformer_attention_heads=H, encoder_config=EncoderConfig(encoder_embedding_size=E),
                  training_config=TrainingConfig(optimizer_lr=1e-3, use_deepspeed_optimisers=False, scheduler_warmup_steps=2, total_steps=6))
