@@ -481,17 +481,19 @@ __global__ __launch_bounds__(G_THREADS, 1) void gemm_nt_glds4_kernel(const bf16_
 }
 
 // ------------------------------------------------------------------------------------------------
-// NT 256 x 256 kernel for large outputs ("stag256"): 8 waves, wave tile 128 x 64 (8 x 4 MFMA tiles), K-tile 32, FOUR LDS stages
-// of 32 KiB.  Per FLOP it moves half the L2->LDS bytes and 3/4 of the fragment reads of the 128 x 128 kernel — the two
-// resources the ablation shows saturated there.  One block per CU means no second block to hide a barrier stall, so the two
-// wave groups (rows 0-127 / 128-255; one wave of each per SIMD) are locked one segment apart by the block barrier; a segment
-// is either the 12 fragment reads of a K-tile or its 32 MFMAs:   2t: g0 L(t) | g1 M(t-1)      2t+1: g0 M(t) | g1 L(t)
-// Tile t+3 is issued (global_load_lds) at the start of segment 2t — its buffer's last reader finished in segment 2t-1 — and
-// tile t+1 is awaited with a COUNTED vmcnt(8) before the barrier ending segment 2t+1: two tiles stay in flight across the
-// barriers (raw s_barrier; a __syncthreads() would drain the DMA queue).  With a single tile in flight the same structure ran
-// 1129 TFLOP/s at 8192^3 and 1789 with the loads ablated: latency, not bandwidth, was the limiter.  The two groups run
-// separate code paths (one loop with per-segment role branches made hipcc spill 90 registers).
-// LDS image [row][32 k] (64-B rows), chunk' = chunk ^ ((row>>2)&3): conflict-free ds_read_b128 fragment reads.
+// 256-row kernels for large outputs: 8 waves, wave tile 128 x 16 NJ (8 x NJ MFMA tiles; block tile 256 x 256 for NJ = 4,
+// 256 x 192 for NJ = 3), K-tile 32, FOUR LDS stages of 32 KiB.  Per FLOP the 256 x 256 form moves half the L2->LDS bytes and
+// 3/4 of the fragment reads of the 128 x 128 kernel — the two resources the ablation shows saturated there.  One block per CU
+// means no second block to hide a barrier stall, so the two wave groups (rows 0-127 / 128-255; one wave of each per SIMD) are
+// locked one segment apart by the block barrier; a segment is either the 8 + NJ fragment reads of a K-tile or its 8 NJ MFMAs:
+//       segment 2t:   g0 reads(t)  | g1 MFMA(t-1)          segment 2t+1:   g0 MFMA(t) | g1 reads(t)
+// DMA (global_load_lds) of tile t+3 is issued by the group that is in its READ segment — group 0 streams the A tile in segment
+// 2t, group 1 the B tile in segment 2t+1; the buffer's last reader finished in segment 2t-1 — never in front of a group's MFMAs
+// (4 DMA instructions cost ~300 issue cycles: 1145 -> 1230 TFLOP/s at 8192^3).  Tile t+1 is awaited with a COUNTED vmcnt before
+// the barrier ending segment 2t+1, so two tiles stay in flight across the barriers (raw s_barrier; a __syncthreads() would
+// drain the DMA queue).  The two groups run separate copies of the loop (one loop with per-segment role branches made hipcc
+// spill 90 registers).  TT = true is the weight-gradient form (both operands K-strided), see H_ISSUE / h_tt_read.
+// NT LDS image [row][32 k] (64-B rows) with the bank-group-exact XOR key h_swz below.
 // ------------------------------------------------------------------------------------------------
 constexpr int H_BM = 256, H_BN = 256, H_BK = 32, H_NS = 4, H_STAGE = (H_BM + H_BN) * H_BK * 2;   // 32 KiB per stage, 128 KiB total
 // The B tile may be narrower: NJ MFMA column tiles per wave -> block tile 256 x (64 NJ); NJ = 3 gives 256 x 192 for N = 768-like widths.
