@@ -68,3 +68,33 @@ def test_full_size_kv_cache_equals_reforward(big):
     for t in range(10, 14):
         l = sess.forward(x[:, t:t + 1])
         assert (l - full[:, t]).abs().max().item() <= 5e-3 * max(1.0, scale), t
+
+
+def test_full_size_full_finetune_with_dropout_properties():
+    """BASELINE configs[2] size (GPT-2-small unfrozen, B=256) with GPT-2 dropout: same seed -> bitwise the same loss and (up to
+    atomic-order rounding) gradients, another seed -> other masks, finite everywhere, and the layer-sliced backward used for
+    all-reduce overlap regenerates exactly the masks of the single-call backward."""
+    import bench
+    c = dict(bench.CONFIGS["3"])
+    me, ge, eng = bench.init_engines(c, torch.device("cuda", 0))
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    embeds = torch.randn(c["B"], c["E"], generator=gen, device="cuda")
+    tokens = torch.randint(1, c["V"], (c["B"], c["cap"]), generator=gen, device="cuda")
+
+    def run(seed, sliced=False):
+        eng.zero_grad()
+        loss = eng.forward_backward(tokens, embeds, dropout=(0.1, 0.1, 0.1, seed), on_grads_ready=(lambda a, lo, hi: None) if sliced else None)
+        torch.cuda.synchronize()
+        return float(loss), me.arena.g32.clone(), ge.arena.g32.clone()
+
+    l0, gm0, gg0 = run(5)
+    l1, gm1, gg1 = run(5)
+    l2, gm2, gg2 = run(5, sliced=True)
+    l3, _, gg3 = run(6)
+    assert torch.isfinite(gm0).all() and torch.isfinite(gg0).all() and abs(l0) < 20
+    assert l1 == l0 and _rel(gm1, gm0) <= 1e-5 and _rel(gg1, gg0) <= 1e-5
+    assert l2 == l0 and _rel(gm2, gm0) <= 1e-4 and _rel(gg2, gg0) <= 1e-4
+    assert l3 != l0 and _rel(gg3, gg0) > 0.05
+    eng.zero_grad()
+    plain = float(eng.forward_backward(tokens, embeds))
+    assert abs(plain - l0) > 1e-4                  # dropout is actually on
