@@ -506,7 +506,7 @@ __device__ __forceinline__ bf16x8 frag_tr(const bf16_t* blk, int nb, int t, int 
 }
 
 template <int HD, bool CAUSAL, bool DROP = false>
-__global__ __launch_bounds__(256) void k_attn_fwd_mfma(const bf16_t* __restrict__ qkv, int B, int S, int H, float scale,
+__global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void k_attn_fwd_mfma(const bf16_t* __restrict__ qkv, int B, int S, int H, float scale,
                                                        bf16_t* __restrict__ out, float* __restrict__ lse_out, Drop drop = Drop()) {
     constexpr int KK = HD / 16, NB = HD / 32, C8 = HD / 8;
     __shared__ __attribute__((aligned(16))) bf16_t vsm[4][32 * AttLd<HD>::v];
@@ -664,7 +664,7 @@ __device__ __forceinline__ bf16x8 load_frag(const bf16_t* row_ptr, bool ok) {
 }
 
 template <int HD, bool CAUSAL, bool DROP = false>
-__global__ __launch_bounds__(256) void k_attn_bwd_dkv(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void k_attn_bwd_dkv(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                       const float* __restrict__ lse, const float* __restrict__ delta, int B, int S, int H,
                                                       float scale, bf16_t* __restrict__ dqkv, Drop drop = Drop()) {
     constexpr int KK = HD / 16, NB = HD / 32;
@@ -783,7 +783,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const bf16_t* __restrict__
 }
 
 template <int HD, bool CAUSAL, bool DROP = false>
-__global__ __launch_bounds__(256) void k_attn_bwd_dq(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const bf16_t* __restrict__ o,
+__global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void k_attn_bwd_dq(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const bf16_t* __restrict__ o,
                                                      const float* __restrict__ lse, float* __restrict__ delta, int B, int S, int H,
                                                      float scale, bf16_t* __restrict__ dqkv, Drop drop = Drop()) {
     constexpr int KK = HD / 16, NB = HD / 32;
