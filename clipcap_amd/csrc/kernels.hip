@@ -783,7 +783,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void k_attn_bwd_dkv(const bf
 }
 
 template <int HD, bool CAUSAL, bool DROP = false>
-__global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void k_attn_bwd_dq(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const bf16_t* __restrict__ o,
+__global__ __launch_bounds__(256, HD == 64 ? 3 : (HD == 96 ? 2 : 1)) void k_attn_bwd_dq(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const bf16_t* __restrict__ o,
                                                      const float* __restrict__ lse, float* __restrict__ delta, int B, int S, int H,
                                                      float scale, bf16_t* __restrict__ dqkv, Drop drop = Drop()) {
     constexpr int KK = HD / 16, NB = HD / 32;
