@@ -192,44 +192,62 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ x, int
                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                 bf16_t* __restrict__ y, float* __restrict__ y32, float* __restrict__ mean,
                                                 float* __restrict__ rstd, int rows, int D, float eps) {
+    constexpr int R = NV <= 4 ? 2 : 1;       // rows per wave, loaded together: one row per wave is a chain of exposed round trips
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const float* xr = x + (size_t)(row_map ? row_map[row] : row) * ldx;
-    float4 v[NV];
-    float s = 0.f;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (row0 >= rows) return;
+    float4 v[R][NV], g[NV], bt[NV];
 #pragma unroll
-    for (int it = 0; it < NV; it++) {
-        const int c = lane * 4 + it * 256;
-        if (c < D) {
-            v[it] = *reinterpret_cast<const float4*>(xr + c);
-            s += v[it].x + v[it].y + v[it].z + v[it].w;
+    for (int r = 0; r < R; r++) {
+        const int row = min(row0 + r, rows - 1);
+        const float* xr = x + (size_t)(row_map ? row_map[row] : row) * ldx;
+#pragma unroll
+        for (int it = 0; it < NV; it++) {
+            const int c = lane * 4 + it * 256;
+            v[r][it] = c < D ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0, 0, 0, 0);
         }
     }
-    const float mu = wave_sum(s) / D;
-    float q = 0.f;
 #pragma unroll
-    for (int it = 0; it < NV; it++) {
+    for (int it = 0; it < NV; it++) {        // affine parameters fetched with the rows, not after the reductions
         const int c = lane * 4 + it * 256;
-        if (c < D) {
-            const float a = v[it].x - mu, b = v[it].y - mu, cc_ = v[it].z - mu, d = v[it].w - mu;
-            q += a * a + b * b + cc_ * cc_ + d * d;
+        g[it] = c < D ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(0, 0, 0, 0);
+        bt[it] = c < D ? *reinterpret_cast<const float4*>(beta + c) : make_float4(0, 0, 0, 0);
+    }
+    float mu[R], rs[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        float s = 0.f;
+#pragma unroll
+        for (int it = 0; it < NV; it++) s += v[r][it].x + v[r][it].y + v[r][it].z + v[r][it].w;
+        mu[r] = wave_sum(s) / D;
+        float q = 0.f;
+#pragma unroll
+        for (int it = 0; it < NV; it++) {
+            const int c = lane * 4 + it * 256;
+            if (c < D) {
+                const float a = v[r][it].x - mu[r], b = v[r][it].y - mu[r], cc_ = v[r][it].z - mu[r], d = v[r][it].w - mu[r];
+                q += a * a + b * b + cc_ * cc_ + d * d;
+            }
         }
-    }
-    const float rs = rsqrtf(wave_sum(q) / D + eps);
-    if (lane == 0) {
-        if (mean) mean[row] = mu;
-        if (rstd) rstd[row] = rs;
+        rs[r] = rsqrtf(wave_sum(q) / D + eps);
     }
 #pragma unroll
-    for (int it = 0; it < NV; it++) {
-        const int c = lane * 4 + it * 256;
-        if (c < D) {
-            const float4 g = *reinterpret_cast<const float4*>(gamma + c), b = *reinterpret_cast<const float4*>(beta + c);
-            const float o0 = (v[it].x - mu) * rs * g.x + b.x, o1 = (v[it].y - mu) * rs * g.y + b.y;
-            const float o2 = (v[it].z - mu) * rs * g.z + b.z, o3 = (v[it].w - mu) * rs * g.w + b.w;
-            if (y) *reinterpret_cast<uint2*>(y + (size_t)row * D + c) = make_uint2(pack2bf(o0, o1), pack2bf(o2, o3));
-            if (y32) *reinterpret_cast<float4*>(y32 + (size_t)row * D + c) = make_float4(o0, o1, o2, o3);
+    for (int r = 0; r < R; r++) {
+        const int row = row0 + r;
+        if (row >= rows) break;
+        if (lane == 0) {
+            if (mean) mean[row] = mu[r];
+            if (rstd) rstd[row] = rs[r];
+        }
+#pragma unroll
+        for (int it = 0; it < NV; it++) {
+            const int c = lane * 4 + it * 256;
+            if (c < D) {
+                const float o0 = (v[r][it].x - mu[r]) * rs[r] * g[it].x + bt[it].x, o1 = (v[r][it].y - mu[r]) * rs[r] * g[it].y + bt[it].y;
+                const float o2 = (v[r][it].z - mu[r]) * rs[r] * g[it].z + bt[it].z, o3 = (v[r][it].w - mu[r]) * rs[r] * g[it].w + bt[it].w;
+                if (y) *reinterpret_cast<uint2*>(y + (size_t)row * D + c) = make_uint2(pack2bf(o0, o1), pack2bf(o2, o3));
+                if (y32) *reinterpret_cast<float4*>(y32 + (size_t)row * D + c) = make_float4(o0, o1, o2, o3);
+            }
         }
     }
 }
@@ -237,7 +255,8 @@ int ln_fwd(const float* x, int ldx, const int* row_map, const float* gamma, cons
            float* mean, float* rstd, int rows, int D, hipStream_t st) {
     if (D > LN_MAXV * 256 || (D & 3) || (ldx & 3)) return CC_ERR_SHAPE;
     if (rows <= 0) return CC_OK;
-    const dim3 gr((rows + 3) / 4);
+    const int rpb = D <= 1024 ? 8 : 4;      // rows per block: 4 waves x (2 rows for NV <= 4, else 1)
+    const dim3 gr((rows + rpb - 1) / rpb);
 #define LN_FWD(NV) hipLaunchKernelGGL(k_ln_fwd<NV>, gr, dim3(256), 0, st, x, ldx, row_map, gamma, beta, y, y32, mean, rstd, rows, D, 1e-5f)
     if (D <= 256) LN_FWD(1); else if (D <= 512) LN_FWD(2); else if (D <= 768) LN_FWD(3); else if (D <= 1024) LN_FWD(4); else LN_FWD(LN_MAXV);
 #undef LN_FWD
