@@ -74,6 +74,7 @@ SIGNATURES = {
     "cc_wgrad_scratch_bytes": (_L, []),
     "cc_gemm_wgrad": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _P]),
     "cc_gemm_tile_mode": (_I, [_I]),
+    "cc_gemm_skinny_mode": (_I, [_I]),
     "cc_gemm_bf16_f32": (_I, [_I, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P]),
     "cc_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "cc_attention_fwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),

@@ -742,6 +742,12 @@ int cc_gemm_tile_mode(int32_t mode) {
     return old;
 }
 
+int cc_gemm_skinny_mode(int32_t mode) {
+    const int old = g_gemm_s64;
+    g_gemm_s64 = mode;
+    return old;
+}
+
 int cc_layernorm_fwd(const float* x, const float* gamma, const float* beta, uint16_t* y, float* mean, float* rstd, int32_t rows, int32_t D,
                      void* stream) {
     if (!x || !gamma || !beta || !y) return CC_ERR_ARG;

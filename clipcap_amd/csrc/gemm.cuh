@@ -136,14 +136,14 @@ template <class E> struct epi_strip_aux<E, decltype((void)sizeof(typename E::Str
 // ---- epilogue: wave-private LDS strip [16][68] fp32; C layout of 16x16x32: col = lane&15, row = (lane>>4)*4 + reg.
 // Every lane ends up with 8 consecutive columns of one row -> vector epilogue.  Caller must have passed a barrier
 // after the last LDS read of the main loop.
-template <class Epi>
+template <class Epi, int I0 = 0, int I1 = 4>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[4][4], char* smem, int wave, int lane, int row0, int col0, const Epi& epi) {
     float* strip = reinterpret_cast<float*>(smem) + wave * (16 * G_EPI_LD);
     const int er = (lane >> 4) * 4, ec = lane & 15;
     if constexpr (epi_strip_aux<Epi>::value) {
         typename Epi::StripAux aux[4][2];
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = I0; i < I1; i++)
 #pragma unroll
             for (int s = 0; s < 2; s++) {
                 const int q = lane + 64 * s;
@@ -151,7 +151,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[4][4], char* smem, in
             }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = I0; i < I1; i++) {
 #pragma unroll
             for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -170,7 +170,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[4][4], char* smem, in
         return;
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = I0; i < I1; i++) {
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -478,6 +478,222 @@ __global__ __launch_bounds__(G_THREADS, 1) void gemm_nt_glds4_kernel(const bf16_
 #undef G4_ISSUE
     __syncthreads();
     gemm_epilogue(acc, smem4, wave, lane, m0 + wm * 64, n0 + wn * 64, epi);
+}
+
+// Small-grid kernel, 8-wave form: the same 128 x 128 tile and 4-stage DMA pipeline, but the two 32-k halves of every K-tile go to
+// two wave groups (waves 0-3 / 4-7, same 64 x 64 wave tiles).  With one block per CU the 4-wave kernel has ONE wave per SIMD, so
+// every fragment read and MFMA chain is exposed; here each SIMD holds two waves with half the per-tile work each, and the DMA issue
+// (4 instead of 8 instructions per wave and tile pair) is spread over twice the waves.  The groups' partial sums are exchanged
+// through LDS after the loop (group 1 hands over row strips 0-1, group 0 strips 2-3) and both groups run half of the epilogue.
+template <class Epi>
+__global__ __launch_bounds__(2 * G_THREADS, 1) void gemm_nt_glds4x2_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                                            GemmShape g, Epi epi) {
+    extern __shared__ __attribute__((aligned(1024))) char smem4[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, w4 = wave & 3;
+    const int wm = w4 >> 1, wn = w4 & 1;
+    const int tiles_n = (g.N + G_BN - 1) / G_BN, tiles_m = (g.M + G_BM - 1) / G_BM;
+    int tm, tn;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, g.group_m, tm, tn);
+    const int m0 = tm * G_BM, n0 = tn * G_BN;
+    const int kbeg = blockIdx.z * g.k_chunk;
+    const int nk = (min(g.K, kbeg + g.k_chunk) - kbeg) / G_BK;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // group 0 streams the A tile, group 1 the B tile: 4 DMA instructions per wave and K-tile
+#define G4_ISSUE(T)                                                                                                      \
+    {                                                                                                                    \
+        char* st_ = smem4 + ((T) & 3) * 2 * G_TILE_BYTES;                                                                \
+        if (grp == 0) glds_tile(A, g.lda, g.M, m0, kbeg + (T)*G_BK, st_, w4, lane);                                      \
+        else glds_tile(B, g.ldb, g.N, n0, kbeg + (T)*G_BK, st_ + G_TILE_BYTES, w4, lane);                                \
+    }
+    G4_ISSUE(0);
+    if (nk > 1) G4_ISSUE(1);
+    if (nk > 2) G4_ISSUE(2);
+    const int frow = lane & 15, fchunk = lane >> 4;
+    for (int kt = 0; kt < nk; kt++) {
+        const int rem = min(nk - 1, kt + 2) - kt;
+        if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 3 < nk) G4_ISSUE(kt + 3);
+        const char* cur = smem4 + (kt & 3) * 2 * G_TILE_BYTES;
+        bf16x8 af[4], bfr[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) af[i] = *reinterpret_cast<const bf16x8*>(cur + g_lds_off(wm * 64 + i * 16 + frow, grp * 4 + fchunk));
+#pragma unroll
+        for (int j = 0; j < 4; j++) bfr[j] = *reinterpret_cast<const bf16x8*>(cur + G_TILE_BYTES + g_lds_off(wn * 64 + j * 16 + frow, grp * 4 + fchunk));
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+#undef G4_ISSUE
+    __syncthreads();
+    // exchange: 8 float4 per thread each way, [tile][thread] so that a wave's ds_write/read_b128 is contiguous
+    f32x4* xch = reinterpret_cast<f32x4*>(smem4 + 4 * 2 * G_TILE_BYTES / 2) + grp * (8 * G_THREADS) + (tid & (G_THREADS - 1));
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) xch[(i * 4 + j) * G_THREADS] = grp ? acc[i][j] : acc[2 + i][j];
+    __syncthreads();
+    const f32x4* xin = reinterpret_cast<const f32x4*>(smem4 + 4 * 2 * G_TILE_BYTES / 2) + (grp ^ 1) * (8 * G_THREADS) + (tid & (G_THREADS - 1));
+    if (grp == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] += xin[(i * 4 + j) * G_THREADS];
+        gemm_epilogue<Epi, 0, 2>(acc, smem4, wave, lane, m0 + wm * 64, n0 + wn * 64, epi);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[2 + i][j] += xin[(i * 4 + j) * G_THREADS];
+        gemm_epilogue<Epi, 2, 4>(acc, smem4, wave, lane, m0 + wm * 64, n0 + wn * 64, epi);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Skinny NT kernel for decode-sized M (a few hundred rows): block tile 64 x (64 NJ), 4 waves as 2 x 2, wave tile 32 x 32 NJ on
+// v_mfma_f32_32x32x16_bf16.  Why not the 128 x 128 kernels: at M = 320 they give 24-96 blocks, and ONE block's K-step is bound by
+// what a single CU can move — 32 KiB L2->LDS (64 B/clk) plus 64 KiB of fragment reads through its LDS (128 B/clk) ~ 1200 clk per
+// 64-k step, independent of M (measured 0.59 us per step for M = 64 ... 320).  Here a K-step moves 16 KiB (NJ = 1) into LDS and
+// reads 16 KiB of fragments (a 32 x 32 x 16 MFMA needs half the operand bytes per flop of the 16 x 16 x 32 form), M = 320 is
+// exactly 5 row tiles, and the grid has 2.5-5x the blocks, two of them co-resident per CU.  Same LDS image as glds_tile (128-B
+// rows, the XOR key is also conflict-free for the 32-row x 2-chunk fragment pattern), NS-stage DMA pipeline with counted vmcnt.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+template <int ROWS>
+__device__ __forceinline__ void glds_rows(const bf16_t* __restrict__ base, int ld, int rows, int r0, int k0, char* lds, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; i++) {                   // ROWS / 8 segments of 1 KiB (8 rows x 128 B); wave w takes w, w+4, ...
+        const int seg = wave + 4 * i;
+        const int row = seg * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7) ^ ((row >> 4) & 3);
+        const int gr = min(r0 + row, rows - 1);
+        const bf16_t* src = base + (size_t)gr * ld + k0 + chunk * 8;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + seg * 1024), 16, 0, 0);
+    }
+}
+template <int N> __device__ __forceinline__ void s_wait_vm() {
+    // s_waitcnt vmcnt(N) only: gfx9 encoding vmcnt = imm[3:0] | imm[15:14], expcnt imm[6:4] and lgkmcnt imm[11:8] left at "don't wait"
+    __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
+    asm volatile("" ::: "memory");
+}
+// KG = 2: eight waves, the two 32-k halves of a K-tile go to two wave groups (same 2 x 2 wave tiles), which halves each wave's
+// serial chain per K-step (DMA issue, fragment reads, MFMAs); the groups swap half of their partial sums through LDS at the end and
+// each finishes 16 of the wave tile's 32 rows.
+template <int ROWS_A, int ROWS_B, int W>
+__device__ __forceinline__ void glds_pair(const bf16_t* __restrict__ A, int lda, int M, int m0, const bf16_t* __restrict__ B, int ldb, int N, int n0,
+                                          int k0, char* lds, int wave, int lane) {
+    // (ROWS_A + ROWS_B) / 8 segments of 1 KiB (8 rows x 128 B), A's first; wave w of W takes w, w + W, ...
+#pragma unroll
+    for (int i = 0; i < (ROWS_A + ROWS_B) / 8 / W; i++) {
+        const bool is_a = W * i < ROWS_A / 8;                 // compile-time: W divides ROWS_A / 8
+        const int seg = wave + W * i - (is_a ? 0 : ROWS_A / 8);
+        const int row = seg * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7) ^ ((row >> 4) & 3);
+        const bf16_t* src = is_a ? A + (size_t)min(m0 + row, M - 1) * lda + k0 + chunk * 8 : B + (size_t)min(n0 + row, N - 1) * ldb + k0 + chunk * 8;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + (is_a ? 0 : ROWS_A * 128) + seg * 1024), 16, 0, 0);
+    }
+}
+template <class Epi, int NJ, int NS, int KG>
+__global__ __launch_bounds__(G_THREADS * KG, (NS * (64 + 64 * NJ) * 128 <= 80 * 1024) ? 2 : 1) void gemm_nt_s64_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, GemmShape g, Epi epi) {
+    extern __shared__ __attribute__((aligned(1024))) char sm64[];
+    constexpr int BN = 64 * NJ, STAGE = (64 + BN) * 128, W = 4 * KG, P = (8 + 8 * NJ) / W;    // P: DMA instructions per wave and K-tile
+    static_assert(NS >= 3 && NS <= 8 && (KG == 1 || KG == 2) && (NS - 2) * P < 64, "stage count / groups");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, w4 = wave & 3;
+    const int wm = w4 >> 1, wn = w4 & 1;
+    const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + 63) / 64;
+    int tm, tn;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, g.group_m, tm, tn);
+    const int m0 = tm * 64, n0 = tn * BN;
+    const int kbeg = blockIdx.z * g.k_chunk;
+    const int nk = (min(g.K, kbeg + g.k_chunk) - kbeg) / G_BK;
+    f32x16 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+#define S64_ISSUE(T, SLOT) glds_pair<64, BN, W>(A, g.lda, g.M, m0, B, g.ldb, g.N, n0, kbeg + (T)*G_BK, sm64 + (SLOT) * STAGE, wave, lane)
+#pragma unroll
+    for (int t = 0; t < NS - 1; t++)
+        if (t < nk) S64_ISSUE(t, t);
+    const int frow = lane & 31, fhalf = lane >> 5;
+    int slot = 0, islot = NS - 1;
+    for (int kt = 0; kt < nk; kt++) {
+        // tile kt must have landed; up to NS-2 later tiles (P DMA instructions per wave each) stay in flight
+        const int rem = min(nk - 1, kt + NS - 2) - kt;
+        if (rem >= 6) s_wait_vm<(NS > 7 ? 6 : 0) * P>();
+        else if (rem == 5) s_wait_vm<(NS > 6 ? 5 : 0) * P>();
+        else if (rem == 4) s_wait_vm<(NS > 5 ? 4 : 0) * P>();
+        else if (rem == 3) s_wait_vm<(NS > 4 ? 3 : 0) * P>();
+        else if (rem == 2) s_wait_vm<(NS > 3 ? 2 : 0) * P>();
+        else if (rem == 1) s_wait_vm<P>();
+        else s_wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + NS - 1 < nk) S64_ISSUE(kt + NS - 1, islot);      // that slot held tile kt-1: every wave is past it
+        const char* cur = sm64 + slot * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 4 / KG; kk++) {
+            const int ch = (grp * (4 / KG) + kk) * 2 + fhalf;
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(cur + g_lds_off(wm * 32 + frow, ch));
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(cur + 64 * 128 + g_lds_off(wn * 32 * NJ + j * 32 + frow, ch));
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+            }
+        }
+        slot = slot + 1 == NS ? 0 : slot + 1;
+        islot = islot + 1 == NS ? 0 : islot + 1;
+    }
+#undef S64_ISSUE
+    __syncthreads();
+    // accumulator (row = 8 (r>>2) + 4 (lane>>5) + (r&3), col = lane&31) -> wave-private LDS strip -> 8 consecutive columns per lane
+    constexpr int SLD = 32 * NJ + 4, CG = 4 * NJ, RPP = 64 / CG;
+    if constexpr (KG == 2) {
+        // group 1 hands over rows 0-15 (registers 0-7), group 0 rows 16-31 (registers 8-15): [reg][thread] float2 pairs
+        float* xo = reinterpret_cast<float*>(sm64 + 32768) + grp * (8 * NJ * G_THREADS) + (tid & (G_THREADS - 1));
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+            for (int r = 0; r < 8; r++) xo[(j * 8 + r) * G_THREADS] = acc[j][grp ? r : 8 + r];
+        __syncthreads();
+        const float* xi = reinterpret_cast<const float*>(sm64 + 32768) + (grp ^ 1) * (8 * NJ * G_THREADS) + (tid & (G_THREADS - 1));
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const float o = xi[(j * 8 + r) * G_THREADS];
+                if (grp) acc[j][8 + r] += o; else acc[j][r] += o;
+            }
+    }
+    float* strip = reinterpret_cast<float*>(sm64) + wave * (32 * SLD);
+    constexpr int R0 = 0, RN = 16 / KG;                 // registers this wave finishes: [8 grp, 8 grp + RN) for KG = 2, all 16 otherwise
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+#pragma unroll
+        for (int rr = R0; rr < RN; rr++) {
+            const int r = (KG == 2 ? 8 * grp : 0) + rr;
+            float val;
+            if constexpr (KG == 2) val = grp ? acc[j][8 + rr] : acc[j][rr]; else val = acc[j][rr];
+            strip[((r >> 2) * 8 + fhalf * 4 + (r & 3)) * SLD + j * 32 + frow] = val;
+        }
+#pragma unroll
+    for (int ps = 0; ps < 32 / RPP / KG; ps++) {
+        const int lr = (KG == 2 ? 16 * grp : 0) + ps * RPP + lane / CG, c8 = lane % CG;
+        const float4 x = *reinterpret_cast<const float4*>(strip + lr * SLD + c8 * 8);
+        const float4 y = *reinterpret_cast<const float4*>(strip + lr * SLD + c8 * 8 + 4);
+        float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+        epi(m0 + wm * 32 + lr, n0 + wn * 32 * NJ + c8 * 8, v);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1054,6 +1270,9 @@ template <> struct epi_row_strip<EpiLMHead> { static constexpr bool value = true
 // Host launcher
 // ------------------------------------------------------------------------------------------------
 template <class Epi>
+inline int launch_gemm_s64(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, int ksplit, int nj, const Epi& epi, int* ks_eff,
+                           hipStream_t st);
+template <class Epi>
 inline int launch_gemm(int al, int bl, const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K,
                        int ksplit, const Epi& epi, hipStream_t st) {
     if (M <= 0 || N <= 0 || K <= 0) return CC_OK;
@@ -1062,6 +1281,10 @@ inline int launch_gemm(int al, int bl, const bf16_t* A, int lda, const bf16_t* B
     if (bl == 0 && (K & 7)) return CC_ERR_SHAPE;
     if (al == 1 && (M & 7)) return CC_ERR_SHAPE;
     if (bl == 1 && (N & 7)) return CC_ERR_SHAPE;
+    if constexpr (!std::is_same<Epi, EpiLMHead>::value && !epi_strip_aux<Epi>::value) {
+        if (g_gemm_s64 > 0 && al == 0 && bl == 0 && (K % G_BK) == 0 && M <= 1024)     // tools/small_gemm_bench.py (CC_GEMM_S64 = 1 / 2)
+            return launch_gemm_s64(A, lda, B, ldb, M, N, K, ksplit, g_gemm_s64, epi, nullptr, st);
+    }
     GemmShape g;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
     static const int env_group = []() { const char* e = getenv("CC_GROUP_M"); return e ? atoi(e) : 0; }();
@@ -1113,8 +1336,13 @@ inline int launch_gemm(int al, int bl, const bf16_t* A, int lda, const bf16_t* B
         // at most one block per CU: nothing co-resident to hide the 2-stage kernel's per-K-step round trip -> 4-stage variant
         constexpr size_t sh4 = (size_t)8 * G_TILE_BYTES;
         static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_glds4_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh4); attr = true; }
-        hipLaunchKernelGGL((gemm_nt_glds4_kernel<Epi>), grid, dim3(G_THREADS), sh4, st, A, B, g, epi);
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)gemm_nt_glds4_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh4);
+            (void)hipFuncSetAttribute((const void*)gemm_nt_glds4x2_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh4);
+            attr = true;
+        }
+        if (g_gemm_small_x2) hipLaunchKernelGGL((gemm_nt_glds4x2_kernel<Epi>), grid, dim3(2 * G_THREADS), sh4, st, A, B, g, epi);
+        else hipLaunchKernelGGL((gemm_nt_glds4_kernel<Epi>), grid, dim3(G_THREADS), sh4, st, A, B, g, epi);
     } else if (al == 0 && bl == 0 && (K % G_BK) == 0)
         hipLaunchKernelGGL((gemm_nt_glds_kernel<Epi>), grid, dim3(G_THREADS), 0, st, A, B, g, epi);
     else if (al == 0 && bl == 0)
@@ -1125,6 +1353,35 @@ inline int launch_gemm(int al, int bl, const bf16_t* A, int lda, const bf16_t* B
         hipLaunchKernelGGL((gemm_bf16_kernel<1, 1, Epi>), grid, dim3(G_THREADS), 0, st, A, B, g, epi);
     else
         return CC_ERR_ARG;
+    return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+}
+
+// Skinny NT launcher (gemm_nt_s64_kernel): K % 64 == 0; nj = 1 (64 x 64 tiles) or 2 (64 x 128); K split over blockIdx.z
+// (epi must be an EpiF32 in slab mode when ksplit > 1).  *ks_eff returns the effective slice count.
+template <class Epi>
+inline int launch_gemm_s64(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, int ksplit, int nj, const Epi& epi, int* ks_eff,
+                           hipStream_t st) {
+    if ((K % G_BK) || (lda & 7) || (ldb & 7) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return CC_ERR_SHAPE;
+    GemmShape g;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
+    g.group_m = 8;
+    if (ksplit < 1) ksplit = 1;
+    const int kt = K / G_BK;
+    const int per = (kt + ksplit - 1) / ksplit;
+    ksplit = (kt + per - 1) / per;
+    g.k_chunk = per * G_BK;
+    if (ks_eff) *ks_eff = ksplit;
+    const int tm = (M + 63) / 64;
+#define S64_LAUNCH(NJ_, NS_, KG_)                                                                                        \
+    {                                                                                                                    \
+        constexpr size_t sh = (size_t)(NS_) * (64 + 64 * (NJ_)) * 128;                                                   \
+        static bool attr = false;                                                                                        \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_s64_kernel<Epi, NJ_, NS_, KG_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr = true; } \
+        hipLaunchKernelGGL((gemm_nt_s64_kernel<Epi, NJ_, NS_, KG_>), dim3((unsigned)(tm * ((N + 64 * (NJ_) - 1) / (64 * (NJ_)))), 1, (unsigned)ksplit), \
+                           dim3(G_THREADS * (KG_)), sh, st, A, B, g, epi);                                               \
+    }
+    if (nj == 2) S64_LAUNCH(2, 3, 1) else S64_LAUNCH(1, 4, 1)
+#undef S64_LAUNCH
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
 

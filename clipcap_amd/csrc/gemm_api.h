@@ -6,6 +6,8 @@ namespace cc {
 // NT tile choice: -1 chooser (default; CC_GEMM_S256 in the environment presets it), 0 = 128 x 128 only, 3 / 4 = force the
 // 256 x 192 / 256 x 256 kernel wherever it is legal.  Test / microbenchmark hook (cc_gemm_tile_mode).
 extern int g_gemm_tile_mode;
+extern int g_gemm_s64;        // > 0: route NT GEMMs with M <= 1024 through the 64-row skinny kernel (bench hook, env CC_GEMM_S64)
+extern int g_gemm_small_x2;   // small-grid NT GEMMs on the 8-wave kernel (env CC_GEMM_X2, default 1)
 // al/bl: 0 = K-contiguous operand ([rows][K]), 1 = K-strided operand ([K][rows]).  See gemm.cuh.
 int gemm_bf16out(int al, int bl, const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, bf16_t* C, int ldc,
                  const float* bias, int act, bf16_t* pre, hipStream_t st);

@@ -5,6 +5,8 @@
 #include "gemm_api.h"
 namespace cc {
 int g_gemm_tile_mode = []() { const char* e = getenv("CC_GEMM_S256"); return e ? atoi(e) : -1; }();
+int g_gemm_s64 = []() { const char* e = getenv("CC_GEMM_S64"); return e ? atoi(e) : -1; }();
+int g_gemm_small_x2 = []() { const char* e = getenv("CC_GEMM_X2"); return e ? atoi(e) : 1; }();
 int gemm_f32out(int al, int bl, const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, float* C, int ldc,
                 const float* bias, int mode, float alpha, int ksplit, hipStream_t st) {
     if ((ldc & 3) || (N & 7)) return CC_ERR_SHAPE;
@@ -246,18 +248,35 @@ int gemm_nt_skinny(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, in
                    float* out32, bf16_t* out16, int ldo, float* scratch, size_t scratch_bytes, hipStream_t st, const SkinnyFuse* fuse) {
     if ((N & 7) || (ldo & 7)) return CC_ERR_SHAPE;
     const int tiles = ((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
-    int ks = 384 / (tiles > 0 ? tiles : 1);
-    const int kmax = K / (2 * G_BK);                       // at least 2 K-steps per slice
-    if (ks > kmax) ks = kmax;
-    if (ks < 1) ks = 1;
     const size_t slab = (size_t)M * N;
     const bool can_slab = scratch && slab && (K % G_BK) == 0 && scratch_bytes >= slab * sizeof(float);
-    if (can_slab) { const size_t fit = scratch_bytes / (slab * sizeof(float)); if ((size_t)ks > fit) ks = (int)fit; }
     const bool fused = fuse && (fuse->ln_out16 || fuse->kcache);
-    // wide-enough grids go single-pass with the epilogue fused into the GEMM (4-stage small-grid kernel): one launch instead of two
-    if (!fused && tiles >= skinny_single_min_tiles()) ks = 1;
+    // decode-sized M: 64 x 64 tiles (gemm_nt_s64_kernel) put 2.5-5x the blocks on the chip; a block's K loop is bound by what one CU
+    // can pull through its L2->LDS path (~57 GB/s measured), so the job is to have every CU pulling
+    const bool s64 = g_gemm_s64 != 0 && (K % G_BK) == 0 && M <= 640 && tiles <= 256 && (lda & 7) == 0 && (ldb & 7) == 0;
+    int ks;
+    if (s64) {
+        const int t64 = ((M + 63) / 64) * ((N + 63) / 64);
+        ks = t64 >= 160 ? 1 : 256 / t64;                    // K slices only while they add blocks up to one per CU
+        const int kmax = K / (4 * G_BK);
+        if (ks > kmax) ks = kmax;
+    } else {
+        ks = 384 / (tiles > 0 ? tiles : 1);
+        const int kmax = K / (2 * G_BK);                    // at least 2 K-steps per slice
+        if (ks > kmax) ks = kmax;
+        // wide-enough grids go single-pass with the epilogue fused into the GEMM (4-stage small-grid kernel): one launch instead of two
+        if (!fused && tiles >= skinny_single_min_tiles()) ks = 1;
+    }
+    if (ks < 1) ks = 1;
+    if (can_slab) { const size_t fit = scratch_bytes / (slab * sizeof(float)); if ((size_t)ks > fit) ks = (int)fit; }
     if (!can_slab || (ks <= 1 && !fused)) {
         if (fused) return CC_ERR_SHAPE;                    // callers only request fusion when the slab path is available
+        if (s64) {
+            if (res) { EpiResid e{out32, res, bias, ldo, M, N}; return launch_gemm_s64(A, lda, B, ldb, M, N, K, 1, 1, e, nullptr, st); }
+            if (out16) { EpiBF16 e{out16, nullptr, bias, ldo, M, N, act}; return launch_gemm_s64(A, lda, B, ldb, M, N, K, 1, 1, e, nullptr, st); }
+            EpiF32 e{out32, bias, ldo, M, N, 0, 1.0f};
+            return launch_gemm_s64(A, lda, B, ldb, M, N, K, 1, 1, e, nullptr, st);
+        }
         if (res) { EpiResid e{out32, res, bias, ldo, M, N}; return launch_gemm(0, 0, A, lda, B, ldb, M, N, K, 1, e, st); }
         if (out16) { EpiBF16 e{out16, nullptr, bias, ldo, M, N, act}; return launch_gemm(0, 0, A, lda, B, ldb, M, N, K, 1, e, st); }
         EpiF32 e{out32, bias, ldo, M, N, 0, 1.0f};
@@ -265,7 +284,7 @@ int gemm_nt_skinny(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, in
     }
     EpiF32 e{scratch, nullptr, N, M, N, 3, 1.0f};
     e.zstride = slab;
-    int rc = launch_gemm(0, 0, A, lda, B, ldb, M, N, K, ks, e, st);
+    int rc = s64 ? launch_gemm_s64(A, lda, B, ldb, M, N, K, ks, 1, e, nullptr, st) : launch_gemm(0, 0, A, lda, B, ldb, M, N, K, ks, e, st);
     if (rc != CC_OK) return rc;
     const int kt = K / G_BK, per = (kt + ks - 1) / ks, ks_eff = (kt + per - 1) / per;
     if (N <= 3072 && (N & 3) == 0) {

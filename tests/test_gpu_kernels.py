@@ -68,6 +68,32 @@ def test_gemm_nt_256_row_tiles(mode, M, N, K):
     assert torch.isnan(Cm[:, N:]).all()
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("M,N,K,ks", [(320, 1024, 1024, 1), (320, 3072, 1024, 1), (5, 2304, 768, 3), (333, 1000, 256, 1), (64, 64, 64, 1),
+                                      (640, 4096, 1024, 1), (77, 200, 4096, 6), (1, 8, 128, 2)])
+def test_gemm_nt_skinny_64_row_tiles(mode, M, N, K, ks):
+    """the 64 x 64 / 64 x 128 decode-sized NT kernels (32x32x16 MFMA), single pass and with K slices (atomic accumulation into a
+    non-zero C), ragged M / N edges and a padded leading dimension"""
+    torch.manual_seed(M + N + K + mode)
+    dev = "cuda"
+    A = _bf(torch.randn(M, K, device=dev))
+    Bt = _bf(torch.randn(N, K, device=dev) * 0.5 + 0.1)
+    bias = torch.randn(N, device=dev)
+    C0 = torch.randn(M, N + 8, device=dev)
+    ref = A.float() @ Bt.float().t() + (bias if ks == 1 else C0[:, :N])
+    Cm = C0.clone()
+    old = _lib().cc_gemm_skinny_mode(mode)
+    try:
+        rc = _lib().cc_gemm_bf16_f32(0, 0, _p(A), K, _p(Bt), K, M, N, K, _p(Cm), N + 8, _p(bias), ks, _st())
+        torch.cuda.synchronize()
+    finally:
+        _lib().cc_gemm_skinny_mode(old)
+    assert rc == 0
+    err = (Cm[:, :N] - ref).abs().max().item()
+    assert err <= 2e-3 * max(1.0, ref.abs().max().item() / 10), err
+    assert torch.equal(Cm[:, N:], C0[:, N:])
+
+
 @pytest.mark.parametrize("mode", [4, 0, -1])
 @pytest.mark.parametrize("K,Mw,Nw", [(5120, 768, 1536), (1024, 264, 200), (96, 8, 8), (2080, 520, 776), (12800, 768, 768), (1237, 192, 264)])
 def test_gemm_wgrad_kernels(mode, K, Mw, Nw):
