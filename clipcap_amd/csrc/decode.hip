@@ -65,19 +65,52 @@ __global__ __launch_bounds__(256) void k_decode_attn(const bf16_t* __restrict__ 
     const bf16_t* knew = qkv + (size_t)r * Tn * 3 * D + D + h * hd;        // K of new position u: knew + u * 3D  (V: + D)
     for (int j = lane; j < nkeys; j += 64) srow[j] = row_map ? row_map[(size_t)j * R + r] : r;
     float m = -INFINITY;
-    for (int j = lane; j < nkeys; j += 64) {
-        float s = 0.f;
-        const bf16_t* krow = (APPEND && j >= pos0) ? knew + (size_t)(j - pos0) * 3 * D : kb + ((size_t)srow[j] * ctx_max + j) * D;
-        for (int d = 0; d < hd; d += 8) {
-            float a[8], b[8];
-            unpack8(*reinterpret_cast<const uint4*>(q + d), a);
-            unpack8(*reinterpret_cast<const uint4*>(krow + d), b);
+    const int nchunk = hd >> 3;
+    if ((nchunk & (nchunk - 1)) == 0 && nchunk <= 16) {
+        // lane = (key group, 16-B chunk of the head slice): one load instruction covers 64 / nchunk whole K rows (full 128-B lines for
+        // hd = 64) instead of 16 B of 64 different rows, SC_U of them in flight; the chunk dot products meet by xor-shuffles
+        constexpr int SC_U = 4;
+        const int kgs = 64 / nchunk, skg = lane / nchunk, sdc = lane - skg * nchunk;
+        float qf[8];
+        unpack8(*reinterpret_cast<const uint4*>(q + sdc * 8), qf);
+        for (int j0 = 0; j0 < nkeys; j0 += kgs * SC_U) {
+            uint4 kv[SC_U];
 #pragma unroll
-            for (int e = 0; e < 8; e++) s += a[e] * b[e];
+            for (int u = 0; u < SC_U; u++) {
+                const int j = min(j0 + u * kgs + skg, nkeys - 1);
+                const bf16_t* krow = (APPEND && j >= pos0) ? knew + (size_t)(j - pos0) * 3 * D : kb + ((size_t)srow[j] * ctx_max + j) * D;
+                kv[u] = *reinterpret_cast<const uint4*>(krow + sdc * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < SC_U; u++) {
+                float b[8], sc = 0.f;
+                unpack8(kv[u], b);
+#pragma unroll
+                for (int e = 0; e < 8; e++) sc += qf[e] * b[e];
+                for (int o = 1; o < nchunk; o <<= 1) sc += __shfl_xor(sc, o);
+                sc *= scale;
+                const int j = j0 + u * kgs + skg;
+                if (j < nkeys) {
+                    if (sdc == 0) p[j] = sc;
+                    m = fmaxf(m, sc);
+                }
+            }
         }
-        s *= scale;
-        p[j] = s;
-        m = fmaxf(m, s);
+    } else {
+        for (int j = lane; j < nkeys; j += 64) {
+            float s = 0.f;
+            const bf16_t* krow = (APPEND && j >= pos0) ? knew + (size_t)(j - pos0) * 3 * D : kb + ((size_t)srow[j] * ctx_max + j) * D;
+            for (int d = 0; d < hd; d += 8) {
+                float a[8], b[8];
+                unpack8(*reinterpret_cast<const uint4*>(q + d), a);
+                unpack8(*reinterpret_cast<const uint4*>(krow + d), b);
+#pragma unroll
+                for (int e = 0; e < 8; e++) s += a[e] * b[e];
+            }
+            s *= scale;
+            p[j] = s;
+            m = fmaxf(m, s);
+        }
     }
     m = wave_max(m);
     float sum = 0.f;
@@ -89,7 +122,7 @@ __global__ __launch_bounds__(256) void k_decode_attn(const bf16_t* __restrict__ 
     sum = wave_sum(sum);
     const float inv = 1.f / sum;
     // wave-private LDS: same-wave writes above are visible to the reads below (in-order DS queue)
-    const int nchunk = hd >> 3, kgroups = min(8, 64 / nchunk);
+    const int kgroups = min(8, 64 / nchunk);
     const int kg = lane / nchunk, dc = lane - kg * nchunk;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (kg < kgroups) {
