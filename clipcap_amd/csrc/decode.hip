@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void k_decode_attn(const bf16_t* __restrict__ 
     int* srow = reinterpret_cast<int*>(p + ctx_max);
     float* red = p + 2 * ctx_max;
     const bf16_t* q = qkv + ((size_t)r * Tn + t) * 3 * D + h * hd;
-    // position j of row r lives in cache row row_map[j*R + r] (beam ancestry table; identity when null)
+    // position j of row r lives in cache row row_map[r*ctx_max + j] (beam ancestry table; identity when null)
     const bf16_t* kb = kc + h * hd;
     const bf16_t* vb = vc + h * hd;
     if (APPEND) {
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void k_decode_attn(const bf16_t* __restrict__ 
         }
     }
     const bf16_t* knew = qkv + (size_t)r * Tn * 3 * D + D + h * hd;        // K of new position u: knew + u * 3D  (V: + D)
-    for (int j = lane; j < nkeys; j += 64) srow[j] = row_map ? row_map[(size_t)j * R + r] : r;
+    for (int j = lane; j < nkeys; j += 64) srow[j] = row_map ? row_map[(size_t)r * ctx_max + j] : r;
     float m = -INFINITY;
     const int nchunk = hd >> 3;
     if ((nchunk & (nchunk - 1)) == 0 && nchunk <= 16) {
@@ -258,8 +258,8 @@ __global__ __launch_bounds__(256) void k_beam_partial(const float* __restrict__ 
                                                       float* __restrict__ pval, int* __restrict__ pidx) {
     __shared__ float red[256];
     __shared__ int redi[256];
-    __shared__ float cval[256 * BEAM_MAX];
-    __shared__ int cidx[256 * BEAM_MAX];
+    __shared__ float cval[TB > 0 ? 1 : 256 * BEAM_MAX];          // candidate arrays: run-time-width fallback only
+    __shared__ int cidx[TB > 0 ? 1 : 256 * BEAM_MAX];
     __shared__ float sel_v[BEAM_MAX];
     __shared__ int sel_i[BEAM_MAX];
     constexpr int LB = TB > 0 ? TB : BEAM_MAX;
@@ -270,33 +270,120 @@ __global__ __launch_bounds__(256) void k_beam_partial(const float* __restrict__ 
     const int per = (total + BEAM_CHUNKS - 1) / BEAM_CHUNKS;
     const int lo = ch * per, hi = min(total, lo + per);
     const float* lg = logits + (size_t)s * beam * ldl;
-    float lv[LB];
-    int li[LB];
+    // a chunk (total / 16 candidates) spans at most two beam rows when V >= per; handled generally by walking row segments.
+    // scan(f): f(idx, v, seg, raw logit) for every candidate of the chunk, SU logits fetched per thread before any is looked at
+    struct Seg { bool st; float m, sum, lsum, sc, inv_len, len; };
+    auto scan = [&](auto&& f) {
+        for (int b = lo / V; b < nrows && b * V < hi; b++) {
+            const int seg_lo = max(lo, b * V), seg_hi = min(hi, (b + 1) * V);
+            Seg g;
+            g.st = !first && stopped[s * beam + b];
+            g.m = rs[2 * (s * beam + b)]; g.sum = rs[2 * (s * beam + b) + 1];
+            g.lsum = logf(g.sum);
+            g.sc = first ? 0.f : scores[s * beam + b];
+            g.len = first ? 1.f : (seq_len[s * beam + b] + (g.st ? 0.f : 1.f));
+            g.inv_len = 1.0f / g.len;
+            const float* row = lg + (size_t)b * ldl - (size_t)b * V;      // row[idx] = lg[b * ldl + (idx - b V)]
+            constexpr int SU = 8;
+            for (int idx0 = seg_lo + tid; idx0 < seg_hi; idx0 += 256 * SU) {
+                float xs[SU];
 #pragma unroll
-    for (int k = 0; k < LB; k++) { lv[k] = -INFINITY; li[k] = 0x7fffffff; }
-    // a chunk (total / 16 candidates) spans at most two beam rows when V >= per; handled generally by walking row segments
-    for (int b = lo / V; b < nrows && b * V < hi; b++) {
-        const int seg_lo = max(lo, b * V), seg_hi = min(hi, (b + 1) * V);
-        const bool st = !first && stopped[s * beam + b];
-        const float m = rs[2 * (s * beam + b)], sum = rs[2 * (s * beam + b) + 1];
-        const float lsum = logf(sum);
-        const float sc = first ? 0.f : scores[s * beam + b];
-        const float inv_len = first ? 1.f : 1.0f / (seq_len[s * beam + b] + (st ? 0.f : 1.f));
-        const float len = first ? 1.f : (seq_len[s * beam + b] + (st ? 0.f : 1.f));
-        const float* row = lg + (size_t)b * ldl - (size_t)b * V;      // row[idx] = lg[b * ldl + (idx - b V)]
-        for (int idx = seg_lo + tid; idx < seg_hi; idx += 256) {
-            const int v = idx - b * V;
-            float val;
-            if (st) {
-                val = (v == 0) ? (first ? 0.f : (sc + 0.f) / len) : -INFINITY;                               // base.py:96-101
-            } else {
-                const float x = row[idx] * inv_temp - m;
-                const float bound = first ? (x - lsum) : (sc + (x - lsum)) * inv_len;
-                const float worst = TB > 0 ? lv[LB - 1] : lv[beam - 1];
-                if (bound + 1e-3f < worst) continue;
-                const float lp = logf(expf(x) / sum);                                                        // softmax().log()
-                val = first ? lp : (sc + lp) / len;                                                          // base.py:99-101
+                for (int u = 0; u < SU; u++) xs[u] = g.st ? 0.f : row[min(idx0 + u * 256, seg_hi - 1)];
+#pragma unroll
+                for (int u = 0; u < SU; u++) {
+                    const int idx = idx0 + u * 256;
+                    if (idx < seg_hi) f(idx, idx - b * V, g, xs[u]);
+                }
             }
+        }
+    };
+    // cheap image of a candidate's value: exact for stopped beams (base.py:96-101: only token 0 continues a stopped beam), within
+    // ~1e-6 of the reference's softmax().log() arithmetic otherwise (x t - m - log(sum) instead of log(exp(x t - m) / sum))
+    auto key_of = [&](int v, const Seg& g, float xraw) -> float {
+        if (g.st) return v == 0 ? (first ? 0.f : (g.sc + 0.f) / g.len) : -INFINITY;
+        const float x = xraw * inv_temp - g.m;
+        return first ? (x - g.lsum) : (g.sc + (x - g.lsum)) * g.inv_len;
+    };
+    auto val_of = [&](int v, const Seg& g, float xraw) -> float {
+        if (g.st) return v == 0 ? (first ? 0.f : (g.sc + 0.f) / g.len) : -INFINITY;
+        const float lp = logf(expf(xraw * inv_temp - g.m) / g.sum);                                           // softmax().log()
+        return first ? lp : (g.sc + lp) / g.len;                                                               // base.py:99-101
+    };
+    const int lane = tid & 63, wv = tid >> 6;
+    bool done = false;
+    if constexpr (TB > 0) {
+        // Two passes instead of a sorted list per thread (with per-thread lists some lane of a wave inserts in almost every iteration,
+        // so every wave ran the ~100-instruction exact-value + insertion path for all of its candidates):
+        //   1. thread maxima of the cheap key; the TB-th largest thread maximum is a lower bound of the chunk's TB-th best value;
+        //   2. only candidates within 1e-3 of that bound get the exact value and go to a small LDS list (a handful per block);
+        //   3. TB rounds of block arg-max over the list (ties -> lowest flat index).
+        constexpr int FCAP = 1024;
+        __shared__ float fcv[FCAP];
+        __shared__ int fci[FCAP];
+        __shared__ int fcount;
+        float tmax = -INFINITY;
+        scan([&](int, int v, const Seg& g, float xraw) { tmax = fmaxf(tmax, key_of(v, g, xraw)); });
+        float thr = -INFINITY;
+        if (tid == 0) fcount = 0;
+        for (int k = 0; k < TB; k++) {
+            float bv = tmax;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) bv = fmaxf(bv, __shfl_xor(bv, o, 64));
+            if (lane == 0) red[(k & 1) * 4 + wv] = bv;
+            __syncthreads();
+            thr = fmaxf(fmaxf(red[(k & 1) * 4], red[(k & 1) * 4 + 1]), fmaxf(red[(k & 1) * 4 + 2], red[(k & 1) * 4 + 3]));
+            if (tmax == thr) tmax = -INFINITY;            // equal maxima leave together: the bound only gets lower (still valid)
+        }
+        scan([&](int idx, int v, const Seg& g, float xraw) {
+            const float key = key_of(v, g, xraw);
+            if (key > -INFINITY && key + 1e-3f >= thr) {
+                const int pos = atomicAdd(&fcount, 1);
+                if (pos < FCAP) { fcv[pos] = val_of(v, g, xraw); fci[pos] = idx; }
+            }
+        });
+        __syncthreads();
+        const int n = fcount;
+        if (n <= FCAP) {
+            for (int k = 0; k < TB; k++) {
+                float bv = -INFINITY;
+                int bi = 0x7fffffff;
+                for (int c = tid; c < n; c += 256)
+                    if (fci[c] != 0x7fffffff && cand_better(fcv[c], fci[c], bv, bi)) { bv = fcv[c]; bi = fci[c]; }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float ov = __shfl_xor(bv, o, 64);
+                    const int oi = __shfl_xor(bi, o, 64);
+                    if (cand_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+                }
+                if (lane == 0) { red[(k & 1) * 4 + wv] = bv; redi[(k & 1) * 4 + wv] = bi; }
+                __syncthreads();
+                bv = red[(k & 1) * 4]; bi = redi[(k & 1) * 4];
+#pragma unroll
+                for (int w = 1; w < 4; w++) {
+                    const float ov = red[(k & 1) * 4 + w];
+                    const int oi = redi[(k & 1) * 4 + w];
+                    if (cand_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+                }
+                for (int c = tid; c < n; c += 256)
+                    if (fci[c] == bi) fci[c] = 0x7fffffff;                  // flat indices are unique: one owner; visible after the next barrier
+                if (tid == 0) { sel_v[k] = bi != 0x7fffffff ? bv : -INFINITY; sel_i[k] = bi; }
+                __syncthreads();
+            }
+            done = true;
+        }
+    }
+    if (!done) {
+        // sorted insertion list per thread: any width (TB = 0: run-time width), and the overflow path of the list above (e.g. all logits equal)
+        float lv[LB];
+        int li[LB];
+#pragma unroll
+        for (int k = 0; k < LB; k++) { lv[k] = -INFINITY; li[k] = 0x7fffffff; }
+        scan([&](int idx, int v, const Seg& g, float xraw) {
+            if (!g.st) {
+                const float worst = TB > 0 ? lv[LB - 1] : lv[beam - 1];
+                if (key_of(v, g, xraw) + 1e-3f < worst) return;
+            }
+            const float val = val_of(v, g, xraw);
             if constexpr (TB > 0) {
                 if (cand_better(val, idx, lv[LB - 1], li[LB - 1])) {
                     lv[LB - 1] = val; li[LB - 1] = idx;
@@ -315,16 +402,42 @@ __global__ __launch_bounds__(256) void k_beam_partial(const float* __restrict__ 
                     lv[k] = val; li[k] = idx;
                 }
             }
+        });
+        if constexpr (TB > 0) {
+            // every thread's list is sorted, so the block's next best is the best list HEAD: wave arg-max by shuffles, the four wave
+            // winners meet in LDS (one barrier per round), the owner pops its list
+            for (int k = 0; k < TB; k++) {
+                float bv = lv[0];
+                int bi = li[0];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float ov = __shfl_xor(bv, o, 64);
+                    const int oi = __shfl_xor(bi, o, 64);
+                    if (cand_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+                }
+                if (lane == 0) { red[(k & 1) * 4 + wv] = bv; redi[(k & 1) * 4 + wv] = bi; }
+                __syncthreads();
+                bv = red[(k & 1) * 4]; bi = redi[(k & 1) * 4];
+#pragma unroll
+                for (int w = 1; w < 4; w++) {
+                    const float ov = red[(k & 1) * 4 + w];
+                    const int oi = redi[(k & 1) * 4 + w];
+                    if (cand_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+                }
+                if (li[0] == bi && bi != 0x7fffffff) {              // flat indices are unique: exactly one owner
+#pragma unroll
+                    for (int q = 0; q + 1 < LB; q++) { lv[q] = lv[q + 1]; li[q] = li[q + 1]; }
+                    lv[LB - 1] = -INFINITY; li[LB - 1] = 0x7fffffff;
+                }
+                if (tid == 0) { sel_v[k] = bi != 0x7fffffff ? bv : -INFINITY; sel_i[k] = bi; }
+            }
+            __syncthreads();
+        } else {
+            for (int k = 0; k < beam; k++) { cval[tid * beam + k] = lv[k]; cidx[tid * beam + k] = li[k]; }
+            __syncthreads();
+            select_top(cval, cidx, 256 * beam, beam, red, redi, sel_v, sel_i, tid, 256);
         }
     }
-    if constexpr (TB > 0) {
-#pragma unroll
-        for (int k = 0; k < LB; k++) { cval[tid * LB + k] = lv[k]; cidx[tid * LB + k] = li[k]; }
-    } else {
-        for (int k = 0; k < beam; k++) { cval[tid * beam + k] = lv[k]; cidx[tid * beam + k] = li[k]; }
-    }
-    __syncthreads();
-    select_top(cval, cidx, 256 * beam, beam, red, redi, sel_v, sel_i, tid, 256);
     if (tid < beam) {
         pval[((size_t)s * BEAM_CHUNKS + ch) * beam + tid] = sel_v[tid];
         pidx[((size_t)s * BEAM_CHUNKS + ch) * beam + tid] = sel_i[tid];

@@ -353,7 +353,7 @@ class ClipCapEngine:
 class DecodeSession:
     """KV-cached GPT-2 decode state for R rows (replaces the per-step full re-forward of the reference's inference/base.py:81).
     The cache is bf16 [n_layer][2][R][ctx_max][D], owned here.  A beam reorder (base.py:93,113) does not move cache data: a small
-    int32 ancestry table ``row_map[j][r]`` names the cache row that holds position j of logical row r, and ``reorder`` permutes it."""
+    int32 ancestry table ``row_map[r][j]`` names the cache row that holds position j of logical row r, and ``reorder`` permutes it."""
 
     def __init__(self, gpt2: Gpt2Engine, rows: int, ctx_max: int):
         _require_cuda(gpt2.arena.w32, "DecodeSession")
@@ -364,7 +364,7 @@ class DecodeSession:
         d = gpt2.dims
         dev = gpt2.arena.device
         self.kv = torch.empty(d["NL"] * 2 * rows * self.ctx_max * d["D"], dtype=torch.bfloat16, device=dev)
-        self.row_map = torch.arange(rows, dtype=torch.int32, device=dev).repeat(self.ctx_max, 1).contiguous()
+        self.row_map = torch.arange(rows, dtype=torch.int32, device=dev).view(rows, 1).repeat(1, self.ctx_max).contiguous()
         self._ws: Dict[int, torch.Tensor] = {}
         self._logits: Optional[torch.Tensor] = None
 
@@ -402,7 +402,7 @@ class DecodeSession:
         """Logical row r continues the history of logical row src_rows[r] (same row count): permutes the ancestry table in place."""
         src = src_rows.to(device=self.g.arena.device, dtype=torch.int64)
         if self.pos > 0:
-            self.row_map[: self.pos] = self.row_map[: self.pos].index_select(1, src)
+            self.row_map[:, : self.pos] = self.row_map.index_select(0, src)[:, : self.pos]
         return self
 
     def expand(self, src_rows: torch.Tensor, rows_out: int) -> "DecodeSession":
@@ -410,7 +410,7 @@ class DecodeSession:
         base.py:93).  The prefix K/V are copied once (cc_decode_reorder)."""
         out = DecodeSession(self.g, rows_out, self.ctx_max)
         out.pos = self.pos
-        src = self.row_map[0].index_select(0, src_rows.to(device=self.g.arena.device, dtype=torch.int64)).to(torch.int32).contiguous() \
+        src = self.row_map[:, 0].index_select(0, src_rows.to(device=self.g.arena.device, dtype=torch.int64)).to(torch.int32).contiguous() \
             if self.pos > 0 else src_rows.to(device=self.g.arena.device, dtype=torch.int32).contiguous()
         check(_lib.lib().cc_decode_reorder(C.byref(self.g.cfg), self.R, rows_out, self.pos, self.ctx_max, _p(self.kv), _p(out.kv), _p(src),
                                           _stream(self.g.arena.device)), "cc_decode_reorder")

@@ -156,7 +156,7 @@ int cc_gpt2_bwd_range(const cc_gpt2_cfg* cfg, const cc_gpt2_shape* shp, const fl
 int64_t cc_decode_ws_bytes(const cc_gpt2_cfg* cfg, int32_t R, int32_t Tnew);
 /* processes Tnew new positions per row (prefill: Tnew = prefix length; step: Tnew = 1) starting at position pos0,
  * appends K/V to the cache (row r writes cache row r) and returns fp32 logits of the LAST new position [R, ldl].
- * x fp32 [R,Tnew,D] WITHOUT wpe.  row_map (int32 [ctx_max][R], may be NULL = identity): cache row that holds position j of
+ * x fp32 [R,Tnew,D] WITHOUT wpe.  row_map (int32 [R][ctx_max], may be NULL = identity): cache row that holds position j of
  * row r — a beam reorder (base.py:93,113) then only permutes this small table instead of copying the cache. */
 int cc_decode_fwd(const cc_gpt2_cfg* cfg, int32_t R, int32_t Tnew, int32_t pos0, int32_t ctx_max, const float* w32,
                   const uint16_t* w16, const float* x, uint16_t* kv, const int32_t* row_map, void* ws, float* logits, int64_t ldl,

@@ -243,6 +243,32 @@ def adamw_step(param, grad, m, v, step: int, lr: float, beta1=0.9, beta2=0.999, 
 # Decode  (clipcap/inference/base.py:55-132 generate_beam; :9-52 filters)
 # --------------------------------------------------------------------------------------------------
 
+def beam_update(logits, scores, seq_lengths, has_stopped, *, beam_size, temperature=1.0, stop_token=50256):
+    """One beam update of generate_beam (inference/base.py:82-119) for one sample.  logits (1, V) on the first step (scores is
+    None), (beam, V) afterwards.  Returns (next_tokens (beam,), src (beam,) or None, scores, seq_lengths, has_stopped)."""
+    logits = logits / (temperature if temperature > 0 else 1.0)
+    logits = logits.softmax(-1).log()
+    if scores is None:
+        scores, next_tokens = logits.topk(beam_size, -1)                      # :86-87
+        next_tokens, scores = next_tokens.permute(1, 0).squeeze(1), scores.squeeze(0)
+        src = None
+    else:
+        logits[has_stopped] = -float("inf")                                   # :96-97
+        logits[has_stopped, 0] = 0
+        scores_sum = scores[:, None] + logits
+        seq_lengths = seq_lengths.clone()
+        seq_lengths[~has_stopped] += 1                                        # :99
+        avg = scores_sum / seq_lengths[:, None]
+        avg, next_tokens = avg.view(-1).topk(beam_size, -1)
+        src = torch.div(next_tokens, scores_sum.shape[1], rounding_mode="trunc")
+        seq_lengths = seq_lengths[src]
+        next_tokens = next_tokens % scores_sum.shape[1]
+        scores = avg * seq_lengths                                            # :110
+        has_stopped = has_stopped[src]
+    has_stopped = has_stopped + next_tokens.eq(stop_token)                    # :119
+    return next_tokens, src, scores, seq_lengths, has_stopped
+
+
 def generate_beam_tokens(p, embeds, *, n_head, n_layer, beam_size=5, entry_length=67, temperature=1.0,
                          stop_token=50256, pre="language_model.", rb=False, trace: Optional[list] = None):
     """Token-level restatement of generate_beam (inference/base.py:55-132) for one sample.
@@ -257,31 +283,17 @@ def generate_beam_tokens(p, embeds, *, n_head, n_layer, beam_size=5, entry_lengt
     seq_lengths = torch.ones(beam_size)
     has_stopped = torch.zeros(beam_size, dtype=torch.bool)
     for _ in range(entry_length):
-        logits = gpt2_logits(p, embeds, n_head, n_layer, pre=pre, rb=rb)
-        logits = logits[:, -1, :] / (temperature if temperature > 0 else 1.0)
-        logits = logits.softmax(-1).log()
-        if scores is None:
-            scores, next_tokens = logits.topk(beam_size, -1)
+        logits = gpt2_logits(p, embeds, n_head, n_layer, pre=pre, rb=rb)[:, -1, :]
+        next_tokens, src, scores, seq_lengths, has_stopped = beam_update(logits, scores, seq_lengths, has_stopped, beam_size=beam_size,
+                                                                         temperature=temperature, stop_token=stop_token)
+        if src is None:
             embeds = embeds.expand(beam_size, *embeds.shape[1:])
-            next_tokens, scores = next_tokens.permute(1, 0), scores.squeeze(0)
-            tokens = next_tokens
+            tokens = next_tokens.unsqueeze(1)
         else:
-            logits[has_stopped] = -float("inf")
-            logits[has_stopped, 0] = 0
-            scores_sum = scores[:, None] + logits
-            seq_lengths[~has_stopped] += 1
-            avg = scores_sum / seq_lengths[:, None]
-            avg, next_tokens = avg.view(-1).topk(beam_size, -1)
-            src = torch.div(next_tokens, scores_sum.shape[1], rounding_mode="trunc")
-            seq_lengths = seq_lengths[src]
-            next_tokens = (next_tokens % scores_sum.shape[1]).unsqueeze(1)
-            tokens = torch.cat((tokens[src], next_tokens), dim=1)
+            tokens = torch.cat((tokens[src], next_tokens.unsqueeze(1)), dim=1)
             embeds = embeds[src]
-            scores = avg * seq_lengths
-            has_stopped = has_stopped[src]
-        nxt = wte[next_tokens.squeeze()].view(embeds.shape[0], 1, -1)
+        nxt = wte[next_tokens].view(embeds.shape[0], 1, -1)
         embeds = torch.cat((embeds, nxt), dim=1)
-        has_stopped = has_stopped + next_tokens.eq(stop_token).squeeze()
         if trace is not None:
             trace.append(dict(tokens=tokens.clone(), scores=scores.clone(), seq_lengths=seq_lengths.clone(),
                               has_stopped=has_stopped.clone()))

@@ -1,0 +1,67 @@
+"""cc_beam_step (the device-side beam update of generate_beam, reference inference/base.py:82-119) against the oracle's beam_update
+at GPT-2's vocabulary size: first step, later steps with stopped beams, compile-time (1-5, 8) and run-time beam widths, a padded
+leading dimension, and the all-ties case (lowest flat index wins; also the overflow path of the candidate list)."""
+import pytest
+import torch
+
+from clipcap_amd.engine import beam_step
+from oracle import clipcap_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_step(lg, first, S, beam, temp, stop, scores, seql, stopped):
+    V = lg.shape[1]
+    nts, srcs = [], []
+    for s in range(S):
+        sl = slice(s * beam, (s + 1) * beam)
+        if first:
+            nt, src, sc, ln, hs = O.beam_update(lg[s * beam:s * beam + 1].clone(), None, seql[sl].clone(), stopped[sl].clone(), beam_size=beam,
+                                                temperature=temp, stop_token=stop)
+            src = torch.zeros(beam, dtype=torch.int64)
+        else:
+            nt, src, sc, ln, hs = O.beam_update(lg[sl].clone(), scores[sl].clone(), seql[sl].clone(), stopped[sl].clone(), beam_size=beam,
+                                                temperature=temp, stop_token=stop)
+        scores[sl], seql[sl], stopped[sl] = sc, ln, hs
+        nts.append(nt)
+        srcs.append(src)
+    return torch.cat(nts), torch.cat(srcs)
+
+
+@pytest.mark.parametrize("beam,V,ld", [(5, 50257, 50304), (3, 50257, 50257), (7, 4099, 4104), (8, 1001, 1001), (1, 50257, 50304)])
+def test_beam_step_matches_oracle(beam, V, ld):
+    torch.manual_seed(beam * 1000 + V)
+    S, temp, stop = 6, 0.9, 17
+    R = S * beam
+    scores = torch.zeros(R, device="cuda")
+    seql = torch.ones(R, device="cuda")
+    stopped = torch.zeros(R, dtype=torch.uint8, device="cuda")
+    o_scores, o_seql, o_stopped = torch.zeros(R), torch.ones(R), torch.zeros(R, dtype=torch.bool)
+    for step in range(5):
+        buf = torch.randn(R, ld, device="cuda") * 3.0
+        if step >= 1:
+            buf[::3, stop] += 25.0                     # some beams pick the stop token and freeze
+        lg = buf[:, :V]
+        nt, sr = beam_step(lg, S, beam, temp, step == 0, stop, scores, seql, stopped)
+        ont, osr = _oracle_step(lg.cpu().float(), step == 0, S, beam, temp, stop, o_scores, o_seql, o_stopped)
+        torch.cuda.synchronize()
+        assert torch.equal(nt.cpu().long(), ont), step
+        if step > 0:
+            assert torch.equal(sr.cpu().long(), osr), step
+        assert torch.allclose(scores.cpu(), o_scores, rtol=1e-5, atol=1e-5), step
+        assert torch.equal(seql.cpu(), o_seql) and torch.equal(stopped.cpu().bool(), o_stopped), step
+    assert o_stopped.any()
+
+
+@pytest.mark.parametrize("beam", [5, 6])
+def test_beam_step_all_ties_lowest_flat_index(beam):
+    S, V = 3, 50257
+    R = S * beam
+    scores = torch.zeros(R, device="cuda")
+    seql = torch.ones(R, device="cuda")
+    stopped = torch.zeros(R, dtype=torch.uint8, device="cuda")
+    lg = torch.zeros(R, V, device="cuda")
+    nt, sr = beam_step(lg, S, beam, 1.0, True, 50256, scores, seql, stopped)
+    assert nt.view(S, beam).cpu().tolist() == [list(range(beam))] * S
+    nt, sr = beam_step(lg, S, beam, 1.0, False, 50256, scores, seql, stopped)
+    assert nt.view(S, beam).cpu().tolist() == [list(range(beam))] * S and sr.view(S, beam).cpu().tolist() == [[0] * beam] * S
