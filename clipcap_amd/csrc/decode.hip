@@ -188,36 +188,44 @@ __device__ __forceinline__ bool cand_better(float a, int ia, float b, int ib) { 
 
 template <bool VEC>   // VEC: rows are 16-B aligned (ldl % 4 == 0, aligned base) -> float4 loads
 __global__ __launch_bounds__(512) void k_beam_rowstats(const float* __restrict__ logits, size_t ldl, int V, float inv_temp, float* __restrict__ rs) {
-    __shared__ float red[8];
+    // one pass: every thread keeps a running (max, sum of exp(x - max)) pair, rescaling the sum when its max moves; pairs are merged
+    // the same way across lanes and waves (the logits matrix, 64 MB at 320 x 50257, is read once instead of twice)
+    __shared__ float redm[8], reds[8];
     const int row = blockIdx.x, tid = threadIdx.x;
     const float* lg = logits + (size_t)row * ldl;
     const int V4 = VEC ? (V >> 2) : 0;
-    float m = -INFINITY;
+    float m = -INFINITY, sum = 0.f;
+    auto add4 = [&](float a, float b, float c, float d) {
+        const float mx = fmaxf(fmaxf(a, b), fmaxf(c, d));
+        if (mx > m) { sum *= expf(m - mx); m = mx; }              // expf(-inf) = 0 on the first group
+        sum += expf(a - m) + expf(b - m) + expf(c - m) + expf(d - m);
+    };
     for (int v = tid; v < V4; v += 512) {
         const float4 x = reinterpret_cast<const float4*>(lg)[v];
-        m = fmaxf(fmaxf(m, fmaxf(x.x, x.y) * inv_temp), fmaxf(x.z, x.w) * inv_temp);      // inv_temp > 0: max(x) t == max(x t)
+        add4(x.x * inv_temp, x.y * inv_temp, x.z * inv_temp, x.w * inv_temp);
     }
-    for (int v = V4 * 4 + tid; v < V; v += 512) m = fmaxf(m, lg[v] * inv_temp);
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((tid & 63) == 0) red[tid >> 6] = m;
-    __syncthreads();
-    m = red[0];
-    for (int i = 1; i < 8; i++) m = fmaxf(m, red[i]);
-    __syncthreads();
-    float sum = 0.f;
-    for (int v = tid; v < V4; v += 512) {
-        const float4 x = reinterpret_cast<const float4*>(lg)[v];
-        sum += expf(x.x * inv_temp - m) + expf(x.y * inv_temp - m) + expf(x.z * inv_temp - m) + expf(x.w * inv_temp - m);
+    for (int v = V4 * 4 + tid; v < V; v += 512) {
+        const float x = lg[v] * inv_temp;
+        if (x > m) { sum *= expf(m - x); m = x; }
+        sum += expf(x - m);
     }
-    for (int v = V4 * 4 + tid; v < V; v += 512) sum += expf(lg[v] * inv_temp - m);
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-    if ((tid & 63) == 0) red[tid >> 6] = sum;
+    auto merge = [&](float om, float os) {
+        const float mx = fmaxf(m, om);
+        if (mx == -INFINITY) return;                               // both empty
+        sum = sum * expf(m - mx) + os * expf(om - mx);
+        m = mx;
+    };
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(m, o, 64), os = __shfl_xor(sum, o, 64);
+        merge(om, os);
+    }
+    if ((tid & 63) == 0) { redm[tid >> 6] = m; reds[tid >> 6] = sum; }
     __syncthreads();
     if (tid == 0) {
-        float t = 0.f;
-        for (int i = 0; i < 8; i++) t += red[i];
+        m = redm[0]; sum = reds[0];
+        for (int i = 1; i < 8; i++) merge(redm[i], reds[i]);
         rs[2 * row] = m;
-        rs[2 * row + 1] = t;
+        rs[2 * row + 1] = sum;
     }
 }
 

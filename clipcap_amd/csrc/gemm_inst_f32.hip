@@ -186,20 +186,46 @@ __global__ __launch_bounds__(256) void k_splitk_finish_row(const float* __restri
     constexpr int MAXV = 3;                // float4 per thread -> N <= 3072
     float4 v[MAXV];
     float s1 = 0.f;
+    // LayerNorm parameters are fetched up front, beside the slab loads, not after the two block reductions
+    float4 lg_[MAXV], lb_[MAXV];
+    if (f.ln_out16) {
+#pragma unroll
+        for (int it = 0; it < MAXV; it++) {
+            const int c = threadIdx.x * 4 + it * 1024;
+            if (c < N) { lg_[it] = *reinterpret_cast<const float4*>(f.ln_gamma + c); lb_[it] = *reinterpret_cast<const float4*>(f.ln_beta + c); }
+        }
+    }
 #pragma unroll
     for (int it = 0; it < MAXV; it++) {
         const int c = threadIdx.x * 4 + it * 1024;
         if (c < N) {
             float4 a = make_float4(0, 0, 0, 0);
-            for (int s = 0; s < ks; s++) {
-                const float4 p = *reinterpret_cast<const float4*>(slabs + s * slab_elems + (size_t)row * N + c);
-                a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+            const float* sp = slabs + (size_t)row * N + c;
+            float4 bb = make_float4(0, 0, 0, 0), rr = make_float4(0, 0, 0, 0);
+            if (bias) bb = *reinterpret_cast<const float4*>(bias + c);
+            if (res) rr = *reinterpret_cast<const float4*>(res + (size_t)row * ldo + c);
+            int s = 0;
+            for (; s + 4 <= ks; s += 4) {                      // four slices in flight
+                const float4 p0 = *reinterpret_cast<const float4*>(sp + (s + 0) * slab_elems), p1 = *reinterpret_cast<const float4*>(sp + (s + 1) * slab_elems);
+                const float4 p2 = *reinterpret_cast<const float4*>(sp + (s + 2) * slab_elems), p3 = *reinterpret_cast<const float4*>(sp + (s + 3) * slab_elems);
+                a.x += (p0.x + p1.x) + (p2.x + p3.x); a.y += (p0.y + p1.y) + (p2.y + p3.y);
+                a.z += (p0.z + p1.z) + (p2.z + p3.z); a.w += (p0.w + p1.w) + (p2.w + p3.w);
             }
-            if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + c); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+            if (ks - s == 3) {
+                const float4 p0 = *reinterpret_cast<const float4*>(sp + (s + 0) * slab_elems), p1 = *reinterpret_cast<const float4*>(sp + (s + 1) * slab_elems);
+                const float4 p2 = *reinterpret_cast<const float4*>(sp + (s + 2) * slab_elems);
+                a.x += (p0.x + p1.x) + p2.x; a.y += (p0.y + p1.y) + p2.y; a.z += (p0.z + p1.z) + p2.z; a.w += (p0.w + p1.w) + p2.w;
+            } else {
+                for (; s < ks; s++) {
+                    const float4 p = *reinterpret_cast<const float4*>(sp + s * slab_elems);
+                    a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+                }
+            }
+            a.x += bb.x; a.y += bb.y; a.z += bb.z; a.w += bb.w;
             if (act == 2) { a.x = gelu_new_f(a.x); a.y = gelu_new_f(a.y); a.z = gelu_new_f(a.z); a.w = gelu_new_f(a.w); }
             else if (act == 1) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
             const size_t o = (size_t)row * ldo + c;
-            if (res) { const float4 r = *reinterpret_cast<const float4*>(res + o); a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w; }
+            a.x += rr.x; a.y += rr.y; a.z += rr.z; a.w += rr.w;
             if (out32) *reinterpret_cast<float4*>(out32 + o) = a;
             const uint2 pk = make_uint2(pack2bf(a.x, a.y), pack2bf(a.z, a.w));
             if (out16) *reinterpret_cast<uint2*>(out16 + o) = pk;
@@ -228,7 +254,7 @@ __global__ __launch_bounds__(256) void k_splitk_finish_row(const float* __restri
     for (int it = 0; it < MAXV; it++) {
         const int c = threadIdx.x * 4 + it * 1024;
         if (c < N) {
-            const float4 g = *reinterpret_cast<const float4*>(f.ln_gamma + c), b = *reinterpret_cast<const float4*>(f.ln_beta + c);
+            const float4 g = lg_[it], b = lb_[it];
             *reinterpret_cast<uint2*>(f.ln_out16 + (size_t)row * N + c) =
                 make_uint2(pack2bf((v[it].x - mu) * rs * g.x + b.x, (v[it].y - mu) * rs * g.y + b.y),
                            pack2bf((v[it].z - mu) * rs * g.z + b.z, (v[it].w - mu) * rs * g.w + b.w));
