@@ -175,6 +175,26 @@ __global__ void k_embed_tokens(const float* __restrict__ wte, const int* __restr
     }
 }
 
+// Bookkeeping between two beam steps in ONE launch (base.py:104-117: tokens = cat(tokens[src], next), embed(next), cache
+// ancestry): row r continues group row g = (r / beam) * beam + src[r].  Replaces ~10 small framework launches per generated token.
+__global__ __launch_bounds__(256) void k_beam_advance(int beam, int D, const float* __restrict__ wte, const int* __restrict__ next_tok,
+                                                      const int* __restrict__ src, int pos, int ctx_max, const int* __restrict__ map_in,
+                                                      int* __restrict__ map_out, int step, int tok_ld, const int* __restrict__ tok_in,
+                                                      int* __restrict__ tok_out, float* __restrict__ x_out) {
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const int g = src ? (r / beam) * beam + src[r] : r;
+    int id = next_tok[r];
+    if (map_out)
+        for (int j = tid; j < ctx_max; j += 256) map_out[(size_t)r * ctx_max + j] = j < pos ? map_in[(size_t)g * ctx_max + j] : r;
+    if (tok_out) {
+        for (int j = tid; j < step; j += 256) tok_out[(size_t)r * tok_ld + j] = tok_in[(size_t)g * tok_ld + j];
+        if (tid == 0) tok_out[(size_t)r * tok_ld + step] = id;
+    }
+    if (id < 0) id = 0;
+    const float4* w = reinterpret_cast<const float4*>(wte + (size_t)id * D);
+    for (int c = tid; c < (D >> 2); c += 256) reinterpret_cast<float4*>(x_out + (size_t)r * D)[c] = w[c];
+}
+
 // ---- beam step (base.py:84-119) in three small kernels so that all CUs take part --------------------------------
 //   k_beam_rowstats : one block per (sample, beam row): max and sum(exp) of logits/temperature
 //   k_beam_partial  : grid (sample, chunk): top-`beam` of the length-normalised candidate scores inside one slice of the
@@ -668,6 +688,18 @@ int cc_embed_tokens(const cc_gpt2_cfg* c, int32_t R, const float* w32, const int
     if (!cfg_ok(c) || R <= 0 || !w32 || !tokens || !out) return CC_ERR_ARG;
     const size_t total = (size_t)R * (c->D >> 2);
     hipLaunchKernelGGL(k_embed_tokens, dim3((int)std::min<size_t>((total + 255) / 256, 2048)), dim3(256), 0, S_(stream), w32, tokens, out, R, c->D);
+    return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+}
+
+int cc_beam_advance(const cc_gpt2_cfg* c, int32_t R, int32_t beam, const float* w32, const int32_t* next_tokens, const int32_t* src_rows,
+                    int32_t pos, int32_t ctx_max, const int32_t* row_map_in, int32_t* row_map_out, int32_t step, int32_t tok_ld,
+                    const int32_t* tokens_in, int32_t* tokens_out, float* x_out, void* stream) {
+    if (!cfg_ok(c) || R <= 0 || beam <= 0 || (R % beam) || !w32 || !next_tokens || !x_out || pos < 0 || pos > ctx_max) return CC_ERR_ARG;
+    if ((row_map_out && (!row_map_in || row_map_in == row_map_out)) || (tokens_out && (step < 0 || step >= tok_ld || (step > 0 && !tokens_in) ||
+                                                                                      tokens_in == tokens_out)))
+        return CC_ERR_ARG;
+    hipLaunchKernelGGL(k_beam_advance, dim3(R), dim3(256), 0, S_(stream), beam, c->D, w32, next_tokens, src_rows, pos, ctx_max, row_map_in, row_map_out,
+                       step, tok_ld, tokens_in, tokens_out, x_out);
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
 

@@ -405,6 +405,18 @@ class DecodeSession:
             self.row_map[:, : self.pos] = self.row_map.index_select(0, src)[:, : self.pos]
         return self
 
+    def beam_advance(self, beam: int, next_tok: torch.Tensor, src_local: Optional[torch.Tensor], wte: torch.Tensor, step: int,
+                     tokens_in: torch.Tensor, tokens_out: torch.Tensor, x_out: torch.Tensor) -> None:
+        """Everything between two beam steps in one launch (cc_beam_advance; reference inference/base.py:104-117): row r continues row
+        (r // beam) * beam + src_local[r] (None: itself) — the ancestry table is permuted (into a second buffer, then swapped),
+        tokens_out[r] = tokens_in[that row][:step] + [next_tok[r]] (int32 (R, n) buffers) and x_out (R, 1, D) fp32 = wte[next_tok]."""
+        if getattr(self, "_row_map_alt", None) is None:
+            self._row_map_alt = torch.empty_like(self.row_map)
+        check(_lib.lib().cc_beam_advance(C.byref(self.g.cfg), self.R, beam, _p(wte), _p(next_tok), _p(src_local) if src_local is not None else None,
+                                        self.pos, self.ctx_max, _p(self.row_map), _p(self._row_map_alt), step, tokens_out.stride(0),
+                                        _p(tokens_in), _p(tokens_out), _p(x_out), _stream(self.g.arena.device)), "cc_beam_advance")
+        self.row_map, self._row_map_alt = self._row_map_alt, self.row_map
+
     def expand(self, src_rows: torch.Tensor, rows_out: int) -> "DecodeSession":
         """A wider session (rows_out rows) whose row r starts from this session's row src_rows[r] (beam fan-out after the prefill,
         base.py:93).  The prefix K/V are copied once (cc_decode_reorder)."""

@@ -51,19 +51,22 @@ def generate_beam_tokens(model, embeds: torch.Tensor, beam_size: int = 5, entry_
     lg[::beam_size] = logits0                                                   # row 0 of every beam set
     next_tok, src = beam_step(lg, S, beam_size, temperature, True, stop_token, scores, seq_lengths, has_stopped)
     sess = sess.expand((base // beam_size).to(torch.int32), R)
-    tokens = next_tok.to(torch.int64).view(R, 1)
+    # token histories (int32, ping-pong), the next input embedding and the cache ancestry are advanced by one launch per step
+    tok = [torch.zeros(R, entry_length, dtype=torch.int32, device=dev) for _ in range(2)]
+    x = torch.empty(R, 1, D, dtype=torch.float32, device=dev)
+    sess.beam_advance(beam_size, next_tok, None, wte, 0, tok[1], tok[0], x)     # step 0: tokens = next_tokens (base.py:94)
+    n = 1
     for step in range(1, entry_length):
         # base.py:120-121 breaks as soon as every beam has stopped.  Steps taken after that point only append token 0 to frozen
         # beams (scores, lengths and the truncated outputs are unchanged), so polling the flag every 4th step — one host sync
         # instead of four — cannot change the result.
         if step % 4 == 1 and bool(has_stopped.all()):
             break
-        x = wte[next_tok.to(torch.int64)].view(R, 1, D)                         # base.py:117
-        logits = sess.forward(x)
+        logits = sess.forward(x)                                                # x = wte[next_tokens] (base.py:117)
         next_tok, src = beam_step(logits, S, beam_size, temperature, False, stop_token, scores, seq_lengths, has_stopped)
-        gsrc = base + src
-        sess = sess.reorder(gsrc)
-        tokens = torch.cat((tokens[gsrc.to(torch.int64)], next_tok.to(torch.int64).view(R, 1)), dim=1)
+        sess.beam_advance(beam_size, next_tok, src, wte, step, tok[(step - 1) & 1], tok[step & 1], x)   # base.py:104-117
+        n = step + 1
+    tokens = tok[(n - 1) & 1][:, :n].to(torch.int64)
     final = scores / seq_lengths                                                # base.py:123
     return tokens.view(S, beam_size, -1), final.view(S, beam_size), seq_lengths.view(S, beam_size)
 

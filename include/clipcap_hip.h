@@ -174,6 +174,13 @@ int cc_beam_step(int32_t S, int32_t beam, int32_t V, const float* logits, int64_
 int64_t cc_beam_ws_bytes(int32_t S, int32_t beam, int32_t V);
 /* gathers wte rows for next tokens: out fp32 [R, D] (base.py:117) */
 int cc_embed_tokens(const cc_gpt2_cfg* cfg, int32_t R, const float* w32, const int32_t* tokens, float* out, void* stream);
+/* Everything between two beam steps in one launch (base.py:104-117): row r continues row g = (r / beam) * beam + src_rows[r] of its beam
+ * group (src_rows NULL: g = r).  x_out fp32 [R, D] = wte[next_tokens[r]] (w32 points at wte);  row_map_out[r][j] = row_map_in[g][j] for
+ * j < pos, r for the positions still to come (tables int32 [R][ctx_max], see cc_decode_fwd; NULL = skip);  tokens_out[r][:step] =
+ * tokens_in[g][:step], tokens_out[r][step] = next_tokens[r] (int32 [R][tok_ld]; NULL = skip).  In / out buffers must differ. */
+int cc_beam_advance(const cc_gpt2_cfg* cfg, int32_t R, int32_t beam, const float* w32, const int32_t* next_tokens, const int32_t* src_rows,
+                    int32_t pos, int32_t ctx_max, const int32_t* row_map_in, int32_t* row_map_out, int32_t step, int32_t tok_ld,
+                    const int32_t* tokens_in, int32_t* tokens_out, float* x_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Optimizer / casts: torch.optim.AdamW as configured by model.py:73-77 (lr schedule is computed by the caller,

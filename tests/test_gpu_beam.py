@@ -65,3 +65,29 @@ def test_beam_step_all_ties_lowest_flat_index(beam):
     assert nt.view(S, beam).cpu().tolist() == [list(range(beam))] * S
     nt, sr = beam_step(lg, S, beam, 1.0, False, 50256, scores, seql, stopped)
     assert nt.view(S, beam).cpu().tolist() == [list(range(beam))] * S and sr.view(S, beam).cpu().tolist() == [[0] * beam] * S
+
+
+def test_beam_advance_matches_indexing():
+    """cc_beam_advance = tokens[src] ++ next, wte[next], ancestry rows gathered (base.py:104-117), against plain tensor indexing."""
+    from clipcap_amd.engine import DecodeSession
+    from clipcap_amd.model.gpt2 import GPT2LM
+    torch.manual_seed(3)
+    lm = GPT2LM(n_embd=64, n_layer=1, n_head=4, vocab_size=211, n_positions=32).to("cuda")
+    wte = lm.get_input_embeddings().weight.detach()
+    S, beam, n = 3, 4, 9
+    R = S * beam
+    sess = DecodeSession(lm.engine, R, 20)
+    sess.forward(torch.randn(R, 6, 64, device="cuda"))
+    sess.row_map[:, :6] = torch.randint(0, R, (R, 6), dtype=torch.int32, device="cuda")
+    before = sess.row_map.clone()
+    tin = torch.randint(0, 211, (R, n), dtype=torch.int32, device="cuda")
+    tout = torch.full((R, n), -7, dtype=torch.int32, device="cuda")
+    nxt = torch.randint(0, 211, (R,), dtype=torch.int32, device="cuda")
+    src = torch.randint(0, beam, (R,), dtype=torch.int32, device="cuda")
+    x = torch.empty(R, 1, 64, device="cuda")
+    sess.beam_advance(beam, nxt, src, wte, 5, tin, tout, x)
+    g = ((torch.arange(R, device="cuda") // beam) * beam + src).long()
+    assert torch.equal(tout[:, :5], tin[g, :5]) and torch.equal(tout[:, 5], nxt) and (tout[:, 6:] == -7).all()
+    assert torch.equal(x.view(R, 64), wte[nxt.long()])
+    assert torch.equal(sess.row_map[:, :6], before[g, :6])
+    assert torch.equal(sess.row_map[:, 6:], torch.arange(R, dtype=torch.int32, device="cuda").view(R, 1).expand(R, 14))
