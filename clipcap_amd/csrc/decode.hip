@@ -126,13 +126,24 @@ __global__ __launch_bounds__(256) void k_decode_attn(const bf16_t* __restrict__ 
     const int kg = lane / nchunk, dc = lane - kg * nchunk;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (kg < kgroups) {
-        for (int j = kg; j < nkeys; j += kgroups) {
-            float v[8];
-            const bf16_t* vrow = (APPEND && j >= pos0) ? knew + D + (size_t)(j - pos0) * 3 * D : vb + ((size_t)srow[j] * ctx_max + j) * D;
-            unpack8(*reinterpret_cast<const uint4*>(vrow + dc * 8), v);
-            const float pj = p[j];
+        constexpr int PV_U = 4;                                // V rows in flight per lane
+        for (int j0 = kg; j0 < nkeys; j0 += kgroups * PV_U) {
+            uint4 vv[PV_U];
+            float pj[PV_U];
 #pragma unroll
-            for (int e = 0; e < 8; e++) acc[e] += pj * v[e];
+            for (int u = 0; u < PV_U; u++) {
+                const int j = min(j0 + u * kgroups, nkeys - 1);
+                const bf16_t* vrow = (APPEND && j >= pos0) ? knew + D + (size_t)(j - pos0) * 3 * D : vb + ((size_t)srow[j] * ctx_max + j) * D;
+                vv[u] = *reinterpret_cast<const uint4*>(vrow + dc * 8);
+                pj[u] = j0 + u * kgroups < nkeys ? p[j] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < PV_U; u++) {
+                float v[8];
+                unpack8(vv[u], v);
+#pragma unroll
+                for (int e = 0; e < 8; e++) acc[e] += pj[u] * v[e];
+            }
         }
 #pragma unroll
         for (int e = 0; e < 8; e++) red[kg * hd + dc * 8 + e] = acc[e];
