@@ -696,6 +696,85 @@ __global__ __launch_bounds__(G_THREADS * KG, (NS * (64 + 64 * NJ) * 128 <= 80 * 
     }
 }
 
+// 64 x 64 skinny kernel, K split over the waves: every wave computes the WHOLE tile for one 16-k quarter of each K-tile (2 + 2 fragment
+// reads and 4 MFMAs per step and wave).  The 2 x 2 wave layout above reads 32 KiB of fragments per step through the CU's 128 B/clk
+// LDS port — 322 of its ~600 cycles per step (tools/probes/step_timing.hip) — this one 16 KiB: 430 cycles per step.  The price is a
+// cross-wave reduction of the four partial tiles through LDS at the end (~4 steps' worth), so gemm_nt_skinny picks it only for
+// >= 12 K-tiles per block and grids of at most one block per CU (two co-resident blocks lose: the probe shows 730 vs 650 cycles).
+template <class Epi>
+__global__ __launch_bounds__(G_THREADS, 2) void gemm_nt_s64kw_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, GemmShape g, Epi epi) {
+    extern __shared__ __attribute__((aligned(1024))) char smkw[];
+    constexpr int NS = 4, STAGE = 128 * 128, P = 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = (g.N + 63) / 64, tiles_m = (g.M + 63) / 64;
+    int tm, tn;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, g.group_m, tm, tn);
+    const int m0 = tm * 64, n0 = tn * 64;
+    const int kbeg = blockIdx.z * g.k_chunk;
+    const int nk = (min(g.K, kbeg + g.k_chunk) - kbeg) / G_BK;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+#define KW_ISSUE(T, SLOT) glds_pair<64, 64, 4>(A, g.lda, g.M, m0, B, g.ldb, g.N, n0, kbeg + (T)*G_BK, smkw + (SLOT) * STAGE, wave, lane)
+#pragma unroll
+    for (int t = 0; t < NS - 1; t++)
+        if (t < nk) KW_ISSUE(t, t);
+    const int frow = lane & 31, ch = wave * 2 + (lane >> 5);
+    int slot = 0, islot = NS - 1;
+    for (int kt = 0; kt < nk; kt++) {
+        const int rem = min(nk - 1, kt + NS - 2) - kt;
+        if (rem >= 2) s_wait_vm<2 * P>();
+        else if (rem == 1) s_wait_vm<P>();
+        else s_wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        const char* cur = smkw + slot * STAGE;
+        bf16x8 a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            a[i] = *reinterpret_cast<const bf16x8*>(cur + g_lds_off(i * 32 + frow, ch));
+            b[i] = *reinterpret_cast<const bf16x8*>(cur + 64 * 128 + g_lds_off(i * 32 + frow, ch));
+        }
+        if (kt + NS - 1 < nk) KW_ISSUE(kt + NS - 1, islot);       // after the reads are issued: the DMA issue cycles hide their latency
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        slot = slot + 1 == NS ? 0 : slot + 1;
+        islot = islot + 1 == NS ? 0 : islot + 1;
+    }
+#undef KW_ISSUE
+    __syncthreads();
+    // partial tiles -> LDS as [wave][tile 2i+j][register][lane] floats (64 KiB = the four stages); element (row, col) of a tile sits in
+    // register 4 (row>>3) + (row&3) of lane (col&31) + 32 ((row>>2)&1), so 8 consecutive columns are 8 consecutive floats
+    float* part = reinterpret_cast<float*>(smkw);
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) part[((wave * 4 + i * 2 + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+    __syncthreads();
+    // wave w finishes rows [16 w, 16 w + 16) of the tile: lane -> (row, 8-column group), two passes
+#pragma unroll
+    for (int ps = 0; ps < 2; ps++) {
+        const int row = wave * 16 + ps * 8 + (lane >> 3), c8 = lane & 7;
+        const int rr = row & 31, reg = (rr >> 3) * 4 + (rr & 3), ls = (c8 & 3) * 8 + 32 * ((rr >> 2) & 1), tile = (row >> 5) * 2 + (c8 >> 2);
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int pw = 0; pw < 4; pw++) {
+            const float* src = part + ((pw * 4 + tile) * 16 + reg) * 64 + ls;
+            const float4 x = *reinterpret_cast<const float4*>(src), y = *reinterpret_cast<const float4*>(src + 4);
+            v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w; v[4] += y.x; v[5] += y.y; v[6] += y.z; v[7] += y.w;
+        }
+        epi(m0 + row, n0 + c8 * 8, v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // 256-row kernels for large outputs: 8 waves, wave tile 128 x 16 NJ (8 x NJ MFMA tiles; block tile 256 x 256 for NJ = 4,
 // 256 x 192 for NJ = 3), K-tile 32, FOUR LDS stages of 32 KiB.  Per FLOP the 256 x 256 form moves half the L2->LDS bytes and
@@ -1380,7 +1459,12 @@ inline int launch_gemm_s64(const bf16_t* A, int lda, const bf16_t* B, int ldb, i
         hipLaunchKernelGGL((gemm_nt_s64_kernel<Epi, NJ_, NS_, KG_>), dim3((unsigned)(tm * ((N + 64 * (NJ_) - 1) / (64 * (NJ_)))), 1, (unsigned)ksplit), \
                            dim3(G_THREADS * (KG_)), sh, st, A, B, g, epi);                                               \
     }
-    if (nj == 2) S64_LAUNCH(2, 3, 1) else S64_LAUNCH(1, 4, 1)
+    if (nj == 3) {                   // K split over the waves (gemm_nt_s64kw_kernel)
+        constexpr size_t sh = (size_t)4 * 128 * 128;
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_s64kw_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr = true; }
+        hipLaunchKernelGGL((gemm_nt_s64kw_kernel<Epi>), dim3((unsigned)(tm * ((N + 63) / 64)), 1, (unsigned)ksplit), dim3(G_THREADS), sh, st, A, B, g, epi);
+    } else if (nj == 2) S64_LAUNCH(2, 3, 1) else S64_LAUNCH(1, 4, 1)
 #undef S64_LAUNCH
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }

@@ -295,13 +295,20 @@ int gemm_nt_skinny(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, in
     }
     if (ks < 1) ks = 1;
     if (can_slab) { const size_t fit = scratch_bytes / (slab * sizeof(float)); if ((size_t)ks > fit) ks = (int)fit; }
+    // K split over the waves of a block (gemm_nt_s64kw_kernel): pays from ~14 K-tiles per block, and only on grids of at most one
+    // block per CU (320 x 3072 x 1024: 9.0 -> 8.3 us, 320 x 1024 x 4096 in one slice: 23.6 -> 18.4 us; c_fc's 320 blocks: no gain)
+    auto s64_form = [&](int slices) {
+        const int t64 = ((M + 63) / 64) * ((N + 63) / 64);
+        return (K / G_BK / (slices > 0 ? slices : 1) >= 14 && (long)t64 * slices <= 256 && g_gemm_s64 != 1) ? 3 : 1;
+    };
     if (!can_slab || (ks <= 1 && !fused)) {
         if (fused) return CC_ERR_SHAPE;                    // callers only request fusion when the slab path is available
         if (s64) {
-            if (res) { EpiResid e{out32, res, bias, ldo, M, N}; return launch_gemm_s64(A, lda, B, ldb, M, N, K, 1, 1, e, nullptr, st); }
-            if (out16) { EpiBF16 e{out16, nullptr, bias, ldo, M, N, act}; return launch_gemm_s64(A, lda, B, ldb, M, N, K, 1, 1, e, nullptr, st); }
+            const int form = s64_form(1);
+            if (res) { EpiResid e{out32, res, bias, ldo, M, N}; return launch_gemm_s64(A, lda, B, ldb, M, N, K, 1, form, e, nullptr, st); }
+            if (out16) { EpiBF16 e{out16, nullptr, bias, ldo, M, N, act}; return launch_gemm_s64(A, lda, B, ldb, M, N, K, 1, form, e, nullptr, st); }
             EpiF32 e{out32, bias, ldo, M, N, 0, 1.0f};
-            return launch_gemm_s64(A, lda, B, ldb, M, N, K, 1, 1, e, nullptr, st);
+            return launch_gemm_s64(A, lda, B, ldb, M, N, K, 1, form, e, nullptr, st);
         }
         if (res) { EpiResid e{out32, res, bias, ldo, M, N}; return launch_gemm(0, 0, A, lda, B, ldb, M, N, K, 1, e, st); }
         if (out16) { EpiBF16 e{out16, nullptr, bias, ldo, M, N, act}; return launch_gemm(0, 0, A, lda, B, ldb, M, N, K, 1, e, st); }
@@ -310,7 +317,7 @@ int gemm_nt_skinny(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, in
     }
     EpiF32 e{scratch, nullptr, N, M, N, 3, 1.0f};
     e.zstride = slab;
-    int rc = s64 ? launch_gemm_s64(A, lda, B, ldb, M, N, K, ks, 1, e, nullptr, st) : launch_gemm(0, 0, A, lda, B, ldb, M, N, K, ks, e, st);
+    int rc = s64 ? launch_gemm_s64(A, lda, B, ldb, M, N, K, ks, s64_form(ks), e, nullptr, st) : launch_gemm(0, 0, A, lda, B, ldb, M, N, K, ks, e, st);
     if (rc != CC_OK) return rc;
     const int kt = K / G_BK, per = (kt + ks - 1) / ks, ks_eff = (kt + per - 1) / per;
     if (N <= 3072 && (N & 3) == 0) {

@@ -234,7 +234,7 @@ int cc_gemm_wgrad(const uint16_t* X, int32_t ldx, const uint16_t* Y, int32_t ldy
 int cc_gemm_tile_mode(int32_t mode);
 /* Decode-sized NT GEMMs (M <= 640 rows: cc_decode_fwd's c_attn / c_proj / c_fc at rows x beams = 320) run on 64-row tiles
  * (gemm_nt_s64_kernel).  -1 = default (those call sites only), 0 = never, 1 / 2 = additionally route cc_gemm_bf16_f32's NT launches with
- * M <= 1024 through the 64 x 64 / 64 x 128 form.  Process-global; returns the previous mode.  For tests and tools/small_gemm_bench.py. */
+ * M <= 1024 through the 64 x 64 / 64 x 128 / 64 x 64 K-split-over-waves (3) form.  Process-global; returns the previous mode.  For tests and tools/small_gemm_bench.py. */
 int cc_gemm_skinny_mode(int32_t mode);
 int cc_layernorm_fwd(const float* x, const float* gamma, const float* beta, uint16_t* y, float* mean, float* rstd, int32_t rows,
                      int32_t D, void* stream);

@@ -68,12 +68,12 @@ def test_gemm_nt_256_row_tiles(mode, M, N, K):
     assert torch.isnan(Cm[:, N:]).all()
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("M,N,K,ks", [(320, 1024, 1024, 1), (320, 3072, 1024, 1), (5, 2304, 768, 3), (333, 1000, 256, 1), (64, 64, 64, 1),
                                       (640, 4096, 1024, 1), (77, 200, 4096, 6), (1, 8, 128, 2)])
 def test_gemm_nt_skinny_64_row_tiles(mode, M, N, K, ks):
-    """the 64 x 64 / 64 x 128 decode-sized NT kernels (32x32x16 MFMA), single pass and with K slices (atomic accumulation into a
-    non-zero C), ragged M / N edges and a padded leading dimension"""
+    """the 64 x 64 / 64 x 128 decode-sized NT kernels (32x32x16 MFMA; mode 3: the 64 x 64 form with K split over the waves), single pass
+    and with K slices (atomic accumulation into a non-zero C), ragged M / N edges and a padded leading dimension"""
     torch.manual_seed(M + N + K + mode)
     dev = "cuda"
     A = _bf(torch.randn(M, K, device=dev))
