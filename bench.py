@@ -269,7 +269,7 @@ def main():
 
     from clipcap_amd import _lib
     from clipcap_amd.train.ddp import GradReducer
-    from oracle.clipcap_oracle import linear_schedule_factor  # schedule arithmetic only (host scalar)
+    from clipcap_amd.model.optim import linear_warmup_decay
     me, ge, eng = init_engines(c, device)
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
     embeds = torch.randn(B, c["E"], generator=gen, device=device)
@@ -278,6 +278,7 @@ def main():
     reducer = GradReducer([a.grads() for a in arenas]) if world > 1 else None
     total_steps = args.steps + args.warmup
     base_lr, warm = 2e-5, 2
+    sched = linear_warmup_decay(warm, total_steps + 1)
 
     def one_step(i):
         eng.zero_grad()
@@ -290,7 +291,7 @@ def main():
             reducer.finish()
         else:
             loss = eng.forward_backward(tokens, embeds, dropout=drop)
-        lr = base_lr * linear_schedule_factor(i, warm, total_steps + 1)
+        lr = base_lr * sched(i)
         for a in arenas:
             a.adamw_step(lr, i + 1)
         return loss
