@@ -106,3 +106,22 @@ def test_context_overflow_and_beam_limits():
     toks, scores, lens = generate_beam_tokens(SimpleNamespace(language_model=lm), torch.randn(2, 4, 64, device="cuda"), beam_size=1,
                                               entry_length=5, stop_token=96)
     assert toks.shape[:2] == (2, 1) and toks.shape[2] <= 5 and torch.isfinite(scores).all()
+
+
+def test_decode_row_count_paths_agree():
+    """cc_decode_fwd picks its GEMM kernels by row count (<= 640 rows: 64-row tiles, with or without K split over the waves; above: the
+    128-row kernels).  The same rows decoded as one 700-row session and as two 350-row sessions must agree to bf16 rounding."""
+    from clipcap_amd.engine import DecodeSession
+    from clipcap_amd.model.gpt2 import GPT2LM
+    torch.manual_seed(5)
+    lm = GPT2LM(n_embd=768, n_layer=2, n_head=12, vocab_size=1000, n_positions=64).to("cuda")
+    x = torch.randn(700, 6, 768, device="cuda") * 0.4
+    big = DecodeSession(lm.engine, 700, 16)
+    lb = [big.forward(x[:, :5]).clone(), big.forward(x[:, 5:6]).clone()]
+    for half in (slice(0, 350), slice(350, 700)):
+        s = DecodeSession(lm.engine, 350, 16)
+        ls = [s.forward(x[half, :5]).clone(), s.forward(x[half, 5:6]).clone()]
+        for a, b in zip(ls, lb):
+            d = (a - b[half]).float()
+            scale = max(1.0, b.abs().max().item())
+            assert d.abs().max().item() <= 8e-3 * scale and d.pow(2).mean().sqrt().item() <= 2e-3 * scale
