@@ -126,6 +126,83 @@ __global__ __launch_bounds__(256, 2) void k_step_v(const char* __restrict__ A, c
     out[(size_t)blockIdx.x * 256 + tid] = s + wm + wn;
     if (lane == 0) stamps[(size_t)blockIdx.x * 4 + wave] = t1 - t0;
 }
+// V3: the 2 x 2 wave layout, software-pipelined: fragment reads of tile t+1 are issued before the MFMAs of tile t, DMA after them.
+// V4: the same with the K split over the waves (whole tile per wave, a quarter of each K-tile).
+template <int V>
+__global__ __launch_bounds__(256, 2) void k_step_p(const char* __restrict__ A, const char* __restrict__ W, int K2, int tiles_m, float* out,
+                                                   unsigned long long* stamps) {
+    extern __shared__ __attribute__((aligned(1024))) char sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tm = blockIdx.x % tiles_m, tn = blockIdx.x / tiles_m;
+    const int nk = K2 / 128;
+    constexpr int NA = V == 3 ? 4 : 2;            // fragments per operand and step
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    auto issue = [&](int t, int slot) {
+        char* st = sm + slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int seg = wave + 4 * i;
+            const int row = (seg & 7) * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7) ^ ((row >> 4) & 3);
+            const char* src = (seg < 8 ? A + (size_t)(tm * 64 + row) * K2 : W + (size_t)(tn * 64 + row) * K2) + t * 128 + chunk * 16;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(st + seg * 1024), 16, 0, 0);
+        }
+    };
+    const int frow = lane & 31, fhalf = lane >> 5;
+    auto readf = [&](int t, bf16x8 (&a)[NA], bf16x8 (&b)[NA]) {
+        const char* cur = sm + (t & 3) * STAGE;
+#pragma unroll
+        for (int q = 0; q < NA; q++) {
+            if (V == 3) {
+                a[q] = *reinterpret_cast<const bf16x8*>(cur + lds_off(wm * 32 + frow, q * 2 + fhalf));
+                b[q] = *reinterpret_cast<const bf16x8*>(cur + 8192 + lds_off(wn * 32 + frow, q * 2 + fhalf));
+            } else {
+                a[q] = *reinterpret_cast<const bf16x8*>(cur + lds_off(q * 32 + frow, wave * 2 + fhalf));
+                b[q] = *reinterpret_cast<const bf16x8*>(cur + 8192 + lds_off(q * 32 + frow, wave * 2 + fhalf));
+            }
+        }
+    };
+    auto mfma = [&](bf16x8 (&a)[NA], bf16x8 (&b)[NA]) {
+        if (V == 3) {
+#pragma unroll
+            for (int q = 0; q < NA; q++) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q], b[q], acc[0][0], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    for (int t = 0; t < NS; t++) if (t < nk) issue(t, t);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // tiles 0 and 1 landed (nk >= 4 here)
+    __builtin_amdgcn_s_barrier();
+    bf16x8 a0[NA], b0[NA], a1[NA], b1[NA];
+    readf(0, a0, b0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    auto step = [&](int kt, bf16x8 (&a)[NA], bf16x8 (&b)[NA], bf16x8 (&an)[NA], bf16x8 (&bn)[NA]) {
+        if (kt + 1 < nk) readf(kt + 1, an, bn);
+        mfma(a, b);
+        if (kt + NS < nk) issue(kt + NS, kt & 3);
+        const int rem = max(0, min(nk - 1, kt + NS) - (kt + 2));
+        if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(kt, a0, b0, a1, b1);
+        if (kt + 1 < nk) step(kt + 1, a1, b1, a0, b0);
+    }
+    float s = 0;
+    for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int r = 0; r < 16; r++) s += acc[i][j][r];
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    out[(size_t)blockIdx.x * 256 + tid] = s + wm + wn;
+    if (lane == 0) stamps[(size_t)blockIdx.x * 4 + wave] = t1 - t0;
+}
 int main() {
     const int M = 320, N = 1024;
     char *A, *W; float* out; unsigned long long* st;
@@ -165,6 +242,8 @@ int main() {
             };
             go("k-split over waves, dma before reads", k_step_v<1>);
             go("k-split over waves, dma after reads", k_step_v<2>);
+            go("2x2 waves, software-pipelined", k_step_p<3>);
+            go("k-split over waves, software-pipelined", k_step_p<4>);
         }
         hipFree(out); hipFree(st);
     }
