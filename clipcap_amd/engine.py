@@ -429,6 +429,13 @@ class DecodeSession:
         return out
 
 
+def embed_tokens(gpt2: "Gpt2Engine", tokens: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out fp32 (R, 1, D) or (R, D) = wte[tokens] for int32 ``tokens`` (R,) in one launch (cc_embed_tokens; reference inference/base.py:117,184)."""
+    wte = gpt2.arena.w32[gpt2.offsets[0]:]
+    check(_lib.lib().cc_embed_tokens(C.byref(gpt2.cfg), tokens.numel(), _p(wte), _p(tokens), _p(out), _stream(gpt2.arena.device)), "cc_embed_tokens")
+    return out
+
+
 def beam_step(logits: torch.Tensor, samples: int, beam: int, temperature: float, first: bool, stop_token: int, scores: torch.Tensor,
               seq_lengths: torch.Tensor, has_stopped: torch.Tensor):
     """One device-side beam update for `samples` independent beam sets (reference inference/base.py:84-119).

@@ -11,7 +11,7 @@ from typing import Callable, List, Optional, Tuple, Union
 
 import torch
 
-from clipcap_amd.engine import DecodeSession, beam_step, sample_step
+from clipcap_amd.engine import DecodeSession, beam_step, embed_tokens, sample_step
 from clipcap_amd.inference.utils import (nucleus_distribution, repetition_penalty_apply, sentence_length_penalty_apply,  # noqa: F401
                                          top_k_top_p_filtering)
 
@@ -101,27 +101,26 @@ def sample_tokens(model, embeds: torch.Tensor, entry_length: int = 67, stop_toke
     dev = g.arena.device
     embeds = embeds.to(dev, torch.float32)
     R, L0, D = embeds.shape
-    wte = lm.get_input_embeddings().weight.detach()
     sess = DecodeSession(g, R, L0 + entry_length)
     toks = torch.zeros(R, entry_length, dtype=torch.int64, device=dev)
-    done = torch.zeros(R, dtype=torch.bool, device=dev)
-    stop_pos = torch.full((R,), entry_length, dtype=torch.int64, device=dev)
+    xbuf = torch.empty(R, 1, D, dtype=torch.float32, device=dev)
     x = embeds
     n = 0
     for step in range(entry_length):
         logits = sess.forward(x)                                                     # (R, V) fp32
         u = torch.rand(R, device=dev, generator=generator)
         nxt = sample_step(logits, u, temperature=temperature, top_k=top_k or 0, top_p=top_p, mode=mode, history=toks, hist_len=step,
-                          repetition_penalty=repetition_penalty).to(torch.int64)
+                          repetition_penalty=repetition_penalty)                     # int32 (R,)
         toks[:, step] = nxt
-        hit = (nxt == stop_token) & ~done
-        stop_pos = torch.where(hit, torch.full_like(stop_pos, step), stop_pos)
-        done |= hit
         n = step + 1
-        if step % 4 == 3 and bool(done.all()):
+        # every row has produced its stop token: polled every 4th step (one host sync instead of four; the extra tokens are cut below)
+        if step % 4 == 3 and bool((toks[:, :n] == stop_token).any(dim=1).all()):
             break
-        x = wte[nxt].view(R, 1, D)
-    return toks[:, :n], stop_pos.clamp(max=n)
+        x = embed_tokens(g, nxt, xbuf)                                               # wte[next] (base.py:184), one launch
+    toks = toks[:, :n]
+    hit = toks == stop_token
+    stop_pos = torch.where(hit.any(dim=1), hit.to(torch.int32).argmax(dim=1), torch.full((R,), n, dtype=torch.int64, device=dev))
+    return toks, stop_pos
 
 
 def _rows_for(embeds: torch.Tensor, number_to_generate: int) -> torch.Tensor:
