@@ -790,7 +790,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void gemm_nt_s64kw_kernel(const bf16_
 // spill 90 registers).  TT = true is the weight-gradient form (both operands K-strided), see H_ISSUE / h_tt_read.
 // NT LDS image [row][32 k] (64-B rows) with the bank-group-exact XOR key h_swz below.
 // ------------------------------------------------------------------------------------------------
-constexpr int H_BM = 256, H_BN = 256, H_BK = 32, H_NS = 4, H_STAGE = (H_BM + H_BN) * H_BK * 2;   // 32 KiB per stage, 128 KiB total
+constexpr int H_BM = 256, H_BN = 256, H_BK = 32, H_NS = 4, H_STAGE = (H_BM + H_BN) * H_BK * 2;   // 32 KiB per stage, 128 KiB total (5 stages = all 160 KiB measured 2-3 % slower)
 // The B tile may be narrower: NJ MFMA column tiles per wave -> block tile 256 x (64 NJ); NJ = 3 gives 256 x 192 for N = 768-like widths.
 // 64-B rows, 4 chunks of 16 B.  ds_read_b128 is serviced in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (guide, LDS
 // table): with lane = (row & 15) + 16 * chunk a group holds rows 0-3 and 12-15 at chunk c and rows 4-11 at chunk c^1, so the XOR
@@ -808,7 +808,7 @@ __device__ __forceinline__ int h_lds_off(int row, int chunk) { return row * 64 +
 __device__ __forceinline__ int h_tt_g(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
 #define H_ISSUE(T, IS_A)                                                                                                 \
     {                                                                                                                    \
-        char* st_ = smem + ((T) & (H_NS - 1)) * H_STAGE + ((IS_A) ? 0 : H_BM * H_BK * 2);                                \
+        char* st_ = smem + ((T) % H_NS) * H_STAGE + ((IS_A) ? 0 : H_BM * H_BK * 2);                                      \
         const int k0_ = kbeg + (T)*H_BK;                                                                                 \
         _Pragma("unroll") for (int i_ = 0; i_ < ((IS_A) ? 4 : NJ); i_++) {                                              \
             const int seg = wn + 4 * i_;                        /* 16 (A) or 4 NJ (B) segments of 1 KiB */                \
@@ -847,7 +847,7 @@ __device__ __forceinline__ bf16x8 h_tt_oper(const HTTFrag& f) {
 }
 #define H_LOADF(T)                                                                                                       \
     {                                                                                                                    \
-        const char* ca_ = smem + ((T) & (H_NS - 1)) * H_STAGE;                                                           \
+        const char* ca_ = smem + ((T) % H_NS) * H_STAGE;                                                                 \
         const char* cb_ = ca_ + H_BM * H_BK * 2;                                                                         \
         if constexpr (TT) {                                                                                              \
             _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) taf[i_] = h_tt_read(ca_, tt_base, ((grp * 16 + 2 * i_) ^ tt_gx) << 4);  \
@@ -875,15 +875,27 @@ __device__ __forceinline__ bf16x8 h_tt_oper(const HTTFrag& f) {
         __builtin_amdgcn_s_barrier();                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
     }
-// tile t+1 must have landed; tiles t+2 and t+3 (CNT DMA instructions per wave each: 4 in group 0, NJ in group 1) may stay in flight
+// tile t+1 must have landed; tiles t+2 .. t+H_NS-1 (CNT DMA instructions per wave each: 4 in group 0, NJ in group 1) may stay in flight
 #define H_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 #define H_WAIT(T, CNT)                                                                                                   \
     {                                                                                                                    \
-        const int rem_ = min(nk - 1, (T) + 3) - ((T) + 1);                                                               \
-        if (rem_ >= 2) { if ((CNT) == 4) H_VMCNT(8); else if ((CNT) == 3) H_VMCNT(6); else H_VMCNT(4); }                 \
+        const int rem_ = min(nk - 1, (T) + H_NS - 1) - ((T) + 1);                                                        \
+        if (rem_ >= 3) { if ((CNT) == 4) H_VMCNT(12); else if ((CNT) == 3) H_VMCNT(9); else H_VMCNT(6); }                \
+        else if (rem_ == 2) { if ((CNT) == 4) H_VMCNT(8); else if ((CNT) == 3) H_VMCNT(6); else H_VMCNT(4); }            \
         else if (rem_ == 1) { if ((CNT) == 4) H_VMCNT(4); else if ((CNT) == 3) H_VMCNT(3); else H_VMCNT(2); }            \
         else H_VMCNT(0);                                                                                                 \
     }
+// tools/probes/stag256_timing.hip compiles this header with CC_STAMP: cycle counts per phase of the main loop, wave 0 of either group
+#ifdef CC_STAMP
+__device__ unsigned long long cc_stamp_buf[2 * 8];
+#define H_STAMP_DECL unsigned long long st_last_ = __builtin_readcyclecounter(), st_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define H_STAMP(I) { const unsigned long long n_ = __builtin_readcyclecounter(); st_acc_[I] += n_ - st_last_; st_last_ = n_; }
+#define H_STAMP_OUT if (blockIdx.x == 7 && wn == 0 && lane == 0) { for (int i_ = 0; i_ < 8; i_++) cc_stamp_buf[grp * 8 + i_] = st_acc_[i_]; }
+#else
+#define H_STAMP_DECL
+#define H_STAMP(I)
+#define H_STAMP_OUT
+#endif
 template <class Epi, int NJ, bool TT = false>
 __global__ __launch_bounds__(512, 1) void gemm_nt_stag256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, GemmShape g, Epi epi) {
     static_assert(NJ >= 2 && NJ <= 4, "wave tile is 128 x (16 NJ)");
@@ -913,34 +925,68 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_stag256_kernel(const bf16_t* _
     const int tt_base = (8 * fchunk + (frow >> 2)) * 512 + ((frow & 3) >> 1) * 16 + (frow & 1) * 8;
     const int tt_gx = h_tt_g(8 * fchunk + (frow >> 2)) << 1;
     (void)tt_base; (void)tt_gx;
+    H_STAMP_DECL
     if (grp == 0) {
         H_ISSUE(0, true);
         if (nk > 1) H_ISSUE(1, true);
         if (nk > 2) H_ISSUE(2, true);
+        if (H_NS > 4 && nk > 3) H_ISSUE(3, true);
         H_WAIT(-1, 4);
         H_SEGEND();
+        H_STAMP(0)                                     // prologue
         for (int t = 0; t < nk; t++) {
-            if (t + 3 < nk) H_ISSUE(t + 3, true);      // buffer (t+3)&3 was last read (by group 1) in segment 2t-1
-            H_LOADF(t); H_SEGEND();
-            H_MFMA(); H_WAIT(t, 4); H_SEGEND();
+            if (t + H_NS - 1 < nk) H_ISSUE(t + H_NS - 1, true);      // that buffer held tile t-1, last read (by group 1) in segment 2t-1
+            H_STAMP(1)                                 // DMA issue
+            H_LOADF(t);
+#ifdef CC_STAMP
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+            H_STAMP(2)                                 // fragment reads + wait
+            H_SEGEND();
+            H_STAMP(3)                                 // barrier (end of read segment)
+            H_MFMA();
+            H_STAMP(4)                                 // MFMA issue
+            H_WAIT(t, 4);
+            H_STAMP(5)                                 // vmcnt wait
+            H_SEGEND();
+            H_STAMP(6)                                 // barrier (end of MFMA segment)
         }
         H_SEGEND();
     } else {
         H_ISSUE(0, false);
         if (nk > 1) H_ISSUE(1, false);
         if (nk > 2) H_ISSUE(2, false);
+        if (H_NS > 4 && nk > 3) H_ISSUE(3, false);
         H_WAIT(-1, NJ);
         H_SEGEND();
+        H_STAMP(0)
         for (int t = 0; t < nk; t++) {
             if (t >= 1) H_MFMA();
+            H_STAMP(4)
             H_SEGEND();
-            if (t + 3 < nk) H_ISSUE(t + 3, false);     // one segment after group 0's half of the same tile
-            H_LOADF(t); H_WAIT(t, NJ); H_SEGEND();
+            H_STAMP(6)
+            if (t + H_NS - 1 < nk) H_ISSUE(t + H_NS - 1, false);     // one segment after group 0's half of the same tile
+            H_STAMP(1)
+            H_LOADF(t);
+#ifdef CC_STAMP
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+            H_STAMP(2)
+            H_WAIT(t, NJ);
+            H_STAMP(5)
+            H_SEGEND();
+            H_STAMP(3)
         }
         H_MFMA(); H_SEGEND();
     }
+    H_STAMP(0)
     gemm_epilogue_regs<Epi, 8, NJ>(acc, lane, m0 + arow, n0 + bcol, epi);
+    H_STAMP(7)                                         // epilogue
+    H_STAMP_OUT
 }
+#undef H_STAMP_DECL
+#undef H_STAMP
+#undef H_STAMP_OUT
 #undef H_ISSUE
 #undef H_LOADF
 #undef H_MFMA
