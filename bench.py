@@ -162,7 +162,10 @@ def decode_bench(args, device):
             "beam_tokens_per_s": round(gen * beam / dt, 1),
             "roofline": {"bound": "hbm", "kernel": "whole decode step (weights once per generated position)",
                          "achieved": round(wbytes * steps_per_decode * args.steps / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(wbytes * steps_per_decode * args.steps / dt / 8e12, 4), "traffic": None}}
+                         "frac": round(wbytes * steps_per_decode * args.steps / dt / 8e12, 4),
+                         # fabric bytes per generated position from the PMC passes in profiles/r01_p_* (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
+                         # summed over the step's kernels): 2.68 GB read + 0.50 GB written vs 0.71 GB of weights
+                         "traffic": 3.18e9 if S == 64 else None}}
 
 
 def sample_bench(args, device):
