@@ -52,15 +52,36 @@ class _Arena:
         self.m: Optional[torch.Tensor] = None
         self.v: Optional[torch.Tensor] = None
         self._w16_version = -1
+        # tensors aliasing w32 whose in-place writes do NOT bump w32._version: nn.Parameters re-pointed with ``p.data = view``
+        # (ArenaModule._rebind) carry their own version counters, so load_state_dict / torch optimizers writing through them
+        # would otherwise leave the bf16 operand copy stale.  The dirty stamp is the sum over w32 and every watched alias.
+        self.watch: List[torch.Tensor] = []
+
+    def _stamp(self) -> int:
+        s = self.w32._version
+        for t in self.watch:
+            s += t._version
+        return s
 
     def sync_bf16(self):
-        """Refresh the bf16 copy if the master changed (version counter is shared by all views)."""
-        if self.w32._version != self._w16_version:
+        """Refresh the bf16 copy if the master changed (through w32, one of its views, or a watched parameter alias)."""
+        if self._stamp() != self._w16_version:
             self.refresh_bf16()
 
     def refresh_bf16(self):
         check(self.sync_fn(_p(self.w32), _p(self.w16), _stream(self.device)), "cc_*_sync_weights")
-        self._w16_version = self.w32._version
+        self._w16_version = self._stamp()
+
+    def moved_to(self, device, sync_fn) -> "_Arena":
+        """A copy of this arena on `device` carrying the master, the gradient arena and the AdamW moments (resume() followed by
+        .to(device) must not lose the optimizer state)."""
+        new = _Arena(self.n, device, sync_fn)
+        new.w32.copy_(self.w32)
+        for name in ("g32", "m", "v"):
+            t = getattr(self, name)
+            if t is not None:
+                setattr(new, name, t.to(new.device))
+        return new
 
     def grads(self) -> torch.Tensor:
         if self.g32 is None:
@@ -125,9 +146,7 @@ class MapperEngine:
         device = torch.device(device)
         if device == self.arena.device:
             return self
-        old = self.arena
-        self.arena = _Arena(old.n, device, self._sync)
-        self.arena.w32.copy_(old.w32)
+        self.arena = self.arena.moved_to(device, self._sync)
         self._ws.clear()
         return self
 
@@ -155,6 +174,9 @@ class MapperEngine:
         check(_lib.lib().cc_mapper_fwd(C.byref(self.cfg), B, _p(self.arena.w32), _p(self.arena.w16), _p(emb), _p(ws), _p(out), int(save),
                                       _stream(self.arena.device)), "cc_mapper_fwd")
         self._last = (B, emb)  # keep the input alive until backward has consumed the workspace
+        if save:
+            self._saved_batch = B
+            self._fwd_serial = getattr(self, "_fwd_serial", 0) + 1
         return out
 
     def layer_span(self, l: int) -> Tuple[int, int]:

@@ -91,10 +91,12 @@ def generate_beam(model, tokenizer: Callable, embeds: torch.Tensor, number_to_ge
 @torch.no_grad()
 def sample_tokens(model, embeds: torch.Tensor, entry_length: int = 67, stop_token: int = 50256, *, mode: int = 0, top_p: float = 0.8,
                   top_k: Optional[int] = None, temperature: float = 1.0, repetition_penalty: float = 1.0,
-                  generator: Optional[torch.Generator] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                  generator: Optional[torch.Generator] = None, head_tokens: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """KV-cached sampling for a batch of prefixes, every step on the device (cc_decode_fwd + cc_sample_step, no host sync except
     an all-rows-stopped poll every 4th step).  embeds fp32 (R, L, D).  mode 0 = the nucleus rule of generate_nucleus_sampling
     (base.py:165-181), mode 1 = top_k_top_p_filtering + softmax (base.py:245-262).
+    ``head_tokens`` int64 (R, H0) or (1, H0): tokens that precede the generated ones in the repetition-penalty history (the
+    reference penalises ``tokens`` = text_prefix_tokens ++ generated, no_beam.py:32,45-48).
     Returns (tokens int64 (R, n), stop_pos int64 (R,)): stop_pos[r] = index of the first stop token of row r (n if none)."""
     lm = model.language_model
     g = lm.engine
@@ -102,14 +104,18 @@ def sample_tokens(model, embeds: torch.Tensor, entry_length: int = 67, stop_toke
     embeds = embeds.to(dev, torch.float32)
     R, L0, D = embeds.shape
     sess = DecodeSession(g, R, L0 + entry_length)
-    toks = torch.zeros(R, entry_length, dtype=torch.int64, device=dev)
+    H0 = 0 if head_tokens is None else int(head_tokens.shape[-1])
+    hist = torch.zeros(R, H0 + entry_length, dtype=torch.int64, device=dev)          # [head | generated]: the penalty's history
+    if H0:
+        hist[:, :H0] = head_tokens.to(dev, torch.int64).reshape(-1, H0).expand(R, H0)
+    toks = hist[:, H0:]
     xbuf = torch.empty(R, 1, D, dtype=torch.float32, device=dev)
     x = embeds
     n = 0
     for step in range(entry_length):
         logits = sess.forward(x)                                                     # (R, V) fp32
         u = torch.rand(R, device=dev, generator=generator)
-        nxt = sample_step(logits, u, temperature=temperature, top_k=top_k or 0, top_p=top_p, mode=mode, history=toks, hist_len=step,
+        nxt = sample_step(logits, u, temperature=temperature, top_k=top_k or 0, top_p=top_p, mode=mode, history=hist, hist_len=H0 + step,
                           repetition_penalty=repetition_penalty)                     # int32 (R,)
         toks[:, step] = nxt
         n = step + 1

@@ -5,19 +5,21 @@ from typing import Callable, Optional
 
 import torch
 
-from clipcap_amd.inference.base import generate_no_beam
+from clipcap_amd.inference.no_beam import generate_no_beam
 
 
 def generate(model, tokenizer: Callable, embeddings: torch.Tensor, top_p: float = 0.95, top_k: int = 0, temperature: float = 1.0,
-             number_to_generate: int = 5, text_prefix: Optional[str] = None, stop_token: Optional[str] = None):
-    assert embeddings.shape[0] == 1, "batch-1 like the reference (generate.py:19-20); use generate_beam for batches"
-    text = tokenizer.bos_token + (text_prefix or "")
-    prefix_tokens = tokenizer.encode(text, return_tensors="pt").to(embeddings.device)
+             number_to_generate: int = 5, text_prefix: Optional[str] = None, stop_token: Optional[str] = None,
+             generator: Optional[torch.Generator] = None):
+    batch_size = embeddings.shape[0]
+    assert batch_size == 1, "Batch size > 1 support coming soon - for now leave embeddings.shape[0] as 1."   # generate.py:19-20
+    text_prefix = tokenizer.bos_token + (text_prefix or "")                                                  # generate.py:22-25
+    text_prefix_tokens = tokenizer.encode(text_prefix, return_tensors="pt").expand(batch_size, -1).to(embeddings.device)
     with torch.no_grad():
-        tok_emb = model.language_model.get_input_embeddings()(prefix_tokens)
-        prefix = model.transformer_mapper(embeddings)
-    inputs = torch.cat((prefix, tok_emb.to(prefix.device)), dim=1)
-    outs = []
-    for _ in range(number_to_generate):
-        outs += generate_no_beam(model, tokenizer, inputs, top_p=top_p, top_k=top_k, temperature=temperature, sweep=False)
-    return outs
+        token_embeddings = model.language_model.get_input_embeddings()(text_prefix_tokens)
+        prefix_projections = model.transformer_mapper(embeddings)
+    inputs_embeds = torch.cat((prefix_projections, token_embeddings.to(prefix_projections.device)), dim=1)
+    # like the reference, generate_no_beam appends the text prefix's embeddings AGAIN (it is given text_prefix_tokens, no_beam.py:28-30):
+    # the language model sees [prefix ; bos+text ; bos+text ; generated...]
+    return generate_no_beam(model, tokenizer, inputs_embeds, number_to_generate=number_to_generate, text_prefix_tokens=text_prefix_tokens,
+                            top_p=top_p, top_k=top_k, temperature=temperature, generator=generator)

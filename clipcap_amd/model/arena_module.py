@@ -3,8 +3,8 @@
 Why: the HIP library works on flat arenas (one fused AdamW launch, one all-reduce, bf16 operand copies refreshed in one
 call) while the reference's callers expect ordinary nn.Modules whose ``state_dict()`` carries the reference's key names
 (clipcap/model/load.py:34 ``load_state_dict(strict=False)``).  Both hold: each nn.Parameter's storage IS a slice of the
-arena, ``.to(device)`` moves the arena and re-points the parameters, and in-place updates bump the arena's version
-counter so the bf16 copy is refreshed lazily.
+arena, ``.to(device)`` moves the arena and re-points the parameters, and in-place updates of a parameter (load_state_dict, torch optimizers, copy_) are
+noticed through the version counters the arena watches, so the bf16 operand copy is refreshed lazily.
 """
 from __future__ import annotations
 
@@ -30,12 +30,15 @@ class ArenaModule(nn.Module):
             p = nn.Parameter(view, requires_grad=True)
             mod.register_parameter(leaf, p)
             self._arena_params[name] = p
+        self.engine.arena.watch = list(self._arena_params.values())
 
     def _rebind(self):
         views = self.engine.views(self.engine.arena.w32)
         for name, p in self._arena_params.items():
             p.data = views[name]
             p.grad = None
+        # p.data = view gives every parameter its own version counter: the arena sums them to notice in-place writes
+        self.engine.arena.watch = list(self._arena_params.values())
 
     def _apply(self, fn, recurse=True):
         # learn the target device from fn (module.to / .cuda / .cpu); dtype changes are ignored: the master stays fp32

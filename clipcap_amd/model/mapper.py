@@ -17,17 +17,30 @@ class _MapperFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, module, x, *params):
+        # grad mode is always OFF inside Function.forward, so "do we need the activations" cannot be asked here: apply() is only
+        # reached from TransformerMapper.forward when a backward is possible, and the forward then always keeps them (save=True).
         ctx.module = module
-        return module.engine.forward(x, save=torch.is_grad_enabled())
+        ctx.batch = x.shape[0]
+        eng = module.engine
+        out = eng.forward(x, save=True)
+        ctx.serial = eng._fwd_serial         # bumped by every saving forward of this engine (fused trainer included)
+        return out
 
     @staticmethod
     def backward(ctx, dout):
         eng = ctx.module.engine
+        if getattr(eng, "_fwd_serial", 0) != ctx.serial or getattr(eng, "_saved_batch", None) != ctx.batch:
+            # the activation workspace is per engine: a later saving forward has overwritten what this graph needs
+            raise RuntimeError("TransformerMapper.backward: the saved activations were overwritten by a later forward; "
+                               "call backward() before running the mapper again")
         g = eng.arena.grads()
+        keep = g.clone()                     # the gradient arena may hold the fused trainer's accumulation: leave it as found
         g.zero_()
         eng.backward(dout.contiguous())
         views = eng.views(g)
-        return (None, None) + tuple(views[n].clone() for n in ctx.module._arena_params)
+        outs = tuple(views[n].clone() for n in ctx.module._arena_params)
+        g.copy_(keep)
+        return (None, None) + outs
 
 
 class TransformerMapper(ArenaModule):

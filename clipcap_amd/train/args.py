@@ -13,6 +13,7 @@ _GROUPS = {
         ("--checkpoint-save-frequency", int, 1, "Write a checkpoint every n epochs."),
         ("--checkpoint-filename-prefix", str, 1, "Checkpoint file name prefix."),
         ("--device", str, "0", "GPU index, comma list, or -1 for all (one process per GPU via torchrun)."),
+        ("--resume-from", str, None, "Checkpoint (.ckpt written by this trainer) to resume from: weights, AdamW state, step, schedule, epoch."),
     ],
     "data": [
         ("--input-dataset", str, "./dataset/", "Preprocessed dataset folder (embeddings/*.npy, captions/*.parquet, encoder_config.yaml)."),

@@ -11,7 +11,6 @@ pinned host staging and an async H2D copy on a side stream so the next batch upl
 from __future__ import annotations
 
 import glob
-import math
 import os
 from typing import Iterator, List, Optional, Tuple
 
@@ -80,7 +79,11 @@ class EmbedDataset(torch.utils.data.IterableDataset):
         self.rank, self.world_size = rank, world_size
 
     def __len__(self) -> int:
-        return math.ceil(self.index.count / (self.batch_size * self.world_size))
+        """Optimizer steps per epoch — identical on every rank.  A trailing global batch with fewer rows than ranks is dropped on
+        ALL ranks: otherwise some ranks would get zero rows and skip the step while the others enter its collectives."""
+        gb = self.batch_size * self.world_size
+        full, tail = divmod(self.index.count, gb)
+        return full + (1 if tail >= self.world_size else 0)
 
     def encode(self, captions: List[str]) -> np.ndarray:
         enc = self.tokenizer.batch_encode_plus(captions)["input_ids"] if hasattr(self.tokenizer, "batch_encode_plus") \
@@ -92,9 +95,9 @@ class EmbedDataset(torch.utils.data.IterableDataset):
         gb = self.batch_size * self.world_size
         for lo in range(0, self.index.count, gb):
             hi = min(self.index.count, lo + gb)
+            if hi - lo < self.world_size:          # fewer rows than ranks: no rank takes this step (see __len__)
+                break
             a, b = shard_range(hi - lo, self.rank, self.world_size)
-            if b <= a:
-                continue
             emb, caps = self.index.rows(lo + a, lo + b)
             yield torch.from_numpy(self.encode(caps)), torch.from_numpy(np.ascontiguousarray(emb))
 
@@ -148,8 +151,13 @@ class DevicePrefetcher:
     def __next__(self):
         if self._next is None:
             raise StopIteration
-        if self.stream is not None:
-            torch.cuda.current_stream(self.device).wait_stream(self.stream)
         cur = self._next
+        if self.stream is not None:
+            compute = torch.cuda.current_stream(self.device)
+            compute.wait_stream(self.stream)
+            # the batch was allocated on the side stream: tell the caching allocator that the compute stream uses it, so that its
+            # block is not handed to a later side-stream upload while this step's kernels are still queued
+            for t in cur:
+                t.record_stream(compute)
         self._next = self._load()
         return cur

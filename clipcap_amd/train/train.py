@@ -15,7 +15,7 @@ from clipcap_amd.encoders.config import EncoderConfig
 from clipcap_amd.model import ClipCapModel, ClipCapModelPrefixOnly, Config, TrainingConfig, add_model_args
 from clipcap_amd.model.optim import linear_warmup_decay
 from clipcap_amd.train.args import add_training_args
-from clipcap_amd.train.callback import CheckpointSaver
+from clipcap_amd.train.callback import CheckpointSaver, resume
 from clipcap_amd.train.dataloader import DevicePrefetcher, get_dataloader
 from clipcap_amd.train.ddp import GradReducer
 
@@ -43,6 +43,21 @@ def train(args: Namespace, tokenizer=None, language_model=None) -> int:
     cls = ClipCapModel if args.train_language_model else ClipCapModelPrefixOnly  # train.py:46-50
     model = cls(config, language_model=language_model).to(device)
     model.train()
+    step, first_epoch = 0, 0
+    if getattr(args, "resume_from", None):
+        # true resume (the reference has none, train.py:17-93): weights, AdamW moments, optimizer step, schedule position, epoch
+        ck = resume(model, args.resume_from)
+        step = int(ck.get("step", ck.get("optimizer_step", 0)))
+        first_epoch = int(ck["epoch"]) + 1 if "epoch" in ck else step // max(1, len(dataset))
+    if world > 1:
+        # every rank must start from the same parameters (and, on resume, the same moments): rank 0's are authoritative
+        for mod in (model.transformer_mapper, model.language_model):
+            a = mod.engine.arena
+            torch.distributed.broadcast(a.w32, src=0)
+            a.w32.add_(0)                 # the collective wrote through a raw pointer: bump the version so bf16 copies refresh
+            if a.m is not None:
+                torch.distributed.broadcast(a.m, src=0)
+                torch.distributed.broadcast(a.v, src=0)
 
     saver = CheckpointSaver(args.output_folder, args.checkpoint_filename_prefix, save_every_n_epochs=args.checkpoint_save_frequency)
     if rank == 0:
@@ -57,8 +72,7 @@ def train(args: Namespace, tokenizer=None, language_model=None) -> int:
             logger = wandb.init(project=args.wandb_project)
         except ImportError:
             logger = None
-    step = 0
-    for epoch in range(args.epochs):
+    for epoch in range(first_epoch, args.epochs):
         for batch in DevicePrefetcher(dataset, device):
             loss = model.fused_step(batch, lr=args.optimizer_lr * sched(step), reducer=reducer)
             step += 1

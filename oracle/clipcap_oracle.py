@@ -357,3 +357,43 @@ def nucleus_final_p(logits: Tensor, top_p: float = 0.8, top_k: Optional[int] = N
     rows = torch.arange(len(pr)).unsqueeze(1).repeat(1, top_k)
     final[rows, idx_sorted] = ren.to(final.dtype)
     return final
+
+
+def no_beam_step_distribution(logits: Tensor, history: Optional[Tensor], *, top_p: float, top_k, temperature: float,
+                              repetition_penalty: float, stop_token: Optional[int] = None, desired_sentence_length: int = 50,
+                              sentence_length_factor: float = 1.0) -> Tensor:
+    """Pre-sampling distribution of one step of inference/no_beam.py:35-63 for 1-D ``logits`` (the variant generate() uses):
+    repetition penalty over ``history`` = text_prefix_tokens ++ generated (:45-48) -> / temperature (:51) ->
+    top_k_top_p_filtering (:52) -> sentence-length penalty (:55-60, value comparison as in the reference) -> softmax (:63)."""
+    lg = logits.clone()
+    has_hist = history is not None and history.numel() > 0
+    if repetition_penalty != 1.0 and has_hist:
+        lg = repetition_penalty_apply(lg, history, repetition_penalty)
+    lg = lg / (temperature if temperature > 0 else 1.0)
+    lg = top_k_top_p_filtering(lg, top_k=int(top_k), top_p=top_p)
+    if has_hist and stop_token is not None:
+        lg = sentence_length_penalty_apply(lg, history, stop_token, history.numel(), desired_sentence_length, sentence_length_factor)
+    return F.softmax(lg, dim=-1)
+
+
+def sampling_trace(p, embeds, forced: List[int], *, n_head, n_layer, rule: str, head: Optional[Tensor] = None, pre="language_model.",
+                   rb=False, **kw) -> List[Tensor]:
+    """Per-step pre-sampling distributions of the reference's sampling loops when the drawn tokens are ``forced`` (full re-forward
+    per step like no_beam.py:38 / nucleus_sampling.py:35).  rule "no_beam": no_beam.py:35-75 (kw: top_p, top_k, temperature,
+    repetition_penalty, stop_token); rule "nucleus": nucleus_sampling.py:34-56 (kw: top_p, top_k (0 = all), temperature).
+    embeds (1, L, D) already holds the text prefix's embeddings; ``head`` (H0,) are the text_prefix_tokens of the penalty history."""
+    wte = p[pre + "transformer.wte.weight"]
+    hist = head.clone() if head is not None and head.numel() else None
+    out = []
+    for tok in forced:
+        logits = gpt2_logits(p, embeds, n_head, n_layer, pre=pre, rb=rb)[0, -1, :]
+        if rule == "no_beam":
+            out.append(no_beam_step_distribution(logits, hist, **kw))
+        else:
+            t = kw.get("temperature", 1.0)
+            out.append(nucleus_final_p((logits / (t if t > 0 else 1.0)).unsqueeze(0), top_p=kw.get("top_p", 0.8),
+                                       top_k=(kw.get("top_k") or None))[0])
+        nt = torch.tensor([tok])
+        hist = nt if hist is None else torch.cat((hist, nt))
+        embeds = torch.cat((embeds, wte[nt].unsqueeze(0)), dim=1)
+    return out

@@ -54,9 +54,209 @@ class FakeTokenizer:
         return " ".join(str(int(i)) for i in ids)
 
 
+def _sampled(d, key, t):
+    """Stores a large tensor as (norm, evenly strided sample) — tests/seeded.py:sample_idx gives the positions."""
+    from tests.seeded import sample_idx
+    a = t.detach().numpy().reshape(-1)
+    d[key + ".norm"] = np.array(float(np.sqrt((a.astype(np.float64) ** 2).sum())))
+    d[key + ".sample"] = a[sample_idx(a.size)].copy()
+
+
+def _seeded_clipcap(tmp, *, E, D, P, L, H, N, NL, n_head, V, NPOS, seed, full):
+    """The REFERENCE's ClipCapModel(PrefixOnly) carrying tests/seeded.py parameters (GPT-2 dropout 0 so train mode is deterministic)."""
+    from transformers import GPT2Config, GPT2LMHeadModel
+    from clipcap.model.model import ClipCapModel, ClipCapModelPrefixOnly
+    from clipcap.model.config import Config, TrainingConfig
+    from clipcap.encoders.config import EncoderConfig
+    from tests import seeded
+    gsd = seeded.state_dict(seeded.gpt2_shapes(D, NL, V, NPOS), seed)
+    msd = seeded.state_dict(seeded.mapper_shapes(E, D, P, L, N), seed + 1)
+    lm = GPT2LMHeadModel(GPT2Config(n_embd=D, n_layer=NL, n_head=n_head, vocab_size=V, n_positions=NPOS, resid_pdrop=0.0, embd_pdrop=0.0,
+                                    attn_pdrop=0.0))
+    missing = lm.load_state_dict({k: torch.from_numpy(v) for k, v in gsd.items()}, strict=False)
+    assert all("attn.bias" in k or "masked_bias" in k or k == "lm_head.weight" for k in missing.missing_keys), missing
+    lm.save_pretrained(tmp)
+    cfg = Config(language_model=tmp, train_language_model=full, prefix_length=L, projection_length=P, transformer_layers=N,
+                 transformer_attention_heads=H, encoder_config=EncoderConfig(encoder_embedding_size=E),
+                 training_config=TrainingConfig(optimizer_lr=1e-3, use_deepspeed_optimisers=False, scheduler_warmup_steps=2, total_steps=6))
+    model = (ClipCapModel if full else ClipCapModelPrefixOnly)(cfg)
+    model.transformer_mapper.load_state_dict({k: torch.from_numpy(v) for k, v in msd.items()})
+    model.train()
+    return model, gsd, msd
+
+
+def _full_model_fixture(name, *, E, D, P, L, H, N, NL, n_head, V, NPOS, seed, full, B=2, cap=40):
+    """Shape-faithful whole-model fixture (BASELINE configs[1] / configs[3] architecture at B=2): the reference's logits (sub-sampled),
+    loss and gradients (sub-sampled) for seeded parameters that the tests regenerate instead of loading."""
+    from tests import seeded
+    tmp = tempfile.mkdtemp()
+    model, gsd, msd = _seeded_clipcap(tmp, E=E, D=D, P=P, L=L, H=H, N=N, NL=NL, n_head=n_head, V=V, NPOS=NPOS, seed=seed, full=full)
+    gen = torch.Generator().manual_seed(seed + 7)
+    tokens = torch.randint(1, V, (B, cap), generator=gen)
+    tokens[0, cap - 6:] = -1
+    tokens[1, 3] = 0
+    embeds = torch.randn(B, E, generator=gen)
+    d = {"in.tokens": tokens.numpy().copy(), "in.embeds": embeds.numpy(),
+         "cfg": np.array([E, D, P, L, H, N, n_head, NL, V, NPOS, seed, int(full)]),
+         "param_checksum": np.concatenate([seeded.checksum(gsd), seeded.checksum(msd)])}
+    loss = model.training_step((tokens.clone(), embeds), 0)
+    loss.backward()
+    d["loss"] = np.array(float(loss))
+    for k, v in model.named_parameters():
+        if v.grad is not None and (full or k.startswith("transformer_mapper.")):
+            _sampled(d, "grad0." + k, v.grad)
+    with torch.no_grad():
+        model.eval()
+        logits = model(torch.where(tokens < 0, 0, tokens), embeds, tokens.ge(0)).logits          # (B, T, V)
+        prefix = model.transformer_mapper(embeds)
+    cols = seeded.sample_idx(V, 1024)
+    d["logits.cols"] = logits[:, :, cols].numpy()                       # every row, 1024 strided vocabulary columns
+    d["logits.rows"] = logits[:, [L - 1, L + 7, L + cap - 2], :].numpy()  # three full rows per sample
+    d["logits.absmax"] = np.array(float(logits.abs().max()))
+    d["prefix"] = prefix.numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print(name, "loss", float(loss), "logits absmax", float(logits.abs().max()))
+
+
 def main():
     _install_pl_stub()
     sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    only = set(sys.argv[1:])
+    if only:
+        return _main_new(only)
+    _main_round1()
+    _main_new(set())
+
+
+def _main_new(only):
+    """Fixtures added in round 2 (selectable by name on the command line; no name = all)."""
+    torch.set_num_threads(8)
+    from tests import seeded
+    from clipcap.model.mapper import TransformerMapper
+    from clipcap.inference import no_beam as inb, nucleus_sampling as ins
+    from transformers import GPT2Config, GPT2LMHeadModel
+    os.makedirs(OUT, exist_ok=True)
+
+    def want(n):
+        return not only or n in only
+
+    # ---- (1b) the shape-faithful mapper of SURVEY.md 8c: E=512, D=768, P=L=10, H=8 (hd 96), N=1, B=2, seeded parameters ----
+    if want("mapper_faithful"):
+        E, D, P, L, H, N, B, seed = 512, 768, 10, 10, 8, 1, 2, 4101
+        msd = seeded.state_dict(seeded.mapper_shapes(E, D, P, L, N), seed)
+        m = TransformerMapper(E, D, L, P, H, N)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in msd.items()})
+        x = torch.randn(B, E, generator=torch.Generator().manual_seed(seed))
+        out = m(x)
+        lin = m.linear(x).view(B, P, -1)
+        h = torch.cat((lin, m.prefix_const.unsqueeze(0).expand(B, L, D)), dim=1)
+        _, atts = m.transformer.forward_with_attention(h)
+        loss = out.square().mean()
+        loss.backward()
+        d = {"in.x": x.numpy(), "out": out.detach().numpy(), "loss": loss.detach().numpy(), "dims": np.array([E, D, P, L, H, N, B, seed]),
+             "param_checksum": seeded.checksum(msd), "att.0": atts[0].detach().numpy()}
+        for k, v in m.named_parameters():
+            _sampled(d, "grad." + k, v.grad)
+        np.savez_compressed(os.path.join(OUT, "mapper_faithful.npz"), **d)
+
+    # ---- (7) the sampling variants generate() uses: no_beam.py:10-82 (stop on ".", repetition penalty 1.2) and
+    #          nucleus_sampling.py:9-74; torch.multinomial patched to record the pre-sampling distribution of every step and to
+    #          force a deterministic token (rank step % 3 of the distribution) so that the history has repeats ----
+    if want("sampling_steps"):
+        WTE_SCALE = 5.0
+        b = np.load(os.path.join(OUT, "gpt2_tiny.npz"))         # the D=64 / V=211 GPT-2 of fixture (2), wte scaled for peakier steps
+        D, n_layer, n_head, V, npos = [int(v) for v in b["cfg"]]
+        lmb = GPT2LMHeadModel(GPT2Config(n_embd=D, n_layer=n_layer, n_head=n_head, vocab_size=V, n_positions=npos, resid_pdrop=0.0,
+                                         embd_pdrop=0.0, attn_pdrop=0.0)).eval()
+        lmb.load_state_dict({k[3:]: torch.from_numpy(b[k]) for k in b.files if k.startswith("sd.")}, strict=False)
+        with torch.no_grad():
+            lmb.transformer.wte.weight.mul_(WTE_SCALE)
+
+        class _M:
+            language_model = lmb
+
+        class DotTokenizer(FakeTokenizer):
+            def encode(self, s):
+                return [self.eos_id]            # "." -> the stop id under test
+
+        real_multinomial = torch.multinomial
+        d = {"wte_scale": np.array(WTE_SCALE)}
+        for case, (fn, kw, stop, head) in {
+                "no_beam": (inb.generate_no_beam, dict(number_to_generate=1, top_p=0.9, top_k=0.0, temperature=0.9, repetition_penalty=1.2), 200,
+                            torch.tensor([[5, 17, 5]])),
+                "no_beam_topk": (inb.generate_no_beam, dict(number_to_generate=1, top_p=0.7, top_k=12, temperature=1.0, repetition_penalty=1.5), 200, None),
+                "nucleus": (ins.generate_nucleus_sampling, dict(number_to_generate=1, top_p=0.8, top_k=0, temperature=1.0), 200, None)}.items():
+            rec, forced = [], []
+
+            def fake_multinomial(pr, num_samples=1, **kw_):
+                pr2 = pr.reshape(-1, pr.shape[-1])
+                rec.append(pr2[0].clone())
+                k = len(rec) % 3
+                nz = int((pr2[0] > 0).sum())
+                tok = pr2[0].argsort(descending=True, stable=True)[min(k, nz - 1)].reshape(1)
+                if tok.item() == stop:          # never force the stop token: keep the trace at full length
+                    tok = pr2[0].argsort(descending=True, stable=True)[0].reshape(1) if nz == 1 else \
+                        pr2[0].argsort(descending=True, stable=True)[(min(k, nz - 1) + 1) % nz].reshape(1)
+                forced.append(int(tok))
+                return tok.reshape(pr.shape[:-1] + (1,)) if pr.dim() > 1 else tok
+
+            torch.multinomial = fake_multinomial
+            try:
+                torch.manual_seed(3000 + len(d))
+                pref = torch.randn(1, 4, D)
+                text = fn(_M, DotTokenizer(stop), pref, text_prefix_tokens=head, entry_length=10, **kw)
+            finally:
+                torch.multinomial = real_multinomial
+            d[case + ".prefix"] = pref.numpy()
+            d[case + ".head"] = (head if head is not None else torch.zeros(1, 0, dtype=torch.int64)).numpy()
+            d[case + ".probs"] = torch.stack(rec).numpy()
+            d[case + ".forced"] = np.array(forced, dtype=np.int64)
+            d[case + ".text"] = np.array([int(s) for s in text[0].split()], dtype=np.int64)
+            d[case + ".kw"] = np.array([kw["top_p"], float(kw["top_k"]), kw["temperature"], kw.get("repetition_penalty", 1.0), stop])
+        np.savez_compressed(os.path.join(OUT, "sampling_steps.npz"), **d)
+
+    # ---- (8) BASELINE configs[1] architecture, full depth: 8-layer mapper + 12-layer GPT-2-small, frozen LM ----
+    if want("config2_full"):
+        _full_model_fixture("config2_full", E=512, D=768, P=10, L=10, H=8, N=8, NL=12, n_head=12, V=50257, NPOS=1024, seed=4201, full=False)
+    # ---- (9) BASELINE configs[3] architecture, full depth: E=1024 -> D=1024 mapper (hd 128) + 24-layer GPT-2-medium, full finetune ----
+    if want("config4_full"):
+        _full_model_fixture("config4_full", E=1024, D=1024, P=10, L=10, H=8, N=8, NL=24, n_head=16, V=50257, NPOS=1024, seed=4301, full=True)
+
+    # ---- (10) BASELINE configs[4]: beam-5 decode at GPT-2-medium width (D=1024, 16 heads, V=50257), 4 of 24 layers, peaky wte ----
+    if want("beam_medium"):
+        from clipcap.inference import base as ibase
+        D, NL, n_head, V, NPOS, seed = 1024, 4, 16, 50257, 128, 4401
+        gsd = seeded.state_dict(seeded.gpt2_shapes(D, NL, V, NPOS), seed)
+        gsd["transformer.wte.weight"] = gsd["transformer.wte.weight"] * 2.0          # peakier next-token distributions (top-beam margins ~0.1)
+        lm = GPT2LMHeadModel(GPT2Config(n_embd=D, n_layer=NL, n_head=n_head, vocab_size=V, n_positions=NPOS, resid_pdrop=0.0, embd_pdrop=0.0,
+                                        attn_pdrop=0.0)).eval()
+        lm.load_state_dict({k: torch.from_numpy(v) for k, v in gsd.items()}, strict=False)
+
+        class _M2:
+            language_model = lm
+
+        d = {"cfg": np.array([D, NL, n_head, V, NPOS, seed]), "wte_scale": np.array(2.0), "param_checksum": seeded.checksum(gsd)}
+        gen = torch.Generator().manual_seed(seed)
+        for i in range(2):
+            pref = torch.randn(1, 10, D, generator=gen) * 0.5
+            # run A: a stop token that is never produced; run B: stop = the 5th token of run A's caption, so beams freeze mid-way
+            texts = ibase.generate_beam(_M2, FakeTokenizer(V - 1), pref, beam_size=5, entry_length=10, temperature=1.0)
+            best = [int(s) for s in texts[0].split()]
+            d[f"beam{i}a.prefix"] = pref.numpy()
+            d[f"beam{i}a.best"] = np.array(best, dtype=np.int64)
+            d[f"beam{i}a.meta"] = np.array([V - 1, 10, 5])
+            eos = best[4]
+            texts = ibase.generate_beam(_M2, FakeTokenizer(eos), pref, beam_size=5, entry_length=10, temperature=1.0)
+            d[f"beam{i}b.prefix"] = pref.numpy()
+            d[f"beam{i}b.best"] = np.array([int(s) for s in texts[0].split()] if texts[0] else [], dtype=np.int64)
+            d[f"beam{i}b.meta"] = np.array([eos, 10, 5])
+        np.savez_compressed(os.path.join(OUT, "beam_medium.npz"), **d)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+def _main_round1():
     torch.set_num_threads(4)
     from transformers import GPT2Config, GPT2LMHeadModel
     from clipcap.model.mapper import TransformerMapper, TransformerMapperWindowed
@@ -66,9 +266,9 @@ def main():
     from clipcap.inference import base as ibase
     os.makedirs(OUT, exist_ok=True)
 
-    # ---------------- (1) mapper: tiny + shape-faithful (1 layer) ----------------
+    # ---------------- (1) mapper: tiny + an hd=96 / S=20 case (the config-2 attention shape at small width) ----------------
     for name, (E, D, P, L, H, N, B) in {"mapper_tiny": (32, 64, 4, 4, 4, 2, 3),
-                                        "mapper_faithful": (64, 192, 10, 10, 2, 2, 2)}.items():
+                                        "mapper_hd96": (64, 192, 10, 10, 2, 2, 2)}.items():
         torch.manual_seed(101)
         m = TransformerMapper(E, D, L, P, H, N)
         x = torch.randn(B, E)

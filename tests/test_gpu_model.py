@@ -30,7 +30,7 @@ def _rel(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
 
 
-@pytest.mark.parametrize("name", ["mapper_tiny", "mapper_faithful"])
+@pytest.mark.parametrize("name", ["mapper_tiny", "mapper_hd96"])
 def test_mapper_fwd_bwd_vs_oracle_and_golden(name):
     g = load_golden(name)
     E, D, P, L, H, N, B = [int(v) for v in g["dims"]]

@@ -118,3 +118,84 @@ def test_draws_follow_the_distribution():
     freq = torch.bincount(nt.cpu().long(), minlength=V).double() / N
     assert (freq - probs[0].cpu().double()).abs().max() < 0.03
     assert freq[probs[0].cpu() == 0].sum() == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The variants generate() uses (inference/no_beam.py, inference/nucleus_sampling.py) end to end on the KV-cached device loop,
+# against the REFERENCE's per-step pre-sampling distributions (tests/golden/sampling_steps.npz: torch.multinomial patched to a
+# forced token sequence with repeats, repetition penalty active from step 0 through the text prefix).
+# ---------------------------------------------------------------------------------------------------------------------------
+
+class _DotTokenizer:
+    eos_token, bos_token = "<eos>", "<bos>"
+
+    def __init__(self, dot):
+        self.dot = dot
+
+    def encode(self, s, return_tensors=None):
+        return [self.dot]
+
+    def decode(self, ids):
+        return " ".join(str(int(i)) for i in ids)
+
+
+@pytest.mark.parametrize("case", ["no_beam", "no_beam_topk", "nucleus"])
+def test_generate_variants_step_distributions_vs_reference(case, monkeypatch):
+    import numpy as np
+    from types import SimpleNamespace
+    from clipcap_amd import engine
+    from clipcap_amd.inference import base, no_beam, nucleus_sampling
+    from clipcap_amd.model.gpt2 import GPT2LM
+    from tests.util import load_golden, sd_of
+    g, b = load_golden("sampling_steps"), load_golden("gpt2_tiny")
+    D, n_layer, n_head, V, npos = [int(v) for v in b["cfg"]]
+    sd = sd_of(b)
+    sd["transformer.wte.weight"] = sd["transformer.wte.weight"] * float(g["wte_scale"])
+    lm = GPT2LM(n_embd=D, n_layer=n_layer, n_head=n_head, vocab_size=V, n_positions=npos)
+    lm.load_state_dict(sd, strict=False)
+    model = SimpleNamespace(language_model=lm.to("cuda"))
+    top_p, top_k, temp, pen, stop = [float(v) for v in g[case + ".kw"]]
+    forced = [int(t) for t in g[case + ".forced"]]
+    head = torch.from_numpy(g[case + ".head"])
+    rec, logit_rec = [], []
+    real = engine.sample_step
+
+    def spy(logits, u, **kw):       # record the product's distribution, then force the reference run's token
+        _, probs = real(logits, u, return_probs=True, **kw)
+        rec.append(probs[0].cpu())
+        logit_rec.append((logits[0].cpu().clone(), kw["history"][0, : kw["hist_len"]].cpu().clone() if kw.get("history") is not None else None))
+        return torch.full((logits.shape[0],), forced[len(rec) - 1], dtype=torch.int32, device=logits.device)
+
+    monkeypatch.setattr(base, "sample_step", spy)
+    pref = torch.from_numpy(g[case + ".prefix"]).cuda()
+    tok = _DotTokenizer(int(stop))
+    if case.startswith("no_beam"):
+        text = no_beam.generate_no_beam(model, tok, pref, number_to_generate=1, text_prefix_tokens=head if head.numel() else None, top_p=top_p,
+                                        top_k=top_k, entry_length=len(forced), temperature=temp, repetition_penalty=pen)
+    else:
+        text = nucleus_sampling.generate_nucleus_sampling(model, tok, pref, number_to_generate=1, entry_length=len(forced), top_p=top_p,
+                                                          top_k=int(top_k), temperature=temp)
+    assert [int(s) for s in text[0].split()] == [int(t) for t in g[case + ".text"]]
+    assert len(rec) == len(forced)
+    got = torch.stack(rec).numpy()
+    ref = g[case + ".probs"]
+    # (1) the sampling rule itself, exactly: the product's distribution == the oracle's restatement applied to the product's own logits
+    for i, (lg, hist) in enumerate(logit_rec):
+        if case.startswith("no_beam"):
+            want = oracle.no_beam_step_distribution(lg, hist if hist is not None and hist.numel() else None, top_p=top_p, top_k=int(top_k),
+                                                    temperature=temp, repetition_penalty=pen)
+        else:
+            want = oracle.nucleus_final_p((lg / temp).unsqueeze(0), top_p=top_p, top_k=(int(top_k) or None))[0]
+        same_set = bool(((got[i] > 0) == (want.numpy() > 0)).all())
+        assert same_set or np.abs(got[i] - want.numpy()).max() <= 2e-3, (case, i)       # cut within rounding of top_p: one token may differ
+        if same_set:
+            assert np.abs(got[i] - want.numpy()).max() <= 2e-6, (case, i)
+    # (2) against the reference's fp32 run: bf16 GPT-2 logits move probabilities by <= 2e-2; the kept set may differ at the top_p cut
+    err = np.abs(got - ref).max(axis=1)
+    print(f"{case}: per-step max |p - reference p| = {np.array2string(err, precision=4)}")
+    assert (err <= 3e-2).sum() >= len(forced) - 2 and np.median(err) <= 1e-2
+    # the repetition penalty is visibly active: without it the distribution of a step with repeats in the history is different
+    if case == "no_beam":
+        lg, hist = logit_rec[3]
+        nopen = oracle.no_beam_step_distribution(lg, hist, top_p=top_p, top_k=int(top_k), temperature=temp, repetition_penalty=1.0)
+        assert np.abs(nopen.numpy() - got[3]).max() > 1e-3

@@ -4,6 +4,7 @@ The reference has no tests / golden vectors of its own; these ar
 Tolerance: fp32, <=1e-5 abs on O(1) values (2e-5 on summed gradients).
 """
 import numpy as np
+import pytest
 import torch
 
 from oracle import clipcap_oracle as O
@@ -37,7 +38,7 @@ def test_mapper_tiny():
 
 
 def test_mapper_shape_faithful_hd96_s20():
-    _mapper_case("mapper_faithful")
+    _mapper_case("mapper_hd96")
 
 
 def test_mapper_windowed():
@@ -148,3 +149,107 @@ def test_filters_and_nucleus_distribution():
     sd = sd_of(b)
     logits = O.gpt2_logits(sd, torch.from_numpy(g["nucleus.prefix"]), n_head, n_layer)[:, -1, :]
     _close(O.nucleus_final_p(logits, top_p=0.8), g["nucleus.final_p"], 1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# round-2 fixtures: shape-faithful cases with seeded parameters (tests/seeded.py), sampling variants, medium-width beam search
+# ---------------------------------------------------------------------------------------------------------------------------
+
+def test_mapper_shape_faithful_config2_one_layer():
+    """E=512, D=768, P=L=10, H=8, N=1, B=2 — output, attention probabilities and every gradient of the reference."""
+    from tests import seeded
+    from tests.util import sampled
+    g = load_golden("mapper_faithful")
+    E, D, P, L, H, N, B, seed = [int(v) for v in g["dims"]]
+    msd = seeded.state_dict(seeded.mapper_shapes(E, D, P, L, N), seed)
+    assert np.array_equal(seeded.checksum(msd), g["param_checksum"])
+    sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in msd.items()}
+    out, _, atts = O.mapper_forward(sd, torch.from_numpy(g["in.x"]), projection_length=P, num_heads=H, num_layers=N, return_all=True)
+    _close(out, g["out"], 2e-5)
+    _close(atts[0], g["att.0"], 1e-5)
+    out.square().mean().backward()
+    for k, v in sd.items():
+        nrm, smp = sampled(v.grad)
+        assert abs(nrm - float(g[f"grad.{k}.norm"])) <= 1e-4 * float(g[f"grad.{k}.norm"]) + 1e-9, k
+        assert np.abs(smp - g[f"grad.{k}.sample"]).max() <= 2e-5 * max(1.0, np.abs(g[f"grad.{k}.sample"]).max()), k
+
+
+@pytest.mark.parametrize("name", ["config2_full", "config4_full"])
+def test_full_depth_model_logits_loss_grads(name):
+    """BASELINE configs[1] / configs[3] architectures at full depth (8-layer mapper + 12-layer GPT-2-small; E=1024 mapper +
+    24-layer GPT-2-medium), B=2: the oracle against the reference's logits, prefix, loss and gradients."""
+    from tests.util import sampled, seeded_full_model
+    from tests.seeded import sample_idx
+    g = load_golden(name)
+    sd, cfg, dims = seeded_full_model(g)
+    train = [k for k in sd if dims["full"] or k.startswith("transformer_mapper.")]
+    for k in train:
+        sd[k].requires_grad_(True)
+    tokens, embeds = torch.from_numpy(g["in.tokens"]), torch.from_numpy(g["in.embeds"])
+    L, V, cap = dims["L"], dims["V"], tokens.shape[1]
+    with torch.no_grad():
+        logits = O.clipcap_logits(sd, tokens.clamp_min(0), embeds, cfg=cfg)
+    # the reference was run with its right-padding attention mask: rows of pad positions differ by construction (and are never
+    # read by the loss); every other row is mask-independent under the causal mask (BASELINE.md 2)
+    valid = torch.cat((torch.ones(tokens.shape[0], L, dtype=torch.bool), tokens.ge(0)), dim=1)
+    _close(logits[:, :, sample_idx(V, 1024)] * valid[:, :, None], g["logits.cols"] * valid[:, :, None].numpy(), 3e-5)
+    rows = [L - 1, L + 7, L + cap - 2]
+    _close(logits[:, rows, :] * valid[:, rows, None], g["logits.rows"] * valid[:, rows, None].numpy(), 3e-5)
+    loss = O.clipcap_loss(sd, tokens, embeds, cfg=cfg)
+    assert abs(float(loss) - float(g["loss"])) <= 2e-5
+    loss.backward()
+    n = 0
+    for k in train:
+        key = "grad0." + k
+        if key + ".norm" not in g:
+            continue
+        nrm, smp = sampled(sd[k].grad)
+        ref = float(g[key + ".norm"])
+        assert abs(nrm - ref) <= 2e-4 * ref + 1e-10, (k, nrm, ref)
+        assert np.abs(smp - g[key + ".sample"]).max() <= 5e-5 * max(np.abs(g[key + ".sample"]).max(), 1e-8) + 1e-9, k
+        n += 1
+    assert n >= (100 if dims["full"] else 90)
+
+
+def test_sampling_variants_step_distributions():
+    """inference/no_beam.py (repetition penalty, '.' stop, text prefix in the history) and inference/nucleus_sampling.py: the
+    pre-sampling distribution of EVERY step of the reference's loop (torch.multinomial patched to a forced token sequence)."""
+    g = load_golden("sampling_steps")
+    b = load_golden("gpt2_tiny")
+    D, n_layer, n_head, V, npos = [int(v) for v in b["cfg"]]
+    sd = {"language_model." + k: v for k, v in sd_of(b).items()}
+    sd["language_model.transformer.wte.weight"] = sd["language_model.transformer.wte.weight"] * float(g["wte_scale"])
+    wte = sd["language_model.transformer.wte.weight"]
+    for case, rule in (("no_beam", "no_beam"), ("no_beam_topk", "no_beam"), ("nucleus", "nucleus")):
+        top_p, top_k, temp, pen, stop = [float(v) for v in g[case + ".kw"]]
+        head = torch.from_numpy(g[case + ".head"]).reshape(-1)
+        emb = torch.from_numpy(g[case + ".prefix"])
+        if head.numel():
+            emb = torch.cat((emb, wte[head].unsqueeze(0)), dim=1)
+        kw = dict(top_p=top_p, top_k=int(top_k), temperature=temp)
+        if rule == "no_beam":
+            kw.update(repetition_penalty=pen, stop_token=int(stop))
+        tr = O.sampling_trace(sd, emb, [int(t) for t in g[case + ".forced"]], n_head=n_head, n_layer=n_layer, rule=rule, head=head, **kw)
+        got = torch.stack(tr).numpy()
+        assert got.shape == g[case + ".probs"].shape
+        assert np.array_equal(got > 0, g[case + ".probs"] > 0), case
+        assert np.abs(got - g[case + ".probs"]).max() <= 2e-6, case
+        assert np.array_equal(np.concatenate([head.numpy(), g[case + ".forced"]]), g[case + ".text"]), case
+
+
+def test_beam_search_medium_width():
+    """BASELINE configs[4] width (D=1024, 16 heads, V=50257; 4 layers): the reference's beam-5 captions, incl. runs that stop on EOS."""
+    from tests import seeded
+    g = load_golden("beam_medium")
+    D, NL, n_head, V, NPOS, seed = [int(v) for v in g["cfg"]]
+    gsd = seeded.state_dict(seeded.gpt2_shapes(D, NL, V, NPOS), seed)
+    gsd["transformer.wte.weight"] = gsd["transformer.wte.weight"] * float(g["wte_scale"])
+    assert np.array_equal(seeded.checksum(gsd), g["param_checksum"])
+    sd = {"language_model." + k: torch.from_numpy(v) for k, v in gsd.items()}
+    torch.set_num_threads(max(1, min(8, torch.get_num_threads())))
+    for case in ("beam0a", "beam0b", "beam1a", "beam1b"):
+        eos, entry, beam = [int(v) for v in g[case + ".meta"]]
+        toks, sc, lens, order = O.generate_beam_tokens(sd, torch.from_numpy(g[case + ".prefix"]), n_head=n_head, n_layer=NL, beam_size=beam,
+                                                       entry_length=entry, stop_token=eos)
+        best = toks[order[0]][: int(lens[order[0]])].numpy()
+        assert np.array_equal(best, g[case + ".best"]), (case, best, g[case + ".best"])
