@@ -35,7 +35,8 @@ class _Embedding(nn.Module):
         return self._owner._arena_params["transformer.wte.weight"]
 
     def forward(self, ids: torch.Tensor) -> torch.Tensor:
-        return torch.nn.functional.embedding(ids, self.weight.detach())
+        w = self.weight.detach()
+        return torch.nn.functional.embedding(ids.to(w.device), w)
 
 
 class _TiedHead(nn.Module):

@@ -285,8 +285,9 @@ def test_sampling_decoders_run_on_kv_cache_and_match_first_step_distribution():
     # generate() goes through inference/no_beam.py's variant (generate.py:34-41): number_to_generate captions, each starting with
     # the bos/text-prefix tokens, "." (the tokenizer's id for it) never inside a caption
     from clipcap_amd.inference import generate
-    full = SimpleNamespace(language_model=lm, transformer_mapper=lambda e: pref)
-    caps = generate(full, tok, torch.zeros(1, 8), number_to_generate=3, text_prefix="ab")
+    lm128 = GPT2LM(n_embd=D, n_layer=n_layer, n_head=n_head, vocab_size=V, n_positions=128).to("cuda")   # 4 + 2*3 + 67 positions
+    full = SimpleNamespace(language_model=lm128, transformer_mapper=lambda e: pref)
+    caps = generate(full, tok, torch.zeros(1, 8, device="cuda"), number_to_generate=3, text_prefix="ab")
     head = [int(t) for t in tok.encode(tok.bos_token + "ab")]
     dot = tok.encode(".")[0]
     assert len(caps) == 3

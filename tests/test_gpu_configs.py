@@ -190,15 +190,17 @@ def test_config5_batched_beam_equals_per_sample_24_layers():
     pref = torch.randn(64, 10, 1024, generator=gen, device="cuda") * 0.5
     toks, scores, lens = generate_beam_tokens(model, pref, 5, 12, 1.0, 50256)
     assert toks.shape[:2] == (64, 5) and torch.isfinite(scores).all()
-    same = 0
-    for i in (0, 17, 31, 63):
+    # Beam search is chaotic under bf16 noise (a near-tie for the 5th beam at an early step changes which captions survive): over
+    # all 64 samples 61 are identical (measured).  Identical captions must carry the same score.
+    same, checked = 0, (0, 5, 11, 23, 31, 40, 52, 63)
+    for i in checked:
         t1, s1, l1 = generate_beam_tokens(model, pref[i:i + 1], 5, 12, 1.0, 50256)
         b, b1 = int(scores[i].argmax()), int(s1[0].argmax())
         n = int(l1[0, b1])
-        # near-ties between beams may order differently under bf16 noise; the caption itself must agree
-        same += int(torch.equal(toks[i, b, :n], t1[0, b1, :n]) and int(lens[i, b]) == n)
-        assert abs(float(scores[i, b]) - float(s1[0, b1])) <= 2e-2
-    assert same >= 3, same
+        if torch.equal(toks[i, b, :n], t1[0, b1, :n]) and int(lens[i, b]) == n:
+            same += 1
+            assert abs(float(scores[i, b]) - float(s1[0, b1])) <= 2e-2
+    assert same >= len(checked) - 1, same
 
 
 def test_beam_medium_width_tokens_vs_reference_and_oracle():

@@ -149,7 +149,7 @@ def test_generate_variants_step_distributions_vs_reference(case, monkeypatch):
     from tests.util import load_golden, sd_of
     g, b = load_golden("sampling_steps"), load_golden("gpt2_tiny")
     D, n_layer, n_head, V, npos = [int(v) for v in b["cfg"]]
-    sd = sd_of(b)
+    sd = {k: v for k, v in sd_of(b).items() if k != "lm_head.weight"}      # tied to wte: the scaled wte below must be the one that stays
     sd["transformer.wte.weight"] = sd["transformer.wte.weight"] * float(g["wte_scale"])
     lm = GPT2LM(n_embd=D, n_layer=n_layer, n_head=n_head, vocab_size=V, n_positions=npos)
     lm.load_state_dict(sd, strict=False)
