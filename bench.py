@@ -296,7 +296,7 @@ def main():
             loss = eng.forward_backward(tokens, embeds, dropout=drop)
         lr = base_lr * sched(i)
         for a in arenas:
-            a.adamw_step(lr, i + 1)
+            a.adamw_step(lr, i + 1, scaler=eng.scaler)
         return loss
 
     def sync():
@@ -329,7 +329,7 @@ def main():
         return
     n = C.c_int32(per_step * args.steps)
     ms = (C.c_float * n.value)()
-    lib.cc_prof_stop(ms, C.byref(n))
+    lib.cc_prof_stop(ms, None, C.byref(n))
     avg_ms = sum(ms[i] for i in range(n.value)) / max(1, n.value)
     T, D, Mc, M = c["L"] + cap, c["D"], B * cap, B * (c["L"] + cap)
     S = c["P"] + c["L"]

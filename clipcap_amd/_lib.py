@@ -23,16 +23,30 @@ class CCError(RuntimeError):
     pass
 
 
+OP_BF16, OP_FP16 = 0, 1      # CC_OP_BF16 / CC_OP_FP16: operand type of a model's 16-bit tensors (cfg.op_dtype)
+
+
+def op_dtype_of(precision) -> int:
+    """--fp-precision of the reference (clipcap/train/args.py:30-34) -> operand type: 16 = fp16 operands (+ loss scaling);
+    32 / 64 / "bf16" = bf16 operands.  Accumulation and master weights are fp32 either way."""
+    if precision in (OP_BF16, "bf16", 32, 64, None):
+        return OP_BF16
+    if precision in (16, "fp16", "16"):
+        return OP_FP16
+    raise ValueError(f"unsupported precision {precision!r}: use 16 (fp16 operands), 32 / 64 or 'bf16' (bf16 operands)")
+
+
 class MapperCfg(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("E", "D", "P", "L", "H", "N", "Hm", "W", "use_pos")]
+    _fields_ = [(n, C.c_int32) for n in ("E", "D", "P", "L", "H", "N", "Hm", "W", "use_pos", "op_dtype")]
 
 
 class Gpt2Cfg(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("D", "H", "NL", "V", "Vp", "NPOS")]
+    _fields_ = [(n, C.c_int32) for n in ("D", "H", "NL", "V", "Vp", "NPOS", "op_dtype")]
 
 
 class Gpt2Shape(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("B", "L", "T", "cap", "mode")]
+    _fields_ = [(n, C.c_int32) for n in ("B", "L", "T", "cap", "mode")] + [(n, C.c_float) for n in ("p_embd", "p_attn", "p_resid")] + \
+               [("drop_seed", C.c_uint64)]
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -58,7 +72,7 @@ SIGNATURES = {
     "cc_gpt2_fwd": (_I, [_GC, _GS, _P, _P, _P, _P]),
     "cc_gpt2_logits": (_I, [_GC, _GS, _P, _P, _P, _P, _L, _P]),
     "cc_lmhead_ce_fwd": (_I, [_GC, _GS, _P, _P, _P, _P, _P, _P]),
-    "cc_lmhead_ce_bwd": (_I, [_GC, _GS, _P, _P, _P, _P, _P, _P]),
+    "cc_lmhead_ce_bwd": (_I, [_GC, _GS, _P, _P, _P, _P, _P, _P, _P]),
     "cc_gpt2_bwd": (_I, [_GC, _GS, _P, _P, _P, _P, _P, _P, _P]),
     "cc_decode_ws_bytes": (_L, [_GC, _I, _I]),
     "cc_decode_fwd": (_I, [_GC, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
@@ -67,25 +81,26 @@ SIGNATURES = {
     "cc_beam_ws_bytes": (_L, [_I, _I, _I]),
     "cc_embed_tokens": (_I, [_GC, _I, _P, _P, _P, _P]),
     "cc_beam_advance": (_I, [_GC, _I, _I, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P]),
-    "cc_adamw_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P]),
-    "cc_cast_bf16": (_I, [_P, _P, _L, _P]),
-    "cc_gpt2_set_dropout": (_I, [_F, _F, _F, C.c_uint64]),
+    "cc_adamw_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P, _P, _P]),
+    "cc_cast_op16": (_I, [_I, _P, _P, _L, _P]),
+    "cc_grad_nonfinite": (_I, [_P, _L, _P, _P]),
+    "cc_loss_scale_update": (_I, [_P, _P, _F, _F, _I, _P]),
     "cc_dropout_mask": (_I, [C.c_uint64, _I, _I, _F, _L, _P, _P]),
     "cc_sample_step": (_I, [_P, _I, _I, _I, _F, _I, _F, _I, _P, _I, _I, _F, _P, _P, _P, _P]),
     "cc_wgrad_scratch_bytes": (_L, []),
-    "cc_gemm_wgrad": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _P]),
+    "cc_gemm_wgrad": (_I, [_I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _P]),
     "cc_gemm_tile_mode": (_I, [_I]),
     "cc_gemm_skinny_mode": (_I, [_I]),
-    "cc_gemm_bf16_f32": (_I, [_I, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P]),
-    "cc_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
-    "cc_attention_fwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
-    "cc_attention_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "cc_gemm_op16_f32": (_I, [_I, _I, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P]),
+    "cc_layernorm_fwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "cc_attention_fwd": (_I, [_I, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "cc_attention_bwd": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "cc_prof_start": (_I, [_I, _I]),
-    "cc_prof_stop": (_I, [C.POINTER(C.c_float), C.POINTER(_I)]),
+    "cc_prof_stop": (_I, [C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(_I)]),
 }
 
 SITES = {"lmhead_fwd": 1, "lmhead_dgrad": 2, "gpt2_fc_fwd": 3, "gpt2_proj2_fwd": 4, "gpt2_fc_dgrad": 5, "mapper_fc1_fwd": 6,
-         "mapper_qkv_fwd": 7, "mapper_wgrad_fc2": 8}
+         "mapper_qkv_fwd": 7, "mapper_wgrad_fc2": 8, "all_gemms": 100}
 
 _lib = None
 _lock = threading.Lock()
@@ -110,7 +125,7 @@ def lib() -> C.CDLL:
                 fn = getattr(l, name)
                 fn.restype = res
                 fn.argtypes = args
-            if l.cc_abi_version() != 1:
+            if l.cc_abi_version() != 2:
                 raise HipExtensionMissing("libclipcap_hip.so ABI version mismatch; rebuild")
             _lib = l
     return _lib

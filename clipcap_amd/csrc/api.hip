@@ -1,11 +1,12 @@
 // C ABI (include/clipcap_hip.h) — orchestration of the mapper and GPT-2 training/inference passes out of the HIP
-// kernels in gemm.cuh / kernels.hip.  No state, no allocation, no synchronisation: everything is enqueued on the
+// kernels in gemm.hip.h / kernels.hip.  No state, no allocation, no synchronisation: everything is enqueued on the
 // caller's stream and lives in caller-owned arenas / workspaces.
 #include "../../include/clipcap_hip.h"
 #include "gemm_api.h"
 #include "kernels.h"
+#include "shared.h"
 
-using namespace cc;
+using namespace CC_NS;
 
 #define CC_TRY(expr)                 \
     do {                             \
@@ -19,32 +20,11 @@ namespace {
 
 constexpr int MAX_LAYERS = 96;
 
-// ---- optional per-call-site timing (cc_prof_start / cc_prof_stop) ----
-struct Prof {
-    int site = 0;
-    int cap = 0;
-    std::vector<hipEvent_t> ev;  // 2 per sample
-    int n = 0;
-} g_prof;
-
-struct ProfScope {
-    hipStream_t st;
-    bool on;
-    ProfScope(int site, hipStream_t s) : st(s), on(g_prof.site == site && g_prof.n < g_prof.cap) {
-        if (on) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], st);
-    }
-    ~ProfScope() {
-        if (on) {
-            (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st);
-            g_prof.n++;
-        }
-    }
-};
-#define CC_TIMED(site, st, expr)  \
-    do {                          \
-        ProfScope _ps(site, st);  \
-        int _e = (expr);          \
-        if (_e != CC_OK) return _e; \
+#define CC_TIMED(site, st, expr)                 \
+    do {                                         \
+        cc_shared::ProfScope _ps(site, st);      \
+        int _e = (expr);                         \
+        if (_e != CC_OK) return _e;              \
     } while (0)
 
 struct Carver {
@@ -75,7 +55,7 @@ struct MapperOff {
 };
 
 bool mapper_cfg_ok(const cc_mapper_cfg* c) {
-    return c && c->E > 0 && c->D > 0 && c->P > 0 && c->L > 0 && c->H > 0 && c->N >= 0 && c->N <= MAX_LAYERS && c->Hm > 0 && c->W >= 1 &&
+    return c && (c->op_dtype == CC_OP) && c->E > 0 && c->D > 0 && c->P > 0 && c->L > 0 && c->H > 0 && c->N >= 0 && c->N <= MAX_LAYERS && c->Hm > 0 && c->W >= 1 &&
            (c->E % 8) == 0 && (c->D % 8) == 0 && (c->Hm % 8) == 0 && (c->D % c->H) == 0 && ((c->D / c->H) % 8) == 0;
 }
 
@@ -105,15 +85,15 @@ void mapper_offsets(const cc_mapper_cfg* c, MapperOff& o) {
 }
 
 struct MapperWS {
-    bf16_t* emb16;
+    op16_t* emb16;
     float* lin_tmp;
     float* x[MAX_LAYERS + 1];
     float* x1[MAX_LAYERS];
-    bf16_t *xn1[MAX_LAYERS], *xn2[MAX_LAYERS], *qkv[MAX_LAYERS], *att[MAX_LAYERS], *h[MAX_LAYERS];
+    op16_t *xn1[MAX_LAYERS], *xn2[MAX_LAYERS], *qkv[MAX_LAYERS], *att[MAX_LAYERS], *h[MAX_LAYERS];
     float *lse[MAX_LAYERS], *mean1[MAX_LAYERS], *rstd1[MAX_LAYERS], *mean2[MAX_LAYERS], *rstd2[MAX_LAYERS];
     // backward scratch
     float* dx32;
-    bf16_t *dx16, *dh16, *dxn16, *datt16, *dqkv16, *dlin16;
+    op16_t *dx16, *dh16, *dxn16, *datt16, *dqkv16, *dlin16;
     float* wg_scratch;
     float* adelta;
     size_t bytes;
@@ -123,7 +103,7 @@ void mapper_carve(const cc_mapper_cfg* c, int B, int save, void* ws, MapperWS& w
     Carver cv(ws);
     const int S = c->W * c->P + c->L;
     const size_t M = (size_t)B * S, D = c->D;
-    w.emb16 = cv.take<bf16_t>((size_t)B * c->W * c->E);
+    w.emb16 = cv.take<op16_t>((size_t)B * c->W * c->E);
     w.lin_tmp = c->W > 1 ? cv.take<float>((size_t)B * c->W * c->P * D) : nullptr;
     const int nx = save ? c->N + 1 : 2;
     float* xb[MAX_LAYERS + 1];
@@ -135,11 +115,11 @@ void mapper_carve(const cc_mapper_cfg* c, int B, int save, void* ws, MapperWS& w
         const int s = fresh ? l : 0;
         if (fresh) {
             w.x1[l] = cv.take<float>(M * D);
-            w.xn1[l] = cv.take<bf16_t>(M * D);
-            w.xn2[l] = cv.take<bf16_t>(M * D);
-            w.qkv[l] = cv.take<bf16_t>(M * 3 * D);
-            w.att[l] = cv.take<bf16_t>(M * D);
-            w.h[l] = cv.take<bf16_t>(M * c->Hm);
+            w.xn1[l] = cv.take<op16_t>(M * D);
+            w.xn2[l] = cv.take<op16_t>(M * D);
+            w.qkv[l] = cv.take<op16_t>(M * 3 * D);
+            w.att[l] = cv.take<op16_t>(M * D);
+            w.h[l] = cv.take<op16_t>(M * c->Hm);
             w.lse[l] = cv.take<float>((size_t)B * c->H * S);
             w.mean1[l] = cv.take<float>(M);
             w.rstd1[l] = cv.take<float>(M);
@@ -152,12 +132,12 @@ void mapper_carve(const cc_mapper_cfg* c, int B, int save, void* ws, MapperWS& w
     }
     if (save) {
         w.dx32 = cv.take<float>(M * D);
-        w.dx16 = cv.take<bf16_t>(M * D);
-        w.dh16 = cv.take<bf16_t>(M * c->Hm);
-        w.dxn16 = cv.take<bf16_t>(M * D);
-        w.datt16 = cv.take<bf16_t>(M * D);
-        w.dqkv16 = cv.take<bf16_t>(M * 3 * D);
-        w.dlin16 = cv.take<bf16_t>((size_t)B * c->W * c->P * D);
+        w.dx16 = cv.take<op16_t>(M * D);
+        w.dh16 = cv.take<op16_t>(M * c->Hm);
+        w.dxn16 = cv.take<op16_t>(M * D);
+        w.datt16 = cv.take<op16_t>(M * D);
+        w.dqkv16 = cv.take<op16_t>(M * 3 * D);
+        w.dlin16 = cv.take<op16_t>((size_t)B * c->W * c->P * D);
         w.wg_scratch = cv.take<float>(WGRAD_SCRATCH_BYTES / sizeof(float));
         w.adelta = cv.take<float>((size_t)B * c->H * S);
     } else {
@@ -178,7 +158,7 @@ struct Gpt2Off {
 };
 
 bool gpt2_cfg_ok(const cc_gpt2_cfg* c) {
-    return c && c->D > 0 && c->H > 0 && c->NL > 0 && c->NL <= MAX_LAYERS && c->V > 0 && c->Vp >= c->V && (c->Vp % 128) == 0 &&
+    return c && (c->op_dtype == CC_OP) && c->D > 0 && c->H > 0 && c->NL > 0 && c->NL <= MAX_LAYERS && c->V > 0 && c->Vp >= c->V && (c->Vp % 128) == 0 &&
            c->NPOS > 0 && (c->D % 8) == 0 && (c->D % c->H) == 0 && ((c->D / c->H) % 8) == 0;
 }
 
@@ -210,17 +190,17 @@ void gpt2_offsets(const cc_gpt2_cfg* c, Gpt2Off& o) {
 struct Gpt2WS {
     float* x[MAX_LAYERS + 1];
     float* x1[MAX_LAYERS];
-    bf16_t *xn1[MAX_LAYERS], *xn2[MAX_LAYERS], *qkv[MAX_LAYERS], *att[MAX_LAYERS], *u[MAX_LAYERS], *hact[MAX_LAYERS];
+    op16_t *xn1[MAX_LAYERS], *xn2[MAX_LAYERS], *qkv[MAX_LAYERS], *att[MAX_LAYERS], *u[MAX_LAYERS], *hact[MAX_LAYERS];
     float *lse[MAX_LAYERS], *mean1[MAX_LAYERS], *rstd1[MAX_LAYERS], *mean2[MAX_LAYERS], *rstd2[MAX_LAYERS];
     // lm head / loss
-    bf16_t* hf16;      // [Mh, D]   ln_f output rows (Mh = max(B*cap, B*T) so the parity API can use it too)
+    op16_t* hf16;      // [Mh, D]   ln_f output rows (Mh = max(B*cap, B*T) so the parity API can use it too)
     float *meanf, *rstdf;
     int *target, *row_map;
-    bf16_t* logits16;  // [B*cap, Vp]
+    op16_t* logits16;  // [B*cap, Vp]
     float *pmax, *psum, *tgt_logit, *lse_row, *row_loss;
     // backward
     float* dx32;
-    bf16_t *dx16, *dhf16, *du16, *dxn16, *datt16, *dqkv16;
+    op16_t *dx16, *dhf16, *du16, *dxn16, *datt16, *dqkv16;
     float* wg_scratch;
     float* adelta;
     size_t bytes;
@@ -237,39 +217,39 @@ void gpt2_carve(const cc_gpt2_cfg* c, int B, int T, int cap, int mode, void* ws,
     for (int l = 0; l < c->NL; l++) {
         const bool k0 = keep || l == 0, f0 = full || l == 0;
         w.x1[l] = k0 ? cv.take<float>(M * D) : w.x1[0];
-        w.qkv[l] = k0 ? cv.take<bf16_t>(M * 3 * D) : w.qkv[0];
-        w.u[l] = k0 ? cv.take<bf16_t>(M * 4 * D) : w.u[0];
+        w.qkv[l] = k0 ? cv.take<op16_t>(M * 3 * D) : w.qkv[0];
+        w.u[l] = k0 ? cv.take<op16_t>(M * 4 * D) : w.u[0];
         w.lse[l] = k0 ? cv.take<float>((size_t)B * c->H * T) : w.lse[0];
         w.mean1[l] = k0 ? cv.take<float>(M) : w.mean1[0];
         w.rstd1[l] = k0 ? cv.take<float>(M) : w.rstd1[0];
         w.mean2[l] = k0 ? cv.take<float>(M) : w.mean2[0];
         w.rstd2[l] = k0 ? cv.take<float>(M) : w.rstd2[0];
-        w.xn1[l] = f0 ? cv.take<bf16_t>(M * D) : w.xn1[0];
-        w.xn2[l] = f0 ? cv.take<bf16_t>(M * D) : w.xn2[0];
-        w.att[l] = k0 ? cv.take<bf16_t>(M * D) : w.att[0];   // attention output: needed by the backward's delta = rowsum(dO*O)
-        w.hact[l] = f0 ? cv.take<bf16_t>(M * 4 * D) : w.hact[0];
+        w.xn1[l] = f0 ? cv.take<op16_t>(M * D) : w.xn1[0];
+        w.xn2[l] = f0 ? cv.take<op16_t>(M * D) : w.xn2[0];
+        w.att[l] = k0 ? cv.take<op16_t>(M * D) : w.att[0];   // attention output: needed by the backward's delta = rowsum(dO*O)
+        w.hact[l] = f0 ? cv.take<op16_t>(M * 4 * D) : w.hact[0];
     }
     const size_t Mh = std::max(M, Mc);
-    w.hf16 = cv.take<bf16_t>(Mh * D);
+    w.hf16 = cv.take<op16_t>(Mh * D);
     w.meanf = cv.take<float>(Mh);
     w.rstdf = cv.take<float>(Mh);
     w.target = cv.take<int>(Mh);
     w.row_map = cv.take<int>(Mh);
     if (keep) {
         const int npart = c->Vp / 64;
-        w.logits16 = cv.take<bf16_t>(Mc * c->Vp);
+        w.logits16 = cv.take<op16_t>(Mc * c->Vp);
         w.pmax = cv.take<float>(Mc * npart);
         w.psum = cv.take<float>(Mc * npart);
         w.tgt_logit = cv.take<float>(Mc);
         w.lse_row = cv.take<float>(Mc);
         w.row_loss = cv.take<float>(Mc);
         w.dx32 = cv.take<float>(M * D);
-        w.dx16 = cv.take<bf16_t>(M * D);
-        w.dhf16 = cv.take<bf16_t>(Mc * D);
-        w.du16 = cv.take<bf16_t>(M * 4 * D);
-        w.dxn16 = cv.take<bf16_t>(M * D);
-        w.datt16 = cv.take<bf16_t>(M * D);
-        w.dqkv16 = cv.take<bf16_t>(M * 3 * D);
+        w.dx16 = cv.take<op16_t>(M * D);
+        w.dhf16 = cv.take<op16_t>(Mc * D);
+        w.du16 = cv.take<op16_t>(M * 4 * D);
+        w.dxn16 = cv.take<op16_t>(M * D);
+        w.datt16 = cv.take<op16_t>(M * D);
+        w.dqkv16 = cv.take<op16_t>(M * 3 * D);
         w.wg_scratch = full ? cv.take<float>(WGRAD_SCRATCH_BYTES / sizeof(float)) : nullptr;
         w.adelta = cv.take<float>((size_t)B * c->H * T);
     } else {
@@ -284,47 +264,20 @@ void gpt2_carve(const cc_gpt2_cfg* c, int B, int T, int cap, int mode, void* ws,
 
 extern "C" {
 
-int cc_abi_version(void) { return CC_ABI_VERSION; }
-
-int cc_prof_start(int32_t site, int32_t max_samples) {
-    if (site < 0 || max_samples < 0 || max_samples > (1 << 16)) return CC_ERR_ARG;
-    for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
-    g_prof.ev.clear();
-    g_prof.n = 0;
-    g_prof.cap = max_samples;
-    g_prof.site = site;
-    for (int i = 0; i < 2 * max_samples; i++) {
-        hipEvent_t e;
-        if (hipEventCreate(&e) != hipSuccess) return CC_ERR_LAUNCH;
-        g_prof.ev.push_back(e);
-    }
-    return CC_OK;
-}
-
-int cc_prof_stop(float* ms_host, int32_t* n_host) {
-    if (!ms_host || !n_host) return CC_ERR_ARG;
-    const int n = std::min(g_prof.n, (int)*n_host);
-    for (int i = 0; i < n; i++) {
-        if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) return CC_ERR_LAUNCH;
-        if (hipEventElapsedTime(&ms_host[i], g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) return CC_ERR_LAUNCH;
-    }
-    *n_host = n;
-    g_prof.site = 0;
-    for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
-    g_prof.ev.clear();
-    g_prof.n = g_prof.cap = 0;
-    return CC_OK;
-}
+int CC_API(cc_mapper_bwd_range)(const cc_mapper_cfg* c, int32_t B, const float* w32, const uint16_t* w16, void* ws, const float* dout, float* g32,
+                        int32_t l_hi, int32_t l_lo, void* stream);
+int CC_API(cc_gpt2_bwd_range)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, const uint16_t* w16, void* ws, const int64_t* tokens,
+                      float* dprefix, float* g32, int32_t l_hi, int32_t l_lo, void* stream);
 
 // ---------------------------------------------------------------- mapper ----------------------------------------
-int64_t cc_mapper_param_count(const cc_mapper_cfg* cfg) {
+int64_t CC_API(cc_mapper_param_count)(const cc_mapper_cfg* cfg) {
     if (!mapper_cfg_ok(cfg)) return CC_ERR_SHAPE;
     MapperOff o;
     mapper_offsets(cfg, o);
     return o.total;
 }
 
-int cc_mapper_param_offsets(const cc_mapper_cfg* cfg, int64_t* offs) {
+int CC_API(cc_mapper_param_offsets)(const cc_mapper_cfg* cfg, int64_t* offs) {
     if (!mapper_cfg_ok(cfg) || !offs) return CC_ERR_SHAPE;
     MapperOff o;
     mapper_offsets(cfg, o);
@@ -338,20 +291,20 @@ int cc_mapper_param_offsets(const cc_mapper_cfg* cfg, int64_t* offs) {
     return CC_OK;
 }
 
-int64_t cc_mapper_ws_bytes(const cc_mapper_cfg* cfg, int32_t B, int32_t save) {
+int64_t CC_API(cc_mapper_ws_bytes)(const cc_mapper_cfg* cfg, int32_t B, int32_t save) {
     if (!mapper_cfg_ok(cfg) || B <= 0) return CC_ERR_SHAPE;
     MapperWS w;
     mapper_carve(cfg, B, save, nullptr, w);
     return (int64_t)w.bytes;
 }
 
-int cc_mapper_sync_weights(const cc_mapper_cfg* c, const float* w32, uint16_t* w16, void* stream) {
+int CC_API(cc_mapper_sync_weights)(const cc_mapper_cfg* c, const float* w32, uint16_t* w16, void* stream) {
     if (!mapper_cfg_ok(c) || !w32 || !w16) return CC_ERR_ARG;
     hipStream_t st = S_(stream);
     MapperOff o;
     mapper_offsets(c, o);
     CC_TRY(f32_to_bf16(w32, w16, (size_t)o.total, st));
-    bf16_t* t = w16 + o.total;
+    op16_t* t = w16 + o.total;
     const int D = c->D, Hm = c->Hm;
     TransposeBatch tb;                      // 8 layers x 4 matrices: one launch per 32 matrices instead of one each
     for (int l = 0; l < c->N; l++) {
@@ -366,7 +319,7 @@ int cc_mapper_sync_weights(const cc_mapper_cfg* c, const float* w32, uint16_t* w
     return CC_OK;
 }
 
-int cc_mapper_fwd(const cc_mapper_cfg* c, int32_t B, const float* w32, const uint16_t* w16, const float* emb, void* ws, float* out,
+int CC_API(cc_mapper_fwd)(const cc_mapper_cfg* c, int32_t B, const float* w32, const uint16_t* w16, const float* emb, void* ws, float* out,
                   int32_t save, void* stream) {
     if (!mapper_cfg_ok(c) || B <= 0 || !w32 || !w16 || !emb || !ws || !out) return CC_ERR_ARG;
     hipStream_t st = S_(stream);
@@ -404,13 +357,13 @@ int cc_mapper_fwd(const cc_mapper_cfg* c, int32_t B, const float* w32, const uin
     return CC_OK;
 }
 
-int cc_mapper_bwd(const cc_mapper_cfg* c, int32_t B, const float* w32, const uint16_t* w16, void* ws, const float* dout, float* g32,
+int CC_API(cc_mapper_bwd)(const cc_mapper_cfg* c, int32_t B, const float* w32, const uint16_t* w16, void* ws, const float* dout, float* g32,
                   void* stream) {
     if (!mapper_cfg_ok(c)) return CC_ERR_ARG;
-    return cc_mapper_bwd_range(c, B, w32, w16, ws, dout, g32, c->N, 0, stream);
+    return CC_API(cc_mapper_bwd_range)(c, B, w32, w16, ws, dout, g32, c->N, 0, stream);
 }
 
-int cc_mapper_bwd_range(const cc_mapper_cfg* c, int32_t B, const float* w32, const uint16_t* w16, void* ws, const float* dout, float* g32,
+int CC_API(cc_mapper_bwd_range)(const cc_mapper_cfg* c, int32_t B, const float* w32, const uint16_t* w16, void* ws, const float* dout, float* g32,
                         int32_t l_hi, int32_t l_lo, void* stream) {
     if (!mapper_cfg_ok(c) || B <= 0 || !w32 || !w16 || !ws || !dout || !g32 || l_lo < 0 || l_hi > c->N || l_lo > l_hi) return CC_ERR_ARG;
     hipStream_t st = S_(stream);
@@ -463,19 +416,20 @@ int cc_mapper_bwd_range(const cc_mapper_cfg* c, int32_t B, const float* w32, con
 
 // ---------------------------------------------------------------- GPT-2 -----------------------------------------
 namespace {
-bool shape_ok(const cc_gpt2_cfg* c, const cc_gpt2_shape* s) {
-    return s && s->B > 0 && s->T > 0 && s->L >= 0 && s->L <= s->T && s->cap >= s->T - s->L && s->mode >= 0 && s->mode <= 2 && s->T <= c->NPOS;
+static bool shape_ok(const cc_gpt2_cfg* c, const cc_gpt2_shape* s) {
+    return s && s->B > 0 && s->T > 0 && s->L >= 0 && s->L <= s->T && s->cap >= s->T - s->L && s->mode >= 0 && s->mode <= 2 && s->T <= c->NPOS &&
+           s->p_embd >= 0.f && s->p_embd < 1.f && s->p_attn >= 0.f && s->p_attn < 1.f && s->p_resid >= 0.f && s->p_resid < 1.f;
 }
 }  // namespace
 
-int64_t cc_gpt2_param_count(const cc_gpt2_cfg* cfg) {
+int64_t CC_API(cc_gpt2_param_count)(const cc_gpt2_cfg* cfg) {
     if (!gpt2_cfg_ok(cfg)) return CC_ERR_SHAPE;
     Gpt2Off o;
     gpt2_offsets(cfg, o);
     return o.total;
 }
 
-int cc_gpt2_param_offsets(const cc_gpt2_cfg* cfg, int64_t* offs) {
+int CC_API(cc_gpt2_param_offsets)(const cc_gpt2_cfg* cfg, int64_t* offs) {
     if (!gpt2_cfg_ok(cfg) || !offs) return CC_ERR_SHAPE;
     Gpt2Off o;
     gpt2_offsets(cfg, o);
@@ -490,20 +444,20 @@ int cc_gpt2_param_offsets(const cc_gpt2_cfg* cfg, int64_t* offs) {
     return CC_OK;
 }
 
-int64_t cc_gpt2_ws_bytes(const cc_gpt2_cfg* cfg, const cc_gpt2_shape* s) {
+int64_t CC_API(cc_gpt2_ws_bytes)(const cc_gpt2_cfg* cfg, const cc_gpt2_shape* s) {
     if (!gpt2_cfg_ok(cfg) || !shape_ok(cfg, s)) return CC_ERR_SHAPE;
     Gpt2WS w;
     gpt2_carve(cfg, s->B, s->T, s->T - s->L, s->mode, nullptr, w);
     return (int64_t)w.bytes;
 }
 
-int cc_gpt2_sync_weights(const cc_gpt2_cfg* c, const float* w32, uint16_t* w16, void* stream) {
+int CC_API(cc_gpt2_sync_weights)(const cc_gpt2_cfg* c, const float* w32, uint16_t* w16, void* stream) {
     if (!gpt2_cfg_ok(c) || !w32 || !w16) return CC_ERR_ARG;
     hipStream_t st = S_(stream);
     Gpt2Off o;
     gpt2_offsets(c, o);
     CC_TRY(f32_to_bf16(w32, w16, (size_t)o.total, st));
-    bf16_t* t = w16 + o.total;
+    op16_t* t = w16 + o.total;
     const int D = c->D;
     CC_TRY(transpose_bf16(w16 + o.wte, t + o.wte, c->Vp, D, st));     // [Vp, D] -> [D, Vp]  (lm_head dgrad)
     TransposeBatch tb;
@@ -519,20 +473,14 @@ int cc_gpt2_sync_weights(const cc_gpt2_cfg* c, const float* w32, uint16_t* w16, 
     return CC_OK;
 }
 
-// GPT-2 dropout (full finetune in train mode).  Process-global like the tile mode: set before a training step's forward, read by
-// cc_gpt2_embed / cc_gpt2_fwd / cc_gpt2_bwd(_range) of that step; all zero (the default) = eval behaviour.
-static struct { float p_embd = 0.f, p_attn = 0.f, p_resid = 0.f; unsigned long long seed = 0; } g_gpt2_drop;
-int cc_gpt2_set_dropout(float p_embd, float p_attn, float p_resid, uint64_t seed) {
-    if (p_embd < 0.f || p_embd >= 1.f || p_attn < 0.f || p_attn >= 1.f || p_resid < 0.f || p_resid >= 1.f) return CC_ERR_ARG;
-    g_gpt2_drop.p_embd = p_embd; g_gpt2_drop.p_attn = p_attn; g_gpt2_drop.p_resid = p_resid; g_gpt2_drop.seed = seed;
-    return CC_OK;
-}
-int cc_dropout_mask(uint64_t seed, int32_t site, int32_t layer, float p, int64_t n, uint8_t* out, void* stream) {
+// GPT-2 dropout (full finetune in train mode) is part of the pass's cc_gpt2_shape: embed / fwd / bwd(_range) of one pass read the
+// same (p_embd, p_attn, p_resid, drop_seed); all zero = eval behaviour.
+int CC_API(cc_dropout_mask)(uint64_t seed, int32_t site, int32_t layer, float p, int64_t n, uint8_t* out, void* stream) {
     if (!out || n < 0 || site < 0 || site > 3 || layer < 0 || layer > 255 || p < 0.f || p >= 1.f) return CC_ERR_ARG;
     return dropout_mask_u8(out, (size_t)n, make_drop(p, seed, (unsigned)site, (unsigned)layer), S_(stream));
 }
 
-int cc_gpt2_embed(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, const float* prefix, const int64_t* tokens, void* ws,
+int CC_API(cc_gpt2_embed)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, const float* prefix, const int64_t* tokens, void* ws,
                   void* stream) {
     if (!gpt2_cfg_ok(c) || !shape_ok(c, s) || !w32 || !ws || (s->L > 0 && !prefix) || (s->T > s->L && !tokens)) return CC_ERR_ARG;
     Gpt2Off o;
@@ -542,10 +490,10 @@ int cc_gpt2_embed(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32
     CC_TRY(embed_concat(prefix, reinterpret_cast<const long long*>(tokens), s->cap, w32 + o.wte, w32 + o.wpe, w.x[0], s->B, s->L, s->T,
                         c->D, 0, S_(stream)));
     // embd dropout on inputs_embeds + position_embeds (hf GPT2Model.forward: self.drop)
-    return dropout_f32(w.x[0], (size_t)s->B * s->T * c->D, make_drop(g_gpt2_drop.p_embd, g_gpt2_drop.seed, DROP_EMBD, 0), S_(stream));
+    return dropout_f32(w.x[0], (size_t)s->B * s->T * c->D, make_drop(s->p_embd, s->drop_seed, DROP_EMBD, 0), S_(stream));
 }
 
-int cc_gpt2_embed_from(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, const float* inputs_embeds, void* ws,
+int CC_API(cc_gpt2_embed_from)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, const float* inputs_embeds, void* ws,
                        void* stream) {
     if (!gpt2_cfg_ok(c) || !shape_ok(c, s) || !w32 || !ws || !inputs_embeds) return CC_ERR_ARG;
     Gpt2Off o;
@@ -555,7 +503,7 @@ int cc_gpt2_embed_from(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float
     return embed_concat(inputs_embeds, nullptr, 0, w32 + o.wte, w32 + o.wpe, w.x[0], s->B, s->T, s->T, c->D, 0, S_(stream));
 }
 
-int cc_gpt2_fwd(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, const uint16_t* w16, void* ws, void* stream) {
+int CC_API(cc_gpt2_fwd)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, const uint16_t* w16, void* ws, void* stream) {
     if (!gpt2_cfg_ok(c) || !shape_ok(c, s) || !w32 || !w16 || !ws) return CC_ERR_ARG;
     hipStream_t st = S_(stream);
     Gpt2Off o;
@@ -569,20 +517,20 @@ int cc_gpt2_fwd(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, 
         // hf :262-310: x1 = x + c_proj(attn(c_attn(ln_1 x)))
         CC_TRY(ln_fwd(w.x[l], D, nullptr, w32 + y.l1w, w32 + y.l1b, w.xn1[l], nullptr, w.mean1[l], w.rstd1[l], M, D, st));
         CC_TRY(gemm_bf16out(0, 0, w.xn1[l], D, w16t + y.aw, D, M, 3 * D, D, w.qkv[l], 3 * D, w32 + y.ab, 0, nullptr, st));
-        CC_TRY(attn_fwd(w.qkv[l], s->B, s->T, H, hd, true, w.att[l], w.lse[l], st, make_drop(g_gpt2_drop.p_attn, g_gpt2_drop.seed, DROP_ATTN, l)));
+        CC_TRY(attn_fwd(w.qkv[l], s->B, s->T, H, hd, true, w.att[l], w.lse[l], st, make_drop(s->p_attn, s->drop_seed, DROP_ATTN, l)));
         CC_TRY(gemm_resid(0, 0, w.att[l], D, w16t + y.pw, D, M, D, D, w.x1[l], w.x[l], D, w32 + y.pb, st,
-                          make_drop(g_gpt2_drop.p_resid, g_gpt2_drop.seed, DROP_RESID_ATTN, l)));
+                          make_drop(s->p_resid, s->drop_seed, DROP_RESID_ATTN, l)));
         // x = x1 + c_proj(gelu_new(c_fc(ln_2 x1)))   (hf :229-243)
         CC_TRY(ln_fwd(w.x1[l], D, nullptr, w32 + y.l2w, w32 + y.l2b, w.xn2[l], nullptr, w.mean2[l], w.rstd2[l], M, D, st));
         CC_TIMED(CC_SITE_GPT2_FC_FWD, st, gemm_bf16out(0, 0, w.xn2[l], D, w16t + y.fw, D, M, 4 * D, D, w.hact[l], 4 * D, w32 + y.fb, 2,
                                                         s->mode >= 1 ? w.u[l] : nullptr, st));
         CC_TIMED(CC_SITE_GPT2_PROJ2_FWD, st, gemm_resid(0, 0, w.hact[l], 4 * D, w16t + y.p2w, 4 * D, M, D, 4 * D, w.x[l + 1], w.x1[l], D, w32 + y.p2b, st,
-                                                       make_drop(g_gpt2_drop.p_resid, g_gpt2_drop.seed, DROP_RESID_MLP, l)));
+                                                       make_drop(s->p_resid, s->drop_seed, DROP_RESID_MLP, l)));
     }
     return CC_OK;
 }
 
-int cc_gpt2_logits(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, const uint16_t* w16, void* ws, float* logits,
+int CC_API(cc_gpt2_logits)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, const uint16_t* w16, void* ws, float* logits,
                    int64_t ldl, void* stream) {
     if (!gpt2_cfg_ok(c) || !shape_ok(c, s) || !w32 || !w16 || !ws || !logits) return CC_ERR_ARG;
     const int Ns = std::min(c->Vp, rup(c->V, 8));
@@ -597,7 +545,7 @@ int cc_gpt2_logits(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w3
     return gemm_f32out(0, 0, w.hf16, D, w16 + o.wte, D, M, Ns, D, logits, (int)ldl, nullptr, 0, 1.0f, 1, st);
 }
 
-int cc_lmhead_ce_fwd(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, const uint16_t* w16, void* ws, const int64_t* tokens,
+int CC_API(cc_lmhead_ce_fwd)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, const uint16_t* w16, void* ws, const int64_t* tokens,
                      float* stats, void* stream) {
     if (!gpt2_cfg_ok(c) || !shape_ok(c, s) || s->mode < 1 || s->L < 1 || !w32 || !w16 || !ws || !tokens || !stats) return CC_ERR_ARG;
     hipStream_t st = S_(stream);
@@ -617,8 +565,8 @@ int cc_lmhead_ce_fwd(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* 
     return CC_OK;
 }
 
-int cc_lmhead_ce_bwd(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, const uint16_t* w16, void* ws, const float* denom,
-                     float* g32, void* stream) {
+int CC_API(cc_lmhead_ce_bwd)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, const uint16_t* w16, void* ws, const float* denom,
+                     const float* loss_scale, float* g32, void* stream) {
     if (!gpt2_cfg_ok(c) || !shape_ok(c, s) || s->mode < 1 || !w32 || !w16 || !ws || !denom || (s->mode == 2 && !g32)) return CC_ERR_ARG;
     hipStream_t st = S_(stream);
     Gpt2Off o;
@@ -628,24 +576,24 @@ int cc_lmhead_ce_bwd(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* 
     gpt2_carve(c, s->B, s->T, cap, s->mode, ws, w);
     const int D = c->D, Mc = s->B * cap, M = s->B * s->T;
     const bool full = s->mode == 2;
-    CC_TRY(ce_dlogits(w.logits16, c->Vp, c->V, w.target, w.lse_row, denom, Mc, st));
+    CC_TRY(ce_dlogits(w.logits16, c->Vp, c->V, w.target, w.lse_row, denom, loss_scale, Mc, st));
     // d hf = dlogits · wte   ([Mc,Vp] x [Vp(k), D(n)])
     CC_TIMED(CC_SITE_LMHEAD_DGRAD, st, gemm_bf16out(0, 0, w.logits16, c->Vp, w16 + o.total + o.wte, c->Vp, Mc, D, c->Vp, w.dhf16, D, nullptr, 0, nullptr, st));
     if (full) CC_TRY(gemm_wgrad(w.logits16, c->Vp, w.hf16, D, c->Vp, D, Mc, g32 + o.wte, D, w.wg_scratch, st));  // tied lm_head: d wte += dlogits^T hf
     if (hipMemsetAsync(w.dx32, 0, (size_t)M * D * sizeof(float), st) != hipSuccess) return CC_ERR_LAUNCH;
-    if (hipMemsetAsync(w.dx16, 0, (size_t)M * D * sizeof(bf16_t), st) != hipSuccess) return CC_ERR_LAUNCH;
+    if (hipMemsetAsync(w.dx16, 0, (size_t)M * D * sizeof(op16_t), st) != hipSuccess) return CC_ERR_LAUNCH;
     CC_TRY(ln_bwd(w.dhf16, w.x[c->NL], D, w.row_map, w.meanf, w.rstdf, w32 + o.lnf_w, nullptr, w.dx32, w.dx16, full ? g32 + o.lnf_w : nullptr,
                   full ? g32 + o.lnf_b : nullptr, Mc, D, st));
     return CC_OK;
 }
 
-int cc_gpt2_bwd(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, const uint16_t* w16, void* ws, const int64_t* tokens,
+int CC_API(cc_gpt2_bwd)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, const uint16_t* w16, void* ws, const int64_t* tokens,
                 float* dprefix, float* g32, void* stream) {
     if (!gpt2_cfg_ok(c)) return CC_ERR_ARG;
-    return cc_gpt2_bwd_range(c, s, w32, w16, ws, tokens, dprefix, g32, c->NL, 0, stream);
+    return CC_API(cc_gpt2_bwd_range)(c, s, w32, w16, ws, tokens, dprefix, g32, c->NL, 0, stream);
 }
 
-int cc_gpt2_bwd_range(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, const uint16_t* w16, void* ws, const int64_t* tokens,
+int CC_API(cc_gpt2_bwd_range)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, const uint16_t* w16, void* ws, const int64_t* tokens,
                       float* dprefix, float* g32, int32_t l_hi, int32_t l_lo, void* stream) {
     if (!gpt2_cfg_ok(c) || !shape_ok(c, s) || s->mode < 1 || !w32 || !w16 || !ws || (s->L > 0 && !dprefix) || (s->mode == 2 && (!g32 || !tokens)) ||
         l_lo < 0 || l_hi > c->NL || l_lo > l_hi)
@@ -661,7 +609,7 @@ int cc_gpt2_bwd_range(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float*
         const auto& y = o.layer[l];
         // residual dropout: the gradient entering a c_proj is the masked residual gradient (its bf16 copy is only read by that
         // c_proj's backward GEMMs, so it is masked in place; dx32, the residual stream's own gradient, stays unmasked)
-        CC_TRY(dropout_bf16(w.dx16, (size_t)M * D, make_drop(g_gpt2_drop.p_resid, g_gpt2_drop.seed, DROP_RESID_MLP, l), st));
+        CC_TRY(dropout_bf16(w.dx16, (size_t)M * D, make_drop(s->p_resid, s->drop_seed, DROP_RESID_MLP, l), st));
         // mlp.c_proj (Conv1D [4D, D]): y = hact W + b
         if (full) {
             CC_TRY(gemm_wgrad(w.hact[l], D4, w.dx16, D, D4, D, M, g32 + y.p2w, D, w.wg_scratch, st));
@@ -677,14 +625,14 @@ int cc_gpt2_bwd_range(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float*
         CC_TRY(ln_bwd(w.dxn16, w.x1[l], D, nullptr, w.mean2[l], w.rstd2[l], w32 + y.l2w, w.dx32, w.dx32, w.dx16, full ? g32 + y.l2w : nullptr,
                       full ? g32 + y.l2b : nullptr, M, D, st));
         // attn.c_proj (Conv1D [D, D])
-        CC_TRY(dropout_bf16(w.dx16, (size_t)M * D, make_drop(g_gpt2_drop.p_resid, g_gpt2_drop.seed, DROP_RESID_ATTN, l), st));
+        CC_TRY(dropout_bf16(w.dx16, (size_t)M * D, make_drop(s->p_resid, s->drop_seed, DROP_RESID_ATTN, l), st));
         if (full) {
             CC_TRY(gemm_wgrad(w.att[l], D, w.dx16, D, D, D, M, g32 + y.pw, D, w.wg_scratch, st));
             CC_TRY(colsum_bf16(w.dx16, D, M, D, g32 + y.pb, st));
         }
         CC_TRY(gemm_bf16out(0, 0, w.dx16, D, w16 + y.pw, D, M, D, D, w.datt16, D, nullptr, 0, nullptr, st));
         CC_TRY(attn_bwd(w.qkv[l], w.datt16, w.att[l], w.lse[l], w.adelta, s->B, s->T, H, hd, true, w.dqkv16, st,
-                        make_drop(g_gpt2_drop.p_attn, g_gpt2_drop.seed, DROP_ATTN, l)));
+                        make_drop(s->p_attn, s->drop_seed, DROP_ATTN, l)));
         // attn.c_attn (Conv1D [D, 3D])
         if (full) {
             CC_TRY(gemm_wgrad(w.xn1[l], D, w.dqkv16, D3, D, D3, M, g32 + y.aw, D3, w.wg_scratch, st));
@@ -695,7 +643,7 @@ int cc_gpt2_bwd_range(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float*
                       full ? g32 + y.l1b : nullptr, M, D, st));
     }
     if (l_lo > 0) return CC_OK;
-    CC_TRY(dropout_f32(w.dx32, (size_t)M * D, make_drop(g_gpt2_drop.p_embd, g_gpt2_drop.seed, DROP_EMBD, 0), st));   // d(inputs + wpe)
+    CC_TRY(dropout_f32(w.dx32, (size_t)M * D, make_drop(s->p_embd, s->drop_seed, DROP_EMBD, 0), st));   // d(inputs + wpe)
     if (s->L > 0) CC_TRY(copy_rows(w.dx32, (size_t)s->T * D, dprefix, (size_t)s->L * D, s->L * D, s->B, st));
     if (full)
         CC_TRY(embed_bwd(w.dx32, reinterpret_cast<const long long*>(tokens), s->cap, g32 + o.wte, g32 + o.wpe, s->B, s->L, s->T, D, st));
@@ -703,24 +651,34 @@ int cc_gpt2_bwd_range(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float*
 }
 
 // ---------------------------------------------------------------- optimizer / casts / test hooks -----------------
-int cc_adamw_step(float* p32, const float* g32, float* m, float* v, uint16_t* p16, int64_t n, float lr, float beta1, float beta2, float eps,
-                  float weight_decay, int32_t step, float grad_scale, void* stream) {
+int CC_API(cc_adamw_step)(float* p32, const float* g32, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int32_t step, float grad_scale, const float* loss_scale, const float* found_inf, void* stream) {
     if (!p32 || !g32 || !m || !v || n < 0 || step < 1) return CC_ERR_ARG;
-    return adamw(p32, g32, m, v, p16, (size_t)n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, S_(stream));
+    return adamw(p32, g32, m, v, (size_t)n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, loss_scale, found_inf, S_(stream));
 }
 
-int cc_cast_bf16(const float* src, uint16_t* dst, int64_t n, void* stream) {
+int CC_API(cc_cast_op16)(const float* src, uint16_t* dst, int64_t n, void* stream) {
     if (!src || !dst || n < 0) return CC_ERR_ARG;
     return f32_to_bf16(src, dst, (size_t)n, S_(stream));
 }
 
-int cc_gemm_bf16_f32(int32_t al, int32_t bl, const uint16_t* A, int32_t lda, const uint16_t* B, int32_t ldb, int32_t M, int32_t N, int32_t K,
+int CC_API(cc_grad_nonfinite)(const float* g32, int64_t n, float* found_inf, void* stream) {
+    if (!g32 || !found_inf || n < 0) return CC_ERR_ARG;
+    return grad_nonfinite(g32, (size_t)n, found_inf, S_(stream));
+}
+
+int CC_API(cc_loss_scale_update)(float* state, float* found_inf, float growth, float backoff, int32_t interval, void* stream) {
+    if (!state || !found_inf || growth < 1.f || backoff <= 0.f || backoff > 1.f || interval < 1) return CC_ERR_ARG;
+    return loss_scale_update(state, found_inf, growth, backoff, interval, S_(stream));
+}
+
+int CC_API(cc_gemm_op16_f32)(int32_t al, int32_t bl, const uint16_t* A, int32_t lda, const uint16_t* B, int32_t ldb, int32_t M, int32_t N, int32_t K,
                      float* C, int32_t ldc, const float* bias, int32_t ksplit, void* stream) {
     if (!A || !B || !C) return CC_ERR_ARG;
     return gemm_f32out(al, bl, A, lda, B, ldb, M, N, K, C, ldc, ksplit > 1 ? nullptr : bias, ksplit > 1 ? 2 : 0, 1.0f, ksplit, S_(stream));
 }
 
-int cc_sample_step(const float* logits, int32_t R, int32_t V, int32_t ld, float temperature, int32_t top_k, float top_p, int32_t mode,
+int CC_API(cc_sample_step)(const float* logits, int32_t R, int32_t V, int32_t ld, float temperature, int32_t top_k, float top_p, int32_t mode,
                    const int64_t* history, int32_t hist_len, int32_t hist_ld, float repetition_penalty, const float* u, int32_t* next_token,
                    float* probs_out, void* stream) {
     if (!logits || !u || !next_token || R < 0) return CC_ERR_ARG;
@@ -728,38 +686,26 @@ int cc_sample_step(const float* logits, int32_t R, int32_t V, int32_t ld, float 
                        repetition_penalty, u, next_token, probs_out, S_(stream));
 }
 
-int64_t cc_wgrad_scratch_bytes(void) { return (int64_t)WGRAD_SCRATCH_BYTES; }
+int64_t CC_API(cc_wgrad_scratch_bytes)(void) { return (int64_t)WGRAD_SCRATCH_BYTES; }
 
-int cc_gemm_wgrad(const uint16_t* X, int32_t ldx, const uint16_t* Y, int32_t ldy, int32_t Mw, int32_t Nw, int32_t K, float* dW, int32_t ldw,
+int CC_API(cc_gemm_wgrad)(const uint16_t* X, int32_t ldx, const uint16_t* Y, int32_t ldy, int32_t Mw, int32_t Nw, int32_t K, float* dW, int32_t ldw,
                   float* scratch, void* stream) {
     if (!X || !Y || !dW) return CC_ERR_ARG;
     return gemm_wgrad(X, ldx, Y, ldy, Mw, Nw, K, dW, ldw, scratch, S_(stream));
 }
 
-int cc_gemm_tile_mode(int32_t mode) {
-    const int old = g_gemm_tile_mode;
-    g_gemm_tile_mode = mode;
-    return old;
-}
-
-int cc_gemm_skinny_mode(int32_t mode) {
-    const int old = g_gemm_s64;
-    g_gemm_s64 = mode;
-    return old;
-}
-
-int cc_layernorm_fwd(const float* x, const float* gamma, const float* beta, uint16_t* y, float* mean, float* rstd, int32_t rows, int32_t D,
+int CC_API(cc_layernorm_fwd)(const float* x, const float* gamma, const float* beta, uint16_t* y, float* mean, float* rstd, int32_t rows, int32_t D,
                      void* stream) {
     if (!x || !gamma || !beta || !y) return CC_ERR_ARG;
     return ln_fwd(x, D, nullptr, gamma, beta, y, nullptr, mean, rstd, rows, D, S_(stream));
 }
 
-int cc_attention_fwd(const uint16_t* qkv, int32_t B, int32_t S, int32_t H, int32_t hd, int32_t causal, uint16_t* out, float* lse, void* stream) {
+int CC_API(cc_attention_fwd)(const uint16_t* qkv, int32_t B, int32_t S, int32_t H, int32_t hd, int32_t causal, uint16_t* out, float* lse, void* stream) {
     if (!qkv || !out) return CC_ERR_ARG;
     return attn_fwd(qkv, B, S, H, hd, causal != 0, out, lse, S_(stream));
 }
 
-int cc_attention_bwd(const uint16_t* qkv, const uint16_t* dout, const uint16_t* o, const float* lse, float* delta_ws, int32_t B, int32_t S,
+int CC_API(cc_attention_bwd)(const uint16_t* qkv, const uint16_t* dout, const uint16_t* o, const float* lse, float* delta_ws, int32_t B, int32_t S,
                      int32_t H, int32_t hd, int32_t causal, uint16_t* dqkv, void* stream) {
     if (!qkv || !dout || !lse || !dqkv) return CC_ERR_ARG;
     return attn_bwd(qkv, dout, o, lse, delta_ws, B, S, H, hd, causal != 0, dqkv, S_(stream));

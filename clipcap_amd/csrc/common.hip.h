@@ -1,0 +1,139 @@
+// Shared device helpers for the ClipCap gfx950 kernels (wave64, CDNA4 only — no portability shims).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// ---- operand type of this build of the kernels ------------------------------------------------------------------------------
+// Every translation unit is compiled twice (Makefile): CC_OP = 0 with bf16 GEMM / attention operands (namespace cc_bf16, C symbols
+// <name>_bf16) and CC_OP = 1 with IEEE fp16 operands (namespace cc_f16, <name>_f16) — the reference's `--fp-precision 16`
+// (clipcap/train/args.py:30-34).  Same MFMA rate, same fp32 accumulation and fp32 master weights / residual streams; fp16 has 3 more
+// mantissa bits (the route to the 1e-3 logits bar at GPT-2 width) and 3 fewer exponent bits (backward runs under a loss scale).
+// abi_dispatch.cpp picks the variant per call from cfg->op_dtype.
+#ifndef CC_OP
+#define CC_OP 0
+#endif
+#if CC_OP == 1
+#define CC_NS cc_f16
+#define CC_API(name) name##_f16
+#else
+#define CC_NS cc_bf16
+#define CC_API(name) name##_bf16
+#endif
+
+// process-wide knobs shared by both variants (shared.cpp): test / measurement hooks only, never touched by the product path
+namespace cc_shared {
+extern int g_gemm_tile_mode;   // cc_gemm_tile_mode
+extern int g_gemm_s64;         // cc_gemm_skinny_mode
+extern int g_gemm_small_x2;    // env CC_GEMM_X2
+}  // namespace cc_shared
+
+namespace CC_NS {
+using cc_shared::g_gemm_s64;
+using cc_shared::g_gemm_small_x2;
+using cc_shared::g_gemm_tile_mode;
+
+typedef unsigned short op16_t;  // raw 16-bit operand storage (bf16 or fp16 bit pattern); conversions are round-to-nearest-even like torch
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2_hw;
+#if CC_OP == 1
+typedef __attribute__((ext_vector_type(8))) _Float16 op16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 op16x2_hw;
+#define CC_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#define CC_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+__device__ __forceinline__ float op2f(op16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+// one 32-bit word holding two operands -> two floats (v_cvt_f32_f16 on each half)
+__device__ __forceinline__ void unpack2(unsigned w, float& lo, float& hi) {
+    const f32x2_hw f = __builtin_convertvector(__builtin_bit_cast(op16x2_hw, w), f32x2_hw);
+    lo = f.x; hi = f.y;
+}
+#else
+typedef __attribute__((ext_vector_type(8))) __bf16 op16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 op16x2_hw;
+#define CC_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define CC_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+__device__ __forceinline__ float op2f(op16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ void unpack2(unsigned w, float& lo, float& hi) {
+    lo = __uint_as_float(w << 16); hi = __uint_as_float(w & 0xffff0000u);
+}
+#endif
+// fp32 -> operand type on the gfx950 converters (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32: round-to-nearest-even, NaN stays NaN) — one
+// instruction per PAIR; the integer-arithmetic bf16 rounding it replaces cost ~7 VALU instructions and a divergent NaN branch per
+// element and made every 16-bit-storing epilogue instruction-bound.
+__device__ __forceinline__ unsigned pack2op(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_hw{lo, hi}, op16x2_hw));
+}
+__device__ __forceinline__ op16_t f2op(float f) { return (op16_t)(pack2op(f, 0.f) & 0xffffu); }
+__device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
+    unpack2(v.x, f[0], f[1]); unpack2(v.y, f[2], f[3]); unpack2(v.z, f[4], f[5]); unpack2(v.w, f[6], f[7]);
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+    return make_uint4(pack2op(f[0], f[1]), pack2op(f[2], f[3]), pack2op(f[4], f[5]), pack2op(f[6], f[7]));
+}
+
+// gelu_new (tanh approximation) and its derivative — transformers.activations.NewGELUActivation.
+// tanh(u) = 1 - 2/(exp(2u)+1) on the hardware exp/rcp units (v_exp_f32 / v_rcp_f32, ~1e-6 relative): libm's tanhf doubled the
+// run time of the GEMMs carrying these epilogues.  Saturates correctly: exp->inf gives 1, exp->0 gives -1.
+__device__ __forceinline__ float fast_tanh(float u) { return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * u) + 1.0f); }
+__device__ __forceinline__ float gelu_new_f(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    const float t = fast_tanh(k0 * (x + k1 * x * x * x));
+    return 0.5f * x * (1.0f + t);
+}
+__device__ __forceinline__ float gelu_new_grad(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    const float t = fast_tanh(k0 * (x + k1 * x * x * x));
+    const float dt = (1.0f - t * t) * k0 * (1.0f + 3.0f * k1 * x * x);
+    return 0.5f * (1.0f + t) + 0.5f * x * dt;
+}
+
+// ---- dropout (GPT-2 full finetune in train mode: embd / attention-probability / residual dropout, hf modeling_gpt2.py) --------
+// Counter-based: keep(element) is a hash of (seed, stream = site * 256 + layer, element index), so the backward pass regenerates the
+// forward's mask instead of storing it.  thresh = p * 2^32 (0 = dropout off); kept values are scaled by 1 / (1 - p).
+struct Drop {
+    unsigned thresh = 0, seed_lo = 0, seed_hi = 0, stream = 0;
+    float scale = 1.0f;
+};
+__host__ __device__ __forceinline__ unsigned drop_hash(unsigned seed_lo, unsigned seed_hi, unsigned stream, unsigned idx) {
+    unsigned x = idx ^ seed_lo;
+    x *= 0x9E3779B1u; x ^= x >> 15;
+    x += (stream * 0x85EBCA6Bu) ^ seed_hi;
+    x *= 0xC2B2AE35u; x ^= x >> 13;
+    x *= 0x27D4EB2Fu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ bool drop_keep(const Drop& d, unsigned idx) { return drop_hash(d.seed_lo, d.seed_hi, d.stream, idx) >= d.thresh; }
+// multiplier of element idx: 0 or 1 / (1 - p)
+__device__ __forceinline__ float drop_mul(const Drop& d, unsigned idx) { return drop_keep(d, idx) ? d.scale : 0.f; }
+enum { DROP_EMBD = 0, DROP_ATTN = 1, DROP_RESID_ATTN = 2, DROP_RESID_MLP = 3 };
+inline Drop make_drop(float p, unsigned long long seed, unsigned site, unsigned layer) {
+    Drop d;
+    if (p > 0.f) {
+        const double t = (double)p * 4294967296.0;
+        d.thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+        d.scale = 1.0f / (1.0f - p);
+        d.seed_lo = (unsigned)seed; d.seed_hi = (unsigned)(seed >> 32); d.stream = site * 256u + layer;
+    }
+    return d;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+}  // namespace CC_NS
+
+// status codes returned across the C ABI (same values as include/clipcap_hip.h)
+#ifndef CC_OK
+#define CC_OK 0
+#define CC_ERR_ARG (-1)
+#define CC_ERR_SHAPE (-2)
+#define CC_ERR_LAUNCH (-3)
+#define CC_ERR_STATE (-4)
+#endif

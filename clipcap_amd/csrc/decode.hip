@@ -1,12 +1,12 @@
 // KV-cached caption decode for gfx950: replaces the reference's full GPT-2 re-forward per generated token
 // (clipcap/inference/base.py:81) with an O(ctx) step, plus the device-side beam-search update of base.py:84-119.
-// Decode is HBM-bound (every weight byte is read once per step); the GEMMs reuse gemm.cuh, attention over the
+// Decode is HBM-bound (every weight byte is read once per step); the GEMMs reuse gemm.hip.h, attention over the
 // cache is one wave per (row, head, new position).
 #include "../../include/clipcap_hip.h"
 #include "gemm_api.h"
 #include "kernels.h"
 
-using namespace cc;
+using namespace CC_NS;
 
 #define CC_TRY(expr)                 \
     do {                             \
@@ -36,8 +36,8 @@ __global__ void k_add_wpe(const float* __restrict__ xin, const float* __restrict
 // APPEND: the wave also writes its own (row, head, new position) K / V slice into the cache (instead of a separate append launch)
 // and reads the keys / values of the NEW positions straight from qkv — other waves' cache writes are not ordered with its reads.
 template <bool APPEND>
-__global__ __launch_bounds__(256) void k_decode_attn(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ kc,
-                                                     bf16_t* __restrict__ vc, const int* __restrict__ row_map, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256) void k_decode_attn(const op16_t* __restrict__ qkv, op16_t* __restrict__ kc,
+                                                     op16_t* __restrict__ vc, const int* __restrict__ row_map, op16_t* __restrict__ out,
                                                      int R, int Tn, int H, int hd, int pos0, int ctx_max, float scale) {
     extern __shared__ float psm[];  // per wave: p[ctx_max] | srow[ctx_max] | red[8][hd]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -49,20 +49,20 @@ __global__ __launch_bounds__(256) void k_decode_attn(const bf16_t* __restrict__ 
     float* p = psm + wave * per_wave;
     int* srow = reinterpret_cast<int*>(p + ctx_max);
     float* red = p + 2 * ctx_max;
-    const bf16_t* q = qkv + ((size_t)r * Tn + t) * 3 * D + h * hd;
+    const op16_t* q = qkv + ((size_t)r * Tn + t) * 3 * D + h * hd;
     // position j of row r lives in cache row row_map[r*ctx_max + j] (beam ancestry table; identity when null)
-    const bf16_t* kb = kc + h * hd;
-    const bf16_t* vb = vc + h * hd;
+    const op16_t* kb = kc + h * hd;
+    const op16_t* vb = vc + h * hd;
     if (APPEND) {
         const int c8 = hd >> 3;                            // 16-B chunks per head slice
         if (lane < 2 * c8) {
             const int which = lane / c8, c = lane - which * c8;
             const uint4 v = *reinterpret_cast<const uint4*>(q + (which + 1) * D + c * 8);
-            bf16_t* dst = (which ? vc : kc) + ((size_t)r * ctx_max + pos0 + t) * D + h * hd + c * 8;
+            op16_t* dst = (which ? vc : kc) + ((size_t)r * ctx_max + pos0 + t) * D + h * hd + c * 8;
             *reinterpret_cast<uint4*>(dst) = v;
         }
     }
-    const bf16_t* knew = qkv + (size_t)r * Tn * 3 * D + D + h * hd;        // K of new position u: knew + u * 3D  (V: + D)
+    const op16_t* knew = qkv + (size_t)r * Tn * 3 * D + D + h * hd;        // K of new position u: knew + u * 3D  (V: + D)
     for (int j = lane; j < nkeys; j += 64) srow[j] = row_map ? row_map[(size_t)r * ctx_max + j] : r;
     float m = -INFINITY;
     const int nchunk = hd >> 3;
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void k_decode_attn(const bf16_t* __restrict__ 
 #pragma unroll
             for (int u = 0; u < SC_U; u++) {
                 const int j = min(j0 + u * kgs + skg, nkeys - 1);
-                const bf16_t* krow = (APPEND && j >= pos0) ? knew + (size_t)(j - pos0) * 3 * D : kb + ((size_t)srow[j] * ctx_max + j) * D;
+                const op16_t* krow = (APPEND && j >= pos0) ? knew + (size_t)(j - pos0) * 3 * D : kb + ((size_t)srow[j] * ctx_max + j) * D;
                 kv[u] = *reinterpret_cast<const uint4*>(krow + sdc * 8);
             }
 #pragma unroll
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void k_decode_attn(const bf16_t* __restrict__ 
     } else {
         for (int j = lane; j < nkeys; j += 64) {
             float s = 0.f;
-            const bf16_t* krow = (APPEND && j >= pos0) ? knew + (size_t)(j - pos0) * 3 * D : kb + ((size_t)srow[j] * ctx_max + j) * D;
+            const op16_t* krow = (APPEND && j >= pos0) ? knew + (size_t)(j - pos0) * 3 * D : kb + ((size_t)srow[j] * ctx_max + j) * D;
             for (int d = 0; d < hd; d += 8) {
                 float a[8], b[8];
                 unpack8(*reinterpret_cast<const uint4*>(q + d), a);
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void k_decode_attn(const bf16_t* __restrict__ 
 #pragma unroll
             for (int u = 0; u < PV_U; u++) {
                 const int j = min(j0 + u * kgroups, nkeys - 1);
-                const bf16_t* vrow = (APPEND && j >= pos0) ? knew + D + (size_t)(j - pos0) * 3 * D : vb + ((size_t)srow[j] * ctx_max + j) * D;
+                const op16_t* vrow = (APPEND && j >= pos0) ? knew + D + (size_t)(j - pos0) * 3 * D : vb + ((size_t)srow[j] * ctx_max + j) * D;
                 vv[u] = *reinterpret_cast<const uint4*>(vrow + dc * 8);
                 pj[u] = j0 + u * kgroups < nkeys ? p[j] : 0.f;
             }
@@ -151,11 +151,11 @@ __global__ __launch_bounds__(256) void k_decode_attn(const bf16_t* __restrict__ 
     for (int d = lane; d < hd; d += 64) {
         float o = 0.f;
         for (int g = 0; g < kgroups; g++) o += red[g * hd + d];
-        out[((size_t)r * Tn + t) * D + h * hd + d] = f2bf(o * inv);
+        out[((size_t)r * Tn + t) * D + h * hd + d] = f2op(o * inv);
     }
 }
 
-__global__ void k_kv_reorder(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, const int* __restrict__ map, int R_src, int R_dst,
+__global__ void k_kv_reorder(const op16_t* __restrict__ src, op16_t* __restrict__ dst, const int* __restrict__ map, int R_src, int R_dst,
                              int ctx, int ctx_max, int D, int NL2) {
     const int d8n = D >> 3;
     const size_t per_row = (size_t)ctx * d8n;
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(64) void k_beam_final(int beam, int V, int first, i
 
 struct DecWS {
     float *x, *x1;
-    bf16_t *xn, *qkv, *att, *hact, *hf;
+    op16_t *xn, *qkv, *att, *hact, *hf;
     float *meanf, *rstdf;
     int* last;
     float* scratch;
@@ -542,11 +542,11 @@ void dec_carve(const cc_gpt2_cfg* c, int R, int Tn, void* ws, DecWS& w) {
     const size_t M = (size_t)R * Tn, D = c->D;
     w.x = (float*)take(M * D * 4);
     w.x1 = (float*)take(M * D * 4);
-    w.xn = (bf16_t*)take(M * D * 2);
-    w.qkv = (bf16_t*)take(M * 3 * D * 2);
-    w.att = (bf16_t*)take(M * D * 2);
-    w.hact = (bf16_t*)take(M * 4 * D * 2);
-    w.hf = (bf16_t*)take((size_t)R * D * 2);
+    w.xn = (op16_t*)take(M * D * 2);
+    w.qkv = (op16_t*)take(M * 3 * D * 2);
+    w.att = (op16_t*)take(M * D * 2);
+    w.hact = (op16_t*)take(M * 4 * D * 2);
+    w.hf = (op16_t*)take((size_t)R * D * 2);
     w.meanf = (float*)take((size_t)R * 4);
     w.rstdf = (float*)take((size_t)R * 4);
     w.last = (int*)take((size_t)R * 4);
@@ -556,7 +556,7 @@ void dec_carve(const cc_gpt2_cfg* c, int R, int Tn, void* ws, DecWS& w) {
 }
 
 bool cfg_ok(const cc_gpt2_cfg* c) {
-    return c && c->D > 0 && c->H > 0 && c->NL > 0 && c->V > 0 && c->Vp >= c->V && (c->Vp % 128) == 0 && (c->D % 8) == 0 && (c->D % c->H) == 0 &&
+    return c && (c->op_dtype == CC_OP) && c->D > 0 && c->H > 0 && c->NL > 0 && c->V > 0 && c->Vp >= c->V && (c->Vp % 128) == 0 && (c->D % 8) == 0 && (c->D % c->H) == 0 &&
            ((c->D / c->H) % 8) == 0;
 }
 
@@ -564,14 +564,14 @@ bool cfg_ok(const cc_gpt2_cfg* c) {
 
 extern "C" {
 
-int64_t cc_decode_ws_bytes(const cc_gpt2_cfg* cfg, int32_t R, int32_t Tnew) {
+int64_t CC_API(cc_decode_ws_bytes)(const cc_gpt2_cfg* cfg, int32_t R, int32_t Tnew) {
     if (!cfg_ok(cfg) || R <= 0 || Tnew <= 0) return CC_ERR_SHAPE;
     DecWS w;
     dec_carve(cfg, R, Tnew, nullptr, w);
     return (int64_t)w.bytes;
 }
 
-int cc_decode_fwd(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int32_t ctx_max, const float* w32, const uint16_t* w16,
+int CC_API(cc_decode_fwd)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int32_t ctx_max, const float* w32, const uint16_t* w16,
                   const float* x, uint16_t* kv, const int32_t* row_map, void* ws, float* logits, int64_t ldl, void* stream) {
     if (!cfg_ok(c) || R <= 0 || Tn <= 0 || pos0 < 0 || !w32 || !w16 || !x || !kv || !ws || !logits) return CC_ERR_ARG;
     const int Ns = std::min(c->Vp, (c->V + 7) / 8 * 8);
@@ -607,8 +607,8 @@ int cc_decode_fwd(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int
         const int64_t fb = p; p += 4 * D;
         const int64_t p2w = p; p += (int64_t)4 * D * D;
         const int64_t p2b = p; p += D;
-        bf16_t* kc = kv + (size_t)l * cache_layer;
-        bf16_t* vc = kc + (size_t)R * ctx_max * D;
+        op16_t* kc = kv + (size_t)l * cache_layer;
+        op16_t* vc = kc + (size_t)R * ctx_max * D;
         // xn = ln_1(x): produced by the previous layer's fused finish when possible
         if (!xn_ready) CC_TRY(ln_fwd(w.x, D, nullptr, w32 + l1w, w32 + l1b, w.xn, nullptr, nullptr, nullptr, M, D, st));
         // c_attn (+ fused KV append into the cache)
@@ -648,7 +648,7 @@ int cc_decode_fwd(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
 
-int cc_decode_reorder(const cc_gpt2_cfg* c, int32_t R_src, int32_t R_dst, int32_t ctx, int32_t ctx_max, const uint16_t* kv_src, uint16_t* kv_dst,
+int CC_API(cc_decode_reorder)(const cc_gpt2_cfg* c, int32_t R_src, int32_t R_dst, int32_t ctx, int32_t ctx_max, const uint16_t* kv_src, uint16_t* kv_dst,
                       const int32_t* src, void* stream) {
     if (!cfg_ok(c) || R_src <= 0 || R_dst <= 0 || ctx < 0 || ctx > ctx_max || !kv_src || !kv_dst || !src || kv_src == kv_dst) return CC_ERR_ARG;
     if (ctx == 0) return CC_OK;
@@ -658,13 +658,13 @@ int cc_decode_reorder(const cc_gpt2_cfg* c, int32_t R_src, int32_t R_dst, int32_
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
 
-int64_t cc_beam_ws_bytes(int32_t S, int32_t beam, int32_t V) {
+int64_t CC_API(cc_beam_ws_bytes)(int32_t S, int32_t beam, int32_t V) {
     (void)V;
     if (S <= 0 || beam <= 0 || beam > BEAM_MAX) return CC_ERR_SHAPE;
     return (int64_t)S * beam * 2 * sizeof(float) + (int64_t)S * BEAM_CHUNKS * beam * (sizeof(float) + sizeof(int)) + 512;
 }
 
-int cc_beam_step(int32_t S, int32_t beam, int32_t V, const float* logits, int64_t ldl, float temperature, int32_t first, int32_t stop_token,
+int CC_API(cc_beam_step)(int32_t S, int32_t beam, int32_t V, const float* logits, int64_t ldl, float temperature, int32_t first, int32_t stop_token,
                  float* scores, float* seq_lengths, uint8_t* has_stopped, int32_t* next_tokens, int32_t* src_rows, void* ws, void* stream) {
     if (S <= 0 || beam <= 0 || beam > BEAM_MAX || V <= 0 || !logits || ldl < V || !scores || !seq_lengths || !has_stopped || !next_tokens ||
         !src_rows || !ws)
@@ -695,14 +695,14 @@ int cc_beam_step(int32_t S, int32_t beam, int32_t V, const float* logits, int64_
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
 
-int cc_embed_tokens(const cc_gpt2_cfg* c, int32_t R, const float* w32, const int32_t* tokens, float* out, void* stream) {
+int CC_API(cc_embed_tokens)(const cc_gpt2_cfg* c, int32_t R, const float* w32, const int32_t* tokens, float* out, void* stream) {
     if (!cfg_ok(c) || R <= 0 || !w32 || !tokens || !out) return CC_ERR_ARG;
     const size_t total = (size_t)R * (c->D >> 2);
     hipLaunchKernelGGL(k_embed_tokens, dim3((int)std::min<size_t>((total + 255) / 256, 2048)), dim3(256), 0, S_(stream), w32, tokens, out, R, c->D);
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
 
-int cc_beam_advance(const cc_gpt2_cfg* c, int32_t R, int32_t beam, const float* w32, const int32_t* next_tokens, const int32_t* src_rows,
+int CC_API(cc_beam_advance)(const cc_gpt2_cfg* c, int32_t R, int32_t beam, const float* w32, const int32_t* next_tokens, const int32_t* src_rows,
                     int32_t pos, int32_t ctx_max, const int32_t* row_map_in, int32_t* row_map_out, int32_t step, int32_t tok_ld,
                     const int32_t* tokens_in, int32_t* tokens_out, float* x_out, void* stream) {
     if (!cfg_ok(c) || R <= 0 || beam <= 0 || (R % beam) || !w32 || !next_tokens || !x_out || pos < 0 || pos > ctx_max) return CC_ERR_ARG;

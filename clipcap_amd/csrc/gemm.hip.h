@@ -20,10 +20,10 @@
 #pragma once
 #include <cstdlib>
 #include <type_traits>
-#include "common.cuh"
+#include "common.hip.h"
 #include "gemm_api.h"
 
-namespace cc {
+namespace CC_NS {
 
 constexpr int G_BM = 128, G_BN = 128, G_BK = 64, G_THREADS = 256;
 constexpr int G_TILE_BYTES = G_BM * G_BK * 2;  // 16 KiB per operand per buffer
@@ -45,7 +45,7 @@ struct StageRegs {
 };
 
 // ---- K-contiguous operand: global [rows][ld]; thread -> (chunk = tid&7, rows tid>>3 + 32 i) ----
-__device__ __forceinline__ void g_load_kc(StageRegs& s, const bf16_t* __restrict__ base, int ld, int rows, int r0,
+__device__ __forceinline__ void g_load_kc(StageRegs& s, const op16_t* __restrict__ base, int ld, int rows, int r0,
                                           int k0, int kend, int tid) {
     const int c = tid & 7, rr = tid >> 3;
     const int k = k0 + c * 8;
@@ -65,7 +65,7 @@ __device__ __forceinline__ void l_store_kc(const StageRegs& s, char* lds, int ti
 }
 
 // ---- K-strided operand: global [k][ld] with the tile's rows contiguous; thread -> 4 k-rows x 8 rows ----
-__device__ __forceinline__ void g_load_ks(StageRegs& s, const bf16_t* __restrict__ base, int ld, int rows, int r0,
+__device__ __forceinline__ void g_load_ks(StageRegs& s, const op16_t* __restrict__ base, int ld, int rows, int r0,
                                           int k0, int kend, int tid) {
     const int ng = (tid & 7) | (((tid >> 4) & 1) << 3);
     const int kg = ((tid >> 3) & 1) | ((tid >> 5) << 1);
@@ -102,7 +102,7 @@ __device__ __forceinline__ void l_store_ks(const StageRegs& s, char* lds, int ti
 }
 
 template <int L>
-__device__ __forceinline__ void g_load(StageRegs& s, const bf16_t* base, int ld, int rows, int r0, int k0, int kend,
+__device__ __forceinline__ void g_load(StageRegs& s, const op16_t* base, int ld, int rows, int r0, int k0, int kend,
                                        int tid) {
     if constexpr (L == 0)
         g_load_kc(s, base, ld, rows, r0, k0, kend, tid);
@@ -270,8 +270,8 @@ __device__ __forceinline__ void tile_coords(int tile, int tiles_m, int tiles_n, 
 }
 
 template <int AL, int BL, class Epi>
-__global__ __launch_bounds__(G_THREADS, 2) void gemm_bf16_kernel(const bf16_t* __restrict__ A,
-                                                                  const bf16_t* __restrict__ B, GemmShape g, Epi epi) {
+__global__ __launch_bounds__(G_THREADS, 2) void gemm_bf16_kernel(const op16_t* __restrict__ A,
+                                                                  const op16_t* __restrict__ B, GemmShape g, Epi epi) {
     __shared__ __attribute__((aligned(16))) char smem[4 * G_TILE_BYTES];  // [buf][A|B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -310,19 +310,19 @@ __global__ __launch_bounds__(G_THREADS, 2) void gemm_bf16_kernel(const bf16_t* _
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
-            bf16x8 af[4], bfr[4];
+            op16x8 af[4], bfr[4];
 #pragma unroll
             for (int i = 0; i < 4; i++)
-                af[i] = *reinterpret_cast<const bf16x8*>(cur + g_lds_off(wm * 64 + i * 16 + frow, ks * 4 + fchunk));
+                af[i] = *reinterpret_cast<const op16x8*>(cur + g_lds_off(wm * 64 + i * 16 + frow, ks * 4 + fchunk));
 #pragma unroll
             for (int j = 0; j < 4; j++)
-                bfr[j] = *reinterpret_cast<const bf16x8*>(cur + G_TILE_BYTES +
+                bfr[j] = *reinterpret_cast<const op16x8*>(cur + G_TILE_BYTES +
                                                           g_lds_off(wn * 64 + j * 16 + frow, ks * 4 + fchunk));
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = CC_MFMA_16x16x32(af[i], bfr[j], acc[i][j]);
         }
         if (more) {
             l_store<AL>(ra, nxt, tid);
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void gemm_bf16_kernel(const bf16_t* _
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-__device__ __forceinline__ void glds_tile(const bf16_t* __restrict__ base, int ld, int rows, int r0, int k0, char* lds, int wave, int lane) {
+__device__ __forceinline__ void glds_tile(const op16_t* __restrict__ base, int ld, int rows, int r0, int k0, char* lds, int wave, int lane) {
     // the tile is 16 wave-segments of 1 KiB (8 rows x 128 B); wave w fills segments w, w+4, w+8, w+12
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -352,7 +352,7 @@ __device__ __forceinline__ void glds_tile(const bf16_t* __restrict__ base, int l
         const int row = seg * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7) ^ ((row >> 4) & 3);
         const int gr = min(r0 + row, rows - 1);
-        const bf16_t* src = base + (size_t)gr * ld + k0 + chunk * 8;
+        const op16_t* src = base + (size_t)gr * ld + k0 + chunk * 8;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + seg * 1024), 16, 0, 0);
     }
 }
@@ -360,7 +360,7 @@ __device__ __forceinline__ void glds_tile(const bf16_t* __restrict__ base, int l
 // ABL: ablation bits for tools/gemm_bench.py (0 in every product instantiation): 1 = no loads in the K loop, 2 = no MFMAs,
 // 4 = no fragment reads (results are then meaningless; timing only)
 template <class Epi, int ABL = 0>
-__global__ __launch_bounds__(G_THREADS, 2) void gemm_nt_glds_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+__global__ __launch_bounds__(G_THREADS, 2) void gemm_nt_glds_kernel(const op16_t* __restrict__ A, const op16_t* __restrict__ B,
                                                                      GemmShape g, Epi epi) {
     __shared__ __attribute__((aligned(1024))) char smem[4 * G_TILE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -393,15 +393,15 @@ __global__ __launch_bounds__(G_THREADS, 2) void gemm_nt_glds_kernel(const bf16_t
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
-            bf16x8 af[4], bfr[4];
+            op16x8 af[4], bfr[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                if (!(ABL & 4) || kt == 0) af[i] = *reinterpret_cast<const bf16x8*>(cur + g_lds_off(wm * 64 + i * 16 + frow, ks * 4 + fchunk));
+                if (!(ABL & 4) || kt == 0) af[i] = *reinterpret_cast<const op16x8*>(cur + g_lds_off(wm * 64 + i * 16 + frow, ks * 4 + fchunk));
                 else asm volatile("" : "=v"(af[i]));
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                if (!(ABL & 4) || kt == 0) bfr[j] = *reinterpret_cast<const bf16x8*>(cur + G_TILE_BYTES + g_lds_off(wn * 64 + j * 16 + frow, ks * 4 + fchunk));
+                if (!(ABL & 4) || kt == 0) bfr[j] = *reinterpret_cast<const op16x8*>(cur + G_TILE_BYTES + g_lds_off(wn * 64 + j * 16 + frow, ks * 4 + fchunk));
                 else asm volatile("" : "=v"(bfr[j]));
             }
             if (ABL & 2) {
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void gemm_nt_glds_kernel(const bf16_t
                 for (int i = 0; i < 4; i++)
 #pragma unroll
                     for (int j = 0; j < 4; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = CC_MFMA_16x16x32(af[i], bfr[j], acc[i][j]);
             }
         }
     }
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void gemm_nt_glds_kernel(const bf16_t
 // at ~0.85 us each.  On grids that fill the CUs twice the 2-stage kernel with two co-resident blocks stays better (measured -30 %
 // for this variant there), so launch_gemm only picks it when tiles <= CUs.
 template <class Epi>
-__global__ __launch_bounds__(G_THREADS, 1) void gemm_nt_glds4_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+__global__ __launch_bounds__(G_THREADS, 1) void gemm_nt_glds4_kernel(const op16_t* __restrict__ A, const op16_t* __restrict__ B,
                                                                       GemmShape g, Epi epi) {
     extern __shared__ __attribute__((aligned(1024))) char smem4[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -464,15 +464,15 @@ __global__ __launch_bounds__(G_THREADS, 1) void gemm_nt_glds4_kernel(const bf16_
         const char* cur = smem4 + (kt & 3) * 2 * G_TILE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
-            bf16x8 af[4], bfr[4];
+            op16x8 af[4], bfr[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) af[i] = *reinterpret_cast<const bf16x8*>(cur + g_lds_off(wm * 64 + i * 16 + frow, ks * 4 + fchunk));
+            for (int i = 0; i < 4; i++) af[i] = *reinterpret_cast<const op16x8*>(cur + g_lds_off(wm * 64 + i * 16 + frow, ks * 4 + fchunk));
 #pragma unroll
-            for (int j = 0; j < 4; j++) bfr[j] = *reinterpret_cast<const bf16x8*>(cur + G_TILE_BYTES + g_lds_off(wn * 64 + j * 16 + frow, ks * 4 + fchunk));
+            for (int j = 0; j < 4; j++) bfr[j] = *reinterpret_cast<const op16x8*>(cur + G_TILE_BYTES + g_lds_off(wn * 64 + j * 16 + frow, ks * 4 + fchunk));
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; j++) acc[i][j] = CC_MFMA_16x16x32(af[i], bfr[j], acc[i][j]);
         }
     }
 #undef G4_ISSUE
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(G_THREADS, 1) void gemm_nt_glds4_kernel(const bf16_
 // (4 instead of 8 instructions per wave and tile pair) is spread over twice the waves.  The groups' partial sums are exchanged
 // through LDS after the loop (group 1 hands over row strips 0-1, group 0 strips 2-3) and both groups run half of the epilogue.
 template <class Epi>
-__global__ __launch_bounds__(2 * G_THREADS, 1) void gemm_nt_glds4x2_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+__global__ __launch_bounds__(2 * G_THREADS, 1) void gemm_nt_glds4x2_kernel(const op16_t* __restrict__ A, const op16_t* __restrict__ B,
                                                                             GemmShape g, Epi epi) {
     extern __shared__ __attribute__((aligned(1024))) char smem4[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -523,15 +523,15 @@ __global__ __launch_bounds__(2 * G_THREADS, 1) void gemm_nt_glds4x2_kernel(const
         __builtin_amdgcn_s_barrier();
         if (kt + 3 < nk) G4_ISSUE(kt + 3);
         const char* cur = smem4 + (kt & 3) * 2 * G_TILE_BYTES;
-        bf16x8 af[4], bfr[4];
+        op16x8 af[4], bfr[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) af[i] = *reinterpret_cast<const bf16x8*>(cur + g_lds_off(wm * 64 + i * 16 + frow, grp * 4 + fchunk));
+        for (int i = 0; i < 4; i++) af[i] = *reinterpret_cast<const op16x8*>(cur + g_lds_off(wm * 64 + i * 16 + frow, grp * 4 + fchunk));
 #pragma unroll
-        for (int j = 0; j < 4; j++) bfr[j] = *reinterpret_cast<const bf16x8*>(cur + G_TILE_BYTES + g_lds_off(wn * 64 + j * 16 + frow, grp * 4 + fchunk));
+        for (int j = 0; j < 4; j++) bfr[j] = *reinterpret_cast<const op16x8*>(cur + G_TILE_BYTES + g_lds_off(wn * 64 + j * 16 + frow, grp * 4 + fchunk));
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; j++) acc[i][j] = CC_MFMA_16x16x32(af[i], bfr[j], acc[i][j]);
     }
 #undef G4_ISSUE
     __syncthreads();
@@ -569,14 +569,14 @@ __global__ __launch_bounds__(2 * G_THREADS, 1) void gemm_nt_glds4x2_kernel(const
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 template <int ROWS>
-__device__ __forceinline__ void glds_rows(const bf16_t* __restrict__ base, int ld, int rows, int r0, int k0, char* lds, int wave, int lane) {
+__device__ __forceinline__ void glds_rows(const op16_t* __restrict__ base, int ld, int rows, int r0, int k0, char* lds, int wave, int lane) {
 #pragma unroll
     for (int i = 0; i < ROWS / 32; i++) {                   // ROWS / 8 segments of 1 KiB (8 rows x 128 B); wave w takes w, w+4, ...
         const int seg = wave + 4 * i;
         const int row = seg * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7) ^ ((row >> 4) & 3);
         const int gr = min(r0 + row, rows - 1);
-        const bf16_t* src = base + (size_t)gr * ld + k0 + chunk * 8;
+        const op16_t* src = base + (size_t)gr * ld + k0 + chunk * 8;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + seg * 1024), 16, 0, 0);
     }
 }
@@ -589,7 +589,7 @@ template <int N> __device__ __forceinline__ void s_wait_vm() {
 // serial chain per K-step (DMA issue, fragment reads, MFMAs); the groups swap half of their partial sums through LDS at the end and
 // each finishes 16 of the wave tile's 32 rows.
 template <int ROWS_A, int ROWS_B, int W>
-__device__ __forceinline__ void glds_pair(const bf16_t* __restrict__ A, int lda, int M, int m0, const bf16_t* __restrict__ B, int ldb, int N, int n0,
+__device__ __forceinline__ void glds_pair(const op16_t* __restrict__ A, int lda, int M, int m0, const op16_t* __restrict__ B, int ldb, int N, int n0,
                                           int k0, char* lds, int wave, int lane) {
     // (ROWS_A + ROWS_B) / 8 segments of 1 KiB (8 rows x 128 B), A's first; wave w of W takes w, w + W, ...
 #pragma unroll
@@ -598,12 +598,12 @@ __device__ __forceinline__ void glds_pair(const bf16_t* __restrict__ A, int lda,
         const int seg = wave + W * i - (is_a ? 0 : ROWS_A / 8);
         const int row = seg * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7) ^ ((row >> 4) & 3);
-        const bf16_t* src = is_a ? A + (size_t)min(m0 + row, M - 1) * lda + k0 + chunk * 8 : B + (size_t)min(n0 + row, N - 1) * ldb + k0 + chunk * 8;
+        const op16_t* src = is_a ? A + (size_t)min(m0 + row, M - 1) * lda + k0 + chunk * 8 : B + (size_t)min(n0 + row, N - 1) * ldb + k0 + chunk * 8;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + (is_a ? 0 : ROWS_A * 128) + seg * 1024), 16, 0, 0);
     }
 }
 template <class Epi, int NJ, int NS, int KG>
-__global__ __launch_bounds__(G_THREADS * KG, (NS * (64 + 64 * NJ) * 128 <= 80 * 1024) ? 2 : 1) void gemm_nt_s64_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, GemmShape g, Epi epi) {
+__global__ __launch_bounds__(G_THREADS * KG, (NS * (64 + 64 * NJ) * 128 <= 80 * 1024) ? 2 : 1) void gemm_nt_s64_kernel(const op16_t* __restrict__ A, const op16_t* __restrict__ B, GemmShape g, Epi epi) {
     extern __shared__ __attribute__((aligned(1024))) char sm64[];
     constexpr int BN = 64 * NJ, STAGE = (64 + BN) * 128, W = 4 * KG, P = (8 + 8 * NJ) / W;    // P: DMA instructions per wave and K-tile
     static_assert(NS >= 3 && NS <= 8 && (KG == 1 || KG == 2) && (NS - 2) * P < 64, "stage count / groups");
@@ -644,11 +644,11 @@ __global__ __launch_bounds__(G_THREADS * KG, (NS * (64 + 64 * NJ) * 128 <= 80 * 
 #pragma unroll
         for (int kk = 0; kk < 4 / KG; kk++) {
             const int ch = (grp * (4 / KG) + kk) * 2 + fhalf;
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(cur + g_lds_off(wm * 32 + frow, ch));
+            const op16x8 a = *reinterpret_cast<const op16x8*>(cur + g_lds_off(wm * 32 + frow, ch));
 #pragma unroll
             for (int j = 0; j < NJ; j++) {
-                const bf16x8 b = *reinterpret_cast<const bf16x8*>(cur + 64 * 128 + g_lds_off(wn * 32 * NJ + j * 32 + frow, ch));
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+                const op16x8 b = *reinterpret_cast<const op16x8*>(cur + 64 * 128 + g_lds_off(wn * 32 * NJ + j * 32 + frow, ch));
+                acc[j] = CC_MFMA_32x32x16(a, b, acc[j]);
             }
         }
         slot = slot + 1 == NS ? 0 : slot + 1;
@@ -702,7 +702,7 @@ __global__ __launch_bounds__(G_THREADS * KG, (NS * (64 + 64 * NJ) * 128 <= 80 * 
 // cross-wave reduction of the four partial tiles through LDS at the end (~4 steps' worth), so gemm_nt_skinny picks it only for
 // >= 12 K-tiles per block and grids of at most one block per CU (two co-resident blocks lose: the probe shows 730 vs 650 cycles).
 template <class Epi>
-__global__ __launch_bounds__(G_THREADS, 2) void gemm_nt_s64kw_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, GemmShape g, Epi epi) {
+__global__ __launch_bounds__(G_THREADS, 2) void gemm_nt_s64kw_kernel(const op16_t* __restrict__ A, const op16_t* __restrict__ B, GemmShape g, Epi epi) {
     extern __shared__ __attribute__((aligned(1024))) char smkw[];
     constexpr int NS = 4, STAGE = 128 * 128, P = 4;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -733,17 +733,17 @@ __global__ __launch_bounds__(G_THREADS, 2) void gemm_nt_s64kw_kernel(const bf16_
         else s_wait_vm<0>();
         __builtin_amdgcn_s_barrier();
         const char* cur = smkw + slot * STAGE;
-        bf16x8 a[2], b[2];
+        op16x8 a[2], b[2];
 #pragma unroll
         for (int i = 0; i < 2; i++) {
-            a[i] = *reinterpret_cast<const bf16x8*>(cur + g_lds_off(i * 32 + frow, ch));
-            b[i] = *reinterpret_cast<const bf16x8*>(cur + 64 * 128 + g_lds_off(i * 32 + frow, ch));
+            a[i] = *reinterpret_cast<const op16x8*>(cur + g_lds_off(i * 32 + frow, ch));
+            b[i] = *reinterpret_cast<const op16x8*>(cur + 64 * 128 + g_lds_off(i * 32 + frow, ch));
         }
         if (kt + NS - 1 < nk) KW_ISSUE(kt + NS - 1, islot);       // after the reads are issued: the DMA issue cycles hide their latency
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
-            for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 2; j++) acc[i][j] = CC_MFMA_32x32x16(a[i], b[j], acc[i][j]);
         slot = slot + 1 == NS ? 0 : slot + 1;
         islot = islot + 1 == NS ? 0 : islot + 1;
     }
@@ -812,7 +812,7 @@ __device__ __forceinline__ int h_tt_g(int k) { return (k & 3) | (((k >> 3) & 1) 
         const int k0_ = kbeg + (T)*H_BK;                                                                                 \
         _Pragma("unroll") for (int i_ = 0; i_ < ((IS_A) ? 4 : NJ); i_++) {                                              \
             const int seg = wn + 4 * i_;                        /* 16 (A) or 4 NJ (B) segments of 1 KiB */                \
-            const bf16_t* src;                                                                                           \
+            const op16_t* src;                                                                                           \
             if constexpr (TT) {                                                                                          \
                 const int kr = seg * 2 + (lane >> 5);           /* 2 k-rows of 512 B per segment */                       \
                 const int c = (lane & 31) ^ (h_tt_g(kr) << 1);                                                            \
@@ -840,10 +840,10 @@ __device__ __forceinline__ HTTFrag h_tt_read(const char* tile, int lane_base, in
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(f.hi) : "v"(a) : "memory");
     return f;
 }
-__device__ __forceinline__ bf16x8 h_tt_oper(const HTTFrag& f) {
+__device__ __forceinline__ op16x8 h_tt_oper(const HTTFrag& f) {
     typedef __attribute__((ext_vector_type(4))) int i32x4_t;
     const i32x4_t v = {f.lo[0], f.lo[1], f.hi[0], f.hi[1]};
-    return __builtin_bit_cast(bf16x8, v);
+    return __builtin_bit_cast(op16x8, v);
 }
 #define H_LOADF(T)                                                                                                       \
     {                                                                                                                    \
@@ -853,8 +853,8 @@ __device__ __forceinline__ bf16x8 h_tt_oper(const HTTFrag& f) {
             _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) taf[i_] = h_tt_read(ca_, tt_base, ((grp * 16 + 2 * i_) ^ tt_gx) << 4);  \
             _Pragma("unroll") for (int j_ = 0; j_ < NJ; j_++) tbf[j_] = h_tt_read(cb_, tt_base, ((wn * 8 + 2 * j_) ^ tt_gx) << 4);  \
         } else {                                                                                                         \
-            _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) af[i_] = *reinterpret_cast<const bf16x8*>(ca_ + h_lds_off(arow + i_ * 16 + frow, fchunk)); \
-            _Pragma("unroll") for (int j_ = 0; j_ < NJ; j_++) bfr[j_] = *reinterpret_cast<const bf16x8*>(cb_ + h_lds_off(bcol + j_ * 16 + frow, fchunk)); \
+            _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) af[i_] = *reinterpret_cast<const op16x8*>(ca_ + h_lds_off(arow + i_ * 16 + frow, fchunk)); \
+            _Pragma("unroll") for (int j_ = 0; j_ < NJ; j_++) bfr[j_] = *reinterpret_cast<const op16x8*>(cb_ + h_lds_off(bcol + j_ * 16 + frow, fchunk)); \
         }                                                                                                                \
     }
 #define H_MFMA()                                                                                                         \
@@ -865,7 +865,7 @@ __device__ __forceinline__ bf16x8 h_tt_oper(const HTTFrag& f) {
         }                                                                                                                \
         __builtin_amdgcn_s_setprio(1);                                                                                   \
         _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) _Pragma("unroll") for (int j_ = 0; j_ < NJ; j_++)                \
-            acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j_], af[i_], acc[i_][j_], 0, 0, 0);                \
+            acc[i_][j_] = CC_MFMA_16x16x32(bfr[j_], af[i_], acc[i_][j_]);                \
         __builtin_amdgcn_s_setprio(0);                                                                                   \
     }
 #define H_SEGEND()                                                                                                       \
@@ -897,7 +897,7 @@ __device__ unsigned long long cc_stamp_buf[2 * 8];
 #define H_STAMP_OUT
 #endif
 template <class Epi, int NJ, bool TT = false>
-__global__ __launch_bounds__(512, 1) void gemm_nt_stag256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, GemmShape g, Epi epi) {
+__global__ __launch_bounds__(512, 1) void gemm_nt_stag256_kernel(const op16_t* __restrict__ A, const op16_t* __restrict__ B, GemmShape g, Epi epi) {
     static_assert(NJ >= 2 && NJ <= 4, "wave tile is 128 x (16 NJ)");
     static_assert(!TT || NJ == 4, "the K-strided image is laid out for 256-column tiles");
     constexpr int BN = 64 * NJ;
@@ -917,7 +917,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_stag256_kernel(const bf16_t* _
     for (int i = 0; i < 8; i++)
 #pragma unroll
         for (int j = 0; j < NJ; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 af[8], bfr[NJ];
+    op16x8 af[8], bfr[NJ];
     HTTFrag taf[TT ? 8 : 1], tbf[TT ? NJ : 1];
     (void)taf; (void)tbf;
     const int frow = lane & 15, fchunk = lane >> 4;
@@ -1008,18 +1008,18 @@ __device__ __forceinline__ HTTFrag g_tt_read(const char* tile, int lane_base, in
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(f.hi) : "v"(a) : "memory");      // + 4 k-rows of 256 B
     return f;
 }
-__device__ __forceinline__ void glds_tile_tt(const bf16_t* __restrict__ base, int ld, int cols, int c0, int k0, char* lds, int wave, int lane) {
+__device__ __forceinline__ void glds_tile_tt(const op16_t* __restrict__ base, int ld, int cols, int c0, int k0, char* lds, int wave, int lane) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int seg = wave + 4 * i;                      // 16 segments of 1 KiB = 4 k-rows x 256 B
         const int kr = seg * 4 + (lane >> 4);
         const int c = (lane & 15) ^ (h_tt_g(kr) << 1);
-        const bf16_t* src = base + (size_t)(k0 + kr) * ld + min(c0 + c * 8, cols - 8);
+        const op16_t* src = base + (size_t)(k0 + kr) * ld + min(c0 + c * 8, cols - 8);
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + seg * 1024), 16, 0, 0);
     }
 }
 template <class Epi>
-__global__ __launch_bounds__(G_THREADS, 1) void gemm_tt_glds4_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+__global__ __launch_bounds__(G_THREADS, 1) void gemm_tt_glds4_kernel(const op16_t* __restrict__ A, const op16_t* __restrict__ B,
                                                                       GemmShape g, Epi epi) {
     extern __shared__ __attribute__((aligned(1024))) char smemt[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1056,11 +1056,11 @@ __global__ __launch_bounds__(G_THREADS, 1) void gemm_tt_glds4_kernel(const bf16_
     }
 #define GT_MFMA(SET)                                                                                                     \
     {                                                                                                                    \
-        bf16x8 af[4], bfr[4];                                                                                            \
+        op16x8 af[4], bfr[4];                                                                                            \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) af[i_] = h_tt_oper(fa[SET][i_]);                                 \
         _Pragma("unroll") for (int j_ = 0; j_ < 4; j_++) bfr[j_] = h_tt_oper(fb[SET][j_]);                                \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) _Pragma("unroll") for (int j_ = 0; j_ < 4; j_++)                 \
-            acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i_], bfr[j_], acc[i_][j_], 0, 0, 0);                \
+            acc[i_][j_] = CC_MFMA_16x16x32(af[i_], bfr[j_], acc[i_][j_]);                \
     }
 #define GT_LGKM0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
     for (int kt = 0; kt < nk; kt++) {
@@ -1105,8 +1105,8 @@ __device__ __forceinline__ void load_bias8(const float* bias, int col, int Ns, f
 }
 
 struct EpiBF16 {
-    bf16_t* C;
-    bf16_t* pre;        // nullable
+    op16_t* C;
+    op16_t* pre;        // nullable
     const float* bias;  // nullable
     int ldc, M, Ns;     // Ns: columns to store (multiple of 8)
     int act;            // 0 none, 1 relu, 2 gelu_new
@@ -1254,8 +1254,8 @@ struct EpiF32 {
 
 // C(bf16) = acc * act'(aux)   (dgrad through relu: aux = post-activation h; through gelu_new: aux = pre-activation u)
 struct EpiDAct {
-    bf16_t* C;
-    const bf16_t* aux;
+    op16_t* C;
+    const op16_t* aux;
     int ldc, M, Ns;
     int act;  // 1 relu, 2 gelu_new
     __device__ __forceinline__ void operator()(int row, int col, float (&v)[8]) const {
@@ -1293,7 +1293,9 @@ struct EpiDAct {
     __device__ __forceinline__ void pre4(int row, int col, f32x4& a) const {        // acc *= act'(aux)
         if (row >= M || col >= Ns) return;
         const uint2 u = *reinterpret_cast<const uint2*>(aux + (size_t)row * ldc + col);
-        const float x[4] = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+        float x[4];
+        unpack2(u.x, x[0], x[1]);
+        unpack2(u.y, x[2], x[3]);
 #pragma unroll
         for (int e = 0; e < 4; e++) a[e] = act == 1 ? (x[e] > 0.f ? a[e] : 0.f) : a[e] * gelu_new_grad(x[e]);
     }
@@ -1309,7 +1311,7 @@ struct EpiDAct {
 
 // lm_head: bf16 logits + per-(row, 64-column block) softmax partials from the fp32 accumulators + exact target logit.
 struct EpiLMHead {
-    bf16_t* C;
+    op16_t* C;
     float* pmax;
     float* psum;           // [M][npart]
     const int* target;     // [M] token id per row (>=0)
@@ -1395,10 +1397,10 @@ template <> struct epi_row_strip<EpiLMHead> { static constexpr bool value = true
 // Host launcher
 // ------------------------------------------------------------------------------------------------
 template <class Epi>
-inline int launch_gemm_s64(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, int ksplit, int nj, const Epi& epi, int* ks_eff,
+inline int launch_gemm_s64(const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, int ksplit, int nj, const Epi& epi, int* ks_eff,
                            hipStream_t st);
 template <class Epi>
-inline int launch_gemm(int al, int bl, const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K,
+inline int launch_gemm(int al, int bl, const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K,
                        int ksplit, const Epi& epi, hipStream_t st) {
     if (M <= 0 || N <= 0 || K <= 0) return CC_OK;
     if ((lda & 7) || (ldb & 7) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return CC_ERR_SHAPE;
@@ -1484,7 +1486,7 @@ inline int launch_gemm(int al, int bl, const bf16_t* A, int lda, const bf16_t* B
 // Skinny NT launcher (gemm_nt_s64_kernel): K % 64 == 0; nj = 1 (64 x 64 tiles) or 2 (64 x 128); K split over blockIdx.z
 // (epi must be an EpiF32 in slab mode when ksplit > 1).  *ks_eff returns the effective slice count.
 template <class Epi>
-inline int launch_gemm_s64(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, int ksplit, int nj, const Epi& epi, int* ks_eff,
+inline int launch_gemm_s64(const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, int ksplit, int nj, const Epi& epi, int* ks_eff,
                            hipStream_t st) {
     if ((K % G_BK) || (lda & 7) || (ldb & 7) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return CC_ERR_SHAPE;
     GemmShape g;
@@ -1519,7 +1521,7 @@ inline int launch_gemm_s64(const bf16_t* A, int lda, const bf16_t* B, int ldb, i
 // and transpose reads; K is split over blockIdx.z (epi must be an EpiF32 in slab mode when ksplit > 1).  K % 32 == 0, M % 8 == 0,
 // N % 8 == 0.  Returns the effective slice count through *ks_eff.
 template <class Epi>
-inline int launch_gemm_tt256(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, int ksplit, const Epi& epi, int* ks_eff,
+inline int launch_gemm_tt256(const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, int ksplit, const Epi& epi, int* ks_eff,
                              hipStream_t st) {
     if ((K % H_BK) || (M & 7) || (N & 7) || (lda & 7) || (ldb & 7) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return CC_ERR_SHAPE;
     GemmShape g;
@@ -1541,7 +1543,7 @@ inline int launch_gemm_tt256(const bf16_t* A, int lda, const bf16_t* B, int ldb,
 
 // TT 128 x 128 launcher (see gemm_tt_glds4_kernel): K % 64 == 0, M % 8 == 0, N % 8 == 0; slices over blockIdx.z.
 template <class Epi>
-inline int launch_gemm_tt128(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, int ksplit, const Epi& epi, int* ks_eff,
+inline int launch_gemm_tt128(const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, int ksplit, const Epi& epi, int* ks_eff,
                              hipStream_t st) {
     if ((K % G_BK) || (M & 7) || (N & 7) || (lda & 7) || (ldb & 7) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return CC_ERR_SHAPE;
     GemmShape g;
@@ -1561,4 +1563,4 @@ inline int launch_gemm_tt128(const bf16_t* A, int lda, const bf16_t* B, int ldb,
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
 
-}  // namespace cc
+}  // namespace CC_NS

@@ -1,24 +1,24 @@
 // Host entry points of the GEMM instantiations (one translation unit per epilogue so they build in parallel).
 #pragma once
-#include "common.cuh"
+#include "common.hip.h"
+#include "shared.h"
 
-namespace cc {
-// NT tile choice: -1 chooser (default; CC_GEMM_S256 in the environment presets it), 0 = 128 x 128 only, 3 / 4 = force the
-// 256 x 192 / 256 x 256 kernel wherever it is legal.  Test / microbenchmark hook (cc_gemm_tile_mode).
-extern int g_gemm_tile_mode;
-extern int g_gemm_s64;        // > 0: route NT GEMMs with M <= 1024 through the 64-row skinny kernel (bench hook, env CC_GEMM_S64)
-extern int g_gemm_small_x2;   // small-grid NT GEMMs on the 8-wave kernel (env CC_GEMM_X2, default 1)
-// al/bl: 0 = K-contiguous operand ([rows][K]), 1 = K-strided operand ([K][rows]).  See gemm.cuh.
-int gemm_bf16out(int al, int bl, const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, bf16_t* C, int ldc,
-                 const float* bias, int act, bf16_t* pre, hipStream_t st);
-int gemm_resid(int al, int bl, const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, float* out, const float* res,
+namespace CC_NS {
+// NT tile choice (cc_shared::g_gemm_tile_mode): -1 chooser (default; CC_GEMM_S256 in the environment presets it), 0 = 128 x 128 only,
+// 3 / 4 = force the 256 x 192 / 256 x 256 kernel wherever it is legal.  g_gemm_s64 > 0: route NT GEMMs with M <= 1024 through the 64-row
+// skinny kernel (env CC_GEMM_S64); g_gemm_small_x2: small-grid NT GEMMs on the 8-wave kernel (env CC_GEMM_X2, default 1).  All three
+// are test / microbenchmark hooks living in shared.cpp.
+// al/bl: 0 = K-contiguous operand ([rows][K]), 1 = K-strided operand ([K][rows]).  See gemm.hip.h.
+int gemm_bf16out(int al, int bl, const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, op16_t* C, int ldc,
+                 const float* bias, int act, op16_t* pre, hipStream_t st);
+int gemm_resid(int al, int bl, const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, float* out, const float* res,
                int ld, const float* bias, hipStream_t st, Drop drop = Drop());
 // mode 0 store (+bias), 1 add, 2 atomic add (required when ksplit > 1)
-int gemm_f32out(int al, int bl, const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, float* C, int ldc,
+int gemm_f32out(int al, int bl, const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, float* C, int ldc,
                 const float* bias, int mode, float alpha, int ksplit, hipStream_t st);
-int gemm_dact(int al, int bl, const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, bf16_t* C, int ldc,
-              const bf16_t* aux, int act, hipStream_t st);
-int gemm_lmhead(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int Vp, int V, int K, bf16_t* C, int ldc, float* pmax,
+int gemm_dact(int al, int bl, const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, op16_t* C, int ldc,
+              const op16_t* aux, int act, hipStream_t st);
+int gemm_lmhead(const op16_t* A, int lda, const op16_t* B, int ldb, int M, int Vp, int V, int K, op16_t* C, int ldc, float* pmax,
                 float* psum, int npart, const int* target, float* tgt_logit, hipStream_t st);
 // weight gradient dW[Mw][Nw] += X^T Y with X stored [K][Mw], Y stored [K][Nw].  Split-K for occupancy: the K slices
 // write fp32 slabs into `scratch` (plain stores) and a second kernel folds them into dW — fp32 atomics on the same
@@ -34,7 +34,7 @@ struct WgradBatch {
     size_t used = 0;      // bytes of scratch already holding parked slabs
 };
 int wgrad_flush(WgradBatch& b, hipStream_t st);
-int gemm_wgrad(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int Mw, int Nw, int K, float* dW, int ldw, float* scratch,
+int gemm_wgrad(const op16_t* X, int ldx, const op16_t* Y, int ldy, int Mw, int Nw, int K, float* dW, int ldw, float* scratch,
                hipStream_t st, WgradBatch* batch = nullptr);
 // Skinny-M NT GEMMs (KV-cached decode: M = beams x samples, a handful of 128x128 tiles): split K over blockIdx.z so every CU
 // streams a distinct slice of the weights, fp32 slabs in `scratch`, then ONE finishing kernel sums the slabs and applies the
@@ -44,15 +44,15 @@ int gemm_wgrad(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int Mw, int N
 struct SkinnyFuse {
     const float* ln_gamma = nullptr;   // LayerNorm over the N columns of (acc + bias + res): out -> ln_out16 [M, N]
     const float* ln_beta = nullptr;
-    bf16_t* ln_out16 = nullptr;
-    bf16_t* kcache = nullptr;          // qkv rows (N == 3*D): columns [D,2D) -> kcache, [2D,3D) -> vcache at (r*ctx_max + pos0 + t)*D
-    bf16_t* vcache = nullptr;
+    op16_t* ln_out16 = nullptr;
+    op16_t* kcache = nullptr;          // qkv rows (N == 3*D): columns [D,2D) -> kcache, [2D,3D) -> vcache at (r*ctx_max + pos0 + t)*D
+    op16_t* vcache = nullptr;
     int Tn = 1, pos0 = 0, ctx_max = 0;
 };
-int gemm_nt_skinny(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const float* bias, int act, const float* res,
-                   float* out32, bf16_t* out16, int ldo, float* scratch, size_t scratch_bytes, hipStream_t st,
+int gemm_nt_skinny(const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, const float* bias, int act, const float* res,
+                   float* out32, op16_t* out16, int ldo, float* scratch, size_t scratch_bytes, hipStream_t st,
                    const SkinnyFuse* fuse = nullptr);
 int skinny_single_min_tiles();   // grids of at least this many 128 x 128 tiles skip split-K (CC_SKINNY_SINGLE; tuning knob)
 // whether gemm_nt_skinny will take the slab + row-finish path for this problem (the only path that supports SkinnyFuse)
 bool gemm_nt_skinny_can_fuse(int M, int N, int K, size_t scratch_bytes);
-}  // namespace cc
+}  // namespace CC_NS

@@ -1,10 +1,11 @@
-#include "gemm.cuh"
+#include "gemm.hip.h"
 #include "gemm_api.h"
-namespace cc {
-int gemm_bf16out(int al, int bl, const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, bf16_t* C, int ldc,
-                 const float* bias, int act, bf16_t* pre, hipStream_t st) {
+namespace CC_NS {
+int gemm_bf16out(int al, int bl, const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, op16_t* C, int ldc,
+                 const float* bias, int act, op16_t* pre, hipStream_t st) {
+    cc_shared::ProfScope _all(cc_shared::SITE_ALL_GEMMS, st, 2.0 * M * N * (double)K);
     if ((ldc & 7) || (N & 7)) return CC_ERR_SHAPE;
     EpiBF16 e{C, pre, bias, ldc, M, N, act};
     return launch_gemm(al, bl, A, lda, B, ldb, M, N, K, 1, e, st);
 }
-}  // namespace cc
+}  // namespace CC_NS

@@ -1,14 +1,12 @@
 // Built with `make ABLATION=1` this TU also carries the timing-only ablation variants of the NT kernel (CC_GEMM_ABL=1|2|4|5|6 at
 // run time, tools/gemm_bench.py); the default build has none, so product code generation is not perturbed by sibling variants.
-#include "gemm.cuh"
+#include "gemm.hip.h"
 #include <algorithm>
 #include "gemm_api.h"
-namespace cc {
-int g_gemm_tile_mode = []() { const char* e = getenv("CC_GEMM_S256"); return e ? atoi(e) : -1; }();
-int g_gemm_s64 = []() { const char* e = getenv("CC_GEMM_S64"); return e ? atoi(e) : -1; }();
-int g_gemm_small_x2 = []() { const char* e = getenv("CC_GEMM_X2"); return e ? atoi(e) : 1; }();
-int gemm_f32out(int al, int bl, const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, float* C, int ldc,
+namespace CC_NS {
+int gemm_f32out(int al, int bl, const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, float* C, int ldc,
                 const float* bias, int mode, float alpha, int ksplit, hipStream_t st) {
+    cc_shared::ProfScope _all(cc_shared::SITE_ALL_GEMMS, st, 2.0 * M * N * (double)K);
     if ((ldc & 3) || (N & 7)) return CC_ERR_SHAPE;
     if (ksplit > 1 && mode != 2) return CC_ERR_ARG;  // slab mode (3) is reached through gemm_wgrad only
     EpiF32 e{C, bias, ldc, M, N, mode, alpha};
@@ -68,8 +66,9 @@ static int wgrad_reduce(const float* slabs, size_t slab, int ks, int Nw, float* 
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
 
-int gemm_wgrad(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int Mw, int Nw, int K, float* dW, int ldw, float* scratch,
+int gemm_wgrad(const op16_t* X, int ldx, const op16_t* Y, int ldy, int Mw, int Nw, int K, float* dW, int ldw, float* scratch,
                hipStream_t st, WgradBatch* batch) {
+    cc_shared::ProfScope _all(cc_shared::SITE_ALL_GEMMS, st, 2.0 * Mw * Nw * (double)K);
     if ((Nw & 7) || (ldw & 3)) return CC_ERR_SHAPE;
     const size_t slab = (size_t)Mw * Nw;
     // the DMA-staged TT kernels need 16-B aligned operands and row strides; anything else takes the register-staged kernel
@@ -132,7 +131,7 @@ int gemm_wgrad(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int Mw, int N
 
 __global__ __launch_bounds__(256) void k_splitk_finish(const float* __restrict__ slabs, size_t slab_elems, int ks, int M, int N,
                                                        const float* __restrict__ bias, int act, const float* __restrict__ res,
-                                                       float* __restrict__ out32, bf16_t* __restrict__ out16, int ldo) {
+                                                       float* __restrict__ out32, op16_t* __restrict__ out16, int ldo) {
     const size_t n8 = (size_t)M * (N >> 3);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
         const int row = (int)(i / (N >> 3)), col = (int)(i % (N >> 3)) * 8;
@@ -180,7 +179,7 @@ __device__ __forceinline__ float block_sum256(float v, float* red) {
 
 __global__ __launch_bounds__(256) void k_splitk_finish_row(const float* __restrict__ slabs, size_t slab_elems, int ks, int M, int N,
                                                            const float* __restrict__ bias, int act, const float* __restrict__ res,
-                                                           float* __restrict__ out32, bf16_t* __restrict__ out16, int ldo, SkinnyFuse f) {
+                                                           float* __restrict__ out32, op16_t* __restrict__ out16, int ldo, SkinnyFuse f) {
     __shared__ float red[4];
     const int row = blockIdx.x;
     constexpr int MAXV = 3;                // float4 per thread -> N <= 3072
@@ -227,13 +226,13 @@ __global__ __launch_bounds__(256) void k_splitk_finish_row(const float* __restri
             const size_t o = (size_t)row * ldo + c;
             a.x += rr.x; a.y += rr.y; a.z += rr.z; a.w += rr.w;
             if (out32) *reinterpret_cast<float4*>(out32 + o) = a;
-            const uint2 pk = make_uint2(pack2bf(a.x, a.y), pack2bf(a.z, a.w));
+            const uint2 pk = make_uint2(pack2op(a.x, a.y), pack2op(a.z, a.w));
             if (out16) *reinterpret_cast<uint2*>(out16 + o) = pk;
             if (f.kcache) {                   // N == 3*D
                 const int D = N / 3, which = c / D, cc_ = c - which * D;
                 if (which > 0) {
                     const int r = row / f.Tn, t = row - r * f.Tn;
-                    bf16_t* dst = (which == 1 ? f.kcache : f.vcache) + ((size_t)r * f.ctx_max + f.pos0 + t) * D + cc_;
+                    op16_t* dst = (which == 1 ? f.kcache : f.vcache) + ((size_t)r * f.ctx_max + f.pos0 + t) * D + cc_;
                     *reinterpret_cast<uint2*>(dst) = pk;
                 }
             }
@@ -256,8 +255,8 @@ __global__ __launch_bounds__(256) void k_splitk_finish_row(const float* __restri
         if (c < N) {
             const float4 g = lg_[it], b = lb_[it];
             *reinterpret_cast<uint2*>(f.ln_out16 + (size_t)row * N + c) =
-                make_uint2(pack2bf((v[it].x - mu) * rs * g.x + b.x, (v[it].y - mu) * rs * g.y + b.y),
-                           pack2bf((v[it].z - mu) * rs * g.z + b.z, (v[it].w - mu) * rs * g.w + b.w));
+                make_uint2(pack2op((v[it].x - mu) * rs * g.x + b.x, (v[it].y - mu) * rs * g.y + b.y),
+                           pack2op((v[it].z - mu) * rs * g.z + b.z, (v[it].w - mu) * rs * g.w + b.w));
         }
     }
 }
@@ -270,8 +269,9 @@ bool gemm_nt_skinny_can_fuse(int M, int N, int K, size_t scratch_bytes) {
     return M > 0 && N > 0 && (N & 7) == 0 && N <= 3072 && (K % G_BK) == 0 && scratch_bytes >= (size_t)M * N * sizeof(float);
 }
 
-int gemm_nt_skinny(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const float* bias, int act, const float* res,
-                   float* out32, bf16_t* out16, int ldo, float* scratch, size_t scratch_bytes, hipStream_t st, const SkinnyFuse* fuse) {
+int gemm_nt_skinny(const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, const float* bias, int act, const float* res,
+                   float* out32, op16_t* out16, int ldo, float* scratch, size_t scratch_bytes, hipStream_t st, const SkinnyFuse* fuse) {
+    cc_shared::ProfScope _all(cc_shared::SITE_ALL_GEMMS, st, 2.0 * M * N * (double)K);
     if ((N & 7) || (ldo & 7)) return CC_ERR_SHAPE;
     const int tiles = ((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
     const size_t slab = (size_t)M * N;
@@ -331,4 +331,4 @@ int gemm_nt_skinny(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, in
     }
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
-}  // namespace cc
+}  // namespace CC_NS

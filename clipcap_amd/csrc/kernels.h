@@ -3,39 +3,39 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
-#include "common.cuh"
+#include "common.hip.h"
 
-namespace cc {
+namespace CC_NS {
 
-int f32_to_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t st);
-int slice_f32_to_bf16(const float* src, size_t src_stride, bf16_t* dst, size_t dst_stride, int len, int B, hipStream_t st);
+int f32_to_bf16(const float* src, op16_t* dst, size_t n, hipStream_t st);
+int slice_f32_to_bf16(const float* src, size_t src_stride, op16_t* dst, size_t dst_stride, int len, int B, hipStream_t st);
 int broadcast_rows(float* dst, size_t dst_stride, const float* src, int len, int B, hipStream_t st);
 int add_rows(float* dst, size_t dst_stride, const float* add, int len, int B, hipStream_t st);
 int batch_sum(const float* src, size_t src_stride, float* dst, int len, int B, hipStream_t st);
 int copy_rows(const float* src, size_t src_stride, float* dst, size_t dst_stride, int len, int B, hipStream_t st);
 
-int transpose_bf16(const bf16_t* src, bf16_t* dst, int R, int C, hipStream_t st);
+int transpose_bf16(const op16_t* src, op16_t* dst, int R, int C, hipStream_t st);
 struct TransposeBatch {
-    struct Item { const bf16_t* src; bf16_t* dst; int R, C; };
+    struct Item { const op16_t* src; op16_t* dst; int R, C; };
     Item it[32];
     int n = 0;
-    void add(const bf16_t* s, bf16_t* d, int R, int C) { it[n++] = Item{s, d, R, C}; }
+    void add(const op16_t* s, op16_t* d, int R, int C) { it[n++] = Item{s, d, R, C}; }
 };
 int transpose_bf16_multi(const TransposeBatch& b, hipStream_t st);   // up to 32 matrices in one launch
 
-int ln_fwd(const float* x, int ldx, const int* row_map, const float* gamma, const float* beta, bf16_t* y, float* y32, float* mean,
+int ln_fwd(const float* x, int ldx, const int* row_map, const float* gamma, const float* beta, op16_t* y, float* y32, float* mean,
            float* rstd, int rows, int D, hipStream_t st);
-int ln_bwd(const bf16_t* dy, const float* x, int ldx, const int* row_map, const float* mean, const float* rstd, const float* gamma,
-           const float* dres, float* dx32, bf16_t* dx16, float* dgamma, float* dbeta, int rows, int D, hipStream_t st);
-int colsum_bf16(const bf16_t* X, int ld, int M, int N, float* out, hipStream_t st);
+int ln_bwd(const op16_t* dy, const float* x, int ldx, const int* row_map, const float* mean, const float* rstd, const float* gamma,
+           const float* dres, float* dx32, op16_t* dx16, float* dgamma, float* dbeta, int rows, int D, hipStream_t st);
+int colsum_bf16(const op16_t* X, int ld, int M, int N, float* out, hipStream_t st);
 
-int attn_fwd(const bf16_t* qkv, int B, int S, int H, int hd, bool causal, bf16_t* out, float* lse, hipStream_t st, Drop drop = Drop());
+int attn_fwd(const op16_t* qkv, int B, int S, int H, int hd, bool causal, op16_t* out, float* lse, hipStream_t st, Drop drop = Drop());
 // o: forward output (for delta = rowsum(dO*O)); delta: fp32 scratch [B*H*S].  Both may be null -> VALU kernel.
-int attn_bwd(const bf16_t* qkv, const bf16_t* dout, const bf16_t* o, const float* lse, float* delta, int B, int S, int H, int hd, bool causal,
-             bf16_t* dqkv, hipStream_t st, Drop drop = Drop());
+int attn_bwd(const op16_t* qkv, const op16_t* dout, const op16_t* o, const float* lse, float* delta, int B, int S, int H, int hd, bool causal,
+             op16_t* dqkv, hipStream_t st, Drop drop = Drop());
 // in-place dropout of an fp32 / bf16 buffer of n elements (n % 4 == 0 / n % 8 == 0): x[i] *= keep(i) / (1 - p)
 int dropout_f32(float* x, size_t n, Drop drop, hipStream_t st);
-int dropout_bf16(bf16_t* x, size_t n, Drop drop, hipStream_t st);
+int dropout_bf16(op16_t* x, size_t n, Drop drop, hipStream_t st);
 int dropout_mask_u8(unsigned char* out, size_t n, Drop drop, hipStream_t st);   // test hook: out[i] = keep(i)
 
 int embed_concat(const float* prefix, const long long* tokens, int cap, const float* wte, const float* wpe, float* x0, int B, int L,
@@ -44,13 +44,16 @@ int embed_bwd(const float* dx0, const long long* tokens, int cap, float* dwte, f
 
 int ce_rows(const float* pmax, const float* psum, int npart, const int* target, const float* tgt_logit, float* lse, float* row_loss,
             float* stats, int M, hipStream_t st);
-int ce_dlogits(bf16_t* logits, int ld, int V, const int* target, const float* lse, const float* denom, int M, hipStream_t st);
+int ce_dlogits(op16_t* logits, int ld, int V, const int* target, const float* lse, const float* denom, const float* loss_scale, int M,
+               hipStream_t st);
 // sample.hip: one sampling step per row (temperature, repetition penalty, top-k, top-p, inverse-CDF draw at u[row])
 int sample_rows(const float* logits, int R, int V, int ld, float temperature, int top_k, float top_p, int mode, const long long* hist,
                 int hist_len, int hist_ld, float rep_pen, const float* u, int* next_token, float* probs_out, hipStream_t st);
 int ce_targets(const long long* tokens, int* target, int* row_map, int B, int cap, int L, int T, hipStream_t st);
 
-int adamw(float* p, const float* g, float* m, float* v, bf16_t* p16, size_t n, float lr, float b1, float b2, float eps, float wd,
-          int step, float gscale, hipStream_t st);
+int adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd, int step, float gscale,
+          const float* loss_scale, const float* found_inf, hipStream_t st);
+int grad_nonfinite(const float* g, size_t n, float* found_inf, hipStream_t st);
+int loss_scale_update(float* state, float* found_inf, float growth, float backoff, int interval, hipStream_t st);
 
-}  // namespace cc
+}  // namespace CC_NS

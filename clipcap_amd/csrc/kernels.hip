@@ -3,19 +3,19 @@
 // All are wave64 code; memory accesses are 16-B vectors wherever the layout allows.
 #include "kernels.h"
 
-namespace cc {
+namespace CC_NS {
 
 // ------------------------------------------------------------------------------------------------------------
 // element-wise helpers
 // ------------------------------------------------------------------------------------------------------------
-__global__ void k_f32_to_bf16(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n8) {
+__global__ void k_f32_to_bf16(const float* __restrict__ src, op16_t* __restrict__ dst, size_t n8) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
         const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
         float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
         reinterpret_cast<uint4*>(dst)[i] = pack8(v);
     }
 }
-int f32_to_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t st) {
+int f32_to_bf16(const float* src, op16_t* dst, size_t n, hipStream_t st) {
     if (n & 7) return CC_ERR_SHAPE;
     const size_t n8 = n >> 3;
     if (!n8) return CC_OK;
@@ -25,7 +25,7 @@ int f32_to_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t st) {
 }
 
 // dst[b*dst_stride + i] = (bf16) src[b*src_stride + i], i < len (len % 8 == 0)
-__global__ void k_slice_f32_to_bf16(const float* __restrict__ src, size_t src_stride, bf16_t* __restrict__ dst,
+__global__ void k_slice_f32_to_bf16(const float* __restrict__ src, size_t src_stride, op16_t* __restrict__ dst,
                                     size_t dst_stride, int len8, int B) {
     const size_t total = (size_t)len8 * B;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -36,7 +36,7 @@ __global__ void k_slice_f32_to_bf16(const float* __restrict__ src, size_t src_st
         *reinterpret_cast<uint4*>(dst + b * dst_stride + (size_t)c * 8) = pack8(v);
     }
 }
-int slice_f32_to_bf16(const float* src, size_t src_stride, bf16_t* dst, size_t dst_stride, int len, int B, hipStream_t st) {
+int slice_f32_to_bf16(const float* src, size_t src_stride, op16_t* dst, size_t dst_stride, int len, int B, hipStream_t st) {
     if (len & 7) return CC_ERR_SHAPE;
     const size_t total = (size_t)(len >> 3) * B;
     if (!total) return CC_OK;
@@ -109,8 +109,8 @@ int copy_rows(const float* src, size_t src_stride, float* dst, size_t dst_stride
 }
 
 // dst[c][r] = src[r][c] for a bf16 matrix [R][C] (R, C multiples of 8): 64x64 tiles through LDS, 16-B global accesses both ways.
-__global__ __launch_bounds__(256) void k_transpose_bf16(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int R, int C) {
-    __shared__ bf16_t tile[64][66];
+__global__ __launch_bounds__(256) void k_transpose_bf16(const op16_t* __restrict__ src, op16_t* __restrict__ dst, int R, int C) {
+    __shared__ op16_t tile[64][66];
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;  // 8 column groups x 32 rows, two passes
 #pragma unroll
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void k_transpose_bf16(const bf16_t* __restrict
         const int r = r0 + rl + 32 * p, c = c0 + cg * 8;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (r < R && c < C) v = *reinterpret_cast<const uint4*>(src + (size_t)r * C + c);
-        const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+        const op16_t* e = reinterpret_cast<const op16_t*>(&v);
 #pragma unroll
         for (int k = 0; k < 8; k++) tile[rl + 32 * p][cg * 8 + k] = e[k];
     }
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void k_transpose_bf16(const bf16_t* __restrict
     for (int p = 0; p < 2; p++) {
         const int c = c0 + rl + 32 * p, r = r0 + cg * 8;   // output row = source column
         if (c < C && r < R) {
-            bf16_t e[8];
+            op16_t e[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) e[k] = tile[cg * 8 + k][rl + 32 * p];
             *reinterpret_cast<uint4*>(dst + (size_t)c * R + r) = *reinterpret_cast<const uint4*>(e);
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_transpose_bf16(const bf16_t* __restrict
 __global__ __launch_bounds__(256) void k_transpose_bf16_multi(TransposeBatch b) {
     const TransposeBatch::Item& m = b.it[blockIdx.z];
     if ((int)blockIdx.x * 64 >= m.C || (int)blockIdx.y * 64 >= m.R) return;
-    __shared__ bf16_t tile[64][66];
+    __shared__ op16_t tile[64][66];
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, R = m.R, C = m.C;
     const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
 #pragma unroll
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void k_transpose_bf16_multi(TransposeBatch b) 
         const int r = r0 + rl + 32 * p, c = c0 + cg * 8;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (r < R && c < C) v = *reinterpret_cast<const uint4*>(m.src + (size_t)r * C + c);
-        const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+        const op16_t* e = reinterpret_cast<const op16_t*>(&v);
 #pragma unroll
         for (int k = 0; k < 8; k++) tile[rl + 32 * p][cg * 8 + k] = e[k];
     }
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void k_transpose_bf16_multi(TransposeBatch b) 
     for (int p = 0; p < 2; p++) {
         const int c = c0 + rl + 32 * p, r = r0 + cg * 8;
         if (c < C && r < R) {
-            bf16_t e[8];
+            op16_t e[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) e[k] = tile[cg * 8 + k][rl + 32 * p];
             *reinterpret_cast<uint4*>(m.dst + (size_t)c * R + r) = *reinterpret_cast<const uint4*>(e);
@@ -174,7 +174,7 @@ int transpose_bf16_multi(const TransposeBatch& b, hipStream_t st) {
     hipLaunchKernelGGL(k_transpose_bf16_multi, dim3((mc + 63) / 64, (mr + 63) / 64, b.n), dim3(256), 0, st, b);
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
-int transpose_bf16(const bf16_t* src, bf16_t* dst, int R, int C, hipStream_t st) {
+int transpose_bf16(const op16_t* src, op16_t* dst, int R, int C, hipStream_t st) {
     if ((R & 7) || (C & 7)) return CC_ERR_SHAPE;
     if (R <= 0 || C <= 0) return CC_OK;
     hipLaunchKernelGGL(k_transpose_bf16, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, st, src, dst, R, C);
@@ -190,7 +190,7 @@ constexpr int LN_MAXV = 8;  // float4 per lane -> D <= 2048
 template <int NV>   // float4 per lane actually used: D <= 256 NV (a run-time bound of 8 kept 8 x 4 registers live per array)
 __global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ x, int ldx, const int* __restrict__ row_map,
                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                bf16_t* __restrict__ y, float* __restrict__ y32, float* __restrict__ mean,
+                                                op16_t* __restrict__ y, float* __restrict__ y32, float* __restrict__ mean,
                                                 float* __restrict__ rstd, int rows, int D, float eps) {
     constexpr int R = NV <= 4 ? 2 : 1;       // rows per wave, loaded together: one row per wave is a chain of exposed round trips
     const int lane = threadIdx.x & 63;
@@ -245,13 +245,13 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ x, int
             if (c < D) {
                 const float o0 = (v[r][it].x - mu[r]) * rs[r] * g[it].x + bt[it].x, o1 = (v[r][it].y - mu[r]) * rs[r] * g[it].y + bt[it].y;
                 const float o2 = (v[r][it].z - mu[r]) * rs[r] * g[it].z + bt[it].z, o3 = (v[r][it].w - mu[r]) * rs[r] * g[it].w + bt[it].w;
-                if (y) *reinterpret_cast<uint2*>(y + (size_t)row * D + c) = make_uint2(pack2bf(o0, o1), pack2bf(o2, o3));
+                if (y) *reinterpret_cast<uint2*>(y + (size_t)row * D + c) = make_uint2(pack2op(o0, o1), pack2op(o2, o3));
                 if (y32) *reinterpret_cast<float4*>(y32 + (size_t)row * D + c) = make_float4(o0, o1, o2, o3);
             }
         }
     }
 }
-int ln_fwd(const float* x, int ldx, const int* row_map, const float* gamma, const float* beta, bf16_t* y, float* y32,
+int ln_fwd(const float* x, int ldx, const int* row_map, const float* gamma, const float* beta, op16_t* y, float* y32,
            float* mean, float* rstd, int rows, int D, hipStream_t st) {
     if (D > LN_MAXV * 256 || (D & 3) || (ldx & 3)) return CC_ERR_SHAPE;
     if (rows <= 0) return CC_OK;
@@ -267,11 +267,11 @@ int ln_fwd(const float* x, int ldx, const int* row_map, const float* gamma, cons
 // bf16 copy of dx_out for the next dgrad GEMM.  Optional dgamma/dbeta (atomic fp32 accumulation, one atomic per
 // column per block).  Each wave walks rows  row = blockIdx*4 + wave + k*gridDim*4.
 template <int NV, bool DG, int NW>   // NV as in k_ln_fwd; DG: accumulate dgamma / dbeta; NW waves per block
-__global__ __launch_bounds__(NW * 64) void k_ln_bwd(const bf16_t* __restrict__ dy, const float* __restrict__ x, int ldx,
+__global__ __launch_bounds__(NW * 64) void k_ln_bwd(const op16_t* __restrict__ dy, const float* __restrict__ x, int ldx,
                                                 const int* __restrict__ row_map, const float* __restrict__ mean,
                                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                 const float* __restrict__ dres, float* __restrict__ dx32,
-                                                bf16_t* __restrict__ dx16, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                op16_t* __restrict__ dx16, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                 int rows, int D) {
     extern __shared__ __attribute__((aligned(16))) float ln_red[];  // [2][NW][D] when dgamma
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -288,8 +288,9 @@ __global__ __launch_bounds__(NW * 64) void k_ln_bwd(const bf16_t* __restrict__ d
             const int c = lane * 4 + it * 256;
             if (c < D) {
                 const uint2 d = *reinterpret_cast<const uint2*>(dy + (size_t)row * D + c);
-                const float d0 = __uint_as_float(d.x << 16), d1 = __uint_as_float(d.x & 0xffff0000u);
-                const float d2 = __uint_as_float(d.y << 16), d3 = __uint_as_float(d.y & 0xffff0000u);
+                float d0, d1, d2, d3;
+                unpack2(d.x, d0, d1);
+                unpack2(d.y, d2, d3);
                 const float4 xv = *reinterpret_cast<const float4*>(x + xr + c);
                 const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
                 rr[it] = dres ? *reinterpret_cast<const float4*>(dres + xr + c) : make_float4(0, 0, 0, 0);   // fetched with the row, not after the reductions
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(NW * 64) void k_ln_bwd(const bf16_t* __restrict__ d
                                        rs * (g[it].z - m1 - xh[it].z * m2), rs * (g[it].w - m1 - xh[it].w * m2));
                 o.x += rr[it].x; o.y += rr[it].y; o.z += rr[it].z; o.w += rr[it].w;
                 *reinterpret_cast<float4*>(dx32 + xr + c) = o;
-                if (dx16) *reinterpret_cast<uint2*>(dx16 + xr + c) = make_uint2(pack2bf(o.x, o.y), pack2bf(o.z, o.w));
+                if (dx16) *reinterpret_cast<uint2*>(dx16 + xr + c) = make_uint2(pack2op(o.x, o.y), pack2op(o.z, o.w));
             }
         }
     }
@@ -337,8 +338,8 @@ __global__ __launch_bounds__(NW * 64) void k_ln_bwd(const bf16_t* __restrict__ d
         }
     }
 }
-int ln_bwd(const bf16_t* dy, const float* x, int ldx, const int* row_map, const float* mean, const float* rstd,
-           const float* gamma, const float* dres, float* dx32, bf16_t* dx16, float* dgamma, float* dbeta, int rows, int D,
+int ln_bwd(const op16_t* dy, const float* x, int ldx, const int* row_map, const float* mean, const float* rstd,
+           const float* gamma, const float* dres, float* dx32, op16_t* dx16, float* dgamma, float* dbeta, int rows, int D,
            hipStream_t st) {
     if (D > LN_MAXV * 256 || (D & 3) || (ldx & 3)) return CC_ERR_SHAPE;
     if (rows <= 0) return CC_OK;
@@ -358,7 +359,7 @@ int ln_bwd(const bf16_t* dy, const float* x, int ldx, const int* row_map, const 
 // ------------------------------------------------------------------------------------------------------------
 // Column sums of a bf16 matrix (bias gradients): out[n] += sum_m X[m][n].  Block = 64 columns x a row slice.
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_colsum_bf16(const bf16_t* __restrict__ X, int ld, int M, int N, float* __restrict__ out,
+__global__ __launch_bounds__(256) void k_colsum_bf16(const op16_t* __restrict__ X, int ld, int M, int N, float* __restrict__ out,
                                                      int rows_per_slice) {
     __shared__ float red[32][65];
     const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(256) void k_colsum_bf16(const bf16_t* __restrict__ 
         if (c < N) __hip_atomic_fetch_add(out + c, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-int colsum_bf16(const bf16_t* X, int ld, int M, int N, float* out, hipStream_t st) {
+int colsum_bf16(const op16_t* X, int ld, int M, int N, float* out, hipStream_t st) {
     if ((N & 7) || (ld & 7)) return CC_ERR_SHAPE;
     if (M <= 0 || N <= 0) return CC_OK;
     const int cb = (N + 63) / 64;
@@ -401,7 +402,7 @@ int colsum_bf16(const bf16_t* X, int ld, int M, int N, float* out, hipStream_t s
 // wave's b128 reads of consecutive rows are conflict-free).  qkv is [B*S][3*D] = [q | k | v], head h at h*hd.
 // Saves the log-sum-exp per (b,h,row) for the backward pass (probabilities are recomputed there).
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void load_head_rows(float* dst, int hdp, const bf16_t* src, size_t ld, int S, int hd) {
+__device__ __forceinline__ void load_head_rows(float* dst, int hdp, const op16_t* src, size_t ld, int S, int hd) {
     const int c8n = hd >> 3;
     for (int idx = threadIdx.x; idx < S * c8n; idx += blockDim.x) {
         const int r = idx / c8n, c = idx % c8n;
@@ -414,8 +415,8 @@ __device__ __forceinline__ void load_head_rows(float* dst, int hdp, const bf16_t
 }
 
 template <bool CAUSAL>
-__global__ __launch_bounds__(256) void k_attn_fwd(const bf16_t* __restrict__ qkv, int S, int H, int hd, float scale,
-                                                  bf16_t* __restrict__ out, float* __restrict__ lse) {
+__global__ __launch_bounds__(256) void k_attn_fwd(const op16_t* __restrict__ qkv, int S, int H, int hd, float scale,
+                                                  op16_t* __restrict__ out, float* __restrict__ lse) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int D = H * hd, hdp = hd + 4, Sp = S + 1;
     float* Qs = sm;
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const bf16_t* __restrict__ qkv
     float* Vs = Ks + S * hdp;
     float* Ps = Vs + S * hdp;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
-    const bf16_t* base = qkv + (size_t)b * S * 3 * D + h * hd;
+    const op16_t* base = qkv + (size_t)b * S * 3 * D + h * hd;
     load_head_rows(Qs, hdp, base, 3 * D, S, hd);
     load_head_rows(Ks, hdp, base + D, 3 * D, S, hd);
     load_head_rows(Vs, hdp, base + 2 * D, 3 * D, S, hd);
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const bf16_t* __restrict__ qkv
         }
         s = wave_sum(s);
         const float inv = 1.f / s;
-        for (int j = lane; j < S; j += 64) Ps[i * Sp + j] = bf2f(f2bf(Ps[i * Sp + j] * inv));   // P enters the PV product in bf16 (as in the MFMA kernel)
+        for (int j = lane; j < S; j += 64) Ps[i * Sp + j] = op2f(f2op(Ps[i * Sp + j] * inv));   // P enters the PV product in bf16 (as in the MFMA kernel)
         if (lane == 0 && lse) lse[((size_t)b * H + h) * S + i] = m + __logf(s);
     }
     __syncthreads();
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const bf16_t* __restrict__ qkv
             const float4 v = *reinterpret_cast<const float4*>(Vs + j * hdp + d0);
             o.x += p * v.x; o.y += p * v.y; o.z += p * v.z; o.w += p * v.w;
         }
-        *reinterpret_cast<uint2*>(out + ((size_t)b * S + i) * D + h * hd + d0) = make_uint2(pack2bf(o.x, o.y), pack2bf(o.z, o.w));
+        *reinterpret_cast<uint2*>(out + ((size_t)b * S + i) * D + h * hd + d0) = make_uint2(pack2op(o.x, o.y), pack2op(o.z, o.w));
     }
 }
 
@@ -511,24 +512,24 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // transpose reads per 16-lane group instead of 8 ds_read_u16 + 4 packs.
 template <int HD> struct AttLd { static constexpr int v = HD == 128 ? 160 : 96; };
 template <int HD>
-__device__ __forceinline__ bf16x8 frag_tr(const bf16_t* blk, int nb, int t, int lane) {
+__device__ __forceinline__ op16x8 frag_tr(const op16_t* blk, int nb, int t, int lane) {
     typedef __attribute__((ext_vector_type(4))) short s16x4_t;
     typedef __attribute__((address_space(3))) s16x4_t* lp_t;
     constexpr int LD = AttLd<HD>::v;
     const int half = lane >> 5, j = lane & 15, dsub = (lane >> 4) & 1;
-    const bf16_t* p = blk + (16 * t + 4 * half + (j >> 2)) * LD + nb * 32 + 16 * dsub + 4 * (j & 3);
+    const op16_t* p = blk + (16 * t + 4 * half + (j >> 2)) * LD + nb * 32 + 16 * dsub + 4 * (j & 3);
     const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)p);
     const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(p + 8 * LD));
     typedef __attribute__((ext_vector_type(8))) short s16x8_t;
     const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, v);
+    return __builtin_bit_cast(op16x8, v);
 }
 
 template <int HD, bool CAUSAL, bool DROP = false>
-__global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void k_attn_fwd_mfma(const bf16_t* __restrict__ qkv, int B, int S, int H, float scale,
-                                                       bf16_t* __restrict__ out, float* __restrict__ lse_out, Drop drop = Drop()) {
+__global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void k_attn_fwd_mfma(const op16_t* __restrict__ qkv, int B, int S, int H, float scale,
+                                                       op16_t* __restrict__ out, float* __restrict__ lse_out, Drop drop = Drop()) {
     constexpr int KK = HD / 16, NB = HD / 32, C8 = HD / 8;
-    __shared__ __attribute__((aligned(16))) bf16_t vsm[4][32 * AttLd<HD>::v];
+    __shared__ __attribute__((aligned(16))) op16_t vsm[4][32 * AttLd<HD>::v];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nqb = (S + 31) >> 5;
     const int item = blockIdx.x * 4 + wave;
@@ -536,16 +537,16 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void k_attn_fwd_mfma(const b
     const int qb = item % nqb, h = (item / nqb) % H, b = item / (nqb * H);
     const int D = H * HD;
     const size_t rs = (size_t)3 * D;
-    const bf16_t* base = qkv + (size_t)b * S * rs + h * HD;
+    const op16_t* base = qkv + (size_t)b * S * rs + h * HD;
     const int half = lane >> 5, q = qb * 32 + (lane & 31);
-    bf16_t* vs = vsm[wave];
+    op16_t* vs = vsm[wave];
 
-    bf16x8 qf[KK];
+    op16x8 qf[KK];
 #pragma unroll
     for (int kk = 0; kk < KK; kk++) {
         uint4 v = *reinterpret_cast<const uint4*>(base + (size_t)min(q, S - 1) * rs + kk * 16 + half * 8);
         if (q >= S) v = make_uint4(0, 0, 0, 0);
-        qf[kk] = __builtin_bit_cast(bf16x8, v);
+        qf[kk] = __builtin_bit_cast(op16x8, v);
     }
     f32x16 o[NB];
 #pragma unroll
@@ -579,7 +580,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void k_attn_fwd_mfma(const b
 #pragma unroll
         for (int r = 0; r < 16; r++) s[r] = 0.f;
 #pragma unroll
-        for (int kk = 0; kk < KK; kk++) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kq[kk]), qf[kk], s, 0, 0, 0);
+        for (int kk = 0; kk < KK; kk++) s = CC_MFMA_32x32x16(__builtin_bit_cast(op16x8, kq[kk]), qf[kk], s);
         // V block -> wave-private LDS, row-major [32 keys][ATT_LD]
 #pragma unroll
         for (int c = 0; c < HD / 16; c++) {
@@ -615,17 +616,17 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void k_attn_fwd_mfma(const b
 #pragma unroll
             for (int r = 0; r < 16; r++) p[r] *= drop_mul(drop, rowbase + min(kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, S - 1));
         }
-        bf16x8 pf[2];
+        op16x8 pf[2];
 #pragma unroll
         for (int t = 0; t < 2; t++) {
-            const uint4 v = make_uint4(pack2bf(p[t * 8 + 0], p[t * 8 + 1]), pack2bf(p[t * 8 + 2], p[t * 8 + 3]),
-                                       pack2bf(p[t * 8 + 4], p[t * 8 + 5]), pack2bf(p[t * 8 + 6], p[t * 8 + 7]));
-            pf[t] = __builtin_bit_cast(bf16x8, v);
+            const uint4 v = make_uint4(pack2op(p[t * 8 + 0], p[t * 8 + 1]), pack2op(p[t * 8 + 2], p[t * 8 + 3]),
+                                       pack2op(p[t * 8 + 4], p[t * 8 + 5]), pack2op(p[t * 8 + 6], p[t * 8 + 7]));
+            pf[t] = __builtin_bit_cast(op16x8, v);
         }
 #pragma unroll
         for (int nb = 0; nb < NB; nb++)
 #pragma unroll
-            for (int t = 0; t < 2; t++) o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<HD>(vs, nb, t, lane), pf[t], o[nb], 0, 0, 0);
+            for (int t = 0; t < 2; t++) o[nb] = CC_MFMA_32x32x16(frag_tr<HD>(vs, nb, t, lane), pf[t], o[nb]);
 #pragma unroll
         for (int kk = 0; kk < KK; kk++) kq[kk] = kn[kk];
 #pragma unroll
@@ -633,21 +634,21 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void k_attn_fwd_mfma(const b
     }
     if (q < S) {
         const float inv = l > 0.f ? 1.f / l : 0.f;
-        bf16_t* orow = out + ((size_t)b * S + q) * D + h * HD;
+        op16_t* orow = out + ((size_t)b * S + q) * D + h * HD;
 #pragma unroll
         for (int nb = 0; nb < NB; nb++)
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int d0 = nb * 32 + 8 * g + 4 * half;
-                *reinterpret_cast<uint2*>(orow + d0) = make_uint2(pack2bf(o[nb][g * 4 + 0] * inv, o[nb][g * 4 + 1] * inv),
-                                                                  pack2bf(o[nb][g * 4 + 2] * inv, o[nb][g * 4 + 3] * inv));
+                *reinterpret_cast<uint2*>(orow + d0) = make_uint2(pack2op(o[nb][g * 4 + 0] * inv, o[nb][g * 4 + 1] * inv),
+                                                                  pack2op(o[nb][g * 4 + 2] * inv, o[nb][g * 4 + 3] * inv));
             }
         if (half == 0 && lse_out) lse_out[((size_t)b * H + h) * S + q] = m + __logf(l);
     }
 }
 
 template <int HD>
-static int attn_fwd_mfma_launch(const bf16_t* qkv, int B, int S, int H, bool causal, bf16_t* out, float* lse, hipStream_t st, Drop drop) {
+static int attn_fwd_mfma_launch(const op16_t* qkv, int B, int S, int H, bool causal, op16_t* out, float* lse, hipStream_t st, Drop drop) {
     const int items = B * H * ((S + 31) / 32);
     const float scale = 1.0f / sqrtf((float)HD);
     if (drop.thresh) {
@@ -671,24 +672,24 @@ static int attn_fwd_mfma_launch(const bf16_t* qkv, int B, int S, int H, bool cau
 //       lane <-> query — so bf16(dS^T) is the B fragment of dQ^T[d][q] += K^T[d][key] dS^T[key][q] (K block via LDS).
 // P is recomputed from the saved log-sum-exp; dS = P (dP - delta) * scale.
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bf16x8 pack_frag(const float* p) {
-    return __builtin_bit_cast(bf16x8, make_uint4(pack2bf(p[0], p[1]), pack2bf(p[2], p[3]), pack2bf(p[4], p[5]), pack2bf(p[6], p[7])));
+__device__ __forceinline__ op16x8 pack_frag(const float* p) {
+    return __builtin_bit_cast(op16x8, make_uint4(pack2op(p[0], p[1]), pack2op(p[2], p[3]), pack2op(p[4], p[5]), pack2op(p[6], p[7])));
 }
 // Row loads are branch-free: the caller clamps the row index into range and the value is zeroed by a select.  A predicated
 // load (`if (ok) v = *p`) puts every load in its own basic block — 43 branches in the dkv loop — and the loads stop overlapping.
-__device__ __forceinline__ bf16x8 load_frag(const bf16_t* row_ptr, bool ok) {
+__device__ __forceinline__ op16x8 load_frag(const op16_t* row_ptr, bool ok) {
     uint4 v = *reinterpret_cast<const uint4*>(row_ptr);
     if (!ok) v = make_uint4(0, 0, 0, 0);
-    return __builtin_bit_cast(bf16x8, v);
+    return __builtin_bit_cast(op16x8, v);
 }
 
 template <int HD, bool CAUSAL, bool DROP = false>
-__global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void k_attn_bwd_dkv(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void k_attn_bwd_dkv(const op16_t* __restrict__ qkv, const op16_t* __restrict__ dout,
                                                       const float* __restrict__ lse, const float* __restrict__ delta, int B, int S, int H,
-                                                      float scale, bf16_t* __restrict__ dqkv, Drop drop = Drop()) {
+                                                      float scale, op16_t* __restrict__ dqkv, Drop drop = Drop()) {
     constexpr int KK = HD / 16, NB = HD / 32;
-    __shared__ __attribute__((aligned(16))) bf16_t qsm[4][32 * AttLd<HD>::v];
-    __shared__ __attribute__((aligned(16))) bf16_t dsm[4][32 * AttLd<HD>::v];
+    __shared__ __attribute__((aligned(16))) op16_t qsm[4][32 * AttLd<HD>::v];
+    __shared__ __attribute__((aligned(16))) op16_t dsm[4][32 * AttLd<HD>::v];
     __shared__ __attribute__((aligned(16))) float ldsm[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nblk = (S + 31) >> 5;
@@ -697,12 +698,12 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void k_attn_bwd_dkv(const bf
     const int j = item % nblk, h = (item / nblk) % H, b = item / (nblk * H);
     const int D = H * HD;
     const size_t rs = (size_t)3 * D;
-    const bf16_t* base = qkv + (size_t)b * S * rs + h * HD;
-    const bf16_t* dbase = dout + (size_t)b * S * D + h * HD;
+    const op16_t* base = qkv + (size_t)b * S * rs + h * HD;
+    const op16_t* dbase = dout + (size_t)b * S * D + h * HD;
     const float* lrow = lse + ((size_t)b * H + h) * S;
     const float* drow = delta + ((size_t)b * H + h) * S;
     const int half = lane >> 5, key = j * 32 + (lane & 31);
-    bf16x8 kf[KK], vf[KK];
+    op16x8 kf[KK], vf[KK];
 #pragma unroll
     for (int kk = 0; kk < KK; kk++) {
         kf[kk] = load_frag(base + D + (size_t)min(key, S - 1) * rs + kk * 16 + half * 8, key < S);
@@ -717,7 +718,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void k_attn_bwd_dkv(const bf
     // otherwise) and the row-major LDS copies the dK / dV products need are written from those same registers: the lanes'
     // fragments (row lane & 31, columns 16 kk + 8 half .. + 7) tile the block exactly.
     const int i0 = CAUSAL ? j : 0;
-    bf16x8 qf[KK], df[KK];
+    op16x8 qf[KK], df[KK];
     {
         const int qa = i0 * 32 + (lane & 31);
 #pragma unroll
@@ -727,7 +728,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void k_attn_bwd_dkv(const bf
         }
     }
     for (int i = i0; i < nblk; i++) {
-        bf16x8 qn[KK], dn[KK];
+        op16x8 qn[KK], dn[KK];
         {
             const int qa = (i + 1) * 32 + (lane & 31);      // block i + 1 (clamped rows; unused after the last iteration)
 #pragma unroll
@@ -741,10 +742,10 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void k_attn_bwd_dkv(const bf
         for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
         for (int kk = 0; kk < KK; kk++) {
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[kk], kf[kk], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[kk], vf[kk], dp, 0, 0, 0);
-            *reinterpret_cast<bf16x8*>(qsm[wave] + (lane & 31) * AttLd<HD>::v + kk * 16 + half * 8) = qf[kk];
-            *reinterpret_cast<bf16x8*>(dsm[wave] + (lane & 31) * AttLd<HD>::v + kk * 16 + half * 8) = df[kk];
+            s = CC_MFMA_32x32x16(qf[kk], kf[kk], s);
+            dp = CC_MFMA_32x32x16(df[kk], vf[kk], dp);
+            *reinterpret_cast<op16x8*>(qsm[wave] + (lane & 31) * AttLd<HD>::v + kk * 16 + half * 8) = qf[kk];
+            *reinterpret_cast<op16x8*>(dsm[wave] + (lane & 31) * AttLd<HD>::v + kk * 16 + half * 8) = df[kk];
         }
         // log-sum-exp and delta of the block's 32 queries: one coalesced load each into a wave-private LDS row, read back as
         // 4 x float4 per lane (queries 4 half + 8 g + 0..3) instead of 32 scalar global loads per iteration
@@ -774,39 +775,39 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void k_attn_bwd_dkv(const bf
                 ds[r] = p[r] * (dp[r] - dq_[r]) * scale;
             }
         }
-        const bf16x8 pf[2] = {pack_frag(p), pack_frag(p + 8)};
-        const bf16x8 dsf[2] = {pack_frag(ds), pack_frag(ds + 8)};
+        const op16x8 pf[2] = {pack_frag(p), pack_frag(p + 8)};
+        const op16x8 dsf[2] = {pack_frag(ds), pack_frag(ds + 8)};
 #pragma unroll
         for (int nb = 0; nb < NB; nb++)
 #pragma unroll
             for (int t = 0; t < 2; t++) {
-                dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<HD>(dsm[wave], nb, t, lane), pf[t], dv[nb], 0, 0, 0);
-                dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<HD>(qsm[wave], nb, t, lane), dsf[t], dk[nb], 0, 0, 0);
+                dv[nb] = CC_MFMA_32x32x16(frag_tr<HD>(dsm[wave], nb, t, lane), pf[t], dv[nb]);
+                dk[nb] = CC_MFMA_32x32x16(frag_tr<HD>(qsm[wave], nb, t, lane), dsf[t], dk[nb]);
             }
 #pragma unroll
         for (int kk = 0; kk < KK; kk++) { qf[kk] = qn[kk]; df[kk] = dn[kk]; }
     }
     if (key < S) {
-        bf16_t* orow = dqkv + ((size_t)b * S + key) * rs + h * HD;
+        op16_t* orow = dqkv + ((size_t)b * S + key) * rs + h * HD;
 #pragma unroll
         for (int nb = 0; nb < NB; nb++)
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int d0 = nb * 32 + 8 * g + 4 * half;
                 *reinterpret_cast<uint2*>(orow + D + d0) =
-                    make_uint2(pack2bf(dk[nb][g * 4 + 0], dk[nb][g * 4 + 1]), pack2bf(dk[nb][g * 4 + 2], dk[nb][g * 4 + 3]));
+                    make_uint2(pack2op(dk[nb][g * 4 + 0], dk[nb][g * 4 + 1]), pack2op(dk[nb][g * 4 + 2], dk[nb][g * 4 + 3]));
                 *reinterpret_cast<uint2*>(orow + 2 * D + d0) =
-                    make_uint2(pack2bf(dv[nb][g * 4 + 0], dv[nb][g * 4 + 1]), pack2bf(dv[nb][g * 4 + 2], dv[nb][g * 4 + 3]));
+                    make_uint2(pack2op(dv[nb][g * 4 + 0], dv[nb][g * 4 + 1]), pack2op(dv[nb][g * 4 + 2], dv[nb][g * 4 + 3]));
             }
     }
 }
 
 template <int HD, bool CAUSAL, bool DROP = false>
-__global__ __launch_bounds__(256, HD == 64 ? 3 : (HD == 96 ? 2 : 1)) void k_attn_bwd_dq(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const bf16_t* __restrict__ o,
+__global__ __launch_bounds__(256, HD == 64 ? 3 : (HD == 96 ? 2 : 1)) void k_attn_bwd_dq(const op16_t* __restrict__ qkv, const op16_t* __restrict__ dout, const op16_t* __restrict__ o,
                                                      const float* __restrict__ lse, float* __restrict__ delta, int B, int S, int H,
-                                                     float scale, bf16_t* __restrict__ dqkv, Drop drop = Drop()) {
+                                                     float scale, op16_t* __restrict__ dqkv, Drop drop = Drop()) {
     constexpr int KK = HD / 16, NB = HD / 32;
-    __shared__ __attribute__((aligned(16))) bf16_t ksm[4][32 * AttLd<HD>::v];
+    __shared__ __attribute__((aligned(16))) op16_t ksm[4][32 * AttLd<HD>::v];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nblk = (S + 31) >> 5;
     const int item = blockIdx.x * 4 + wave;
@@ -814,11 +815,11 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : (HD == 96 ? 2 : 1)) void k_attn
     const int i = item % nblk, h = (item / nblk) % H, b = item / (nblk * H);
     const int D = H * HD;
     const size_t rs = (size_t)3 * D;
-    const bf16_t* base = qkv + (size_t)b * S * rs + h * HD;
-    const bf16_t* dbase = dout + (size_t)b * S * D + h * HD;
+    const op16_t* base = qkv + (size_t)b * S * rs + h * HD;
+    const op16_t* dbase = dout + (size_t)b * S * D + h * HD;
     const int half = lane >> 5, q = i * 32 + (lane & 31);
     const float my_lse = q < S ? lse[((size_t)b * H + h) * S + q] : 0.f;
-    bf16x8 qf[KK], dof[KK];
+    op16x8 qf[KK], dof[KK];
     // delta[q] = sum_d dO[q,d] O[q,d]: in this orientation a lane owns half of its query's row, so the dot product is 4 fragment
     // products + one cross-half shuffle.  Computed here and stored for the dK/dV kernel, which runs after this one (the separate
     // k_attn_delta launch is gone).
@@ -827,7 +828,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : (HD == 96 ? 2 : 1)) void k_attn
     for (int kk = 0; kk < KK; kk++) {
         qf[kk] = load_frag(base + (size_t)min(q, S - 1) * rs + kk * 16 + half * 8, q < S);
         dof[kk] = load_frag(dbase + (size_t)min(q, S - 1) * D + kk * 16 + half * 8, q < S);
-        const bf16x8 of = load_frag(o + ((size_t)b * S + min(q, S - 1)) * D + h * HD + kk * 16 + half * 8, q < S);
+        const op16x8 of = load_frag(o + ((size_t)b * S + min(q, S - 1)) * D + h * HD + kk * 16 + half * 8, q < S);
         float x[8], y[8];
         unpack8(__builtin_bit_cast(uint4, dof[kk]), x);
         unpack8(__builtin_bit_cast(uint4, of), y);
@@ -843,7 +844,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : (HD == 96 ? 2 : 1)) void k_attn
         for (int r = 0; r < 16; r++) dq[nb][r] = 0.f;
     const int jend = CAUSAL ? i + 1 : nblk;
     // K / V fragments one key block ahead; the row-major K copy for dQ^T += K^T dS^T is written from the K fragment registers
-    bf16x8 kf[KK], vf[KK];
+    op16x8 kf[KK], vf[KK];
     {
         const int key = lane & 31;
 #pragma unroll
@@ -853,7 +854,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : (HD == 96 ? 2 : 1)) void k_attn
         }
     }
     for (int j = 0; j < jend; j++) {
-        bf16x8 kn[KK], vn[KK];
+        op16x8 kn[KK], vn[KK];
         {
             const int key = (j + 1) * 32 + (lane & 31);
 #pragma unroll
@@ -867,9 +868,9 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : (HD == 96 ? 2 : 1)) void k_attn
         for (int r = 0; r < 16; r++) { st[r] = 0.f; dpt[r] = 0.f; }
 #pragma unroll
         for (int kk = 0; kk < KK; kk++) {
-            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[kk], st, 0, 0, 0);
-            dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kk], dof[kk], dpt, 0, 0, 0);
-            *reinterpret_cast<bf16x8*>(ksm[wave] + (lane & 31) * AttLd<HD>::v + kk * 16 + half * 8) = kf[kk];
+            st = CC_MFMA_32x32x16(kf[kk], qf[kk], st);
+            dpt = CC_MFMA_32x32x16(vf[kk], dof[kk], dpt);
+            *reinterpret_cast<op16x8*>(ksm[wave] + (lane & 31) * AttLd<HD>::v + kk * 16 + half * 8) = kf[kk];
         }
         float ds[16];
 #pragma unroll
@@ -880,31 +881,31 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : (HD == 96 ? 2 : 1)) void k_attn
             const float mk = DROP ? drop_mul(drop, ((unsigned)(b * H + h) * S + min(q, S - 1)) * S + min(kr, S - 1)) : 1.0f;
             ds[r] = p * (mk * dpt[r] - my_delta) * scale;
         }
-        const bf16x8 dsf[2] = {pack_frag(ds), pack_frag(ds + 8)};
+        const op16x8 dsf[2] = {pack_frag(ds), pack_frag(ds + 8)};
 #pragma unroll
         for (int nb = 0; nb < NB; nb++)
 #pragma unroll
             for (int t = 0; t < 2; t++)
-                dq[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<HD>(ksm[wave], nb, t, lane), dsf[t], dq[nb], 0, 0, 0);
+                dq[nb] = CC_MFMA_32x32x16(frag_tr<HD>(ksm[wave], nb, t, lane), dsf[t], dq[nb]);
 #pragma unroll
         for (int kk = 0; kk < KK; kk++) { kf[kk] = kn[kk]; vf[kk] = vn[kk]; }
     }
     if (q < S) {
-        bf16_t* orow = dqkv + ((size_t)b * S + q) * rs + h * HD;
+        op16_t* orow = dqkv + ((size_t)b * S + q) * rs + h * HD;
 #pragma unroll
         for (int nb = 0; nb < NB; nb++)
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int d0 = nb * 32 + 8 * g + 4 * half;
                 *reinterpret_cast<uint2*>(orow + d0) =
-                    make_uint2(pack2bf(dq[nb][g * 4 + 0], dq[nb][g * 4 + 1]), pack2bf(dq[nb][g * 4 + 2], dq[nb][g * 4 + 3]));
+                    make_uint2(pack2op(dq[nb][g * 4 + 0], dq[nb][g * 4 + 1]), pack2op(dq[nb][g * 4 + 2], dq[nb][g * 4 + 3]));
             }
     }
 }
 
 template <int HD>
-static int attn_bwd_mfma_launch(const bf16_t* qkv, const bf16_t* dout, const bf16_t* o, const float* lse, float* delta, int B, int S, int H,
-                                bool causal, bf16_t* dqkv, hipStream_t st, Drop drop) {
+static int attn_bwd_mfma_launch(const op16_t* qkv, const op16_t* dout, const op16_t* o, const float* lse, float* delta, int B, int S, int H,
+                                bool causal, op16_t* dqkv, hipStream_t st, Drop drop) {
     const int items = B * H * ((S + 31) / 32);
     const float scale = 1.0f / sqrtf((float)HD);
     // dQ first: it also produces delta, which the dK/dV kernel reads
@@ -925,7 +926,7 @@ static int attn_bwd_mfma_launch(const bf16_t* qkv, const bf16_t* dout, const bf1
 static size_t attn_fwd_lds(int S, int hd) { return ((size_t)3 * S * (hd + 4) + (size_t)S * (S + 1)) * 4; }
 static size_t attn_bwd_lds(int S, int hd) { return ((size_t)4 * S * (hd + 4) + (size_t)2 * S * (S + 1)) * 4; }
 
-int attn_fwd(const bf16_t* qkv, int B, int S, int H, int hd, bool causal, bf16_t* out, float* lse, hipStream_t st, Drop drop) {
+int attn_fwd(const op16_t* qkv, int B, int S, int H, int hd, bool causal, op16_t* out, float* lse, hipStream_t st, Drop drop) {
     if ((hd & 7) || S <= 0) return CC_ERR_SHAPE;
     static const bool no_mfma = getenv("CC_ATTN_VALU") != nullptr;   // A/B switch for profiling
     if (!no_mfma || drop.thresh) {
@@ -950,9 +951,9 @@ int attn_fwd(const bf16_t* qkv, int B, int S, int H, int hd, bool causal, bf16_t
 // Backward: recompute P from the saved lse; dP = dO V^T; delta_i = sum_j P_ij dP_ij (== dO_i . O_i);
 // dS = P (dP - delta) * scale; dQ = dS K; dK = dS^T Q; dV = P^T dO.  Writes dqkv (bf16) in the qkv layout.
 template <bool CAUSAL>
-__global__ __launch_bounds__(256) void k_attn_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(256) void k_attn_bwd(const op16_t* __restrict__ qkv, const op16_t* __restrict__ dout,
                                                   const float* __restrict__ lse, int S, int H, int hd, float scale,
-                                                  bf16_t* __restrict__ dqkv) {
+                                                  op16_t* __restrict__ dqkv) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int D = H * hd, hdp = hd + 4, Sp = S + 1;
     float* Qs = sm;
@@ -962,7 +963,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd(const bf16_t* __restrict__ qkv
     float* Ps = Os + S * hdp;
     float* Ds = Ps + S * Sp;   // dP then dS
     const int b = blockIdx.x / H, h = blockIdx.x % H;
-    const bf16_t* base = qkv + (size_t)b * S * 3 * D + h * hd;
+    const op16_t* base = qkv + (size_t)b * S * 3 * D + h * hd;
     load_head_rows(Qs, hdp, base, 3 * D, S, hd);
     load_head_rows(Ks, hdp, base + D, 3 * D, S, hd);
     load_head_rows(Vs, hdp, base + 2 * D, 3 * D, S, hd);
@@ -1029,14 +1030,14 @@ __global__ __launch_bounds__(256) void k_attn_bwd(const bf16_t* __restrict__ qkv
             dk.x += w * q.x; dk.y += w * q.y; dk.z += w * q.z; dk.w += w * q.w;
             dv.x += p * o.x; dv.y += p * o.y; dv.z += p * o.z; dv.w += p * o.w;
         }
-        bf16_t* o = dqkv + ((size_t)b * S + r) * 3 * D + h * hd + d0;
-        *reinterpret_cast<uint2*>(o) = make_uint2(pack2bf(dq.x, dq.y), pack2bf(dq.z, dq.w));
-        *reinterpret_cast<uint2*>(o + D) = make_uint2(pack2bf(dk.x, dk.y), pack2bf(dk.z, dk.w));
-        *reinterpret_cast<uint2*>(o + 2 * D) = make_uint2(pack2bf(dv.x, dv.y), pack2bf(dv.z, dv.w));
+        op16_t* o = dqkv + ((size_t)b * S + r) * 3 * D + h * hd + d0;
+        *reinterpret_cast<uint2*>(o) = make_uint2(pack2op(dq.x, dq.y), pack2op(dq.z, dq.w));
+        *reinterpret_cast<uint2*>(o + D) = make_uint2(pack2op(dk.x, dk.y), pack2op(dk.z, dk.w));
+        *reinterpret_cast<uint2*>(o + 2 * D) = make_uint2(pack2op(dv.x, dv.y), pack2op(dv.z, dv.w));
     }
 }
-int attn_bwd(const bf16_t* qkv, const bf16_t* dout, const bf16_t* o, const float* lse, float* delta, int B, int S, int H, int hd, bool causal,
-             bf16_t* dqkv, hipStream_t st, Drop drop) {
+int attn_bwd(const op16_t* qkv, const op16_t* dout, const op16_t* o, const float* lse, float* delta, int B, int S, int H, int hd, bool causal,
+             op16_t* dqkv, hipStream_t st, Drop drop) {
     if ((hd & 7) || S <= 0) return CC_ERR_SHAPE;
     static const bool no_mfma = getenv("CC_ATTN_VALU") != nullptr;
     if ((!no_mfma || drop.thresh) && o && delta) {
@@ -1062,7 +1063,7 @@ int attn_bwd(const bf16_t* qkv, const bf16_t* dout, const bf16_t* o, const float
 // GPT-2 input assembly: x0[b,t,:] = (t < L ? prefix[b,t,:] : wte[tok[b,t-L],:]) + wpe[pos0 + t,:]   (fp32)
 // (clipcap/model/model.py:45-49 + hf modeling_gpt2.py:571-577).  tokens < 0 (pads) are read as id 0 (model.py:104).
 // ------------------------------------------------------------------------------------------------------------
-// In-place dropout (common.cuh: counter-based mask): embedding dropout on x0 / dx0 (fp32) and the masked bf16 copy of the residual
+// In-place dropout (common.hip.h: counter-based mask): embedding dropout on x0 / dx0 (fp32) and the masked bf16 copy of the residual
 // gradient that feeds a c_proj backward.
 // ------------------------------------------------------------------------------------------------------------
 __global__ void k_dropout_f32(float* __restrict__ x, size_t n4, Drop d) {
@@ -1073,7 +1074,7 @@ __global__ void k_dropout_f32(float* __restrict__ x, size_t n4, Drop d) {
         reinterpret_cast<float4*>(x)[i] = v;
     }
 }
-__global__ void k_dropout_bf16(bf16_t* __restrict__ x, size_t n8, Drop d) {
+__global__ void k_dropout_bf16(op16_t* __restrict__ x, size_t n8, Drop d) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
         float f[8];
         unpack8(reinterpret_cast<const uint4*>(x)[i], f);
@@ -1093,7 +1094,7 @@ int dropout_f32(float* x, size_t n, Drop d, hipStream_t st) {
     hipLaunchKernelGGL(k_dropout_f32, dim3((int)std::min<size_t>((n / 4 + 255) / 256, 4096)), dim3(256), 0, st, x, n / 4, d);
     return CC_OK;
 }
-int dropout_bf16(bf16_t* x, size_t n, Drop d, hipStream_t st) {
+int dropout_bf16(op16_t* x, size_t n, Drop d, hipStream_t st) {
     if (!d.thresh || !n) return CC_OK;
     if (n & 7) return CC_ERR_SHAPE;
     hipLaunchKernelGGL(k_dropout_bf16, dim3((int)std::min<size_t>((n / 8 + 255) / 256, 4096)), dim3(256), 0, st, x, n / 8, d);
@@ -1215,16 +1216,17 @@ int ce_rows(const float* pmax, const float* psum, int npart, const int* target, 
     return CC_OK;
 }
 
-__global__ __launch_bounds__(256) void k_ce_dlogits(bf16_t* __restrict__ logits, int ld, int V, const int* __restrict__ target,
-                                                    const float* __restrict__ lse, const float* __restrict__ denom, int M) {
+__global__ __launch_bounds__(256) void k_ce_dlogits(op16_t* __restrict__ logits, int ld, int V, const int* __restrict__ target,
+                                                    const float* __restrict__ lse, const float* __restrict__ denom,
+                                                    const float* __restrict__ loss_scale, int M) {
     const int col = (blockIdx.x * 256 + threadIdx.x) * 8;
     if (col >= ld) return;
-    const float inv = 1.0f / fmaxf(denom[0], 1.0f);
+    const float inv = (loss_scale ? loss_scale[0] : 1.0f) / fmaxf(denom[0], 1.0f);
     for (int row = blockIdx.y; row < M; row += gridDim.y) {
         const int t = target[row];
         const float l = lse[row];
         const float w = (t != 0) ? inv : 0.f;
-        bf16_t* p = logits + (size_t)row * ld + col;
+        op16_t* p = logits + (size_t)row * ld + col;
         float f[8];
         unpack8(*reinterpret_cast<const uint4*>(p), f);
 #pragma unroll
@@ -1235,10 +1237,11 @@ __global__ __launch_bounds__(256) void k_ce_dlogits(bf16_t* __restrict__ logits,
         *reinterpret_cast<uint4*>(p) = pack8(f);
     }
 }
-int ce_dlogits(bf16_t* logits, int ld, int V, const int* target, const float* lse, const float* denom, int M, hipStream_t st) {
+int ce_dlogits(op16_t* logits, int ld, int V, const int* target, const float* lse, const float* denom, const float* loss_scale, int M,
+               hipStream_t st) {
     if (ld & 7) return CC_ERR_SHAPE;
     if (M <= 0) return CC_OK;
-    hipLaunchKernelGGL(k_ce_dlogits, dim3((ld / 8 + 255) / 256, std::min(M, 32768)), dim3(256), 0, st, logits, ld, V, target, lse, denom, M);
+    hipLaunchKernelGGL(k_ce_dlogits, dim3((ld / 8 + 255) / 256, std::min(M, 32768)), dim3(256), 0, st, logits, ld, V, target, lse, denom, loss_scale, M);
     return CC_OK;
 }
 
@@ -1259,12 +1262,16 @@ int ce_targets(const long long* tokens, int* target, int* row_map, int B, int ca
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Flat AdamW (torch.optim.AdamW math, decoupled decay) over one parameter arena; also refreshes the bf16 copy the
-// GEMMs read.  HBM-bound: 16 B read + 14 B written per parameter.
+// Flat AdamW (torch.optim.AdamW math, decoupled decay) over one parameter arena.  HBM-bound: 16 B read + 12 B written per
+// parameter.  inv_scale (device, nullable) = loss scale to divide out of the gradients; found_inf (device, nullable) != 0 skips
+// the whole step (the GradScaler rule for an overflowed fp16 backward).
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                               float* __restrict__ v, bf16_t* __restrict__ p16, size_t n4, float lr, float b1, float b2,
-                                               float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+                                               float* __restrict__ v, size_t n4, float lr, float b1, float b2, float eps, float wd, float bc1,
+                                               float bc2_sqrt, float gscale, const float* __restrict__ loss_scale,
+                                               const float* __restrict__ found_inf) {
+    if (found_inf && found_inf[0] != 0.f) return;
+    if (loss_scale) gscale /= loss_scale[0];
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 P = reinterpret_cast<float4*>(p)[i], G = reinterpret_cast<const float4*>(g)[i];
         float4 M = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i];
@@ -1281,19 +1288,57 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const floa
         reinterpret_cast<float4*>(p)[i] = P;
         reinterpret_cast<float4*>(m)[i] = M;
         reinterpret_cast<float4*>(v)[i] = V;
-        if (p16) reinterpret_cast<uint2*>(p16)[i] = make_uint2(pack2bf(P.x, P.y), pack2bf(P.z, P.w));
     }
 }
-int adamw(float* p, const float* g, float* m, float* v, bf16_t* p16, size_t n, float lr, float b1, float b2, float eps, float wd,
-          int step, float gscale, hipStream_t st) {
+int adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd, int step, float gscale,
+          const float* loss_scale, const float* found_inf, hipStream_t st) {
     if (n & 3) return CC_ERR_SHAPE;
     if (!n) return CC_OK;
     const float bc1 = 1.0f - powf(b1, (float)step);
     const float bc2s = sqrtf(1.0f - powf(b2, (float)step));
     const size_t n4 = n >> 2;
-    hipLaunchKernelGGL(k_adamw, dim3((int)std::min<size_t>((n4 + 255) / 256, 4096)), dim3(256), 0, st, p, g, m, v, p16, n4, lr, b1, b2,
-                       eps, wd, bc1, bc2s, gscale);
+    hipLaunchKernelGGL(k_adamw, dim3((int)std::min<size_t>((n4 + 255) / 256, 4096)), dim3(256), 0, st, p, g, m, v, n4, lr, b1, b2, eps, wd,
+                       bc1, bc2s, gscale, loss_scale, found_inf);
     return CC_OK;
 }
 
-}  // namespace cc
+// ---- dynamic loss scaling (fp16 operands; torch.cuda.amp.GradScaler semantics, all on the device) ----
+__global__ __launch_bounds__(256) void k_grad_nonfinite(const float* __restrict__ g, size_t n4, float* __restrict__ found_inf) {
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 G = reinterpret_cast<const float4*>(g)[i];
+        // (x - x) is 0 for finite x and NaN for inf / NaN
+        const float z = (G.x - G.x) + (G.y - G.y) + (G.z - G.z) + (G.w - G.w);
+        bad |= !(z == 0.f);
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) found_inf[0] = 1.0f;      // benign race: every writer stores the same value
+}
+int grad_nonfinite(const float* g, size_t n, float* found_inf, hipStream_t st) {
+    if (n & 3) return CC_ERR_SHAPE;
+    if (!n) return CC_OK;
+    const size_t n4 = n >> 2;
+    hipLaunchKernelGGL(k_grad_nonfinite, dim3((int)std::min<size_t>((n4 + 255) / 256, 2048)), dim3(256), 0, st, g, n4, found_inf);
+    return CC_OK;
+}
+__global__ void k_loss_scale_update(float* state, float* found_inf, float growth, float backoff, int interval) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (found_inf[0] != 0.f) {
+        state[0] = fmaxf(state[0] * backoff, 1.0f);
+        state[1] = 0.f;
+    } else {
+        const float good = state[1] + 1.f;
+        if (good >= (float)interval) {
+            state[0] = fminf(state[0] * growth, 16777216.0f);
+            state[1] = 0.f;
+        } else {
+            state[1] = good;
+        }
+    }
+    found_inf[0] = 0.f;
+}
+int loss_scale_update(float* state, float* found_inf, float growth, float backoff, int interval, hipStream_t st) {
+    hipLaunchKernelGGL(k_loss_scale_update, dim3(1), dim3(64), 0, st, state, found_inf, growth, backoff, interval);
+    return CC_OK;
+}
+
+}  // namespace CC_NS

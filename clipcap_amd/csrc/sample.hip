@@ -8,7 +8,7 @@
 // from outside torch, and parity is on the pre-sampling distribution (probs_out), as SURVEY.md 8(a13) says.
 #include "kernels.h"
 
-namespace cc {
+namespace CC_NS {
 
 constexpr int SM_T = 1024;          // threads per row
 constexpr int SM_NB = 2048;         // radix buckets (11 bits)
@@ -380,4 +380,4 @@ int sample_rows(const float* logits, int R, int V, int ld, float temperature, in
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
 
-}  // namespace cc
+}  // namespace CC_NS

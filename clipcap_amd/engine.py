@@ -15,7 +15,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from clipcap_amd import _lib
-from clipcap_amd._lib import Gpt2Cfg, Gpt2Shape, MapperCfg, check
+from clipcap_amd._lib import OP_BF16, OP_FP16, Gpt2Cfg, Gpt2Shape, MapperCfg, check, op_dtype_of
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -41,13 +41,16 @@ GPT2_LAYER_NAMES = ["ln_1.weight", "ln_1.bias", "attn.c_attn.weight", "attn.c_at
 class _Arena:
     """fp32 master + bf16 operand copy (+ lazily a gradient arena and AdamW state) for one parameter family."""
 
-    def __init__(self, n: int, device, sync_fn=None):
+    def __init__(self, n: int, device, sync_fn=None, op_dtype: int = OP_BF16):
         self.n = n
         self.device = torch.device(device)
         self.sync_fn = sync_fn   # (w32_ptr, w16_ptr, stream) -> rc : cast + transposed GEMM-weight copies
+        self.op_dtype = op_dtype
         self.w32 = torch.zeros(n, dtype=torch.float32, device=self.device)
-        # [0,n): bf16 cast of the master; [n,2n): transposed copies of the GEMM weights (include/clipcap_hip.h Conventions)
-        self.w16 = torch.zeros(2 * n, dtype=torch.bfloat16, device=self.device) if self.device.type == "cuda" else None
+        # [0,n): 16-bit cast of the master (bf16 or fp16, cfg.op_dtype); [n,2n): transposed copies of the GEMM weights
+        # (include/clipcap_hip.h Conventions)
+        self.w16 = torch.zeros(2 * n, dtype=torch.float16 if op_dtype == OP_FP16 else torch.bfloat16, device=self.device) \
+            if self.device.type == "cuda" else None
         self.g32: Optional[torch.Tensor] = None
         self.m: Optional[torch.Tensor] = None
         self.v: Optional[torch.Tensor] = None
@@ -72,10 +75,18 @@ class _Arena:
         check(self.sync_fn(_p(self.w32), _p(self.w16), _stream(self.device)), "cc_*_sync_weights")
         self._w16_version = self._stamp()
 
+    def set_op_dtype(self, op_dtype: int) -> None:
+        """Switch the 16-bit operand copy between bf16 and fp16 (re-cast lazily from the fp32 master)."""
+        if op_dtype != self.op_dtype:
+            self.op_dtype = op_dtype
+            if self.w16 is not None:
+                self.w16 = torch.zeros(2 * self.n, dtype=torch.float16 if op_dtype == OP_FP16 else torch.bfloat16, device=self.device)
+            self._w16_version = -1
+
     def moved_to(self, device, sync_fn) -> "_Arena":
         """A copy of this arena on `device` carrying the master, the gradient arena and the AdamW moments (resume() followed by
         .to(device) must not lose the optimizer state)."""
-        new = _Arena(self.n, device, sync_fn)
+        new = _Arena(self.n, device, sync_fn, self.op_dtype)
         new.w32.copy_(self.w32)
         for name in ("g32", "m", "v"):
             t = getattr(self, name)
@@ -88,29 +99,59 @@ class _Arena:
             self.g32 = torch.zeros(self.n, dtype=torch.float32, device=self.device)
         return self.g32
 
-    def adamw_step(self, lr: float, step: int, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, grad_scale: float = 1.0):
-        """torch.optim.AdamW math (reference model.py:73-77) over the whole arena, refreshing the bf16 copy."""
+    def adamw_step(self, lr: float, step: int, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, grad_scale: float = 1.0,
+                   scaler: Optional["LossScaler"] = None):
+        """torch.optim.AdamW math (reference model.py:73-77) over the whole arena, refreshing the 16-bit operand copy.
+        ``scaler`` (fp16 operands): the gradients carry its loss scale, and a step whose backward overflowed is skipped on the device."""
         if self.m is None:
             self.m = torch.zeros_like(self.w32)
             self.v = torch.zeros_like(self.w32)
-        check(_lib.lib().cc_adamw_step(_p(self.w32), _p(self.grads()), _p(self.m), _p(self.v), None, self.n, lr, betas[0], betas[1],
-                                       eps, weight_decay, step, grad_scale, _stream(self.device)), "cc_adamw_step")
+        check(_lib.lib().cc_adamw_step(_p(self.w32), _p(self.grads()), _p(self.m), _p(self.v), self.n, lr, betas[0], betas[1], eps,
+                                       weight_decay, step, grad_scale, _p(scaler.scale) if scaler is not None else None,
+                                       _p(scaler.found_inf) if scaler is not None else None, _stream(self.device)), "cc_adamw_step")
         self.refresh_bf16()
+
+
+class LossScaler:
+    """Dynamic loss scale for fp16-operand training, torch.cuda.amp.GradScaler semantics (init 2^16, x2 every 2000 good steps, x0.5
+    on overflow) — what Lightning wraps around the reference's model for ``--fp-precision 16`` — kept entirely on the device:
+    ``state`` = [scale, good-step counter], ``found_inf`` is raised by cc_grad_nonfinite and read by cc_adamw_step (which then skips
+    the step) and by cc_loss_scale_update.  No host synchronisation anywhere."""
+
+    def __init__(self, device, init_scale: float = 65536.0, growth: float = 2.0, backoff: float = 0.5, interval: int = 2000):
+        self.device = torch.device(device)
+        self.state = torch.tensor([init_scale, 0.0], dtype=torch.float32, device=self.device)
+        self.found_inf = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.growth, self.backoff, self.interval = growth, backoff, interval
+
+    @property
+    def scale(self) -> torch.Tensor:
+        return self.state[0:1]
+
+    def check(self, arena: "_Arena") -> None:
+        """Raise found_inf if the arena's (scaled) gradients hold an inf / nan.  Multi-GPU: call after the all-reduce."""
+        check(_lib.lib().cc_grad_nonfinite(_p(arena.grads()), arena.n, _p(self.found_inf), _stream(self.device)), "cc_grad_nonfinite")
+
+    def update(self) -> None:
+        """After the optimizer steps of this iteration: adjust the scale and clear found_inf."""
+        check(_lib.lib().cc_loss_scale_update(_p(self.state), _p(self.found_inf), self.growth, self.backoff, self.interval,
+                                              _stream(self.device)), "cc_loss_scale_update")
 
 
 class MapperEngine:
     """TransformerMapper / TransformerMapperWindowed (reference clipcap/model/mapper.py:113-160) on the HIP library."""
 
     def __init__(self, E: int, D: int, prefix_length: int, projection_length: int, num_heads: int, num_layers: int, window: int = 1,
-                 use_pos: bool = False, device="cpu"):
+                 use_pos: bool = False, device="cpu", precision=None):
         self.dims = dict(E=E, D=D, P=projection_length, L=prefix_length, H=num_heads, N=num_layers, Hm=int(D * 2.0), W=window,
                          use_pos=int(bool(use_pos) and window > 1))
-        self.cfg = MapperCfg(**self.dims)
+        self.op_dtype = op_dtype_of(precision)
+        self.cfg = MapperCfg(op_dtype=self.op_dtype, **self.dims)
         l = _lib.lib()
         n = l.cc_mapper_param_count(C.byref(self.cfg))
         if n < 0:
             raise _lib.CCError(f"unsupported mapper configuration {self.dims}: dims must be multiples of 8 (head dim too)")
-        self.arena = _Arena(n, device, self._sync)
+        self.arena = _Arena(n, device, self._sync, self.op_dtype)
         offs = (C.c_int64 * (4 + 12 * num_layers))()
         check(l.cc_mapper_param_offsets(C.byref(self.cfg), offs))
         self.offsets = list(offs)
@@ -149,6 +190,13 @@ class MapperEngine:
         self.arena = self.arena.moved_to(device, self._sync)
         self._ws.clear()
         return self
+
+    def set_precision(self, precision) -> None:
+        """16 -> fp16 operands (the reference's --fp-precision 16), 32 / 64 / 'bf16' -> bf16 operands.  fp32 master unchanged."""
+        self.op_dtype = op_dtype_of(precision)
+        self.cfg.op_dtype = self.op_dtype
+        self.arena.set_op_dtype(self.op_dtype)
+        self._ws.clear()
 
     def _workspace(self, B: int, save: int) -> torch.Tensor:
         key = (B, save)
@@ -219,14 +267,15 @@ class MapperEngine:
 class Gpt2Engine:
     """HF GPT2LMHeadModel arithmetic (transformers modeling_gpt2.py) on the HIP library; arena keeps HF layouts."""
 
-    def __init__(self, n_embd: int, n_head: int, n_layer: int, vocab_size: int, n_positions: int, device="cpu"):
+    def __init__(self, n_embd: int, n_head: int, n_layer: int, vocab_size: int, n_positions: int, device="cpu", precision=None):
         self.dims = dict(D=n_embd, H=n_head, NL=n_layer, V=vocab_size, Vp=(vocab_size + 127) // 128 * 128, NPOS=n_positions)
-        self.cfg = Gpt2Cfg(**self.dims)
+        self.op_dtype = op_dtype_of(precision)
+        self.cfg = Gpt2Cfg(op_dtype=self.op_dtype, **self.dims)
         l = _lib.lib()
         n = l.cc_gpt2_param_count(C.byref(self.cfg))
         if n < 0:
             raise _lib.CCError(f"unsupported GPT-2 configuration {self.dims}")
-        self.arena = _Arena(n, device, self._sync)
+        self.arena = _Arena(n, device, self._sync, self.op_dtype)
         offs = (C.c_int64 * (2 + 12 * n_layer + 2))()
         check(l.cc_gpt2_param_offsets(C.byref(self.cfg), offs))
         self.offsets = list(offs)
@@ -249,14 +298,18 @@ class Gpt2Engine:
 
     views = MapperEngine.views
     to = MapperEngine.to
+    set_precision = MapperEngine.set_precision
 
     def layer_span(self, l: int) -> Tuple[int, int]:
         lo = self.offsets[2 + 12 * l]
         hi = self.offsets[2 + 12 * (l + 1)]      # the entry after the last layer is ln_f.weight
         return lo, hi
 
-    def shape(self, B: int, L: int, T: int, cap: int, mode: int) -> Gpt2Shape:
-        return Gpt2Shape(B, L, T, cap, mode)
+    def shape(self, B: int, L: int, T: int, cap: int, mode: int, dropout=None) -> Gpt2Shape:
+        """dropout: optional (p_embd, p_attn, p_resid, seed) of this pass (full finetune in train mode); None = eval behaviour."""
+        if dropout is None:
+            return Gpt2Shape(B, L, T, cap, mode, 0.0, 0.0, 0.0, 0)
+        return Gpt2Shape(B, L, T, cap, mode, float(dropout[0]), float(dropout[1]), float(dropout[2]), int(dropout[3]) & 0xFFFFFFFFFFFFFFFF)
 
     def workspace(self, shp: Gpt2Shape) -> torch.Tensor:
         """One buffer per mode, grown on demand: the library carves its layout from the base pointer on every call, so a buffer
@@ -298,6 +351,31 @@ class ClipCapEngine:
         self.gpt2 = gpt2
         self.train_lm = train_lm
         self.stats: Optional[torch.Tensor] = None
+        # fp16 operands: the backward pass runs under a dynamic loss scale (gradients in g32 are scale x the true ones until
+        # optimizer_step divides it out); bf16 operands need none
+        self.scaler: Optional[LossScaler] = None
+
+    def _scaler(self, dev) -> Optional[LossScaler]:
+        if OP_FP16 not in (self.gpt2.op_dtype, self.mapper.op_dtype):
+            return None
+        if self.scaler is None or self.scaler.device != dev:
+            self.scaler = LossScaler(dev)
+        return self.scaler
+
+    def arenas(self) -> List[_Arena]:
+        return [self.mapper.arena] + ([self.gpt2.arena] if self.train_lm else [])
+
+    def optimizer_step(self, lr: float, step: int, **adamw_kw) -> None:
+        """AdamW over every trained arena (reference model.py:67-91).  With fp16 operands: overflow check of the scaled gradients
+        (after any all-reduce), the step is skipped on the device if they overflowed, then the loss scale is adjusted."""
+        sc = self.scaler
+        if sc is not None:
+            for a in self.arenas():
+                sc.check(a)
+        for a in self.arenas():
+            a.adamw_step(lr, step, scaler=sc, **adamw_kw)
+        if sc is not None:
+            sc.update()
 
     def forward_backward(self, tokens: torch.Tensor, embeds: torch.Tensor, reduce_stats=None, backward: bool = True,
                          on_grads_ready=None, dropout=None) -> torch.Tensor:
@@ -310,7 +388,10 @@ class ClipCapEngine:
         arena 0 (mapper) / 1 (GPT-2) are enqueued, in the order backward finishes them (GPT-2 top layers first, mapper last), so
         the caller can launch the all-reduce of that slice underneath the remaining backward kernels.
         ``dropout``: optional (p_embd, p_attn, p_resid, seed) — GPT-2 train-mode dropout for this step (full finetune; the masks
-        are a hash of (seed, site, layer, element) regenerated by the backward kernels, cc_gpt2_set_dropout).
+        are a hash of (seed, site, layer, element) regenerated by the backward kernels; the setting travels in this pass's
+        cc_gpt2_shape, so concurrent engines on other streams are unaffected).
+        With fp16 operands the gradients left in the arenas are multiplied by the current loss scale (self.scaler.scale);
+        optimizer_step() divides it out.
         """
         l = _lib.lib()
         g, m = self.gpt2, self.mapper
@@ -321,20 +402,13 @@ class ClipCapEngine:
         L = m.dims["L"]
         T = L + cap
         mode = 2 if self.train_lm else 1
-        shp = g.shape(B, L, T, cap, mode)
+        shp = g.shape(B, L, T, cap, mode, dropout)
         ws = g.workspace(shp)
         g.arena.sync_bf16()
         st = _stream(dev)
         ga = g.arena
         prefix = m.forward(embeds, save=True)
-        if dropout is not None:
-            check(l.cc_gpt2_set_dropout(float(dropout[0]), float(dropout[1]), float(dropout[2]), int(dropout[3]) & 0xFFFFFFFFFFFFFFFF),
-                  "cc_gpt2_set_dropout")
-        try:
-            return self._forward_backward(l, g, m, ga, shp, ws, st, prefix, tokens, reduce_stats, backward, on_grads_ready, dev)
-        finally:
-            if dropout is not None:
-                l.cc_gpt2_set_dropout(0.0, 0.0, 0.0, 0)          # the setting is process-global: never leak it into eval / decode
+        return self._forward_backward(l, g, m, ga, shp, ws, st, prefix, tokens, reduce_stats, backward, on_grads_ready, dev)
 
     def _forward_backward(self, l, g, m, ga, shp, ws, st, prefix, tokens, reduce_stats, backward, on_grads_ready, dev):
         check(l.cc_gpt2_embed(C.byref(g.cfg), C.byref(shp), _p(ga.w32), _p(prefix), _p(tokens), _p(ws), st), "cc_gpt2_embed")
@@ -348,7 +422,9 @@ class ClipCapEngine:
         if backward:
             g32 = ga.grads() if self.train_lm else None
             denom = stats[1:2]
-            check(l.cc_lmhead_ce_bwd(C.byref(g.cfg), C.byref(shp), _p(ga.w32), _p(ga.w16), _p(ws), _p(denom), _p(g32), st), "cc_lmhead_ce_bwd")
+            sc = self._scaler(dev)
+            check(l.cc_lmhead_ce_bwd(C.byref(g.cfg), C.byref(shp), _p(ga.w32), _p(ga.w16), _p(ws), _p(denom),
+                                     _p(sc.scale) if sc is not None else None, _p(g32), st), "cc_lmhead_ce_bwd")
             dprefix = torch.empty_like(prefix)
             if on_grads_ready is None or not self.train_lm:
                 check(l.cc_gpt2_bwd(C.byref(g.cfg), C.byref(shp), _p(ga.w32), _p(ga.w16), _p(ws), _p(tokens), _p(dprefix), _p(g32), st), "cc_gpt2_bwd")
@@ -385,7 +461,7 @@ class DecodeSession:
         self.pos = 0
         d = gpt2.dims
         dev = gpt2.arena.device
-        self.kv = torch.empty(d["NL"] * 2 * rows * self.ctx_max * d["D"], dtype=torch.bfloat16, device=dev)
+        self.kv = torch.empty(d["NL"] * 2 * rows * self.ctx_max * d["D"], dtype=gpt2.arena.w16.dtype, device=dev)
         self.row_map = torch.arange(rows, dtype=torch.int32, device=dev).view(rows, 1).repeat(1, self.ctx_max).contiguous()
         self._ws: Dict[int, torch.Tensor] = {}
         self._logits: Optional[torch.Tensor] = None

@@ -54,6 +54,12 @@ class ArenaModule(nn.Module):
         for name, p in self._arena_params.items():
             p.grad = g[name]
 
+    def set_precision(self, precision):
+        """16 = fp16 GEMM / attention operands (the reference's ``--fp-precision 16``, clipcap/train/args.py:30-34; training then
+        runs under a dynamic loss scale); 32 / 64 / "bf16" = bf16 operands.  Master weights, accumulation and the optimizer stay fp32."""
+        self.engine.set_precision(precision)
+        return self
+
     @property
     def device(self):
         return self.engine.arena.device

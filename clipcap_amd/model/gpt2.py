@@ -50,14 +50,14 @@ class _TiedHead(nn.Module):
 class GPT2LM(ArenaModule):
     def __init__(self, n_embd: int = 768, n_layer: int = 12, n_head: int = 12, vocab_size: int = 50257, n_positions: int = 1024,
                  initializer_range: float = 0.02, name_or_path: str = "", embd_pdrop: float = 0.1, attn_pdrop: float = 0.1,
-                 resid_pdrop: float = 0.1):
+                 resid_pdrop: float = 0.1, precision=None):
         super().__init__()
         # *_pdrop: GPT2Config defaults (0.1); they act only in train mode of a full finetune (ClipCapModel), through the HIP kernels'
-        # counter-based masks (cc_gpt2_set_dropout)
+        # counter-based masks (cc_gpt2_shape.p_embd / p_attn / p_resid / drop_seed)
         self.config = SimpleNamespace(n_embd=n_embd, n_layer=n_layer, n_head=n_head, vocab_size=vocab_size, n_positions=n_positions,
                                       initializer_range=initializer_range, name_or_path=name_or_path, embd_pdrop=embd_pdrop,
                                       attn_pdrop=attn_pdrop, resid_pdrop=resid_pdrop)
-        self.engine = Gpt2Engine(n_embd, n_head, n_layer, vocab_size, n_positions)
+        self.engine = Gpt2Engine(n_embd, n_head, n_layer, vocab_size, n_positions, precision=precision)
         self._bind_parameters()
         self.lm_head = _TiedHead(self._arena_params["transformer.wte.weight"])
         self._emb = _Embedding(self)

@@ -45,12 +45,12 @@ class _MapperFn(torch.autograd.Function):
 
 class TransformerMapper(ArenaModule):
     def __init__(self, encoder_embedding_size: int, lm_embedding_size: int, prefix_length: int, projection_length: int,
-                 num_heads: int = 8, num_layers: int = 8, *, window_size: int = 1, use_pos_embeddings: bool = False):
+                 num_heads: int = 8, num_layers: int = 8, *, window_size: int = 1, use_pos_embeddings: bool = False, precision=None):
         super().__init__()
         self.projection_length = projection_length
         self.window_size = window_size
         self.engine = MapperEngine(encoder_embedding_size, lm_embedding_size, prefix_length, projection_length, num_heads, num_layers,
-                                   window=window_size, use_pos=use_pos_embeddings)
+                                   window=window_size, use_pos=use_pos_embeddings, precision=precision)
         self._bind_parameters()
         self.reset_parameters()
 

@@ -46,6 +46,9 @@ class _StepLoss(torch.autograd.Function):
         outs = []
         mg = model.transformer_mapper.engine.views(model.transformer_mapper.engine.arena.grads())
         lg = model.language_model.engine.views(model.language_model.engine.arena.grads()) if model._train_lm else {}
+        sc = model.engine.scaler          # fp16 operands: the arenas hold loss-scale x gradient
+        if sc is not None:
+            gout = gout / sc.scale
         for owner, name in model._param_index:
             src = mg if owner == 0 else lg
             outs.append(src[name] * gout if name in src else None)
@@ -109,10 +112,16 @@ class ClipCapModel(nn.Module):
         else:
             loss = eng.forward_backward(tokens, embeds, dropout=self._dropout())
         self._opt_step += 1
-        self.transformer_mapper.engine.arena.adamw_step(lr, self._opt_step)
-        if self._train_lm:
-            self.language_model.engine.arena.adamw_step(lr, self._opt_step)
+        eng.optimizer_step(lr, self._opt_step)
         return loss
+
+    def set_precision(self, precision) -> "ClipCapModel":
+        """What the reference hands to ``pl.Trainer(precision=args.fp_precision)`` (clipcap/train/train.py:82): 16 selects fp16 MFMA
+        operands + dynamic loss scaling for mapper and language model, 32 / 64 the default bf16 operands."""
+        self.transformer_mapper.set_precision(precision)
+        self.language_model.set_precision(precision)
+        self._engine = None
+        return self
 
     # ---- reference surface ----
     def forward(self, tokens: torch.Tensor, embeddings: torch.Tensor, mask: Optional[torch.Tensor] = None):

@@ -9,7 +9,7 @@ _GROUPS = {
         ("--epochs", int, 5, "Passes over the training data."),
         ("--optimizer-lr", float, 2e-5, "AdamW learning rate."),
         ("--scheduler-warmup-steps", int, 5000, "Linear warm-up length in optimizer steps."),
-        ("--fp-precision", int, 32, "Accepted for compatibility (16/32/64); GEMMs run bf16 x bf16 -> fp32, master weights fp32."),
+        ("--fp-precision", int, 32, "Floating point precision (16/32/64): 16 = fp16 MFMA operands + dynamic loss scaling, 32/64 = bf16 operands; fp32 accumulate and master weights."),
         ("--checkpoint-save-frequency", int, 1, "Write a checkpoint every n epochs."),
         ("--checkpoint-filename-prefix", str, 1, "Checkpoint file name prefix."),
         ("--device", str, "0", "GPU index, comma list, or -1 for all (one process per GPU via torchrun)."),

@@ -41,7 +41,7 @@ def train(args: Namespace, tokenizer=None, language_model=None) -> int:
     config.training_config = TrainingConfig.from_args(args)
     config.encoder_config = encoder_config
     cls = ClipCapModel if args.train_language_model else ClipCapModelPrefixOnly  # train.py:46-50
-    model = cls(config, language_model=language_model).to(device)
+    model = cls(config, language_model=language_model).set_precision(args.fp_precision).to(device)   # train.py:82 precision=
     model.train()
     step, first_epoch = 0, 0
     if getattr(args, "resume_from", None):

@@ -7,14 +7,23 @@
  *
  * Conventions
  *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless it says "host".
- *   - the caller owns every buffer (parameters, gradients, optimizer state, workspace, KV cache).  The library keeps
- *     no global state and never allocates or synchronises; all work is enqueued on the caller's hipStream_t
- *     (passed as void*; NULL = default stream).
+ *   - the caller owns every buffer (parameters, gradients, optimizer state, workspace, KV cache).  The compute entry
+ *     points keep no state and never allocate or synchronise; all work is enqueued on the caller's hipStream_t (passed
+ *     as void*; NULL = default stream), so calls on different streams / from different host threads are independent.
+ *     Per-step settings (GPT-2 dropout, loss scale) travel in the call's own arguments.  The only process-wide state is
+ *     the three test / measurement hooks at the end of this file (cc_gemm_tile_mode, cc_gemm_skinny_mode, cc_prof_*),
+ *     which the product path never touches.
  *   - return value: 0 = ok, <0 = error (CC_ERR_*), never throws across the ABI.
- *   - bf16 tensors are raw 16-bit patterns (uint16_t), round-to-nearest-even like torch.bfloat16.
+ *   - OPERAND TYPE.  GEMM / attention operands and the stored 16-bit activations are bf16 (CC_OP_BF16, default) or IEEE
+ *     fp16 (CC_OP_FP16 = the reference's `--fp-precision 16`, clipcap/train/args.py:30-34), selected per model by
+ *     cfg->op_dtype; accumulation, master weights, residual streams, LayerNorm statistics, the loss and the optimizer are
+ *     fp32 in both.  16-bit tensors cross the ABI as raw bit patterns (uint16_t), round-to-nearest-even like
+ *     torch.bfloat16 / torch.float16.  fp16 training runs its backward pass under a loss scale (cc_lmhead_ce_bwd,
+ *     cc_grad_nonfinite, cc_loss_scale_update, cc_adamw_step) exactly as torch.cuda.amp.GradScaler does for the
+ *     reference's Lightning fp16 path.
  *   - parameters live in flat arenas whose element offsets are defined by cc_*_param_offsets(); the fp32 arena is
- *     the master copy (nn.Parameter views alias it).  The bf16 operand arena has 2*count elements: [0,count) is the
- *     bf16 cast of the master (same offsets, reference state-dict layouts: torch.nn.Linear weight [out,in]; HF Conv1D
+ *     the master copy (nn.Parameter views alias it).  The 16-bit operand arena has 2*count elements: [0,count) is the
+ *     cast of the master (same offsets, reference state-dict layouts: torch.nn.Linear weight [out,in]; HF Conv1D
  *     weight [in,out]); [count, 2*count) holds, at the same offsets, the TRANSPOSE of every 2-D GEMM weight, so that
  *     forward and dgrad GEMMs are both "NT" (both operands K-contiguous, the direct-to-LDS fast path).  It is
  *     refreshed from the master by cc_mapper_sync_weights / cc_gpt2_sync_weights after every optimizer step.
@@ -34,8 +43,11 @@ extern "C" {
 #define CC_ERR_LAUNCH (-3)
 #define CC_ERR_STATE (-4)
 
-#define CC_ABI_VERSION 1
+#define CC_ABI_VERSION 2
 int cc_abi_version(void);
+
+#define CC_OP_BF16 0
+#define CC_OP_FP16 1
 
 /* ------------------------------------------------------------------------------------------------------------
  * Mapper: clipcap/model/mapper.py:113-130 TransformerMapper (+ :133-160 windowed), layers :91-110, MLP :70-88,
@@ -51,6 +63,7 @@ typedef struct {
     int32_t Hm;      /* MLP hidden = int(D * 2.0) (mapper.py:10,100) */
     int32_t W;       /* window count (1 = TransformerMapper; window_size+1 for TransformerMapperWindowed, model.py:28) */
     int32_t use_pos; /* windowed: learned pos_embeddings present (mapper.py:142-145) */
+    int32_t op_dtype; /* CC_OP_BF16 / CC_OP_FP16: type of the w16 arena and of every 16-bit activation of this model */
 } cc_mapper_cfg;
 
 /* number of per-model tensors ahead of the layers (linear.weight, linear.bias, prefix_const, pos_embeddings) */
@@ -95,6 +108,7 @@ typedef struct {
     int32_t V;     /* vocab_size */
     int32_t Vp;    /* vocab rows of the arenas' wte: V rounded up to a multiple of 128 (zero rows) */
     int32_t NPOS;  /* n_positions */
+    int32_t op_dtype; /* CC_OP_BF16 / CC_OP_FP16 (see Conventions) */
 } cc_gpt2_cfg;
 
 #define CC_GPT2_HEAD_TENSORS 2   /* wte [Vp,D], wpe [NPOS,D] */
@@ -111,6 +125,13 @@ typedef struct {
     int32_t T;     /* total rows per sample (prefix + caption tokens) */
     int32_t cap;   /* row stride of `tokens` (int64 [B, cap]); the loss uses T-L = cap columns */
     int32_t mode;  /* 0 inference (no activations kept); 1 training, frozen LM (dgrad only); 2 full finetune (+wgrad) */
+    /* GPT-2 dropout of THIS pass (full finetune in train mode: the reference's ClipCapModel leaves the HF GPT-2 in train mode,
+     * model.py:19; hf modeling_gpt2.py: embd_pdrop on inputs+positions, attn_pdrop on the attention probabilities, resid_pdrop
+     * after both c_proj).  Masks are a counter-based hash of (drop_seed, site, layer, element) regenerated by the backward
+     * kernels — nothing is stored; cc_gpt2_embed / cc_gpt2_fwd / cc_gpt2_bwd(_range) of one pass must be given the same values.
+     * All-zero probabilities = eval behaviour (ClipCapModelPrefixOnly keeps GPT-2 in eval, model.py:120-123). */
+    float p_embd, p_attn, p_resid;
+    uint64_t drop_seed;
 } cc_gpt2_shape;
 
 int64_t cc_gpt2_param_count(const cc_gpt2_cfg* cfg);
@@ -138,9 +159,12 @@ int cc_gpt2_logits(const cc_gpt2_cfg* cfg, const cc_gpt2_shape* shp, const float
 int cc_lmhead_ce_fwd(const cc_gpt2_cfg* cfg, const cc_gpt2_shape* shp, const float* w32, const uint16_t* w16, void* ws,
                      const int64_t* tokens, float* stats, void* stream);
 /* backward of the above through lm_head and ln_f into the residual-stream gradient kept in the workspace.
- * denom (device float[1]) = divisor of the mean (local or all-reduced kept-row count).  g32 may be NULL unless mode 2. */
+ * denom (device float[1]) = divisor of the mean (local or all-reduced kept-row count).  loss_scale (device float[1], NULL = 1):
+ * every gradient of this backward pass (dprefix and what is accumulated into the g32 arenas) is multiplied by it — fp16 operands
+ * need it to keep d logits = (softmax - onehot) / denom above the fp16 underflow threshold; cc_adamw_step divides it out again.
+ * g32 may be NULL unless mode 2. */
 int cc_lmhead_ce_bwd(const cc_gpt2_cfg* cfg, const cc_gpt2_shape* shp, const float* w32, const uint16_t* w16, void* ws,
-                     const float* denom, float* g32, void* stream);
+                     const float* denom, const float* loss_scale, float* g32, void* stream);
 /* backward through the blocks.  dprefix fp32 [B, L, D] receives d loss / d prefix (rows 0..L-1 of d x0).
  * mode 2 additionally accumulates all GPT-2 weight gradients (incl. wte/wpe) into g32. */
 int cc_gpt2_bwd(const cc_gpt2_cfg* cfg, const cc_gpt2_shape* shp, const float* w32, const uint16_t* w16, void* ws,
@@ -184,22 +208,25 @@ int cc_beam_advance(const cc_gpt2_cfg* cfg, int32_t R, int32_t beam, const float
 
 /* ------------------------------------------------------------------------------------------------------------
  * Optimizer / casts: torch.optim.AdamW as configured by model.py:73-77 (lr schedule is computed by the caller,
- * model.py:79-83).  Flat over one arena; refreshes the bf16 operand copy (p16 may be NULL).
+ * model.py:79-83), flat over one arena.  The gradient used is g32 * grad_scale / (*loss_scale) (loss_scale: device float[1],
+ * NULL = 1).  found_inf (device float[1], NULL = never): a non-zero value skips the update of every element — the step a
+ * GradScaler drops when the scaled fp16 backward overflowed — and leaves m, v and the parameters untouched.
  * ------------------------------------------------------------------------------------------------------------ */
-int cc_adamw_step(float* p32, const float* g32, float* m, float* v, uint16_t* p16, int64_t n, float lr, float beta1, float beta2,
-                  float eps, float weight_decay, int32_t step, float grad_scale, void* stream);
-int cc_cast_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
+int cc_adamw_step(float* p32, const float* g32, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int32_t step, float grad_scale, const float* loss_scale, const float* found_inf, void* stream);
+/* dst = cast of src to the 16-bit operand type op_dtype */
+int cc_cast_op16(int32_t op_dtype, const float* src, uint16_t* dst, int64_t n, void* stream);
+/* Dynamic loss scaling for CC_OP_FP16 training (torch.cuda.amp.GradScaler semantics; what Lightning wraps around the reference's
+ * model when --fp-precision 16, clipcap/train/train.py:77-85), entirely on the device:
+ *   cc_grad_nonfinite: *found_inf = 1 if any of the n gradients is inf / nan (never clears it; call once per arena, after the
+ *                      all-reduce in a multi-GPU step so that every rank takes the same decision);
+ *   cc_loss_scale_update: state[0] = scale, state[1] = consecutive good steps.  found_inf != 0: scale *= backoff, counter = 0;
+ *                      else counter += 1 and, at `interval`, scale *= growth and counter = 0.  Clears *found_inf. */
+int cc_grad_nonfinite(const float* g32, int64_t n, float* found_inf, void* stream);
+int cc_loss_scale_update(float* state, float* found_inf, float growth, float backoff, int32_t interval, void* stream);
 
-/* ------------------------------------------------------------------------------------------------------------
- * GPT-2 dropout for full-finetune training (reference: ClipCapModel in train mode leaves the HF GPT-2 in train mode, model.py:19;
- * hf modeling_gpt2.py: embd_pdrop on inputs+positions, attn_pdrop on the attention probabilities, resid_pdrop after both c_proj).
- * Masks are a counter-based hash of (seed, site, layer, element) regenerated in the backward pass — nothing is stored.  The
- * setting is process-global: call before a step's cc_gpt2_embed; cc_gpt2_fwd / cc_gpt2_bwd(_range) of that step read the same
- * values.  All-zero probabilities (the default) = eval behaviour (ClipCapModelPrefixOnly keeps GPT-2 in eval, model.py:120-123).
- * cc_dropout_mask (test hook) writes keep flags of one stream: site 0 embd [B*T*D], 1 attention [B*H*T*T], 2 residual after
- * attn.c_proj [B*T*D], 3 residual after mlp.c_proj [B*T*D].
- * ------------------------------------------------------------------------------------------------------------ */
-int cc_gpt2_set_dropout(float p_embd, float p_attn, float p_resid, uint64_t seed);
+/* test hook for the dropout of cc_gpt2_shape: keep flags of one mask stream — site 0 embd [B*T*D], 1 attention [B*H*T*T],
+ * 2 residual after attn.c_proj [B*T*D], 3 residual after mlp.c_proj [B*T*D]. */
 int cc_dropout_mask(uint64_t seed, int32_t site, int32_t layer, float p, int64_t n, uint8_t* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -219,34 +246,37 @@ int cc_sample_step(const float* logits, int32_t R, int32_t V, int32_t ld, float 
                    float* probs_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
- * Unit-test hook: one bf16 MFMA GEMM C = A·B (+bias) with fp32 output, any of the three operand layouts
+ * Unit-test hooks (first argument op_dtype = CC_OP_BF16 / CC_OP_FP16: the type of the 16-bit tensors).
+ * cc_gemm_op16_f32: one MFMA GEMM C = A·B (+bias) with fp32 output, any of the three operand layouts
  * (al/bl: 0 = [rows][K], 1 = [K][rows]); ksplit>1 accumulates atomically into C (caller zeroes C).
  * ------------------------------------------------------------------------------------------------------------ */
-int cc_gemm_bf16_f32(int32_t al, int32_t bl, const uint16_t* A, int32_t lda, const uint16_t* B, int32_t ldb, int32_t M, int32_t N,
+int cc_gemm_op16_f32(int32_t op_dtype, int32_t al, int32_t bl, const uint16_t* A, int32_t lda, const uint16_t* B, int32_t ldb, int32_t M, int32_t N,
                      int32_t K, float* C, int32_t ldc, const float* bias, int32_t ksplit, void* stream);
 /* Weight-gradient GEMM as the backward passes run it: dW[Mw][Nw] += X^T Y with X stored [K][Mw], Y stored [K][Nw] (bf16), fp32
  * accumulation into dW; K is split into slices whose partial sums go through `scratch` (cc_wgrad_scratch_bytes() bytes, device). */
 int64_t cc_wgrad_scratch_bytes(void);
-int cc_gemm_wgrad(const uint16_t* X, int32_t ldx, const uint16_t* Y, int32_t ldy, int32_t Mw, int32_t Nw, int32_t K, float* dW, int32_t ldw,
+int cc_gemm_wgrad(int32_t op_dtype, const uint16_t* X, int32_t ldx, const uint16_t* Y, int32_t ldy, int32_t Mw, int32_t Nw, int32_t K, float* dW, int32_t ldw,
                   float* scratch, void* stream);
-/* NT GEMM tile choice: -1 = cost-model chooser (default), 0 = 128x128 kernels only (also for cc_gemm_wgrad), 3 / 4 = force the 256x192 / 256x256
- * kernel wherever it is legal.  Process-global; returns the previous mode.  For tests and tools/gemm_bench.py only. */
+/* PROCESS-WIDE test knob.  NT GEMM tile choice: -1 = cost-model chooser (default), 0 = 128x128 kernels only (also for cc_gemm_wgrad), 3 / 4 =
+ * force the 256x192 / 256x256 kernel wherever it is legal.  Returns the previous mode.  For tests and tools/gemm_bench.py only. */
 int cc_gemm_tile_mode(int32_t mode);
 /* Decode-sized NT GEMMs (M <= 640 rows: cc_decode_fwd's c_attn / c_proj / c_fc at rows x beams = 320) run on 64-row tiles
  * (gemm_nt_s64_kernel).  -1 = default (those call sites only), 0 = never, 1 / 2 = additionally route cc_gemm_bf16_f32's NT launches with
- * M <= 1024 through the 64 x 64 / 64 x 128 / 64 x 64 K-split-over-waves (3) form.  Process-global; returns the previous mode.  For tests and tools/small_gemm_bench.py. */
+ * M <= 1024 through the 64 x 64 / 64 x 128 / 64 x 64 K-split-over-waves (3) form.  PROCESS-WIDE test knob; returns the previous mode.  For tests and
+ * tools/small_gemm_bench.py. */
 int cc_gemm_skinny_mode(int32_t mode);
-int cc_layernorm_fwd(const float* x, const float* gamma, const float* beta, uint16_t* y, float* mean, float* rstd, int32_t rows,
+int cc_layernorm_fwd(int32_t op_dtype, const float* x, const float* gamma, const float* beta, uint16_t* y, float* mean, float* rstd, int32_t rows,
                      int32_t D, void* stream);
-int cc_attention_fwd(const uint16_t* qkv, int32_t B, int32_t S, int32_t H, int32_t hd, int32_t causal, uint16_t* out, float* lse,
+int cc_attention_fwd(int32_t op_dtype, const uint16_t* qkv, int32_t B, int32_t S, int32_t H, int32_t hd, int32_t causal, uint16_t* out, float* lse,
                      void* stream);
 /* o = forward output and delta_ws = fp32 scratch [B*H*S] select the MFMA kernels (hd 64/96/128); NULL -> LDS/VALU kernel */
-int cc_attention_bwd(const uint16_t* qkv, const uint16_t* dout, const uint16_t* o, const float* lse, float* delta_ws, int32_t B, int32_t S,
+int cc_attention_bwd(int32_t op_dtype, const uint16_t* qkv, const uint16_t* dout, const uint16_t* o, const float* lse, float* delta_ws, int32_t B, int32_t S,
                      int32_t H, int32_t hd, int32_t causal, uint16_t* dqkv, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
- * Measurement aid for bench.py's roofline line: brackets every launch of ONE GEMM call site with HIP events recorded
- * on the launch stream.  This is the only process-global state in the library and is off by default.
+ * Measurement aid for bench.py's roofline line: brackets every launch of ONE GEMM call site — or, with CC_SITE_ALL_GEMMS, every
+ * GEMM host launch of the library — with HIP events recorded on the launch stream.  PROCESS-WIDE, off by default, never used by
+ * the product path.
  * ------------------------------------------------------------------------------------------------------------ */
 #define CC_SITE_LMHEAD_FWD 1      /* [B*cap, D] x wte^T           (cc_lmhead_ce_fwd) */
 #define CC_SITE_LMHEAD_DGRAD 2    /* dlogits [B*cap, Vp] x wte    (cc_lmhead_ce_bwd) */
@@ -256,9 +286,11 @@ int cc_attention_bwd(const uint16_t* qkv, const uint16_t* dout, const uint16_t* 
 #define CC_SITE_MAPPER_FC1_FWD 6  /* fc1 [B*S, D] x [Hm, D]^T     (cc_mapper_fwd) */
 #define CC_SITE_MAPPER_QKV_FWD 7  /* fused q/kv projection         (cc_mapper_fwd) */
 #define CC_SITE_MAPPER_WGRAD_FC2 8 /* dW2 = dx^T h (split-K)       (cc_mapper_bwd) */
+#define CC_SITE_ALL_GEMMS 100      /* every MFMA GEMM launch (forward, dgrad, wgrad, lm_head, decode), with its 2*M*N*K */
 int cc_prof_start(int32_t site, int32_t max_samples);
-/* waits for the recorded events; writes up to *n (in: capacity, out: count) durations in milliseconds (host arrays) */
-int cc_prof_stop(float* ms_host, int32_t* n_host);
+/* waits for the recorded events; writes up to *n (in: capacity, out: count) durations in milliseconds and (flops_host nullable) the
+ * algorithmic FLOPs 2*M*N*K of each bracketed launch (host arrays) */
+int cc_prof_stop(float* ms_host, double* flops_host, int32_t* n_host);
 
 #ifdef __cplusplus
 }

@@ -10,8 +10,9 @@ reference's so a reference checkpoint can be fed to these func
 
 ``rb=True`` switches on "bf16 rounding points": every tensor the HIP kernels hold in bf16 (GEMM operands,
 stored qkv / attention output / MLP hidden / logits-for-backward) is rounded to bf16 at the same place the
-kernels round it, with fp32 accumulation everywhere.  That is the like-for-like yardstick for the 1e-3
-logits target (SURVEY.md §7 "Tolerance").
+kernels round it, with fp32 accumulation everywhere.  ``rb="fp16"`` does the same with IEEE half, the operand
+type of the kernels' fp16 build (the reference's ``--fp-precision 16``).  That is the like-for-like yardstick
+for the 1e-3 logits target (SURVEY.md §7 "Tolerance").
 """
 from __future__ import annotations
 
@@ -24,9 +25,12 @@ import torch.nn.functional as F
 Tensor = torch.Tensor
 
 
-def _r(t: Tensor, rb: bool) -> Tensor:
-    """bf16 rounding point (identity unless rb)."""
-    return t.bfloat16().float() if rb else t
+def _r(t: Tensor, rb) -> Tensor:
+    """16-bit rounding point: identity unless rb; rb = True / "bf16" rounds to bf16, rb = "fp16" to IEEE half (the operand type of
+    the kernels' --fp-precision 16 build).  Works for fp32 and fp64 tensors (the noise-floor runs evaluate the same points in fp64)."""
+    if not rb:
+        return t
+    return t.to(torch.float16 if rb == "fp16" else torch.bfloat16).to(t.dtype)
 
 
 def _linear(x: Tensor, w: Tensor, b: Optional[Tensor], rb: bool) -> Tensor:

@@ -44,7 +44,17 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(l, name), f"{name} declared in clipcap_hip.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
-    assert l.cc_abi_version() == 1
+    assert l.cc_abi_version() == 2
+    # both operand-type builds are linked in: every dispatched entry point exists as <name>_bf16 and <name>_f16
+    for name in ("cc_mapper_fwd", "cc_gpt2_fwd", "cc_decode_fwd", "cc_lmhead_ce_fwd", "cc_attention_fwd"):
+        assert hasattr(l, name + "_bf16") and hasattr(l, name + "_f16"), name
+
+
+def test_abi_dispatch_file_is_current():
+    """clipcap_amd/csrc/abi_dispatch.cpp is generated from include/clipcap_hip.h (tools/gen_abi.py): stale output = missing symbols."""
+    import subprocess
+    import sys
+    assert subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_abi.py"), "--check"]).returncode == 0
 
 
 def test_param_layout_matches_reference_counts():

@@ -22,10 +22,10 @@ from tests.util import load_golden, sampled, seeded_full_model
 pytestmark = pytest.mark.gpu
 
 
-def _engines(sd, dims):
+def _engines(sd, dims, precision=None):
     from clipcap_amd.engine import ClipCapEngine, Gpt2Engine, MapperEngine
-    me = MapperEngine(dims["E"], dims["D"], dims["L"], dims["P"], dims["H"], dims["N"], device="cuda")
-    ge = Gpt2Engine(dims["D"], dims["n_head"], dims["NL"], dims["V"], dims["NPOS"], device="cuda")
+    me = MapperEngine(dims["E"], dims["D"], dims["L"], dims["P"], dims["H"], dims["N"], device="cuda", precision=precision)
+    ge = Gpt2Engine(dims["D"], dims["n_head"], dims["NL"], dims["V"], dims["NPOS"], device="cuda", precision=precision)
     for pre, eng in (("transformer_mapper.", me), ("language_model.", ge)):
         for k, v in eng.views(eng.arena.w32).items():
             v.copy_(sd[pre + k])
@@ -36,10 +36,14 @@ def _rel(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-20))
 
 
-def _full_model_case(name, tol):
+def _full_model_case(name, tol, precision=None):
+    """precision None = bf16 operands (oracle with bf16 rounding points), 16 = fp16 operands (oracle with fp16 rounding points; the
+    gradients in the arenas then carry the engine's loss scale)."""
     g = load_golden(name)
     sd, cfg, dims = seeded_full_model(g)
-    me, ge, eng = _engines(sd, dims)
+    me, ge, eng = _engines(sd, dims, precision)
+    rb = "fp16" if precision == 16 else True
+    pts = "fp16 points" if precision == 16 else "bf16 points"
     tokens, embeds = torch.from_numpy(g["in.tokens"]), torch.from_numpy(g["in.embeds"])
     L, V, cap, B = dims["L"], dims["V"], tokens.shape[1], tokens.shape[0]
     valid = torch.cat((torch.ones(B, L, dtype=torch.bool), tokens.ge(0)), dim=1)
@@ -51,9 +55,9 @@ def _full_model_case(name, tol):
     x = torch.cat((prefix, wte[tokens.clamp_min(0)].cuda()), dim=1)
     logits = ge.logits(x).cpu()
     with torch.no_grad():
-        ref_rb = O.clipcap_logits(sd, tokens.clamp_min(0), embeds, cfg=cfg, rb=True)
+        ref_rb = O.clipcap_logits(sd, tokens.clamp_min(0), embeds, cfg=cfg, rb=rb)
         pre_rb = O.mapper_forward(sd, embeds, projection_length=dims["P"], num_heads=dims["H"], num_layers=dims["N"],
-                                  pre="transformer_mapper.", rb=True)
+                                  pre="transformer_mapper.", rb=rb)
     e_pre_rb = float((prefix.cpu() - pre_rb).abs().max())
     e_pre_32 = float((prefix.cpu() - torch.from_numpy(g["prefix"])).abs().max())
     e_rb = float(((logits - ref_rb) * valid[:, :, None]).abs().max())
@@ -61,28 +65,30 @@ def _full_model_case(name, tol):
     e_32 = max(float(((logits[:, :, cols] - torch.from_numpy(g["logits.cols"])) * valid[:, :, None]).abs().max()),
                float(((logits[:, rows, :] - torch.from_numpy(g["logits.rows"])) * valid[:, rows, None]).abs().max()))
     drift = max(float(((ref_rb[:, :, cols] - torch.from_numpy(g["logits.cols"])) * valid[:, :, None]).abs().max()), 1e-9)
-    print(f"{name}: prefix |max| {float(torch.from_numpy(g['prefix']).abs().max()):.2f}: vs oracle(bf16 points) {e_pre_rb:.3e}, vs reference fp32 "
-          f"{e_pre_32:.3e};  logits |max| {float(g['logits.absmax']):.2f}: vs oracle(bf16 points) {e_rb:.3e}, vs reference fp32 {e_32:.3e} "
-          f"(bf16-points oracle vs reference fp32: {drift:.3e})")
+    print(f"{name}: prefix |max| {float(torch.from_numpy(g['prefix']).abs().max()):.2f}: vs oracle({pts}) {e_pre_rb:.3e}, vs reference fp32 "
+          f"{e_pre_32:.3e};  logits |max| {float(g['logits.absmax']):.2f}: vs oracle({pts}) {e_rb:.3e}, vs reference fp32 {e_32:.3e} "
+          f"({pts} oracle vs reference fp32: {drift:.3e})")
     pscale = float(torch.from_numpy(g["prefix"]).abs().max())
     assert e_pre_rb <= tol["prefix_rb"] * pscale and e_pre_32 <= tol["prefix_32"] * pscale
     assert e_rb <= tol["logits_rb"] and e_32 <= tol["logits_32"]
     assert e_32 <= 2.0 * drift + 1e-3          # no further from the reference than the rounding points themselves put the oracle
+    out = dict(e_rb=e_rb, e_32=e_32, drift=drift, e_pre_rb=e_pre_rb, e_pre_32=e_pre_32)
 
     # ---- training step: loss + gradients (model.py:94-113) ----
     eng.zero_grad()
     loss = float(eng.forward_backward(tokens.cuda(), embeds.cuda()))
     train = [k for k in sd if dims["full"] or k.startswith("transformer_mapper.")]
     sdr = {k: (v.clone().requires_grad_(True) if k in train else v) for k, v in sd.items()}
-    ref_loss = O.clipcap_loss(sdr, tokens, embeds, cfg=cfg, rb=True)
+    ref_loss = O.clipcap_loss(sdr, tokens, embeds, cfg=cfg, rb=rb)
     ref_loss.backward()
-    print(f"{name}: loss {loss:.6f}; oracle(bf16 points) {float(ref_loss):.6f}; reference fp32 {float(g['loss']):.6f}")
+    print(f"{name}: loss {loss:.6f}; oracle({pts}) {float(ref_loss):.6f}; reference fp32 {float(g['loss']):.6f}")
     assert abs(loss - float(ref_loss)) <= tol["loss_rb"] and abs(loss - float(g["loss"])) <= tol["loss_32"]
+    unscale = 1.0 / float(eng.scaler.scale) if eng.scaler is not None else 1.0
     gm, gg = me.views(me.arena.g32), (ge.views(ge.arena.g32) if dims["full"] else {})
     worst_rb, worst_32, n = ("", 0.0), ("", 0.0), 0
     for k in train:
         mine = gm[k[len("transformer_mapper."):]] if k.startswith("transformer_mapper.") else gg[k[len("language_model."):]]
-        mine = mine.cpu()
+        mine = mine.cpu() * unscale
         if k.endswith("wte.weight"):
             mine = mine[:V]
         r = _rel(mine, sdr[k].grad)
@@ -96,8 +102,10 @@ def _full_model_case(name, tol):
         assert abs(nrm - ref_n) <= tol["grad_32"] * ref_n, (k, nrm, ref_n)
         assert rs <= tol["grad_32"], (k, rs)
         n += 1
-    print(f"{name}: {n} gradient tensors; worst rel. L2 vs oracle(bf16 points) {worst_rb[1]:.3e} ({worst_rb[0]}); worst vs reference fp32 "
+    out.update(grad_rb=worst_rb[1], grad_32=worst_32[1], loss=loss)
+    print(f"{name}: {n} gradient tensors; worst rel. L2 vs oracle({pts}) {worst_rb[1]:.3e} ({worst_rb[0]}); worst vs reference fp32 "
           f"(strided sample) {worst_32[1]:.3e} ({worst_32[0]})")
+    return out
 
 
 def test_config2_full_depth_logits_loss_grads():

@@ -1,0 +1,141 @@
+"""fp16 operand mode (the reference's ``--fp-precision 16``, clipcap/train/args.py:30-34 -> Lightning AMP fp16 + GradScaler) on the
+HIP path: cfg.op_dtype = CC_OP_FP16 selects the fp16 build of every kernel (v_mfma_f32_*_f16, fp16 activations, fp32 accumulate
+and master weights); training runs under a device-side dynamic loss scale.
+
+north_star: "logits matching the reference PyTorch path within 1e-3 fp16 on identical inputs".  Measured against the reference's
+own fp32 logits of the FULL-depth configs[1] model (tests/golden/config2_full: 8-layer mapper + 12-layer GPT-2-small, D=768) and
+against the oracle evaluated with fp16 rounding points.  Yardstick: the reference's own fp16-autocast drift on this architecture is
+3.4e-3.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import clipcap_oracle as O
+from tests.test_gpu_configs import _full_model_case
+from tests.util import load_golden, sd_of
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fp16_full_depth_config2_logits_within_1e3_of_reference():
+    """8 + 12 layers, D=768, V=50257, B=2: every logit of every loss-relevant row vs the REFERENCE's fp32 logits."""
+    r = _full_model_case("config2_full", dict(prefix_rb=1e-3, prefix_32=1.5e-3, logits_rb=2e-3, logits_32=2e-3, loss_rb=2e-4, loss_32=2e-4,
+                                              grad_rb=1e-2, grad_32=1e-2), precision=16)
+    # the north-star bar, stated: max |logit - reference fp32 logit| over 2 x 50 rows x (1024 strided + 3 full) vocabulary columns
+    print(f"fp16 operands, config2 full depth: max |logits - reference fp32| = {r['e_32']:.3e} (bar 1e-3; reference's own fp16 autocast 3.4e-3)")
+    assert r["e_32"] <= 1e-3, r
+    assert r["e_rb"] <= 1e-3, r
+
+
+def test_fp16_full_depth_config4_medium():
+    """E=1024 -> D=1024 mapper (hd 128) + 24-layer GPT-2-medium, full finetune, fp16 operands: logits, loss, mapper + GPT-2 gradients
+    (unscaled by the engine's loss scale) vs the fp16-points oracle and the reference."""
+    r = _full_model_case("config4_full", dict(prefix_rb=1e-3, prefix_32=1.5e-3, logits_rb=3e-3, logits_32=3e-3, loss_rb=3e-4, loss_32=3e-4,
+                                              grad_rb=2e-2, grad_32=2e-2), precision=16)
+    print(f"fp16 operands, config4 full depth: max |logits - reference fp32| = {r['e_32']:.3e}")
+
+
+def _tiny_model(mode, precision):
+    from clipcap_amd.encoders import EncoderConfig
+    from clipcap_amd.model import ClipCapModel, ClipCapModelPrefixOnly, Config, TrainingConfig
+    from clipcap_amd.model.gpt2 import GPT2LM
+    g = load_golden(f"train_{mode}")
+    E, D, P, L, H, N, n_head, n_layer, V, npos = [int(v) for v in g["cfg"]]
+    lm = GPT2LM(n_embd=D, n_layer=n_layer, n_head=n_head, vocab_size=V, n_positions=npos, embd_pdrop=0.0, attn_pdrop=0.0, resid_pdrop=0.0)
+    cfg = Config(language_model="unused", train_language_model=(mode == "full"), prefix_length=L, projection_length=P, transformer_layers=N,
+                 transformer_attention_heads=H, encoder_config=EncoderConfig(encoder_embedding_size=E),
+                 training_config=TrainingConfig(optimizer_lr=1e-3, use_deepspeed_optimisers=False, scheduler_warmup_steps=2, total_steps=6))
+    m = (ClipCapModel if mode == "full" else ClipCapModelPrefixOnly)(cfg, language_model=lm)
+    m.load_state_dict(sd_of(g), strict=True)
+    return m.set_precision(precision).to("cuda"), g
+
+
+@pytest.mark.parametrize("mode", ["prefix_only", "full"])
+def test_fp16_three_optimizer_steps_with_loss_scaling(mode):
+    """fused_step x3 with fp16 operands: the loss trajectory follows the reference's (tests/golden/train_*), the loss scale stays at
+    its initial 2^16 (no overflow on a healthy model), and the gradients in the arena are exactly scale x the unscaled ones."""
+    from clipcap_amd.model.optim import linear_warmup_decay
+    m, g = _tiny_model(mode, 16)
+    m.train()
+    assert m.language_model.engine.arena.w16.dtype == torch.float16 and m.transformer_mapper.engine.cfg.op_dtype == 1
+    tokens, embeds = torch.from_numpy(g["in.tokens"]).cuda(), torch.from_numpy(g["in.embeds"]).cuda()
+    sched = linear_warmup_decay(2, 6)
+    losses = [float(m.fused_step((tokens.clone(), embeds), lr=1e-3 * sched(s))) for s in range(3)]
+    print(mode, "fp16 losses", losses, "golden", g["losses"])
+    assert np.abs(np.array(losses) - g["losses"]).max() <= 5e-3          # bf16 operands: 3e-2
+    sc = m.engine.scaler
+    assert sc is not None and float(sc.scale) == 65536.0 and float(sc.state[1]) == 3.0 and float(sc.found_inf) == 0.0
+    # gradients of the first step vs the reference's (grad0.*), through the engine directly so that the arena can be inspected
+    m2, _ = _tiny_model(mode, 16)
+    m2.train()
+    eng = m2.engine
+    eng.zero_grad()
+    eng.forward_backward(tokens.clone(), embeds)
+    scale = float(eng.scaler.scale)
+    gv = m2.transformer_mapper.engine.views(m2.transformer_mapper.engine.arena.g32)
+    worst = 0.0
+    for k, v in gv.items():
+        ref = torch.from_numpy(g["grad0.transformer_mapper." + k])
+        rel = float((v.cpu() / scale - ref).norm() / ref.norm().clamp_min(1e-12))
+        worst = max(worst, rel)
+        assert rel <= 8e-3, (k, rel)
+    print(mode, "fp16 worst relative mapper-gradient error vs the reference:", worst)
+
+
+def test_fp16_overflow_skips_the_step_and_backs_off():
+    """An overflowing backward (forced by an absurd loss scale) raises found_inf: parameters and moments are untouched, the scale
+    halves, and the next healthy step trains again — GradScaler behaviour, with no host synchronisation in the step."""
+    m, g = _tiny_model("prefix_only", 16)
+    m.train()
+    tokens, embeds = torch.from_numpy(g["in.tokens"]).cuda(), torch.from_numpy(g["in.embeds"]).cuda()
+    eng = m.engine
+    m.fused_step((tokens.clone(), embeds), lr=1e-3)
+    a = m.transformer_mapper.engine.arena
+    before = (a.w32.clone(), a.m.clone(), a.v.clone())
+    eng.scaler.state[0] = 2.0 ** 40                     # fp16 activation gradients overflow at this scale
+    m.fused_step((tokens.clone(), embeds), lr=1e-3)
+    assert torch.equal(a.w32, before[0]) and torch.equal(a.m, before[1]) and torch.equal(a.v, before[2])
+    assert float(eng.scaler.scale) == 2.0 ** 39 and float(eng.scaler.found_inf) == 0.0
+    eng.scaler.state[0] = 65536.0
+    m.fused_step((tokens.clone(), embeds), lr=1e-3)
+    assert not torch.equal(a.w32, before[0]) and torch.isfinite(a.w32).all()
+
+
+def test_fp16_full_size_step_and_decode():
+    """configs[1] at bench size (B=256) with fp16 operands: finite gradients, no overflow at the initial scale, loss equal to the bf16
+    run's to bf16 noise; KV-cached decode == re-forward with the fp16 kernels."""
+    import bench
+    from clipcap_amd.engine import DecodeSession
+    c = dict(bench.CONFIGS["2"])
+    dev = torch.device("cuda", 0)
+    me, ge, eng = bench.init_engines(c, dev)
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    embeds = torch.randn(c["B"], c["E"], generator=gen, device="cuda")
+    tokens = torch.randint(1, c["V"], (c["B"], c["cap"]), generator=gen, device="cuda")
+    tokens[::7, 30:] = -1
+    eng.zero_grad()
+    l_bf = float(eng.forward_backward(tokens, embeds))
+    g_bf = me.arena.g32.clone()
+    for e in (me, ge):
+        e.set_precision(16)
+    from clipcap_amd.engine import ClipCapEngine
+    eng16 = ClipCapEngine(me, ge, train_lm=False)
+    me.arena.g32.zero_()
+    l_16 = float(eng16.forward_backward(tokens, embeds))
+    eng16.scaler.check(me.arena)
+    g_16 = me.arena.g32 / float(eng16.scaler.scale)
+    assert float(eng16.scaler.found_inf) == 0.0 and torch.isfinite(g_16).all()
+    rel = float((g_16 - g_bf).norm() / g_bf.norm())
+    print(f"config 2, B=256: loss bf16 {l_bf:.5f} fp16 {l_16:.5f}; mapper gradient fp16 vs bf16 rel. L2 {rel:.3e}")
+    assert abs(l_bf - l_16) <= 2e-3 and rel <= 3e-2
+    torch.manual_seed(1)
+    x = torch.randn(4, 14, c["D"], device="cuda") * 0.3
+    full = ge.logits(x)
+    sess = DecodeSession(ge, 4, 32)
+    l = sess.forward(x[:, :10]).clone()
+    scale = max(1.0, full.abs().max().item())
+    assert (l - full[:, 9]).abs().max().item() <= 2e-3 * scale
+    for t in range(10, 14):
+        l = sess.forward(x[:, t:t + 1])
+        assert (l - full[:, t]).abs().max().item() <= 2e-3 * scale, t

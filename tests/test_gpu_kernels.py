@@ -1,5 +1,6 @@
 """GPU parity of the individual HIP kernels, called through the C ABI (ctypes), against torch fp32 math on the SAME
-bf16-rounded inputs.  Asymmetric random operands everywhere (a transposed result cannot pass)."""
+16-bit-rounded inputs — every test runs for both operand types of the library (bf16, and fp16 = the reference's --fp-precision 16).
+Asymmetric random operands everywhere (a transposed result cannot pass)."""
 import ctypes as C
 
 import pytest
@@ -21,8 +22,18 @@ def _st():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+OP = [0, torch.bfloat16]       # [cfg.op_dtype value, torch dtype] of the running parametrisation
+
+
+@pytest.fixture(autouse=True, params=["bf16", "fp16"])
+def op_dtype(request):
+    OP[0], OP[1] = (0, torch.bfloat16) if request.param == "bf16" else (1, torch.float16)
+    yield request.param
+    OP[0], OP[1] = 0, torch.bfloat16
+
+
 def _bf(t):
-    return t.to(torch.bfloat16)
+    return t.to(OP[1])
 
 
 @pytest.mark.parametrize("al,bl", [(0, 0), (0, 1), (1, 1)])
@@ -37,7 +48,7 @@ def test_gemm_layouts(al, bl, M, N, K):
     Ast = A.t().contiguous() if al else A.contiguous()            # al=1: stored [K][M]
     Bst = B.contiguous() if bl else B.t().contiguous()            # bl=0: stored [N][K]
     Cm = torch.full((M, N + 8), float("nan"), device=dev)
-    rc = _lib().cc_gemm_bf16_f32(al, bl, _p(Ast), Ast.shape[1], _p(Bst), Bst.shape[1], M, N, K, _p(Cm), N + 8, _p(bias), 1, _st())
+    rc = _lib().cc_gemm_op16_f32(OP[0], al, bl, _p(Ast), Ast.shape[1], _p(Bst), Bst.shape[1], M, N, K, _p(Cm), N + 8, _p(bias), 1, _st())
     assert rc == 0
     torch.cuda.synchronize()
     err = (Cm[:, :N] - ref).abs().max().item()
@@ -58,7 +69,7 @@ def test_gemm_nt_256_row_tiles(mode, M, N, K):
     Cm = torch.full((M, N + 8), float("nan"), device=dev)
     old = _lib().cc_gemm_tile_mode(mode)
     try:
-        rc = _lib().cc_gemm_bf16_f32(0, 0, _p(A), K, _p(Bt), K, M, N, K, _p(Cm), N + 8, _p(bias), 1, _st())
+        rc = _lib().cc_gemm_op16_f32(OP[0], 0, 0, _p(A), K, _p(Bt), K, M, N, K, _p(Cm), N + 8, _p(bias), 1, _st())
         torch.cuda.synchronize()
     finally:
         _lib().cc_gemm_tile_mode(old)
@@ -84,7 +95,7 @@ def test_gemm_nt_skinny_64_row_tiles(mode, M, N, K, ks):
     Cm = C0.clone()
     old = _lib().cc_gemm_skinny_mode(mode)
     try:
-        rc = _lib().cc_gemm_bf16_f32(0, 0, _p(A), K, _p(Bt), K, M, N, K, _p(Cm), N + 8, _p(bias), ks, _st())
+        rc = _lib().cc_gemm_op16_f32(OP[0], 0, 0, _p(A), K, _p(Bt), K, M, N, K, _p(Cm), N + 8, _p(bias), ks, _st())
         torch.cuda.synchronize()
     finally:
         _lib().cc_gemm_skinny_mode(old)
@@ -109,7 +120,7 @@ def test_gemm_wgrad_kernels(mode, K, Mw, Nw):
     scratch = torch.empty(_lib().cc_wgrad_scratch_bytes(), dtype=torch.uint8, device=dev)
     old = _lib().cc_gemm_tile_mode(mode)
     try:
-        rc = _lib().cc_gemm_wgrad(_p(X), Mw, _p(Y), Nw, Mw, Nw, K, _p(dW), Nw + 4, _p(scratch), _st())
+        rc = _lib().cc_gemm_wgrad(OP[0], _p(X), Mw, _p(Y), Nw, Mw, Nw, K, _p(dW), Nw + 4, _p(scratch), _st())
         torch.cuda.synchronize()
     finally:
         _lib().cc_gemm_tile_mode(old)
@@ -128,7 +139,7 @@ def test_gemm_wgrad_split_k_atomic(ksplit):
     Y = _bf(torch.randn(Kk, Nw, device=dev))
     ref = X.float().t() @ Y.float()
     Cm = torch.zeros(Mw, Nw, device=dev)
-    rc = _lib().cc_gemm_bf16_f32(1, 1, _p(X), Mw, _p(Y), Nw, Mw, Nw, Kk, _p(Cm), Nw, None, ksplit, _st())
+    rc = _lib().cc_gemm_op16_f32(OP[0], 1, 1, _p(X), Mw, _p(Y), Nw, Mw, Nw, Kk, _p(Cm), Nw, None, ksplit, _st())
     assert rc == 0
     torch.cuda.synchronize()
     assert (Cm - ref).abs().max().item() <= 5e-3
@@ -139,7 +150,7 @@ def test_gemm_rejects_misaligned():
     A = _bf(torch.randn(16, 20, device=dev))
     B = _bf(torch.randn(16, 20, device=dev))
     Cm = torch.zeros(16, 16, device=dev)
-    assert _lib().cc_gemm_bf16_f32(0, 0, _p(A), 20, _p(B), 20, 16, 16, 20, _p(Cm), 16, None, 1, _st()) == -2
+    assert _lib().cc_gemm_op16_f32(OP[0], 0, 0, _p(A), 20, _p(B), 20, 16, 16, 20, _p(Cm), 16, None, 1, _st()) == -2
 
 
 @pytest.mark.parametrize("rows,D", [(7, 64), (130, 768), (33, 1024), (5, 1600)])
@@ -148,10 +159,10 @@ def test_layernorm_fwd(rows, D):
     x = torch.randn(rows, D, device="cuda") * 2 + 0.3
     g = torch.randn(D, device="cuda")
     b = torch.randn(D, device="cuda")
-    y = torch.empty(rows, D, dtype=torch.bfloat16, device="cuda")
+    y = torch.empty(rows, D, dtype=OP[1], device="cuda")
     mean = torch.empty(rows, device="cuda")
     rstd = torch.empty(rows, device="cuda")
-    assert _lib().cc_layernorm_fwd(_p(x), _p(g), _p(b), _p(y), _p(mean), _p(rstd), rows, D, _st()) == 0
+    assert _lib().cc_layernorm_fwd(OP[0], _p(x), _p(g), _p(b), _p(y), _p(mean), _p(rstd), rows, D, _st()) == 0
     ref = torch.nn.functional.layer_norm(x, (D,), g, b, 1e-5)
     torch.cuda.synchronize()
     assert (mean - x.mean(1)).abs().max() <= 1e-5
@@ -181,9 +192,9 @@ def test_attention_fwd_bwd(B, S, H, hd, causal, mfma_bwd):
     torch.manual_seed(S * 3 + hd)
     D = H * hd
     qkv = _bf(torch.randn(B * S, 3 * D, device="cuda"))
-    out = torch.empty(B * S, D, dtype=torch.bfloat16, device="cuda")
+    out = torch.empty(B * S, D, dtype=OP[1], device="cuda")
     lse = torch.empty(B, H, S, device="cuda")
-    assert _lib().cc_attention_fwd(_p(qkv), B, S, H, hd, causal, _p(out), _p(lse), _st()) == 0
+    assert _lib().cc_attention_fwd(OP[0], _p(qkv), B, S, H, hd, causal, _p(out), _p(lse), _st()) == 0
     qkv_r = qkv.float().requires_grad_(True)
     ref, lse_ref = _attn_ref(qkv_r, B, S, H, hd, causal)
     torch.cuda.synchronize()
@@ -194,7 +205,7 @@ def test_attention_fwd_bwd(B, S, H, hd, causal, mfma_bwd):
     dout = _bf(torch.randn(B * S, D, device="cuda"))
     dqkv = torch.full_like(qkv, float("nan"))
     delta = torch.empty(B * H * S, device="cuda")
-    rc = _lib().cc_attention_bwd(_p(qkv), _p(dout), _p(out) if mfma_bwd else None, _p(lse), _p(delta) if mfma_bwd else None, B, S, H, hd, causal,
+    rc = _lib().cc_attention_bwd(OP[0], _p(qkv), _p(dout), _p(out) if mfma_bwd else None, _p(lse), _p(delta) if mfma_bwd else None, B, S, H, hd, causal,
                                  _p(dqkv), _st())
     assert rc == 0
     ref.backward(dout.float().view(B, S, D))
@@ -206,7 +217,9 @@ def test_attention_fwd_bwd(B, S, H, hd, causal, mfma_bwd):
     assert rel <= 1e-2 and err <= 3e-2 * max(1.0, g.abs().max().item()), (rel, err)
 
 
-def test_adamw_matches_torch():
+def test_adamw_matches_torch_and_loss_scaling_rules():
+    """cc_adamw_step == torch.optim.AdamW (model.py:73-77 defaults); with a loss scale the scaled gradients give the same update; a
+    raised found_inf skips the step; cc_grad_nonfinite / cc_loss_scale_update follow torch.cuda.amp.GradScaler."""
     torch.manual_seed(0)
     n = 4096 + 64
     p = torch.randn(n, device="cuda")
@@ -214,12 +227,35 @@ def test_adamw_matches_torch():
     opt = torch.optim.AdamW([ref_p], lr=3e-3)
     m = torch.zeros(n, device="cuda")
     v = torch.zeros(n, device="cuda")
-    p16 = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+    scale = torch.tensor([1024.0, 0.0], device="cuda")
+    found = torch.zeros(1, device="cuda")
+    l = _lib()
     for step in range(1, 4):
         g = torch.randn(n, device="cuda")
         ref_p.grad = g.clone()
         opt.step()
-        assert _lib().cc_adamw_step(_p(p), _p(g), _p(m), _p(v), _p(p16), n, 3e-3, 0.9, 0.999, 1e-8, 0.01, step, 1.0, _st()) == 0
+        if step == 2:      # scaled gradients + loss-scale pointer == unscaled gradients
+            gs = g * 1024.0
+            assert l.cc_adamw_step(_p(p), _p(gs), _p(m), _p(v), n, 3e-3, 0.9, 0.999, 1e-8, 0.01, step, 1.0, _p(scale), _p(found), _st()) == 0
+        else:
+            assert l.cc_adamw_step(_p(p), _p(g), _p(m), _p(v), n, 3e-3, 0.9, 0.999, 1e-8, 0.01, step, 1.0, None, None, _st()) == 0
     torch.cuda.synchronize()
     assert (p - ref_p.detach()).abs().max().item() <= 2e-6
-    assert torch.equal(p16, p.to(torch.bfloat16))
+    # overflow: found_inf is raised by an inf or a nan anywhere, the step is skipped, the scale halves and the flag clears
+    before = (p.clone(), m.clone(), v.clone())
+    for bad in (float("inf"), float("nan")):
+        g = torch.randn(n, device="cuda")
+        g[n - 3] = bad
+        assert l.cc_grad_nonfinite(_p(g), n, _p(found), _st()) == 0
+        assert float(found) == 1.0
+        assert l.cc_adamw_step(_p(p), _p(g), _p(m), _p(v), n, 3e-3, 0.9, 0.999, 1e-8, 0.01, 4, 1.0, _p(scale), _p(found), _st()) == 0
+        assert torch.equal(p, before[0]) and torch.equal(m, before[1]) and torch.equal(v, before[2])
+        s0 = float(scale[0])
+        assert l.cc_loss_scale_update(_p(scale), _p(found), 2.0, 0.5, 3, _st()) == 0
+        assert float(scale[0]) == s0 * 0.5 and float(scale[1]) == 0.0 and float(found) == 0.0
+    g = torch.randn(n, device="cuda")
+    assert l.cc_grad_nonfinite(_p(g), n, _p(found), _st()) == 0 and float(found) == 0.0
+    s0 = float(scale[0])
+    for i in range(3):     # growth after `interval` consecutive good steps
+        assert l.cc_loss_scale_update(_p(scale), _p(found), 2.0, 0.5, 3, _st()) == 0
+        assert float(scale[0]) == (s0 if i < 2 else 2 * s0) and float(scale[1]) == (i + 1 if i < 2 else 0)

@@ -16,7 +16,7 @@ def run(al, bl, M, N, K, ks, iters=20):
     A = torch.randn((K, M) if al else (M, K), device="cuda").bfloat16()
     B = torch.randn((K, N) if bl else (N, K), device="cuda").bfloat16()
     Cm = torch.zeros(M, N, device="cuda")
-    f = lambda: lib.cc_gemm_bf16_f32(al, bl, P(A), A.shape[1], P(B), B.shape[1], M, N, K, P(Cm), N, None, ks, st())
+    f = lambda: lib.cc_gemm_op16_f32(0, al, bl, P(A), A.shape[1], P(B), B.shape[1], M, N, K, P(Cm), N, None, ks, st())
     for _ in range(3):
         assert f() == 0
     torch.cuda.synchronize()

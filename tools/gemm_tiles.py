@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""NT GEMM tile-kernel comparison behind the chooser in gemm.cuh: per shape, the 128x128, 256x192 and 256x256 kernels are timed
+"""NT GEMM tile-kernel comparison behind the chooser in gemm.hip.h: per shape, the 128x128, 256x192 and 256x256 kernels are timed
 interleaved (3 rounds, >= 20 ms each, best round kept) so clock drift does not favour one of them."""
 import ctypes as C
 import sys
@@ -18,7 +18,7 @@ SHAPES = [(10240, 50304, 768), (10240, 768, 50304), (12800, 2304, 768), (12800, 
 
 def time_mode(mode, A, B, Cm, M, N, K):
     lib.cc_gemm_tile_mode(mode)
-    f = lambda: lib.cc_gemm_bf16_f32(0, 0, P(A), K, P(B), K, M, N, K, P(Cm), N, None, 1, st())
+    f = lambda: lib.cc_gemm_op16_f32(0, 0, 0, P(A), K, P(B), K, M, N, K, P(Cm), N, None, 1, st())
     assert f() == 0
     iters = max(5, int(20e-3 / (2.0 * M * N * K / 600e12)))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

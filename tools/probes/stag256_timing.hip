@@ -1,7 +1,7 @@
 // Where does a K-step of the 256-row staggered GEMM kernel go?  Includes the product header with CC_STAMP (cycle stamps around each
 // phase of the main loop, wave 0 of either group of one block).
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -DCC_STAMP -I../../clipcap_amd/csrc -o stag256_timing stag256_timing.hip
-#include "gemm.cuh"
+#include "gemm.hip.h"
 #include <cstdio>
 #include <vector>
 using namespace cc;

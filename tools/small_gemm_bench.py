@@ -18,7 +18,7 @@ for M, N, K in shapes:
     A = torch.randn(M, K, device="cuda").bfloat16()
     B = torch.randn(N, K, device="cuda").bfloat16()
     Cm = torch.zeros(M, N, device="cuda")
-    f = lambda: lib.cc_gemm_bf16_f32(0, 0, P(A), K, P(B), K, M, N, K, P(Cm), N, None, 1, st())
+    f = lambda: lib.cc_gemm_op16_f32(0, 0, 0, P(A), K, P(B), K, M, N, K, P(Cm), N, None, 1, st())
     for _ in range(3):
         assert f() == 0
     ref = A.float() @ B.float().t()

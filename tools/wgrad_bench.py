@@ -31,7 +31,7 @@ def main():
         for _ in range(3):
             for mode in (0, 4, -1):
                 lib.cc_gemm_tile_mode(mode)
-                f = lambda: lib.cc_gemm_wgrad(P(X), Mw, P(Y), Nw, Mw, Nw, K, P(dW), Nw, P(scratch), st())
+                f = lambda: lib.cc_gemm_wgrad(0, P(X), Mw, P(Y), Nw, Mw, Nw, K, P(dW), Nw, P(scratch), st())
                 assert f() == 0
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
