@@ -39,6 +39,10 @@ CONFIGS = {
 }
 
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
+# Offline PMC measurements quoted in the JSON line (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 gfx950
+# correction; see the profile files).  They describe the build the profile was taken from; bench.py itself does not read counters.
+LMHEAD_TRAFFIC = {"bytes": (2 * 604061 + 1097837) * 1024, "source": "profiles/r01_i_pmc_fetch_write.md (offline PMC, round 1 build)"}
+DECODE_TRAFFIC = {"bytes": 3.18e9, "source": "profiles/r01_p_decode_kernel_stats.md (offline PMC, round 1 build)"}
 
 
 def mapper_flops_fwd(c):   # 2*E*P*D + N*[S*2*D*(D+2D+D+rD+rD) + 4*S^2*D], r=2
@@ -82,13 +86,13 @@ def init_engines(c, device, seed=1234):
     return me, ge, ClipCapEngine(me, ge, c["train_lm"])
 
 
-def cpu_baseline(c, max_seconds=25.0):
+def cpu_baseline(c, warm=3, timed=10, max_seconds=75.0):
     """The CPU oracle (oracle/clipcap_oracle.py, fp32 torch-CPU restatement pinned to the reference's golden outputs) timed on
-    this box's host cores on a bounded sample of the same workload: the same model at batch 16 (BASELINE configs[0] size)."""
+    this box's host cores on a bounded sample of the same workload: the same model at batch 16 (BASELINE configs[0] size),
+    BASELINE.md 3: 3 warm-up + 10 timed training steps (fwd + bwd + AdamW + schedule), median step time; stops early at max_seconds."""
     from oracle import clipcap_oracle as O
     torch.manual_seed(0)
     Bc = 16
-    me, ge, _ = None, None, None
     from clipcap_amd.engine import Gpt2Engine, MapperEngine
     me = MapperEngine(c["E"], c["D"], c["L"], c["P"], c["H"], c["N"], device="cpu")
     ge = Gpt2Engine(c["D"], c["n_head"], c["n_layer"], c["V"], c["npos"], device="cpu")
@@ -110,29 +114,63 @@ def cpu_baseline(c, max_seconds=25.0):
     v = {k: torch.zeros_like(sd[k]) for k in train}
     times = []
     t_begin = time.time()
-    step = 0
-    while True:
+    for step in range(warm + timed):
         t0 = time.time()
         for k in train:
             sd[k].grad = None
         loss = O.clipcap_loss(sd, tokens, embeds, cfg=cfg)
         loss.backward()
+        lr = 2e-5 * O.linear_schedule_factor(step, 2, warm + timed + 1)
         with torch.no_grad():
             for k in train:
-                pn, m[k], v[k] = O.adamw_step(sd[k], sd[k].grad, m[k], v[k], step + 1, 2e-5)
+                pn, m[k], v[k] = O.adamw_step(sd[k], sd[k].grad, m[k], v[k], step + 1, lr)
                 sd[k].copy_(pn)
         times.append(time.time() - t0)
-        step += 1
-        if step >= 3 or time.time() - t_begin > max_seconds:
+        if time.time() - t_begin > max_seconds and len(times) > warm + 1:
             break
-    steady = sorted(times[1:] or times)[len(times[1:] or times) // 2]
-    return {"value": Bc / steady, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle fp32 torch-CPU training step (fwd+bwd+AdamW), same model, batch {Bc}, {len(times)} steps, median of steady steps"}
+    steady = sorted(times[warm:])
+    med = steady[len(steady) // 2]
+    return {"value": round(Bc / med, 3), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle fp32 torch-CPU training step (fwd+bwd+AdamW+schedule), same model, batch {Bc}: {warm} warm-up + "
+                      f"{len(steady)} timed steps, median {med * 1e3:.0f} ms (min {steady[0] * 1e3:.0f}, max {steady[-1] * 1e3:.0f})"}
+
+
+def cpu_decode_baseline(max_seconds=14.0):
+    """CPU decode baselines of BASELINE.md 3 on the oracle: beam 5, GPT-2-medium (random init), ONE prefix of 10 rows, reference
+    semantics (no KV cache: the whole sequence is re-forwarded every step, inference/base.py:80-121) and the same search with a
+    KV cache.  Bounded: 16 generated positions (no-cache) / 32 (cached); generated best-beam tokens per second."""
+    from oracle import clipcap_oracle as O
+    from clipcap_amd.engine import Gpt2Engine
+    torch.manual_seed(0)
+    D, NL, H = 1024, 24, 16
+    ge = Gpt2Engine(D, H, NL, 50257, 1024, device="cpu")
+    sd = {}
+    for k, v in ge.views(ge.arena.w32).items():
+        if "ln_" in k:
+            v.fill_(1.0 if k.endswith("weight") else 0.0)
+        else:
+            v.normal_(0, 0.02)
+        sd["language_model." + k] = v
+    pref = torch.randn(1, 10, D) * 0.5
+    out = {}
+    with torch.no_grad():
+        for name, n, kv in (("no_cache", 16, False), ("kv_cache", 32, True)):
+            O.generate_beam_tokens(sd, pref, n_head=H, n_layer=NL, beam_size=5, entry_length=2, stop_token=50256, kv_cache=kv)   # warm-up
+            t0 = time.time()
+            toks, sc, lens, order = O.generate_beam_tokens(sd, pref, n_head=H, n_layer=NL, beam_size=5, entry_length=n, stop_token=50256,
+                                                           kv_cache=kv)
+            dt = time.time() - t0
+            out[name] = {"value": round(float(lens[order[0]]) / dt, 2), "unit": "tokens/s", "generated_positions": int(toks.shape[1]),
+                         "seconds": round(dt, 2)}
+    out.update(cores=torch.get_num_threads(), kind="port",
+               sample="oracle beam-5 decode, GPT-2-medium random init, 1 prefix x 10 rows; no_cache = the reference's full re-forward per step")
+    return out
 
 
 def decode_bench(args, device):
     """BASELINE configs[4]: beam-search (beam=5) caption decode, GPT-2-medium, KV-cached HIP kernels, 64 prefixes per step.
-    A "step" = decoding the whole batch (prefill of the 10-row prefix + up to 67 generated tokens per beam)."""
+    A "step" = decoding the whole batch (prefill of the 10-row prefix + up to 67 generated tokens per beam).
+    traffic: HBM bytes per generated position from offline PMC passes (tagged with their source) — not measured by this run."""
     from types import SimpleNamespace
     from clipcap_amd.inference.base import generate_beam_tokens
     from clipcap_amd.model.gpt2 import GPT2LM
@@ -163,9 +201,12 @@ def decode_bench(args, device):
             "roofline": {"bound": "hbm", "kernel": "whole decode step (weights once per generated position)",
                          "achieved": round(wbytes * steps_per_decode * args.steps / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(wbytes * steps_per_decode * args.steps / dt / 8e12, 4),
-                         # fabric bytes per generated position from the PMC passes in profiles/r01_p_* (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
-                         # summed over the step's kernels): 2.68 GB read + 0.50 GB written vs 0.71 GB of weights
-                         "traffic": 3.18e9 if S == 64 else None}}
+                         "algorithmic_bytes_per_position": int(wbytes),
+                         # fabric bytes per generated position from separate PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, summed over
+                         # the step's kernels) — an OFFLINE measurement of an earlier build, quoted with its source, not of this run
+                         "traffic": DECODE_TRAFFIC["bytes"] if S == 64 else None,
+                         "traffic_source": DECODE_TRAFFIC["source"] if S == 64 else None,
+                         "traffic_over_algorithmic": round(DECODE_TRAFFIC["bytes"] / wbytes, 2) if S == 64 else None}}
 
 
 def sample_bench(args, device):
@@ -230,16 +271,41 @@ def mapper_bench(args, device):
                          "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": None}}
 
 
+def executed_step_flops(c):
+    """FLOPs the kernels actually run per sample: lm_head forward + dgrad (+wgrad) on the 40 caption rows the loss reads instead of
+    all T = 50 (SURVEY.md 8d asks for the reduced figure to be stated next to the algorithmic one)."""
+    skipped_rows = c["L"]
+    head = 2 * c["D"] * c["V"] * skipped_rows
+    return step_flops(c) - (3 if c["train_lm"] else 2) * head
+
+
+def profile_sites(lib, one_step, sync, n_steps, site, per_step, first_step):
+    """n_steps extra steps with HIP events (recorded on the launch stream by the library) around one call site's launches."""
+    from clipcap_amd import _lib
+    lib.cc_prof_start(_lib.SITES[site], per_step * n_steps)
+    sync()
+    for i in range(first_step, first_step + n_steps):
+        one_step(i)
+    sync()
+    n = C.c_int32(per_step * n_steps)
+    ms = (C.c_float * n.value)()
+    fl = (C.c_double * n.value)()
+    lib.cc_prof_stop(ms, fl, C.byref(n))
+    return [ms[i] for i in range(n.value)], [fl[i] for i in range(n.value)]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mode", default="train", choices=["train", "decode", "mapper", "sample"])
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="2", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
-    ap.add_argument("--site", default="lmhead_fwd", help="GEMM call site timed for the roofline object")
+    ap.add_argument("--site", default="lmhead_fwd", help="single GEMM call site timed for the roofline_lmhead object")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "16"], help="operand type: bf16 (default) or 16 = fp16 + loss scaling")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sub-benches", action="store_true", help="skip the mapper / decode sub-objects of the default N=1 line")
     ap.add_argument("--no-dropout", action="store_true", help="configs 3/4: run the full finetune without GPT-2 dropout")
     args = ap.parse_args()
 
@@ -252,6 +318,7 @@ def main():
     dev_index = int(os.environ.get("CC_BENCH_DEVICE", local))
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -274,29 +341,30 @@ def main():
     from clipcap_amd.train.ddp import GradReducer
     from clipcap_amd.model.optim import linear_warmup_decay
     me, ge, eng = init_engines(c, device)
+    if args.precision == "16":
+        me.set_precision(16)
+        ge.set_precision(16)
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
     embeds = torch.randn(B, c["E"], generator=gen, device=device)
     tokens = torch.randint(1, c["V"], (B, cap), generator=gen, device=device)
-    arenas = [me.arena] + ([ge.arena] if c["train_lm"] else [])
+    arenas = eng.arenas()
     reducer = GradReducer([a.grads() for a in arenas]) if world > 1 else None
     total_steps = args.steps + args.warmup
     base_lr, warm = 2e-5, 2
-    sched = linear_warmup_decay(warm, total_steps + 1)
+    sched = linear_warmup_decay(warm, 4 * total_steps + 64)
 
-    def one_step(i):
+    def one_step(i, reduce=True):
         eng.zero_grad()
         # full finetune: GPT-2 train-mode dropout (p = 0.1 on embeddings, attention probabilities and both residual branches, the
         # GPT2Config defaults the reference runs with), a new mask seed per step and rank
         drop = (0.1, 0.1, 0.1, 1000003 * (i + 1) + rank) if (c["train_lm"] and not args.no_dropout) else None
-        if reducer:   # all-reduce of each layer slice starts as soon as its backward kernels are enqueued
+        if reducer and reduce:   # all-reduce of each layer slice starts as soon as its backward kernels are enqueued
             reducer.begin()
             loss = eng.forward_backward(tokens, embeds, reduce_stats=reducer.reduce_stats, on_grads_ready=reducer.on_grads_ready, dropout=drop)
             reducer.finish()
         else:
             loss = eng.forward_backward(tokens, embeds, dropout=drop)
-        lr = base_lr * sched(i)
-        for a in arenas:
-            a.adamw_step(lr, i + 1, scaler=eng.scaler)
+        eng.optimizer_step(base_lr * sched(i), i + 1)
         return loss
 
     def sync():
@@ -307,57 +375,108 @@ def main():
     for i in range(args.warmup):
         loss = one_step(i)
     sync()
-    lib = _lib.lib()
-    site_id = _lib.SITES[args.site]
-    per_step = {"lmhead_fwd": 1, "lmhead_dgrad": 1, "gpt2_fc_fwd": c["n_layer"], "gpt2_proj2_fwd": c["n_layer"], "gpt2_fc_dgrad": c["n_layer"],
-                "mapper_fc1_fwd": c["N"], "mapper_qkv_fwd": c["N"], "mapper_wgrad_fc2": c["N"]}[args.site]
-    if rank == 0:
-        lib.cc_prof_start(site_id, per_step * args.steps)
-    sync()
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         loss = one_step(i)
     sync()
     dt = time.perf_counter() - t0
+    nxt = args.warmup + args.steps
+    exposed_ms = None
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+        # the same steps with the gradient all-reduce left out (timing only): the difference is the all-reduce time that backward
+        # did not hide
+        k2 = max(5, args.steps // 8)
+        sync()
+        t1 = time.perf_counter()
+        for i in range(nxt, nxt + k2):
+            one_step(i, reduce=False)
+        sync()
+        t2 = torch.tensor([(time.perf_counter() - t1) / k2], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t2, op=torch.distributed.ReduceOp.MAX)
+        exposed_ms = max(0.0, dt / args.steps - float(t2.item())) * 1e3
+        nxt += k2
+    ms_per_step = dt / args.steps * 1e3
+    lib = _lib.lib()
+    T, D, Mc, M = c["L"] + cap, c["D"], B * cap, B * (c["L"] + cap)
+    S = c["P"] + c["L"]
+    if True:   # every rank runs the profiled extra steps (their collectives must match); rank 0 reports
+        # ---- roofline of the dominant kernel family: every MFMA GEMM launch of the step (forward, dgrad, wgrad, lm_head), bracketed
+        # with HIP events on the launch stream during 5 extra steps; achieved = sum of 2MNK / sum of launch durations ----
+        n_prof = 5
+        per_step_cap = 64 + 24 * c["N"] + 16 * c["n_layer"]
+        ms, fl = profile_sites(lib, one_step, sync, n_prof, "all_gemms", per_step_cap, nxt)
+        nxt += n_prof
+        gemm_ms, gemm_fl = sum(ms), sum(fl)
+        fam = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        roof = {}
+        roof["roofline"] = {"bound": "mfma", "kernel": "bf16 MFMA GEMM family (gemm.hip.h: every NT / TT / lm_head launch of the step)",
+                           "achieved": round(fam, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fam / PEAK_BF16_TFLOPS, 4),
+                           "launches_per_step": len(ms) // n_prof, "avg_launch_ms": round(gemm_ms / max(1, len(ms)), 4),
+                           "time_share_of_step": round(gemm_ms / n_prof / ms_per_step, 3),
+                           "flops_per_step": gemm_fl / n_prof, "traffic": None}
+        # ---- second entry: the largest single launch (lm_head forward) at its own call site, 20 extra steps ----
+        per_step = {"lmhead_fwd": 1, "lmhead_dgrad": 1, "gpt2_fc_fwd": c["n_layer"], "gpt2_proj2_fwd": c["n_layer"], "gpt2_fc_dgrad": c["n_layer"],
+                    "mapper_fc1_fwd": c["N"], "mapper_qkv_fwd": c["N"], "mapper_wgrad_fc2": c["N"]}[args.site]
+        ms, _ = profile_sites(lib, one_step, sync, 20, args.site, per_step, nxt)
+        nxt += 20
+        avg_ms = sum(ms) / max(1, len(ms))
+        site_flops = {"lmhead_fwd": 2.0 * Mc * c["V"] * D, "lmhead_dgrad": 2.0 * Mc * c["V"] * D, "gpt2_fc_fwd": 2.0 * M * D * 4 * D,
+                      "gpt2_proj2_fwd": 2.0 * M * D * 4 * D, "gpt2_fc_dgrad": 2.0 * M * D * 4 * D, "mapper_fc1_fwd": 2.0 * B * S * D * 2 * D,
+                      "mapper_qkv_fwd": 2.0 * B * S * D * 3 * D, "mapper_wgrad_fc2": 2.0 * B * S * D * 2 * D}[args.site]
+        ach = site_flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        default_site = args.site == "lmhead_fwd" and args.config == "2" and not args.batch
+        roof["roofline_lmhead" if args.site == "lmhead_fwd" else "roofline_site"] = {
+            "bound": "mfma", "kernel": ("gemm_nt_stag256_kernel<EpiLMHead,4>" if args.site == "lmhead_fwd" else "NT GEMM") + f" @ {args.site}",
+            "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+            "avg_launch_ms": round(avg_ms, 4), "launches": len(ms), "time_share_of_step": round(avg_ms * per_step / ms_per_step, 3),
+            "traffic": LMHEAD_TRAFFIC["bytes"] if default_site else None, "traffic_source": LMHEAD_TRAFFIC["source"] if default_site else None,
+            "algorithmic_bytes": int(2 * (Mc * D + c["V"] * D + Mc * ((c["V"] + 127) // 128 * 128)) + 8 * Mc * ((c["V"] + 127) // 128 * 2))
+            if args.site == "lmhead_fwd" else None}
     if rank != 0:
         if world > 1:
             torch.distributed.destroy_process_group()
         return
-    n = C.c_int32(per_step * args.steps)
-    ms = (C.c_float * n.value)()
-    lib.cc_prof_stop(ms, None, C.byref(n))
-    avg_ms = sum(ms[i] for i in range(n.value)) / max(1, n.value)
-    T, D, Mc, M = c["L"] + cap, c["D"], B * cap, B * (c["L"] + cap)
-    S = c["P"] + c["L"]
-    site_flops = {"lmhead_fwd": 2.0 * Mc * c["V"] * D, "lmhead_dgrad": 2.0 * Mc * c["V"] * D, "gpt2_fc_fwd": 2.0 * M * D * 4 * D,
-                  "gpt2_proj2_fwd": 2.0 * M * D * 4 * D, "gpt2_fc_dgrad": 2.0 * M * D * 4 * D, "mapper_fc1_fwd": 2.0 * B * S * D * 2 * D,
-                  "mapper_qkv_fwd": 2.0 * B * S * D * 3 * D, "mapper_wgrad_fc2": 2.0 * B * S * D * 2 * D}[args.site]
-    ach = site_flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
     value = B * world * args.steps / dt
     step_tflops = step_flops(c) * B * world * args.steps / dt / 1e12
+    exec_tflops = executed_step_flops(c) * B * world * args.steps / dt / 1e12
     out = {
         "metric": "train samples/sec (512-d prefix, 40-tok caption)", "value": round(value, 2), "unit": "samples/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f16", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{int(args.config) - 1}]: {c['name']}", "per_gpu_batch": B, "global_batch": B * world,
                    "caption_tokens": cap, "encoder_dim": c["E"], "train_language_model": c["train_lm"],
                    "parallelism": f"dp{world}", "final_loss": round(float(loss.item()), 4)},
         "step_algorithmic_tflops": round(step_tflops, 1),
+        "step_executed_tflops": round(exec_tflops, 1),
         "step_frac_of_bf16_peak": round(step_tflops / (PEAK_BF16_TFLOPS * world), 4),
-        "roofline": {"bound": "mfma", "kernel": ("gemm_nt_stag256_kernel<EpiLMHead,4>" if args.site == "lmhead_fwd" else "NT GEMM") + f" @ {args.site}", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
-                     "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "avg_launch_ms": round(avg_ms, 4), "launches": n.value,
-                     # fabric bytes per launch from the PMC passes in profiles/r01_i_pmc_fetch_write.md (FETCH_SIZE x2 gfx950
-                     # correction + WRITE_SIZE, calibrated 1.0 on k_ce_dlogits); only measured for the default site/config
-                     "traffic": (2 * 604061 + 1097837) * 1024 if (args.site == "lmhead_fwd" and args.config == "2" and not args.batch) else None,
-                     "algorithmic_bytes": int(2 * (Mc * D + c["V"] * D + Mc * ((c["V"] + 127) // 128 * 128)) + 8 * Mc * ((c["V"] + 127) // 128 * 2))
-                     if args.site == "lmhead_fwd" else None},
+        "step_executed_frac_of_bf16_peak": round(exec_tflops / (PEAK_BF16_TFLOPS * world), 4),
     }
-    if not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(c)
+    if world > 1:
+        out["rccl_ranks"] = world if backend == "nccl" else 0
+        out["collective_backend"] = "rccl" if backend == "nccl" else backend
+        out["allreduce_exposed_ms"] = round(exposed_ms, 3)
+        out["gradient_payload_bytes"] = int(sum(a.n for a in arenas) * 4)
+    out.update(roof)
+    if world == 1:
+        if not args.no_sub_benches:
+            # north_star sub-targets in the same line: mapping-transformer fwd+bwd alone (target >= 40 % of the bf16 peak at batch 256)
+            # and KV-cached beam decode (BASELINE configs[4])
+            sub = argparse.Namespace(config=args.config if args.config in ("2", "3", "4") else "2", batch=0, steps=100, warmup=5)
+            mb = mapper_bench(sub, device)
+            out["mapper"] = {"ms_fwd_bwd": mb["ms_per_step"], "samples_per_s": mb["value"], "tflops": mb["roofline"]["achieved"],
+                             "frac_of_bf16_peak": mb["roofline"]["frac"], "target_frac": 0.40, "batch": CONFIGS[sub.config]["B"]}
+            del mb
+            torch.cuda.empty_cache()
+            db = decode_bench(argparse.Namespace(batch=0, steps=4, warmup=1), device)
+            out["decode"] = {"metric": db["metric"], "tokens_per_s": db["value"], "beam_tokens_per_s": db["beam_tokens_per_s"],
+                             "ms_per_batch": db["ms_per_step"], "config": db["config"]["workload"], "roofline": db["roofline"]}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(c)
+            if not args.no_sub_benches:
+                out["cpu_decode_baseline"] = cpu_decode_baseline()
     print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

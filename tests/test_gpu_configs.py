@@ -72,7 +72,8 @@ def _full_model_case(name, tol, precision=None):
     assert e_pre_rb <= tol["prefix_rb"] * pscale and e_pre_32 <= tol["prefix_32"] * pscale
     assert e_rb <= tol["logits_rb"] and e_32 <= tol["logits_32"]
     assert e_32 <= 2.0 * drift + 1e-3          # no further from the reference than the rounding points themselves put the oracle
-    out = dict(e_rb=e_rb, e_32=e_32, drift=drift, e_pre_rb=e_pre_rb, e_pre_32=e_pre_32)
+    out = dict(e_rb=e_rb, e_32=e_32, drift=drift, e_pre_rb=e_pre_rb, e_pre_32=e_pre_32, logits=logits, ref_rb=ref_rb, valid=valid, sd=sd,
+               cfg=cfg, tokens=tokens, embeds=embeds, ge=ge, dims=dims, golden=g)
 
     # ---- training step: loss + gradients (model.py:94-113) ----
     eng.zero_grad()
