@@ -304,6 +304,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
     ap.add_argument("--site", default="lmhead_fwd", help="single GEMM call site timed for the roofline_lmhead object")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "16"], help="operand type: bf16 (default) or 16 = fp16 + loss scaling")
+    ap.add_argument("--comm", default="torch", choices=["torch", "cabi"],
+                    help="N>1 collectives: torch.distributed (backend nccl = RCCL) or the library's own C-ABI RCCL communicator")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sub-benches", action="store_true", help="skip the mapper / decode sub-objects of the default N=1 line")
     ap.add_argument("--no-dropout", action="store_true", help="configs 3/4: run the full finetune without GPT-2 dropout")
@@ -348,7 +350,11 @@ def main():
     embeds = torch.randn(B, c["E"], generator=gen, device=device)
     tokens = torch.randint(1, c["V"], (B, cap), generator=gen, device=device)
     arenas = eng.arenas()
-    reducer = GradReducer([a.grads() for a in arenas]) if world > 1 else None
+    comm = None
+    if world > 1 and args.comm == "cabi":
+        from clipcap_amd.train.ddp import CAbiComm
+        comm = CAbiComm.from_process_group(device)
+    reducer = GradReducer([a.grads() for a in arenas], comm=comm) if world > 1 else None
     total_steps = args.steps + args.warmup
     base_lr, warm = 2e-5, 2
     sched = linear_warmup_decay(warm, 4 * total_steps + 64)
@@ -456,7 +462,7 @@ def main():
     }
     if world > 1:
         out["rccl_ranks"] = world if backend == "nccl" else 0
-        out["collective_backend"] = "rccl" if backend == "nccl" else backend
+        out["collective_backend"] = "rccl (C ABI cc_allreduce_bucket)" if comm is not None else ("rccl" if backend == "nccl" else backend)
         out["allreduce_exposed_ms"] = round(exposed_ms, 3)
         out["gradient_payload_bytes"] = int(sum(a.n for a in arenas) * 4)
     out.update(roof)

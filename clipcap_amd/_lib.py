@@ -61,6 +61,7 @@ SIGNATURES = {
     "cc_mapper_sync_weights": (_I, [_MC, _P, _P, _P]),
     "cc_gpt2_sync_weights": (_I, [_GC, _P, _P, _P]),
     "cc_mapper_fwd": (_I, [_MC, _I, _P, _P, _P, _P, _P, _I, _P]),
+    "cc_mapper_attention_probs": (_I, [_MC, _I, _P, _I, _P, _P]),
     "cc_mapper_bwd": (_I, [_MC, _I, _P, _P, _P, _P, _P, _P]),
     "cc_mapper_bwd_range": (_I, [_MC, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
     "cc_gpt2_bwd_range": (_I, [_GC, _GS, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
@@ -95,6 +96,10 @@ SIGNATURES = {
     "cc_layernorm_fwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "cc_attention_fwd": (_I, [_I, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "cc_attention_bwd": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "cc_comm_unique_id": (_I, [_P]),
+    "cc_comm_create": (_I, [C.POINTER(_P), _I, _I, _P]),
+    "cc_allreduce_bucket": (_I, [_P, _P, _L, _I, _P]),
+    "cc_comm_destroy": (_I, [_P]),
     "cc_prof_start": (_I, [_I, _I]),
     "cc_prof_stop": (_I, [C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(_I)]),
 }

@@ -357,6 +357,14 @@ int CC_API(cc_mapper_fwd)(const cc_mapper_cfg* c, int32_t B, const float* w32, c
     return CC_OK;
 }
 
+int CC_API(cc_mapper_attention_probs)(const cc_mapper_cfg* c, int32_t B, void* ws, int32_t layer, float* out, void* stream) {
+    if (!mapper_cfg_ok(c) || B <= 0 || !ws || !out || layer < 0 || layer >= c->N) return CC_ERR_ARG;
+    MapperWS w;
+    mapper_carve(c, B, 1, ws, w);
+    const int S = c->W * c->P + c->L;
+    return attn_probs(w.qkv[layer], B, S, c->H, c->D / c->H, out, S_(stream));
+}
+
 int CC_API(cc_mapper_bwd)(const cc_mapper_cfg* c, int32_t B, const float* w32, const uint16_t* w16, void* ws, const float* dout, float* g32,
                   void* stream) {
     if (!mapper_cfg_ok(c)) return CC_ERR_ARG;

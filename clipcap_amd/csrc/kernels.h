@@ -29,6 +29,7 @@ int ln_bwd(const op16_t* dy, const float* x, int ldx, const int* row_map, const 
            const float* dres, float* dx32, op16_t* dx16, float* dgamma, float* dbeta, int rows, int D, hipStream_t st);
 int colsum_bf16(const op16_t* X, int ld, int M, int N, float* out, hipStream_t st);
 
+int attn_probs(const op16_t* qkv, int B, int S, int H, int hd, float* out, hipStream_t st);
 int attn_fwd(const op16_t* qkv, int B, int S, int H, int hd, bool causal, op16_t* out, float* lse, hipStream_t st, Drop drop = Drop());
 // o: forward output (for delta = rowsum(dO*O)); delta: fp32 scratch [B*H*S].  Both may be null -> VALU kernel.
 int attn_bwd(const op16_t* qkv, const op16_t* dout, const op16_t* o, const float* lse, float* delta, int B, int S, int H, int hd, bool causal,

@@ -926,6 +926,44 @@ static int attn_bwd_mfma_launch(const op16_t* qkv, const op16_t* dout, const op1
 static size_t attn_fwd_lds(int S, int hd) { return ((size_t)3 * S * (hd + 4) + (size_t)S * (S + 1)) * 4; }
 static size_t attn_bwd_lds(int S, int hd) { return ((size_t)4 * S * (hd + 4) + (size_t)2 * S * (S + 1)) * 4; }
 
+// Attention probabilities of an un-masked self-attention layer, recomputed from the stored qkv rows: what the reference's
+// MultiHeadAttention.forward returns as its second value (attention.py:32-42, layout (b, n, m, h)).  One wave per (b, h, query);
+// an inspection / visualisation output, not on the training path.
+__global__ __launch_bounds__(256) void k_attn_probs(const op16_t* __restrict__ qkv, int B, int S, int H, int hd, float scale,
+                                                    float* __restrict__ out) {
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (wave >= B * H * S) return;
+    const int n = wave % S, h = (wave / S) % H, b = wave / (S * H);
+    const int D = H * hd;
+    const op16_t* q = qkv + ((size_t)b * S + n) * 3 * D + h * hd;
+    float mx = -INFINITY;
+    for (int m0 = 0; m0 < S; m0 += 64) {
+        const int m = m0 + lane;
+        float sc = -INFINITY;
+        if (m < S) {
+            const op16_t* k = qkv + ((size_t)b * S + m) * 3 * D + D + h * hd;
+            float acc = 0.f;
+            for (int d = 0; d < hd; d++) acc += op2f(q[d]) * op2f(k[d]);
+            sc = acc * scale;
+            out[(((size_t)b * S + n) * S + m) * H + h] = sc;
+        }
+        mx = fmaxf(mx, wave_max(sc));
+    }
+    float sum = 0.f;
+    for (int m = lane; m < S; m += 64) sum += __expf(out[(((size_t)b * S + n) * S + m) * H + h] - mx);
+    sum = wave_sum(sum);
+    for (int m = lane; m < S; m += 64) {
+        float* o = out + (((size_t)b * S + n) * S + m) * H + h;
+        *o = __expf(*o - mx) / sum;
+    }
+}
+int attn_probs(const op16_t* qkv, int B, int S, int H, int hd, float* out, hipStream_t st) {
+    const int waves = B * H * S;
+    if (waves <= 0) return CC_OK;
+    hipLaunchKernelGGL(k_attn_probs, dim3((waves + 3) / 4), dim3(256), 0, st, qkv, B, S, H, hd, 1.0f / sqrtf((float)hd), out);
+    return CC_OK;
+}
+
 int attn_fwd(const op16_t* qkv, int B, int S, int H, int hd, bool causal, op16_t* out, float* lse, hipStream_t st, Drop drop) {
     if ((hd & 7) || S <= 0) return CC_ERR_SHAPE;
     static const bool no_mfma = getenv("CC_ATTN_VALU") != nullptr;   // A/B switch for profiling

@@ -1,8 +1,11 @@
 // Variant-independent part of the C ABI: version, the process-wide test knobs and the measurement hooks (include/clipcap_hip.h).
 #include "../../include/clipcap_hip.h"
 #include "shared.h"
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 namespace cc_shared {
 int g_gemm_tile_mode = []() { const char* e = getenv("CC_GEMM_S256"); return e ? atoi(e) : -1; }();
@@ -60,6 +63,71 @@ int cc_prof_stop(float* ms_host, double* flops_host, int32_t* n_host) {
     g_prof.flops.clear();
     g_prof.n = g_prof.cap = 0;
     return CC_OK;
+}
+
+// ---------------------------------------------------------------- RCCL collective (cc_allreduce_bucket) ----------
+// RCCL is bound at run time (dlopen of the librccl the process already carries — PyTorch-ROCm ships one — or the ROCm one), so the
+// library has no link-time dependency on a particular copy and single-GPU users never load it.
+namespace {
+struct Rccl {
+    void* h = nullptr;
+    ncclResult_t (*get_uid)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*init_rank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*all_reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*destroy)(ncclComm_t) = nullptr;
+    bool ok = false;
+    Rccl() {
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names)
+            if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!h) return;
+        get_uid = reinterpret_cast<decltype(get_uid)>(dlsym(h, "ncclGetUniqueId"));
+        init_rank = reinterpret_cast<decltype(init_rank)>(dlsym(h, "ncclCommInitRank"));
+        all_reduce = reinterpret_cast<decltype(all_reduce)>(dlsym(h, "ncclAllReduce"));
+        destroy = reinterpret_cast<decltype(destroy)>(dlsym(h, "ncclCommDestroy"));
+        ok = get_uid && init_rank && all_reduce && destroy;
+    }
+};
+Rccl& rccl() {
+    static Rccl r;
+    return r;
+}
+static_assert(sizeof(ncclUniqueId) == CC_COMM_UID_BYTES, "cc_comm unique id size");
+}  // namespace
+
+int cc_comm_unique_id(uint8_t* uid_host) {
+    if (!uid_host) return CC_ERR_ARG;
+    if (!rccl().ok) return CC_ERR_STATE;
+    ncclUniqueId id;
+    if (rccl().get_uid(&id) != ncclSuccess) return CC_ERR_LAUNCH;
+    memcpy(uid_host, &id, sizeof(id));
+    return CC_OK;
+}
+
+int cc_comm_create(void** comm, int32_t nranks, int32_t rank, const uint8_t* uid_host) {
+    if (!comm || !uid_host || nranks < 1 || rank < 0 || rank >= nranks) return CC_ERR_ARG;
+    if (!rccl().ok) return CC_ERR_STATE;
+    ncclUniqueId id;
+    memcpy(&id, uid_host, sizeof(id));
+    ncclComm_t c = nullptr;
+    if (rccl().init_rank(&c, nranks, id, rank) != ncclSuccess) return CC_ERR_LAUNCH;
+    *comm = c;
+    return CC_OK;
+}
+
+int cc_allreduce_bucket(void* comm, void* buf, int64_t count, int32_t dtype, void* stream) {
+    if (!comm || !buf || count < 0 || dtype < CC_RED_F32 || dtype > CC_RED_F16) return CC_ERR_ARG;
+    if (!rccl().ok) return CC_ERR_STATE;
+    if (count == 0) return CC_OK;
+    const ncclDataType_t t = dtype == CC_RED_F32 ? ncclFloat32 : dtype == CC_RED_BF16 ? ncclBfloat16 : ncclFloat16;
+    return rccl().all_reduce(buf, buf, (size_t)count, t, ncclSum, static_cast<ncclComm_t>(comm), static_cast<hipStream_t>(stream)) == ncclSuccess
+               ? CC_OK : CC_ERR_LAUNCH;
+}
+
+int cc_comm_destroy(void* comm) {
+    if (!comm) return CC_ERR_ARG;
+    if (!rccl().ok) return CC_ERR_STATE;
+    return rccl().destroy(static_cast<ncclComm_t>(comm)) == ncclSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
 
 }  // extern "C"

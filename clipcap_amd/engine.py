@@ -227,6 +227,22 @@ class MapperEngine:
             self._fwd_serial = getattr(self, "_fwd_serial", 0) + 1
         return out
 
+    def attention_probs(self, B: int) -> List[torch.Tensor]:
+        """Per layer, the attention probabilities (B, S, S, H) of the last forward(save=True) with batch B — the second return value
+        of the reference's MultiHeadAttention.forward (attention.py:32-42)."""
+        ws = self._ws.get((B, 1))
+        if ws is None or getattr(self, "_saved_batch", None) != B:
+            raise RuntimeError("MapperEngine.attention_probs needs a preceding forward(save=True) with the same batch")
+        d = self.dims
+        S = d["W"] * d["P"] + d["L"]
+        outs = []
+        for l in range(d["N"]):
+            out = torch.empty(B, S, S, d["H"], dtype=torch.float32, device=self.arena.device)
+            check(_lib.lib().cc_mapper_attention_probs(C.byref(self.cfg), B, _p(ws), l, _p(out), _stream(self.arena.device)),
+                  "cc_mapper_attention_probs")
+            outs.append(out)
+        return outs
+
     def layer_span(self, l: int) -> Tuple[int, int]:
         """[lo, hi) element range of layer l's parameters in the arenas (layers are contiguous, head tensors come first)."""
         lo = self.offsets[4 + 12 * l]
@@ -534,6 +550,9 @@ def embed_tokens(gpt2: "Gpt2Engine", tokens: torch.Tensor, out: torch.Tensor) ->
     return out
 
 
+_BEAM_BUFFERS: Dict[tuple, tuple] = {}
+
+
 def beam_step(logits: torch.Tensor, samples: int, beam: int, temperature: float, first: bool, stop_token: int, scores: torch.Tensor,
               seq_lengths: torch.Tensor, has_stopped: torch.Tensor):
     """One device-side beam update for `samples` independent beam sets (reference inference/base.py:84-119).
@@ -542,9 +561,15 @@ def beam_step(logits: torch.Tensor, samples: int, beam: int, temperature: float,
     dev = logits.device
     V = logits.shape[1]
     ldl = logits.stride(0)
-    nt = torch.empty(samples * beam, dtype=torch.int32, device=dev)
-    sr = torch.empty(samples * beam, dtype=torch.int32, device=dev)
-    ws = torch.empty(_lib.lib().cc_beam_ws_bytes(samples, beam, V), dtype=torch.uint8, device=dev)
+    key = (dev, samples, beam, V)
+    bufs = _BEAM_BUFFERS.get(key)
+    if bufs is None:       # outputs + scratch are reused from step to step (consumed by cc_beam_advance before the next update)
+        if len(_BEAM_BUFFERS) > 8:
+            _BEAM_BUFFERS.clear()
+        bufs = (torch.empty(samples * beam, dtype=torch.int32, device=dev), torch.empty(samples * beam, dtype=torch.int32, device=dev),
+                torch.empty(_lib.lib().cc_beam_ws_bytes(samples, beam, V), dtype=torch.uint8, device=dev))
+        _BEAM_BUFFERS[key] = bufs
+    nt, sr, ws = bufs
     check(_lib.lib().cc_beam_step(samples, beam, V, _p(logits), ldl, float(temperature), int(first), int(stop_token), _p(scores), _p(seq_lengths),
                                  _p(has_stopped), _p(nt), _p(sr), _p(ws), _stream(dev)), "cc_beam_step")
     return nt, sr

@@ -77,6 +77,14 @@ class TransformerMapper(ArenaModule):
         return self.engine.forward(x, save=False)
 
 
+    @torch.no_grad()
+    def forward_with_attention(self, x: torch.Tensor):
+        """(prefix, [attention (B, S, S, H) per layer]) — the reference's Transformer.forward_with_attention (mapper.py:45-52) seen
+        from the mapper: S = window * projection_length + prefix_length rows, probabilities over the key axis (dim 2)."""
+        out = self.engine.forward(x, save=True)
+        return out, self.engine.attention_probs(x.shape[0])
+
+
 class TransformerMapperWindowed(TransformerMapper):
     """mapper.py:133-160: input (B, window_size, E); sequence = window_size*projection_length + prefix_length."""
 

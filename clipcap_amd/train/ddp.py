@@ -29,12 +29,60 @@ def shard_batch(tokens: torch.Tensor, embeds: torch.Tensor, rank: int, world: in
     return tokens[lo:hi], embeds[lo:hi]
 
 
-class GradReducer:
-    """Bucketed SUM all-reduce of flat gradient arenas plus the loss-statistics reduction."""
+class CAbiComm:
+    """RCCL communicator owned through the C ABI (cc_comm_create / cc_allreduce_bucket / cc_comm_destroy, include/clipcap_hip.h) —
+    the collective a reference-side binder gets without torch.distributed.  The 128-byte unique id is created on
+    rank 0 and shipped by whatever the host has; ``from_process_group`` uses an already initialised torch.distributed group (gloo is
+    enough: it only carries the id)."""
 
-    def __init__(self, flats: Sequence[torch.Tensor], bucket_bytes: int = 256 << 20, group=None):
+    def __init__(self, nranks: int, rank: int, uid: bytes, device):
+        import ctypes as C
+        from clipcap_amd import _lib
+        self._lib, self._C = _lib, C
+        self.nranks, self.rank, self.device = nranks, rank, torch.device(device)
+        torch.cuda.set_device(self.device)
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        self._comm = C.c_void_p()
+        _lib.check(_lib.lib().cc_comm_create(C.byref(self._comm), nranks, rank, buf), "cc_comm_create")
+        self.stream = torch.cuda.Stream(self.device)          # collectives run beside the backward kernels
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+        from clipcap_amd import _lib
+        buf = (C.c_uint8 * 128)()
+        _lib.check(_lib.lib().cc_comm_unique_id(buf), "cc_comm_unique_id")
+        return bytes(buf)
+
+    @classmethod
+    def from_process_group(cls, device, group=None) -> "CAbiComm":
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return cls(world, rank, box[0], device)
+
+    def all_reduce_(self, t: torch.Tensor, stream: Optional[torch.cuda.Stream] = None) -> None:
+        """In-place SUM of a contiguous fp32 / bf16 / fp16 tensor, enqueued on ``stream`` (default: the current stream)."""
+        code = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[t.dtype]
+        assert t.is_contiguous() and t.device == self.device
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        self._lib.check(self._lib.lib().cc_allreduce_bucket(self._comm, self._C.c_void_p(t.data_ptr()), t.numel(), code,
+                                                            self._C.c_void_p(st.cuda_stream)), "cc_allreduce_bucket")
+
+    def close(self) -> None:
+        if self._comm:
+            self._lib.lib().cc_comm_destroy(self._comm)
+            self._comm = self._C.c_void_p()
+
+
+class GradReducer:
+    """Bucketed SUM all-reduce of flat gradient arenas plus the loss-statistics reduction.  Collectives go through torch.distributed
+    (backend "nccl" = RCCL) or, with ``comm=CAbiComm(...)``, through the library's own C-ABI communicator."""
+
+    def __init__(self, flats: Sequence[torch.Tensor], bucket_bytes: int = 256 << 20, group=None, comm: Optional[CAbiComm] = None):
         self.flats = list(flats)
         self.group = group
+        self.comm = comm
         self.buckets: List[torch.Tensor] = []
         for f in self.flats:
             assert f.dim() == 1 and f.is_contiguous()
@@ -43,10 +91,17 @@ class GradReducer:
                 self.buckets.append(f[lo:lo + per])
 
     def reduce_stats(self, stats: torch.Tensor) -> None:
+        if self.comm is not None:
+            self.comm.all_reduce_(stats)                 # on the compute stream: backward needs the global divisor next
+            return
         dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.group)
 
     def all_reduce(self) -> None:
         """Non-overlapped form: everything at once, after backward."""
+        if self.comm is not None:
+            for b in self.buckets:
+                self.comm.all_reduce_(b)
+            return
         works = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for b in self.buckets]
         for w in works:
             w.wait()
@@ -62,6 +117,12 @@ class GradReducer:
         the backward kernels of the layers below."""
         if hi <= lo:
             return
+        if self.comm is not None:
+            side = self.comm.stream
+            side.wait_stream(torch.cuda.current_stream(self.comm.device))    # after the kernels that produced the slice
+            self.comm.all_reduce_(self.flats[arena][lo:hi], side)
+            self._covered[arena] += hi - lo
+            return
         self._works.append(dist.all_reduce(self.flats[arena][lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self._covered[arena] += hi - lo
 
@@ -69,6 +130,8 @@ class GradReducer:
         """Blocks the current stream until every slice is reduced; checks that the slices tiled each arena exactly once."""
         for w in self._works:
             w.wait()
+        if self.comm is not None:
+            torch.cuda.current_stream(self.comm.device).wait_stream(self.comm.stream)
         for f, c in zip(self.flats, self._covered):
             assert c == f.numel(), f"overlapped all-reduce covered {c} of {f.numel()} gradient elements"
         self._works = []

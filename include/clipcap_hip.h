@@ -87,6 +87,10 @@ int cc_mapper_sync_weights(const cc_mapper_cfg* cfg, const float* w32, uint16_t*
  * docs/inference.md:24).  emb fp32 [B, W, E]; out fp32 [B, L, D]. */
 int cc_mapper_fwd(const cc_mapper_cfg* cfg, int32_t B, const float* w32, const uint16_t* w16, const float* emb, void* ws,
                   float* out, int32_t save, void* stream);
+/* the second return value of MultiHeadAttention.forward (attention.py:32-42; Transformer.forward_with_attention, mapper.py:45-52):
+ * softmax attention probabilities of one layer, fp32 [B, S, S, H] (query n, key m, head h), recomputed from the activations a
+ * save=1 forward left in ws.  Inspection output; not used by training or decode. */
+int cc_mapper_attention_probs(const cc_mapper_cfg* cfg, int32_t B, void* ws, int32_t layer, float* out, void* stream);
 /* autograd of the above (what loss.backward() does to mapper.py in the reference).  dout fp32 [B, L, D];
  * g32 (flat, same offsets as w32) is ACCUMULATED into.  Requires the workspace of a save=1 forward. */
 int cc_mapper_bwd(const cc_mapper_cfg* cfg, int32_t B, const float* w32, const uint16_t* w16, void* ws, const float* dout,
@@ -228,6 +232,26 @@ int cc_loss_scale_update(float* state, float* found_inf, float growth, float bac
 /* test hook for the dropout of cc_gpt2_shape: keep flags of one mask stream — site 0 embd [B*T*D], 1 attention [B*H*T*T],
  * 2 residual after attn.c_proj [B*T*D], 3 residual after mlp.c_proj [B*T*D]. */
 int cc_dropout_mask(uint64_t seed, int32_t site, int32_t layer, float p, int64_t n, uint8_t* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Data-parallel collective: SUM all-reduce of a gradient bucket over RCCL / xGMI, one communicator per process
+ * (= per GPU).  What Lightning / DeepSpeed do implicitly around the reference's training_step (clipcap/train/train.py:77-85).
+ * The communicator handle is the only object the library allocates; it carries no other state.
+ *   rank 0: cc_comm_unique_id(uid) -> the caller ships the 128 bytes to the other ranks (MPI, a TCP store, torch.distributed ...)
+ *   every rank, with its GPU current (hipSetDevice): cc_comm_create(&comm, nranks, rank, uid)
+ *   per step: cc_allreduce_bucket(comm, g32 + lo, hi - lo, CC_RED_F32, stream) for each finished slice of the gradient arena
+ *             (cc_*_bwd_range), enqueued on a side stream that waits on the backward stream — in place, asynchronous
+ *   cc_comm_destroy(comm)
+ * RCCL is bound at run time; CC_ERR_STATE = no librccl could be loaded.
+ * ------------------------------------------------------------------------------------------------------------ */
+#define CC_COMM_UID_BYTES 128
+#define CC_RED_F32 0
+#define CC_RED_BF16 1
+#define CC_RED_F16 2
+int cc_comm_unique_id(uint8_t* uid_host);
+int cc_comm_create(void** comm, int32_t nranks, int32_t rank, const uint8_t* uid_host);
+int cc_allreduce_bucket(void* comm, void* buf, int64_t count, int32_t dtype, void* stream);
+int cc_comm_destroy(void* comm);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Sampling decoders (replaces the per-step torch ops of clipcap/inference/base.py:159-184 generate_nucleus_sampling and

@@ -406,3 +406,22 @@ def test_train_cli_resume_from_restores_schedule_and_state(tmp_path):
         assert torch.allclose(v, b["state_dict"][k], atol=1e-6, rtol=0), k
     for part in a["optimizer_state"]:
         assert torch.allclose(a["optimizer_state"][part]["m"], b["optimizer_state"][part]["m"], atol=1e-7, rtol=1e-5)
+
+
+def test_mapper_forward_with_attention_matches_reference_probabilities():
+    """a4: the (b, n, m, h) attention tensor MultiHeadAttention.forward returns (attention.py:32-42), per layer, vs the reference's own
+    values (tests/golden/mapper_tiny att.*, mapper_hd96 att.*)."""
+    from clipcap_amd.model.mapper import TransformerMapper
+    for name in ("mapper_tiny", "mapper_hd96"):
+        g = load_golden(name)
+        E, D, P, L, H, N, B = [int(v) for v in g["dims"]]
+        m = TransformerMapper(E, D, L, P, H, N)
+        m.load_state_dict(sd_of(g))
+        m = m.to("cuda")
+        out, atts = m.forward_with_attention(torch.from_numpy(g["in.x"]).cuda())
+        assert len(atts) == N and (out.cpu() - torch.from_numpy(g["out"])).abs().max().item() <= 3e-2
+        for i, a in enumerate(atts):
+            ref = torch.from_numpy(g[f"att.{i}"])
+            assert a.shape == ref.shape
+            assert (a.cpu() - ref).abs().max().item() <= 5e-3, (name, i)
+            assert (a.sum(dim=2) - 1).abs().max().item() <= 1e-5
