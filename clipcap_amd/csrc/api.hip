@@ -93,7 +93,7 @@ struct MapperWS {
     float *lse[MAX_LAYERS], *mean1[MAX_LAYERS], *rstd1[MAX_LAYERS], *mean2[MAX_LAYERS], *rstd2[MAX_LAYERS];
     // backward scratch
     float* dx32;
-    op16_t *dx16, *dh16, *dxn16, *datt16, *dqkv16, *dlin16;
+    op16_t *dx16, *dx16b, *dh16, *dxn16, *datt16, *dqkv16, *dlin16;
     float* wg_scratch;
     float* adelta;
     size_t bytes;
@@ -133,6 +133,8 @@ void mapper_carve(const cc_mapper_cfg* c, int B, int save, void* ws, MapperWS& w
     if (save) {
         w.dx32 = cv.take<float>(M * D);
         w.dx16 = cv.take<op16_t>(M * D);
+        w.dx16b = cv.take<op16_t>(M * D);       // gradient after the LN2 backward: a second buffer so that the layer's four weight
+                                                // gradients can run as one grouped launch once all their operands exist
         w.dh16 = cv.take<op16_t>(M * c->Hm);
         w.dxn16 = cv.take<op16_t>(M * D);
         w.datt16 = cv.take<op16_t>(M * D);
@@ -141,7 +143,7 @@ void mapper_carve(const cc_mapper_cfg* c, int B, int save, void* ws, MapperWS& w
         w.wg_scratch = cv.take<float>(WGRAD_SCRATCH_BYTES / sizeof(float));
         w.adelta = cv.take<float>((size_t)B * c->H * S);
     } else {
-        w.dx32 = nullptr; w.dx16 = w.dh16 = w.dxn16 = w.datt16 = w.dqkv16 = w.dlin16 = nullptr; w.wg_scratch = nullptr; w.adelta = nullptr;
+        w.dx32 = nullptr; w.dx16 = w.dx16b = w.dh16 = w.dxn16 = w.datt16 = w.dqkv16 = w.dlin16 = nullptr; w.wg_scratch = nullptr; w.adelta = nullptr;
     }
     w.bytes = (cv.off + 255) & ~size_t(255);
 }
@@ -200,7 +202,7 @@ struct Gpt2WS {
     float *pmax, *psum, *tgt_logit, *lse_row, *row_loss;
     // backward
     float* dx32;
-    op16_t *dx16, *dhf16, *du16, *dxn16, *datt16, *dqkv16;
+    op16_t *dx16, *dx16b, *dhf16, *du16, *dxn16, *datt16, *dqkv16;
     float* wg_scratch;
     float* adelta;
     size_t bytes;
@@ -245,6 +247,7 @@ void gpt2_carve(const cc_gpt2_cfg* c, int B, int T, int cap, int mode, void* ws,
         w.row_loss = cv.take<float>(Mc);
         w.dx32 = cv.take<float>(M * D);
         w.dx16 = cv.take<op16_t>(M * D);
+        w.dx16b = full ? cv.take<op16_t>(M * D) : w.dx16;   // full finetune: second copy so a layer's weight gradients can run grouped
         w.dhf16 = cv.take<op16_t>(Mc * D);
         w.du16 = cv.take<op16_t>(M * 4 * D);
         w.dxn16 = cv.take<op16_t>(M * D);
@@ -255,7 +258,7 @@ void gpt2_carve(const cc_gpt2_cfg* c, int B, int T, int cap, int mode, void* ws,
     } else {
         w.wg_scratch = nullptr; w.adelta = nullptr;
         w.logits16 = nullptr; w.pmax = w.psum = w.tgt_logit = w.lse_row = w.row_loss = nullptr;
-        w.dx32 = nullptr; w.dx16 = w.dhf16 = w.du16 = w.dxn16 = w.datt16 = w.dqkv16 = nullptr;
+        w.dx32 = nullptr; w.dx16 = w.dx16b = w.dhf16 = w.du16 = w.dxn16 = w.datt16 = w.dqkv16 = nullptr;
     }
     w.bytes = (cv.off + 255) & ~size_t(255);
 }
@@ -387,7 +390,8 @@ int CC_API(cc_mapper_bwd_range)(const cc_mapper_cfg* c, int32_t B, const float* 
         CC_TRY(copy_rows(dout, (size_t)c->L * D, w.dx32 + (size_t)PP * D, (size_t)S * D, c->L * D, B, st));
         CC_TRY(f32_to_bf16(w.dx32, w.dx16, (size_t)M * D, st));
     }
-    WgradBatch wb;          // one slab-reduce launch per layer for its four weight gradients
+    WgradBatch wb;          // per layer: its four weight gradients as ONE grouped GEMM launch + ONE slab reduce (wgrad_flush)
+    wb.defer = true;
     for (int l = l_hi - 1; l >= l_lo; l--) {
         const auto& y = o.layer[l];
         // fc2: y = h W2^T + b2
@@ -398,19 +402,21 @@ int CC_API(cc_mapper_bwd_range)(const cc_mapper_cfg* c, int32_t B, const float* 
         CC_TRY(gemm_wgrad(w.dh16, Hm, w.xn2[l], D, Hm, D, M, g32 + y.w1, D, w.wg_scratch, st, &wb));
         CC_TRY(colsum_bf16(w.dh16, Hm, M, Hm, g32 + y.b1, st));
         CC_TRY(gemm_bf16out(0, 0, w.dh16, Hm, w16t + y.w1, Hm, M, D, Hm, w.dxn16, D, nullptr, 0, nullptr, st));   // W1^T [D, Hm]
-        CC_TRY(ln_bwd(w.dxn16, w.x1[l], D, nullptr, w.mean2[l], w.rstd2[l], w32 + y.n2w, w.dx32, w.dx32, w.dx16, g32 + y.n2w,
+        CC_TRY(ln_bwd(w.dxn16, w.x1[l], D, nullptr, w.mean2[l], w.rstd2[l], w32 + y.n2w, w.dx32, w.dx32, w.dx16b, g32 + y.n2w,
                       g32 + y.n2b, M, D, st));
         // project
-        CC_TRY(gemm_wgrad(w.dx16, D, w.att[l], D, D, D, M, g32 + y.wp, D, w.wg_scratch, st, &wb));
-        CC_TRY(colsum_bf16(w.dx16, D, M, D, g32 + y.bp, st));
-        CC_TRY(gemm_bf16out(0, 0, w.dx16, D, w16t + y.wp, D, M, D, D, w.datt16, D, nullptr, 0, nullptr, st));     // Wp^T
+        CC_TRY(gemm_wgrad(w.dx16b, D, w.att[l], D, D, D, M, g32 + y.wp, D, w.wg_scratch, st, &wb));
+        CC_TRY(colsum_bf16(w.dx16b, D, M, D, g32 + y.bp, st));
+        CC_TRY(gemm_bf16out(0, 0, w.dx16b, D, w16t + y.wp, D, M, D, D, w.datt16, D, nullptr, 0, nullptr, st));     // Wp^T
         CC_TRY(attn_bwd(w.qkv[l], w.datt16, w.att[l], w.lse[l], w.adelta, B, S, H, hd, false, w.dqkv16, st));
         // fused q/kv projection (to_queries.weight ++ to_keys_values.weight = [3D, D])
         CC_TRY(gemm_wgrad(w.dqkv16, 3 * D, w.xn1[l], D, 3 * D, D, M, g32 + y.wq, D, w.wg_scratch, st, &wb));
         CC_TRY(gemm_bf16out(0, 0, w.dqkv16, 3 * D, w16t + y.wq, 3 * D, M, D, 3 * D, w.dxn16, D, nullptr, 0, nullptr, st));  // Wqkv^T [D, 3D]
+        // the deferred weight gradients read dx16 (layer input gradient), dh16, dx16b, dqkv16: all still intact here — run them
+        // before the LN1 backward overwrites dx16 with the next layer's input gradient
+        CC_TRY(wgrad_flush(wb, st));
         CC_TRY(ln_bwd(w.dxn16, w.x[l], D, nullptr, w.mean1[l], w.rstd1[l], w32 + y.n1w, w.dx32, w.dx32, w.dx16, g32 + y.n1w,
                       g32 + y.n1b, M, D, st));
-        CC_TRY(wgrad_flush(wb, st));
     }
     if (l_lo > 0) return CC_OK;
     // prefix_const, pos_embeddings, linear
@@ -613,40 +619,45 @@ int CC_API(cc_gpt2_bwd_range)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, cons
     gpt2_carve(c, s->B, s->T, s->T - s->L, s->mode, ws, w);
     const int D = c->D, M = s->B * s->T, H = c->H, hd = D / H, D3 = 3 * D, D4 = 4 * D;
     const bool full = s->mode == 2;
+    WgradBatch wb;          // full finetune: a layer's four weight gradients as one grouped launch + one slab reduce
+    wb.defer = full;
+    WgradBatch* wbp = full ? &wb : nullptr;
     for (int l = l_hi - 1; l >= l_lo; l--) {
         const auto& y = o.layer[l];
-        // residual dropout: the gradient entering a c_proj is the masked residual gradient (its bf16 copy is only read by that
+        // residual dropout: the gradient entering a c_proj is the masked residual gradient (its 16-bit copy is only read by that
         // c_proj's backward GEMMs, so it is masked in place; dx32, the residual stream's own gradient, stays unmasked)
         CC_TRY(dropout_bf16(w.dx16, (size_t)M * D, make_drop(s->p_resid, s->drop_seed, DROP_RESID_MLP, l), st));
         // mlp.c_proj (Conv1D [4D, D]): y = hact W + b
         if (full) {
-            CC_TRY(gemm_wgrad(w.hact[l], D4, w.dx16, D, D4, D, M, g32 + y.p2w, D, w.wg_scratch, st));
+            CC_TRY(gemm_wgrad(w.hact[l], D4, w.dx16, D, D4, D, M, g32 + y.p2w, D, w.wg_scratch, st, wbp));
             CC_TRY(colsum_bf16(w.dx16, D, M, D, g32 + y.p2b, st));
         }
         CC_TRY(gemm_dact(0, 0, w.dx16, D, w16 + y.p2w, D, M, D4, D, w.du16, D4, w.u[l], 2, st));
         // mlp.c_fc (Conv1D [D, 4D])
         if (full) {
-            CC_TRY(gemm_wgrad(w.xn2[l], D, w.du16, D4, D, D4, M, g32 + y.fw, D4, w.wg_scratch, st));
+            CC_TRY(gemm_wgrad(w.xn2[l], D, w.du16, D4, D, D4, M, g32 + y.fw, D4, w.wg_scratch, st, wbp));
             CC_TRY(colsum_bf16(w.du16, D4, M, D4, g32 + y.fb, st));
         }
         CC_TIMED(CC_SITE_GPT2_FC_DGRAD, st, gemm_bf16out(0, 0, w.du16, D4, w16 + y.fw, D4, M, D, D4, w.dxn16, D, nullptr, 0, nullptr, st));
-        CC_TRY(ln_bwd(w.dxn16, w.x1[l], D, nullptr, w.mean2[l], w.rstd2[l], w32 + y.l2w, w.dx32, w.dx32, w.dx16, full ? g32 + y.l2w : nullptr,
+        CC_TRY(ln_bwd(w.dxn16, w.x1[l], D, nullptr, w.mean2[l], w.rstd2[l], w32 + y.l2w, w.dx32, w.dx32, w.dx16b, full ? g32 + y.l2w : nullptr,
                       full ? g32 + y.l2b : nullptr, M, D, st));
         // attn.c_proj (Conv1D [D, D])
-        CC_TRY(dropout_bf16(w.dx16, (size_t)M * D, make_drop(s->p_resid, s->drop_seed, DROP_RESID_ATTN, l), st));
+        CC_TRY(dropout_bf16(w.dx16b, (size_t)M * D, make_drop(s->p_resid, s->drop_seed, DROP_RESID_ATTN, l), st));
         if (full) {
-            CC_TRY(gemm_wgrad(w.att[l], D, w.dx16, D, D, D, M, g32 + y.pw, D, w.wg_scratch, st));
-            CC_TRY(colsum_bf16(w.dx16, D, M, D, g32 + y.pb, st));
+            CC_TRY(gemm_wgrad(w.att[l], D, w.dx16b, D, D, D, M, g32 + y.pw, D, w.wg_scratch, st, wbp));
+            CC_TRY(colsum_bf16(w.dx16b, D, M, D, g32 + y.pb, st));
         }
-        CC_TRY(gemm_bf16out(0, 0, w.dx16, D, w16 + y.pw, D, M, D, D, w.datt16, D, nullptr, 0, nullptr, st));
+        CC_TRY(gemm_bf16out(0, 0, w.dx16b, D, w16 + y.pw, D, M, D, D, w.datt16, D, nullptr, 0, nullptr, st));
         CC_TRY(attn_bwd(w.qkv[l], w.datt16, w.att[l], w.lse[l], w.adelta, s->B, s->T, H, hd, true, w.dqkv16, st,
                         make_drop(s->p_attn, s->drop_seed, DROP_ATTN, l)));
         // attn.c_attn (Conv1D [D, 3D])
         if (full) {
-            CC_TRY(gemm_wgrad(w.xn1[l], D, w.dqkv16, D3, D, D3, M, g32 + y.aw, D3, w.wg_scratch, st));
+            CC_TRY(gemm_wgrad(w.xn1[l], D, w.dqkv16, D3, D, D3, M, g32 + y.aw, D3, w.wg_scratch, st, wbp));
             CC_TRY(colsum_bf16(w.dqkv16, D3, M, D3, g32 + y.ab, st));
         }
         CC_TRY(gemm_bf16out(0, 0, w.dqkv16, D3, w16 + y.aw, D3, M, D, D3, w.dxn16, D, nullptr, 0, nullptr, st));
+        // deferred weight gradients: dx16 (masked layer-input gradient), du16, dx16b, dqkv16 are all still intact here
+        if (full) CC_TRY(wgrad_flush(wb, st));
         CC_TRY(ln_bwd(w.dxn16, w.x[l], D, nullptr, w.mean1[l], w.rstd1[l], w32 + y.l1w, w.dx32, w.dx32, w.dx16, full ? g32 + y.l1w : nullptr,
                       full ? g32 + y.l1b : nullptr, M, D, st));
     }

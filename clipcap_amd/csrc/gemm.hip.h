@@ -896,21 +896,23 @@ __device__ unsigned long long cc_stamp_buf[2 * 8];
 #define H_STAMP(I)
 #define H_STAMP_OUT
 #endif
-template <class Epi, int NJ, bool TT = false>
-__global__ __launch_bounds__(512, 1) void gemm_nt_stag256_kernel(const op16_t* __restrict__ A, const op16_t* __restrict__ B, GemmShape g, Epi epi) {
+// body shared by the single-problem kernels and the grouped weight-gradient kernel: `tile` = logical tile of this block inside its
+// problem (XCD remap applied by the caller), `zslice` = its K slice
+template <class Epi, int NJ, bool TT>
+__device__ __forceinline__ void gemm_stag256_body(const op16_t* __restrict__ A, const op16_t* __restrict__ B, const GemmShape& g, const Epi& epi,
+                                                  int tile, int zslice, char* smem) {
     static_assert(NJ >= 2 && NJ <= 4, "wave tile is 128 x (16 NJ)");
     static_assert(!TT || NJ == 4, "the K-strided image is laid out for 256-column tiles");
     constexpr int BN = 64 * NJ;
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wn = wave & 3;
     const int arow = grp * 128, bcol = wn * (16 * NJ);
     const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + H_BM - 1) / H_BM;
     int tm, tn;
-    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, g.group_m, tm, tn);
+    tile_coords(tile, tiles_m, tiles_n, g.group_m, tm, tn);
     const int m0 = tm * H_BM, n0 = tn * BN;
-    const int kbeg = blockIdx.z * g.k_chunk;                  // split-K slice (k_chunk is a multiple of 64)
+    const int kbeg = zslice * g.k_chunk;                      // split-K slice (k_chunk is a multiple of 64)
     const int nk = (min(g.K, kbeg + g.k_chunk) - kbeg) / H_BK;
     f32x4 acc[8][NJ];
 #pragma unroll
@@ -984,6 +986,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_stag256_kernel(const op16_t* _
     H_STAMP(7)                                         // epilogue
     H_STAMP_OUT
 }
+template <class Epi, int NJ, bool TT = false>
+__global__ __launch_bounds__(512, 1) void gemm_nt_stag256_kernel(const op16_t* __restrict__ A, const op16_t* __restrict__ B, GemmShape g, Epi epi) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    gemm_stag256_body<Epi, NJ, TT>(A, B, g, epi, xcd_remap(blockIdx.x, gridDim.x), (int)blockIdx.z, smem);
+}
 #undef H_STAMP_DECL
 #undef H_STAMP
 #undef H_STAMP_OUT
@@ -1018,18 +1025,19 @@ __device__ __forceinline__ void glds_tile_tt(const op16_t* __restrict__ base, in
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + seg * 1024), 16, 0, 0);
     }
 }
+// body shared by the single-problem kernel and the grouped kernel: `tile` = logical tile index of this block inside its problem (XCD
+// remap already applied by the caller), `zslice` = its K slice
 template <class Epi>
-__global__ __launch_bounds__(G_THREADS, 1) void gemm_tt_glds4_kernel(const op16_t* __restrict__ A, const op16_t* __restrict__ B,
-                                                                      GemmShape g, Epi epi) {
-    extern __shared__ __attribute__((aligned(1024))) char smemt[];
+__device__ __forceinline__ void gemm_tt_glds4_body(const op16_t* __restrict__ A, const op16_t* __restrict__ B, const GemmShape& g, const Epi& epi,
+                                                   int tile, int zslice, char* smemt) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_n = (g.N + G_BN - 1) / G_BN, tiles_m = (g.M + G_BM - 1) / G_BM;
     int tm, tn;
-    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, g.group_m, tm, tn);
+    tile_coords(tile, tiles_m, tiles_n, g.group_m, tm, tn);
     const int m0 = tm * G_BM, n0 = tn * G_BN;
-    const int kbeg = blockIdx.z * g.k_chunk;
+    const int kbeg = zslice * g.k_chunk;
     const int nk = (min(g.K, kbeg + g.k_chunk) - kbeg) / G_BK;
     f32x4 acc[4][4];
 #pragma unroll
@@ -1085,6 +1093,12 @@ __global__ __launch_bounds__(G_THREADS, 1) void gemm_tt_glds4_kernel(const op16_
 #undef GT_LGKM0
     __syncthreads();
     gemm_epilogue(acc, smemt, wave, lane, m0 + wm * 64, n0 + wn * 64, epi);
+}
+template <class Epi>
+__global__ __launch_bounds__(G_THREADS, 1) void gemm_tt_glds4_kernel(const op16_t* __restrict__ A, const op16_t* __restrict__ B,
+                                                                      GemmShape g, Epi epi) {
+    extern __shared__ __attribute__((aligned(1024))) char smemt[];
+    gemm_tt_glds4_body(A, B, g, epi, xcd_remap(blockIdx.x, gridDim.x), (int)blockIdx.z, smemt);
 }
 
 
@@ -1538,6 +1552,64 @@ inline int launch_gemm_tt256(const op16_t* A, int lda, const op16_t* B, int ldb,
     if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_stag256_kernel<Epi, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr = true; }
     const dim3 gr((unsigned)(((M + H_BM - 1) / H_BM) * ((N + H_BN - 1) / H_BN)), 1, (unsigned)ksplit);
     hipLaunchKernelGGL((gemm_nt_stag256_kernel<Epi, 4, true>), gr, dim3(512), sh, st, A, B, g, epi);
+    return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+}
+
+// Grouped form: up to 4 independent weight-gradient problems (one mapper / GPT-2 layer's dW's) in ONE launch.  The blocks of all
+// problems and all their K slices form one 1-D grid (problem i owns logical blocks [first[i], first[i+1]), slice-major inside), so the
+// launch fills the CUs with ONE tail instead of four, and the per-launch floor is paid once.  Each problem writes fp32 slabs (C of
+// its functor + slice * zstride) that the batched slab reduce folds into dW.
+struct TTGroup {
+    const op16_t* A[4];
+    const op16_t* B[4];
+    GemmShape g[4];
+    float* slab[4];        // slab base of problem i (slice z at + z * zstride[i]); row stride = g[i].N
+    size_t zstride[4];
+    int first[5];          // logical block ranges
+    int n;
+};
+static __global__ __launch_bounds__(G_THREADS, 1) void gemm_tt_glds4_group_kernel(TTGroup grp) {
+    extern __shared__ __attribute__((aligned(1024))) char smemt[];
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < 4; k++)
+        if (k < grp.n && L >= grp.first[k]) i = k;
+    const GemmShape g = grp.g[i];
+    const int tiles = ((g.M + G_BM - 1) / G_BM) * ((g.N + G_BN - 1) / G_BN);
+    const int local = L - grp.first[i];
+    const int z = local / tiles, tile = local - z * tiles;
+    EpiF32 e{grp.slab[i] + (size_t)z * grp.zstride[i], nullptr, g.N, g.M, g.N, 0, 1.0f};
+    gemm_tt_glds4_body(grp.A[i], grp.B[i], g, e, tile, z, smemt);
+}
+// the same grouping on the 256 x 256 transpose-read kernel (8 waves, one block per CU): fewer, fatter blocks — wins when the group's
+// tiles x slices fill the CUs in one round (a mapper layer: 72 tiles x 3 slices)
+static __global__ __launch_bounds__(512, 1) void gemm_tt_stag256_group_kernel(TTGroup grp) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < 4; k++)
+        if (k < grp.n && L >= grp.first[k]) i = k;
+    const GemmShape g = grp.g[i];
+    const int tiles = ((g.M + H_BM - 1) / H_BM) * ((g.N + H_BN - 1) / H_BN);
+    const int local = L - grp.first[i];
+    const int z = local / tiles, tile = local - z * tiles;
+    EpiF32 e{grp.slab[i] + (size_t)z * grp.zstride[i], nullptr, g.N, g.M, g.N, 0, 1.0f};
+    gemm_stag256_body<EpiF32, 4, true>(grp.A[i], grp.B[i], g, e, tile, z, smem);
+}
+inline int launch_gemm_tt256_group(const TTGroup& grp, hipStream_t st) {
+    constexpr size_t sh = (size_t)H_NS * H_STAGE;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tt_stag256_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr = true; }
+    hipLaunchKernelGGL(gemm_tt_stag256_group_kernel, dim3((unsigned)grp.first[grp.n]), dim3(512), sh, st, grp);
+    return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+}
+inline int launch_gemm_tt128_group(const TTGroup& grp, hipStream_t st) {
+    const size_t sh = 4 * 2 * G_TILE_BYTES;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tt_glds4_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr = true; }
+    hipLaunchKernelGGL(gemm_tt_glds4_group_kernel, dim3((unsigned)grp.first[grp.n]), dim3(G_THREADS), sh, st, grp);
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
 

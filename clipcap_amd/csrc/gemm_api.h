@@ -32,6 +32,14 @@ struct WgradBatch {
     Item it[8];
     int n = 0;
     size_t used = 0;      // bytes of scratch already holding parked slabs
+    // defer = true: weight gradients that fit the 128 x 128 TT kernel are not launched by gemm_wgrad but collected (up to 4, same K)
+    // and run by wgrad_flush as ONE grouped launch (gemm_tt_glds4_group_kernel) + one slab reduce.  The caller must keep every
+    // operand unchanged until the flush.
+    bool defer = false;
+    struct Deferred { const op16_t* X; const op16_t* Y; int ldx, ldy, Mw, Nw, K; float* dW; int ldw; };
+    Deferred d[4];
+    int nd = 0;
+    float* scratch = nullptr;
 };
 int wgrad_flush(WgradBatch& b, hipStream_t st);
 int gemm_wgrad(const op16_t* X, int ldx, const op16_t* Y, int ldy, int Mw, int Nw, int K, float* dW, int ldw, float* scratch,

@@ -42,7 +42,67 @@ __global__ __launch_bounds__(256) void k_slab_reduce_multi(SlabItems items) {
         *reinterpret_cast<float4*>(d) = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
     }
 }
+// the deferred problems of a batch as one grouped launch: a common slice count ks is chosen to minimise
+// rounds x (K-steps per block + fixed per-block cost), rounds = ceil(blocks / CUs), then the slabs are parked for the batched reduce
+static int wgrad_launch_group(WgradBatch& b, hipStream_t st) {
+    if (b.nd == 0) return CC_OK;
+    TTGroup grp;
+    grp.n = b.nd;
+    const int K = b.d[0].K;
+    size_t slab_sum = 0;
+    for (int i = 0; i < b.nd; i++) slab_sum += (((size_t)b.d[i].Mw * b.d[i].Nw * sizeof(float)) + 255) & ~size_t(255);
+    const size_t room = WGRAD_SCRATCH_BYTES - b.used;
+    // tile kernel: 256 x 256 (8 waves, fewer / fatter blocks) or 128 x 128; slice count: minimise rounds x (K-steps + fixed per-block
+    // cost), rounds = ceil(blocks / CUs).  CC_WGRAD_TILE / CC_WGRAD_KS override (tuning knobs).
+    static const int force_tile = []() { const char* e = getenv("CC_WGRAD_TILE"); return e ? atoi(e) : 0; }();
+    static const int force_ks = []() { const char* e = getenv("CC_WGRAD_KS"); return e ? atoi(e) : 0; }();
+    int best_tile = 128, best_ks = 1;
+    double best_cost = 1e30;
+    for (int tile : {256, 128}) {
+        if (force_tile && tile != force_tile) continue;
+        if (tile == 256 && (K % H_BK)) continue;
+        const int bk = tile == 256 ? H_BK : G_BK, ksteps = K / bk;
+        int total = 0;
+        for (int i = 0; i < b.nd; i++) total += ((b.d[i].Mw + tile - 1) / tile) * ((b.d[i].Nw + tile - 1) / tile);
+        // per K-step cost in units of a 128-tile step (measured: 256-tile step of 32 ~ 0.8 us for 4x the tile area, 128-tile step of 64 ~ 0.65 us)
+        const double step_cost = tile == 256 ? 1.25 : 1.0, fixed = tile == 256 ? 16.0 : 14.0;
+        for (int ks = 1; ks <= 8 && (size_t)ks * slab_sum <= room && ksteps / ks >= 8; ks++) {
+            if (force_ks && ks != force_ks) continue;
+            const int per = (ksteps + ks - 1) / ks;
+            const int rounds = (total * ks + 255) / 256;
+            const double cost = rounds * (per * step_cost + fixed);
+            if (cost < best_cost) { best_cost = cost; best_tile = tile; best_ks = ks; }
+        }
+    }
+    const int bk = best_tile == 256 ? H_BK : G_BK, ksteps = K / bk;
+    // slices are multiples of 64 deep for both kernels (k_chunk convention of GemmShape)
+    const int kt64 = (K + G_BK - 1) / G_BK;
+    const int per64 = (kt64 + best_ks - 1) / best_ks, ks = (kt64 + per64 - 1) / per64;
+    (void)ksteps;
+    int first = 0;
+    for (int i = 0; i < b.nd; i++) {
+        const auto& d = b.d[i];
+        const size_t slab = (size_t)d.Mw * d.Nw;
+        float* sc = b.scratch + b.used / sizeof(float);
+        const int tiles = ((d.Mw + best_tile - 1) / best_tile) * ((d.Nw + best_tile - 1) / best_tile);
+        grp.A[i] = d.X; grp.B[i] = d.Y;
+        grp.g[i] = GemmShape{d.Mw, d.Nw, d.K, d.ldx, d.ldy, per64 * G_BK, 8};
+        grp.slab[i] = sc; grp.zstride[i] = slab;
+        grp.first[i] = first;
+        first += tiles * ks;
+        b.it[b.n++] = WgradBatch::Item{sc, slab, ks, d.Nw, d.dW, d.ldw, slab / 4};
+        b.used += (size_t)ks * slab * sizeof(float);
+        b.used = (b.used + 255) & ~size_t(255);
+    }
+    grp.first[b.nd] = first;
+    for (int i = b.nd + 1; i < 5; i++) grp.first[i] = first;
+    b.nd = 0;
+    return best_tile == 256 ? launch_gemm_tt256_group(grp, st) : launch_gemm_tt128_group(grp, st);
+}
+
 int wgrad_flush(WgradBatch& b, hipStream_t st) {
+    const int rcg = wgrad_launch_group(b, st);
+    if (rcg != CC_OK) return rcg;
     if (b.n == 0) return CC_OK;
     SlabItems items;
     size_t nmax = 0;
@@ -78,6 +138,14 @@ int gemm_wgrad(const op16_t* X, int ldx, const op16_t* Y, int ldy, int Mw, int N
         const int rcf = wgrad_flush(*batch, st);
         if (rcf != CC_OK) return rcf;
     }
+    // grouped path: park the problem; wgrad_flush launches the layer's gradients together (one tail, one launch floor)
+    if (batch && batch->defer && g_gemm_tile_mode != 0 && tt_ok && scratch && (K % G_BK) == 0 && K >= 1024 && (slab & 3) == 0 &&
+        (batch->nd == 0 || batch->d[0].K == K)) {
+        if (batch->nd == 4 || batch->n + batch->nd >= 8) { const int rcf = wgrad_flush(*batch, st); if (rcf != CC_OK) return rcf; }
+        batch->scratch = scratch;
+        batch->d[batch->nd++] = WgradBatch::Deferred{X, Y, ldx, ldy, Mw, Nw, K, dW, ldw};
+        return CC_OK;
+    }
     const size_t used = (batch && scratch) ? batch->used : 0;
     float* sc = scratch ? scratch + used / sizeof(float) : nullptr;
     const size_t fit = scratch ? (WGRAD_SCRATCH_BYTES - used) / (slab * sizeof(float)) : 1;
@@ -103,6 +171,7 @@ int gemm_wgrad(const op16_t* X, int ldx, const op16_t* Y, int ldy, int Mw, int N
     const int tiles = ((Mw + G_BM - 1) / G_BM) * ((Nw + G_BN - 1) / G_BN);
     // small weight gradients (mapper, K = 5120): 128 x 128 TT kernel, 4-stage DMA pipeline + transpose reads, one block per CU
     if (g_gemm_tile_mode != 0 && tt_ok && (K % G_BK) == 0 && K >= 1024 && tiles <= 256 && scratch && fit >= 1) {
+
         int ks = std::max(1, 256 / tiles);
         ks = std::min(ks, std::max(1, K / (4 * G_BK)));
         if ((size_t)ks > fit) ks = (int)fit;
