@@ -396,17 +396,18 @@ int CC_API(cc_mapper_bwd_range)(const cc_mapper_cfg* c, int32_t B, const float* 
         const auto& y = o.layer[l];
         // fc2: y = h W2^T + b2
         CC_TIMED(CC_SITE_MAPPER_WGRAD_FC2, st, gemm_wgrad(w.dx16, D, w.h[l], Hm, D, Hm, M, g32 + y.w2, Hm, w.wg_scratch, st, &wb));
-        CC_TRY(colsum_bf16(w.dx16, D, M, D, g32 + y.b2, st));
+        // fc2.bias gradient = column sums of dx16: for every layer but the top one the LN1 backward of the layer above produced
+        // them together with dx16 (ln_bwd dcol); the top layer's dx16 comes from the seed
+        if (l == c->N - 1) CC_TRY(colsum_bf16(w.dx16, D, M, D, g32 + y.b2, st));
         CC_TRY(gemm_dact(0, 0, w.dx16, D, w16t + y.w2, D, M, Hm, D, w.dh16, Hm, w.h[l], 1, st));          // W2^T [Hm, D]
         // fc1
         CC_TRY(gemm_wgrad(w.dh16, Hm, w.xn2[l], D, Hm, D, M, g32 + y.w1, D, w.wg_scratch, st, &wb));
         CC_TRY(colsum_bf16(w.dh16, Hm, M, Hm, g32 + y.b1, st));
         CC_TRY(gemm_bf16out(0, 0, w.dh16, Hm, w16t + y.w1, Hm, M, D, Hm, w.dxn16, D, nullptr, 0, nullptr, st));   // W1^T [D, Hm]
         CC_TRY(ln_bwd(w.dxn16, w.x1[l], D, nullptr, w.mean2[l], w.rstd2[l], w32 + y.n2w, w.dx32, w.dx32, w.dx16b, g32 + y.n2w,
-                      g32 + y.n2b, M, D, st));
+                      g32 + y.n2b, M, D, st, g32 + y.bp));         // + project.bias gradient (column sums of dx16b)
         // project
         CC_TRY(gemm_wgrad(w.dx16b, D, w.att[l], D, D, D, M, g32 + y.wp, D, w.wg_scratch, st, &wb));
-        CC_TRY(colsum_bf16(w.dx16b, D, M, D, g32 + y.bp, st));
         CC_TRY(gemm_bf16out(0, 0, w.dx16b, D, w16t + y.wp, D, M, D, D, w.datt16, D, nullptr, 0, nullptr, st));     // Wp^T
         CC_TRY(attn_bwd(w.qkv[l], w.datt16, w.att[l], w.lse[l], w.adelta, B, S, H, hd, false, w.dqkv16, st));
         // fused q/kv projection (to_queries.weight ++ to_keys_values.weight = [3D, D])
@@ -416,7 +417,7 @@ int CC_API(cc_mapper_bwd_range)(const cc_mapper_cfg* c, int32_t B, const float* 
         // before the LN1 backward overwrites dx16 with the next layer's input gradient
         CC_TRY(wgrad_flush(wb, st));
         CC_TRY(ln_bwd(w.dxn16, w.x[l], D, nullptr, w.mean1[l], w.rstd1[l], w32 + y.n1w, w.dx32, w.dx32, w.dx16, g32 + y.n1w,
-                      g32 + y.n1b, M, D, st));
+                      g32 + y.n1b, M, D, st, l > 0 ? g32 + o.layer[l - 1].b2 : nullptr));   // + fc2.bias gradient of the layer below
     }
     if (l_lo > 0) return CC_OK;
     // prefix_const, pos_embeddings, linear
@@ -622,6 +623,10 @@ int CC_API(cc_gpt2_bwd_range)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, cons
     WgradBatch wb;          // full finetune: a layer's four weight gradients as one grouped launch + one slab reduce
     wb.defer = full;
     WgradBatch* wbp = full ? &wb : nullptr;
+    // bias gradients of the two c_proj's = column sums of the (dropout-masked) residual gradient copies.  Without residual dropout
+    // the LayerNorm backward that produces the copy sums its columns as well (ln_bwd dcol); with dropout the mask is applied
+    // afterwards, so the separate column-sum launch stays.
+    const bool fold = full && s->p_resid == 0.f;
     for (int l = l_hi - 1; l >= l_lo; l--) {
         const auto& y = o.layer[l];
         // residual dropout: the gradient entering a c_proj is the masked residual gradient (its 16-bit copy is only read by that
@@ -630,7 +635,7 @@ int CC_API(cc_gpt2_bwd_range)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, cons
         // mlp.c_proj (Conv1D [4D, D]): y = hact W + b
         if (full) {
             CC_TRY(gemm_wgrad(w.hact[l], D4, w.dx16, D, D4, D, M, g32 + y.p2w, D, w.wg_scratch, st, wbp));
-            CC_TRY(colsum_bf16(w.dx16, D, M, D, g32 + y.p2b, st));
+            if (!fold || l == c->NL - 1) CC_TRY(colsum_bf16(w.dx16, D, M, D, g32 + y.p2b, st));   // top layer: dx16 comes from ln_f's backward
         }
         CC_TRY(gemm_dact(0, 0, w.dx16, D, w16 + y.p2w, D, M, D4, D, w.du16, D4, w.u[l], 2, st));
         // mlp.c_fc (Conv1D [D, 4D])
@@ -640,12 +645,12 @@ int CC_API(cc_gpt2_bwd_range)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, cons
         }
         CC_TIMED(CC_SITE_GPT2_FC_DGRAD, st, gemm_bf16out(0, 0, w.du16, D4, w16 + y.fw, D4, M, D, D4, w.dxn16, D, nullptr, 0, nullptr, st));
         CC_TRY(ln_bwd(w.dxn16, w.x1[l], D, nullptr, w.mean2[l], w.rstd2[l], w32 + y.l2w, w.dx32, w.dx32, w.dx16b, full ? g32 + y.l2w : nullptr,
-                      full ? g32 + y.l2b : nullptr, M, D, st));
+                      full ? g32 + y.l2b : nullptr, M, D, st, fold ? g32 + y.pb : nullptr));
         // attn.c_proj (Conv1D [D, D])
         CC_TRY(dropout_bf16(w.dx16b, (size_t)M * D, make_drop(s->p_resid, s->drop_seed, DROP_RESID_ATTN, l), st));
         if (full) {
             CC_TRY(gemm_wgrad(w.att[l], D, w.dx16b, D, D, D, M, g32 + y.pw, D, w.wg_scratch, st, wbp));
-            CC_TRY(colsum_bf16(w.dx16b, D, M, D, g32 + y.pb, st));
+            if (!fold) CC_TRY(colsum_bf16(w.dx16b, D, M, D, g32 + y.pb, st));
         }
         CC_TRY(gemm_bf16out(0, 0, w.dx16b, D, w16 + y.pw, D, M, D, D, w.datt16, D, nullptr, 0, nullptr, st));
         CC_TRY(attn_bwd(w.qkv[l], w.datt16, w.att[l], w.lse[l], w.adelta, s->B, s->T, H, hd, true, w.dqkv16, st,
@@ -659,7 +664,7 @@ int CC_API(cc_gpt2_bwd_range)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, cons
         // deferred weight gradients: dx16 (masked layer-input gradient), du16, dx16b, dqkv16 are all still intact here
         if (full) CC_TRY(wgrad_flush(wb, st));
         CC_TRY(ln_bwd(w.dxn16, w.x[l], D, nullptr, w.mean1[l], w.rstd1[l], w32 + y.l1w, w.dx32, w.dx32, w.dx16, full ? g32 + y.l1w : nullptr,
-                      full ? g32 + y.l1b : nullptr, M, D, st));
+                      full ? g32 + y.l1b : nullptr, M, D, st, (fold && l > 0) ? g32 + o.layer[l - 1].p2b : nullptr));
     }
     if (l_lo > 0) return CC_OK;
     CC_TRY(dropout_f32(w.dx32, (size_t)M * D, make_drop(s->p_embd, s->drop_seed, DROP_EMBD, 0), st));   // d(inputs + wpe)

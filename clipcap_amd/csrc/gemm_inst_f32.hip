@@ -49,6 +49,9 @@ static int wgrad_launch_group(WgradBatch& b, hipStream_t st) {
     TTGroup grp;
     grp.n = b.nd;
     const int K = b.d[0].K;
+    double flops = 0.0;
+    for (int i = 0; i < b.nd; i++) flops += 2.0 * b.d[i].Mw * b.d[i].Nw * (double)K;
+    cc_shared::ProfScope _all(cc_shared::SITE_ALL_GEMMS, st, flops);
     size_t slab_sum = 0;
     for (int i = 0; i < b.nd; i++) slab_sum += (((size_t)b.d[i].Mw * b.d[i].Nw * sizeof(float)) + 255) & ~size_t(255);
     const size_t room = WGRAD_SCRATCH_BYTES - b.used;
@@ -128,7 +131,6 @@ static int wgrad_reduce(const float* slabs, size_t slab, int ks, int Nw, float* 
 
 int gemm_wgrad(const op16_t* X, int ldx, const op16_t* Y, int ldy, int Mw, int Nw, int K, float* dW, int ldw, float* scratch,
                hipStream_t st, WgradBatch* batch) {
-    cc_shared::ProfScope _all(cc_shared::SITE_ALL_GEMMS, st, 2.0 * Mw * Nw * (double)K);
     if ((Nw & 7) || (ldw & 3)) return CC_ERR_SHAPE;
     const size_t slab = (size_t)Mw * Nw;
     // the DMA-staged TT kernels need 16-B aligned operands and row strides; anything else takes the register-staged kernel
@@ -146,6 +148,7 @@ int gemm_wgrad(const op16_t* X, int ldx, const op16_t* Y, int ldy, int Mw, int N
         batch->d[batch->nd++] = WgradBatch::Deferred{X, Y, ldx, ldy, Mw, Nw, K, dW, ldw};
         return CC_OK;
     }
+    cc_shared::ProfScope _all(cc_shared::SITE_ALL_GEMMS, st, 2.0 * Mw * Nw * (double)K);
     const size_t used = (batch && scratch) ? batch->used : 0;
     float* sc = scratch ? scratch + used / sizeof(float) : nullptr;
     const size_t fit = scratch ? (WGRAD_SCRATCH_BYTES - used) / (slab * sizeof(float)) : 1;

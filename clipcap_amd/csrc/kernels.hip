@@ -265,19 +265,21 @@ int ln_fwd(const float* x, int ldx, const int* row_map, const float* gamma, cons
 
 // LayerNorm backward.  dy(bf16)[r]; x[map(r)]; mean/rstd[r].  dx_out[map(r)] = (dres ? dres[map(r)] : 0) + dLN ; also a
 // bf16 copy of dx_out for the next dgrad GEMM.  Optional dgamma/dbeta (atomic fp32 accumulation, one atomic per
-// column per block).  Each wave walks rows  row = blockIdx*4 + wave + k*gridDim*4.
+// column per block) and, with them, dcol[c] += sum_r dx16[r][c] — the bias gradient of the Linear whose output gradient dx16 is
+// (column sums of the 16-bit values, exactly what k_colsum_bf16 on dx16 gives): one launch less per bias.
+// Each wave walks rows  row = blockIdx*4 + wave + k*gridDim*4.
 template <int NV, bool DG, int NW>   // NV as in k_ln_fwd; DG: accumulate dgamma / dbeta; NW waves per block
 __global__ __launch_bounds__(NW * 64) void k_ln_bwd(const op16_t* __restrict__ dy, const float* __restrict__ x, int ldx,
                                                 const int* __restrict__ row_map, const float* __restrict__ mean,
                                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                 const float* __restrict__ dres, float* __restrict__ dx32,
                                                 op16_t* __restrict__ dx16, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                int rows, int D) {
+                                                float* __restrict__ dcol, int rows, int D) {
     extern __shared__ __attribute__((aligned(16))) float ln_red[];  // [2][NW][D] when dgamma
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float4 pg[DG ? NV : 1], pb[DG ? NV : 1];
+    float4 pg[DG ? NV : 1], pb[DG ? NV : 1], pc[DG ? NV : 1];
 #pragma unroll
-    for (int it = 0; it < (DG ? NV : 1); it++) pg[it] = pb[it] = make_float4(0, 0, 0, 0);
+    for (int it = 0; it < (DG ? NV : 1); it++) pg[it] = pb[it] = pc[it] = make_float4(0, 0, 0, 0);
     for (int row = blockIdx.x * NW + wave; row < rows; row += gridDim.x * NW) {
         const size_t xr = (size_t)(row_map ? row_map[row] : row) * ldx;
         const float mu = mean[row], rs = rstd[row];
@@ -313,7 +315,18 @@ __global__ __launch_bounds__(NW * 64) void k_ln_bwd(const op16_t* __restrict__ d
                                        rs * (g[it].z - m1 - xh[it].z * m2), rs * (g[it].w - m1 - xh[it].w * m2));
                 o.x += rr[it].x; o.y += rr[it].y; o.z += rr[it].z; o.w += rr[it].w;
                 *reinterpret_cast<float4*>(dx32 + xr + c) = o;
-                if (dx16) *reinterpret_cast<uint2*>(dx16 + xr + c) = make_uint2(pack2op(o.x, o.y), pack2op(o.z, o.w));
+                if (dx16) {
+                    const uint2 pk = make_uint2(pack2op(o.x, o.y), pack2op(o.z, o.w));
+                    *reinterpret_cast<uint2*>(dx16 + xr + c) = pk;
+                    if constexpr (DG) {
+                        if (dcol) {
+                            float r0, r1, r2, r3;
+                            unpack2(pk.x, r0, r1);
+                            unpack2(pk.y, r2, r3);
+                            pc[it].x += r0; pc[it].y += r1; pc[it].z += r2; pc[it].w += r3;
+                        }
+                    }
+                }
             }
         }
     }
@@ -336,19 +349,34 @@ __global__ __launch_bounds__(NW * 64) void k_ln_bwd(const op16_t* __restrict__ d
             __hip_atomic_fetch_add(dgamma + c, sg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_add(dbeta + c, sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (dcol) {                          // third reduction through the same buffer
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < NV; it++) {
+                const int c = lane * 4 + it * 256;
+                if (c < D) *reinterpret_cast<float4*>(rg + wave * D + c) = pc[it];
+            }
+            __syncthreads();
+            for (int c = threadIdx.x; c < D; c += NW * 64) {
+                float sc = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; w++) sc += rg[w * D + c];
+                __hip_atomic_fetch_add(dcol + c, sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 int ln_bwd(const op16_t* dy, const float* x, int ldx, const int* row_map, const float* mean, const float* rstd,
            const float* gamma, const float* dres, float* dx32, op16_t* dx16, float* dgamma, float* dbeta, int rows, int D,
-           hipStream_t st) {
-    if (D > LN_MAXV * 256 || (D & 3) || (ldx & 3)) return CC_ERR_SHAPE;
+           hipStream_t st, float* dcol) {
+    if (D > LN_MAXV * 256 || (D & 3) || (ldx & 3) || (dcol && (!dgamma || !dx16 || row_map))) return CC_ERR_SHAPE;
     if (rows <= 0) return CC_OK;
     // with parameter gradients every block ends with 2*D fp32 atomics: keep the block count low (one per CU) so that the
     // atomic tail (measured: it dominated at 1024 blocks) stays ~0.4 M atomics per launch, and give those blocks 8 waves
     const int nw = (dgamma && (size_t)16 * D * sizeof(float) <= 65536) ? 8 : 4;      // 8-wave reduction buffer within the 64 KiB default
     const int grid = std::min((rows + nw - 1) / nw, dgamma ? 256 : 8192);
     const size_t sh = dgamma ? (size_t)2 * nw * D * sizeof(float) : 0;
-#define LN_BWD(NV, DG, NW) hipLaunchKernelGGL((k_ln_bwd<NV, DG, NW>), dim3(grid), dim3(NW * 64), sh, st, dy, x, ldx, row_map, mean, rstd, gamma, dres, dx32, dx16, dgamma, dbeta, rows, D)
+#define LN_BWD(NV, DG, NW) hipLaunchKernelGGL((k_ln_bwd<NV, DG, NW>), dim3(grid), dim3(NW * 64), sh, st, dy, x, ldx, row_map, mean, rstd, gamma, dres, dx32, dx16, dgamma, dbeta, dcol, rows, D)
 #define LN_BWD_D(DG, NW) { if (D <= 256) LN_BWD(1, DG, NW); else if (D <= 512) LN_BWD(2, DG, NW); else if (D <= 768) LN_BWD(3, DG, NW); else if (D <= 1024) LN_BWD(4, DG, NW); else LN_BWD(LN_MAXV, DG, NW); }
     if (dgamma && nw == 8) LN_BWD_D(true, 8) else if (dgamma) LN_BWD_D(true, 4) else LN_BWD_D(false, 4)
 #undef LN_BWD_D
