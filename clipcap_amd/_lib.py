@@ -72,6 +72,7 @@ SIGNATURES = {
     "cc_gpt2_embed_from": (_I, [_GC, _GS, _P, _P, _P, _P]),
     "cc_gpt2_fwd": (_I, [_GC, _GS, _P, _P, _P, _P]),
     "cc_gpt2_logits": (_I, [_GC, _GS, _P, _P, _P, _P, _L, _P]),
+    "cc_gpt2_logits_bwd": (_I, [_GC, _GS, _P, _P, _P, _P, _L, _P, _P, _P]),
     "cc_lmhead_ce_fwd": (_I, [_GC, _GS, _P, _P, _P, _P, _P, _P]),
     "cc_lmhead_ce_bwd": (_I, [_GC, _GS, _P, _P, _P, _P, _P, _P, _P]),
     "cc_gpt2_bwd": (_I, [_GC, _GS, _P, _P, _P, _P, _P, _P, _P]),

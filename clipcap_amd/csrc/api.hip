@@ -602,6 +602,29 @@ int CC_API(cc_lmhead_ce_bwd)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const
     return CC_OK;
 }
 
+int CC_API(cc_gpt2_logits_bwd)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, const uint16_t* w16, void* ws, const float* dlogits,
+                       int64_t ldl, float* dx0, float* g32, void* stream) {
+    if (!gpt2_cfg_ok(c) || !shape_ok(c, s) || s->mode < 1 || s->L != 0 || !w32 || !w16 || !ws || !dlogits || ldl < c->V || (s->mode == 2 && !g32))
+        return CC_ERR_ARG;
+    hipStream_t st = S_(stream);
+    Gpt2Off o;
+    gpt2_offsets(c, o);
+    Gpt2WS w;
+    gpt2_carve(c, s->B, s->T, s->T, s->mode, ws, w);      // L == 0: the loss-side buffers are sized for all B*T rows
+    const int D = c->D, M = s->B * s->T;
+    const bool full = s->mode == 2;
+    CC_TRY(f32_to_op16_pad(dlogits, ldl, c->V, w.logits16, c->Vp, M, st));
+    // d hf = dlogits · wte ([M,Vp] x [Vp(k), D(n)]); tied lm_head: d wte += dlogits^T hf (hf16 = the rows cc_gpt2_logits normalised)
+    CC_TRY(gemm_bf16out(0, 0, w.logits16, c->Vp, w16 + o.total + o.wte, c->Vp, M, D, c->Vp, w.dhf16, D, nullptr, 0, nullptr, st));
+    if (full) CC_TRY(gemm_wgrad(w.logits16, c->Vp, w.hf16, D, c->Vp, D, M, g32 + o.wte, D, w.wg_scratch, st));
+    if (hipMemsetAsync(w.dx32, 0, (size_t)M * D * sizeof(float), st) != hipSuccess) return CC_ERR_LAUNCH;
+    CC_TRY(ln_bwd(w.dhf16, w.x[c->NL], D, nullptr, w.meanf, w.rstdf, w32 + o.lnf_w, nullptr, w.dx32, w.dx16, full ? g32 + o.lnf_w : nullptr,
+                  full ? g32 + o.lnf_b : nullptr, M, D, st));
+    CC_TRY(CC_API(cc_gpt2_bwd_range)(c, s, w32, w16, ws, nullptr, nullptr, g32, c->NL, 0, stream));
+    if (dx0 && hipMemcpyAsync(dx0, w.dx32, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return CC_ERR_LAUNCH;
+    return CC_OK;
+}
+
 int CC_API(cc_gpt2_bwd)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, const uint16_t* w16, void* ws, const int64_t* tokens,
                 float* dprefix, float* g32, void* stream) {
     if (!gpt2_cfg_ok(c)) return CC_ERR_ARG;
@@ -610,7 +633,7 @@ int CC_API(cc_gpt2_bwd)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const floa
 
 int CC_API(cc_gpt2_bwd_range)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, const uint16_t* w16, void* ws, const int64_t* tokens,
                       float* dprefix, float* g32, int32_t l_hi, int32_t l_lo, void* stream) {
-    if (!gpt2_cfg_ok(c) || !shape_ok(c, s) || s->mode < 1 || !w32 || !w16 || !ws || (s->L > 0 && !dprefix) || (s->mode == 2 && (!g32 || !tokens)) ||
+    if (!gpt2_cfg_ok(c) || !shape_ok(c, s) || s->mode < 1 || !w32 || !w16 || !ws || (s->L > 0 && !dprefix) || (s->mode == 2 && !g32) ||
         l_lo < 0 || l_hi > c->NL || l_lo > l_hi)
         return CC_ERR_ARG;
     hipStream_t st = S_(stream);

@@ -42,6 +42,7 @@ int dropout_mask_u8(unsigned char* out, size_t n, Drop drop, hipStream_t st);   
 
 int embed_concat(const float* prefix, const long long* tokens, int cap, const float* wte, const float* wpe, float* x0, int B, int L,
                  int T, int D, int pos0, hipStream_t st);
+int f32_to_op16_pad(const float* src, long long lds, int V, op16_t* dst, int ldd, int M, hipStream_t st);
 int embed_bwd(const float* dx0, const long long* tokens, int cap, float* dwte, float* dwpe, int B, int L, int T, int D, hipStream_t st);
 
 int ce_rows(const float* pmax, const float* psum, int npart, const int* target, const float* tgt_logit, float* lse, float* row_loss,

@@ -77,17 +77,34 @@ int add_rows(float* dst, size_t dst_stride, const float* add, int len, int B, hi
     return CC_OK;
 }
 
-// dst[i] += sum_b src[b*src_stride + i]   (gradient of a broadcast block)
-__global__ void k_batch_sum(const float* __restrict__ src, size_t src_stride, float* __restrict__ dst, int len, int B) {
+// dst[i] += sum_b src[b*src_stride + i]   (gradient of a broadcast block).  Grid = column blocks x batch slices: each thread sums its
+// slice of the batch with 4 independent loads in flight, one fp32 atomic per (column, slice) folds the slices (a single thread per
+// column walking all B rows took 58 us for 256 x 7680 floats: 30 blocks, one load in flight each).
+__global__ __launch_bounds__(256) void k_batch_sum(const float* __restrict__ src, size_t src_stride, float* __restrict__ dst, int len, int B,
+                                                    int per) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= len) return;
-    float s = 0.f;
-    for (int b = 0; b < B; b++) s += src[b * src_stride + i];
-    dst[i] += s;
+    const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = b0;
+    for (; b + 3 < b1; b += 4) {
+        s0 += src[(size_t)b * src_stride + i];
+        s1 += src[(size_t)(b + 1) * src_stride + i];
+        s2 += src[(size_t)(b + 2) * src_stride + i];
+        s3 += src[(size_t)(b + 3) * src_stride + i];
+    }
+    for (; b < b1; b++) s0 += src[(size_t)b * src_stride + i];
+    const float s = (s0 + s1) + (s2 + s3);
+    if (gridDim.y == 1) dst[i] += s;
+    else __hip_atomic_fetch_add(dst + i, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 int batch_sum(const float* src, size_t src_stride, float* dst, int len, int B, hipStream_t st) {
-    if (!len) return CC_OK;
-    hipLaunchKernelGGL(k_batch_sum, dim3((len + 255) / 256), dim3(256), 0, st, src, src_stride, dst, len, B);
+    if (!len || B <= 0) return CC_OK;
+    const int colb = (len + 255) / 256;
+    int slices = std::max(1, std::min(B / 8, 1024 / colb));        // ~1k blocks, at least 8 rows per slice
+    const int per = (B + slices - 1) / slices;
+    slices = (B + per - 1) / per;
+    hipLaunchKernelGGL(k_batch_sum, dim3(colb, slices), dim3(256), 0, st, src, src_stride, dst, len, B, per);
     return CC_OK;
 }
 
@@ -374,7 +391,8 @@ int ln_bwd(const op16_t* dy, const float* x, int ldx, const int* row_map, const 
     // with parameter gradients every block ends with 2*D fp32 atomics: keep the block count low (one per CU) so that the
     // atomic tail (measured: it dominated at 1024 blocks) stays ~0.4 M atomics per launch, and give those blocks 8 waves
     const int nw = (dgamma && (size_t)16 * D * sizeof(float) <= 65536) ? 8 : 4;      // 8-wave reduction buffer within the 64 KiB default
-    const int grid = std::min((rows + nw - 1) / nw, dgamma ? 256 : 8192);
+    static const int dg_grid = []() { const char* e = getenv("CC_LNBWD_GRID"); return e ? atoi(e) : 256; }();   // tuning knob
+    const int grid = std::min((rows + nw - 1) / nw, dgamma ? dg_grid : 8192);
     const size_t sh = dgamma ? (size_t)2 * nw * D * sizeof(float) : 0;
 #define LN_BWD(NV, DG, NW) hipLaunchKernelGGL((k_ln_bwd<NV, DG, NW>), dim3(grid), dim3(NW * 64), sh, st, dy, x, ldx, row_map, mean, rstd, gamma, dres, dx32, dx16, dgamma, dbeta, dcol, rows, D)
 #define LN_BWD_D(DG, NW) { if (D <= 256) LN_BWD(1, DG, NW); else if (D <= 512) LN_BWD(2, DG, NW); else if (D <= 768) LN_BWD(3, DG, NW); else if (D <= 1024) LN_BWD(4, DG, NW); else LN_BWD(LN_MAXV, DG, NW); }
@@ -1212,12 +1230,28 @@ __global__ void k_embed_bwd(const float* __restrict__ dx0, const long long* __re
         const int t = (int)((i / D) % T), b = (int)(i / ((size_t)D * T));
         const float g = dx0[i];
         __hip_atomic_fetch_add(dwpe + (size_t)t * D + d, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t >= L) {
+        if (t >= L && tokens) {
             long long id = tokens[(size_t)b * cap + (t - L)];
             if (id < 0) id = 0;
             __hip_atomic_fetch_add(dwte + (size_t)id * D + d, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+}
+// dst[r][c] = op16(src[r][c]) for c < V, 0 for V <= c < ldd (gradient of caller-visible fp32 logits -> the GEMM operand layout)
+__global__ __launch_bounds__(256) void k_f32_to_op16_pad(const float* __restrict__ src, long long lds, int V, op16_t* __restrict__ dst, int ldd,
+                                                         int M) {
+    const size_t total = (size_t)M * ldd;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % ldd);
+        const size_t r = i / ldd;
+        dst[i] = c < V ? f2op(src[r * lds + c]) : (op16_t)0;
+    }
+}
+int f32_to_op16_pad(const float* src, long long lds, int V, op16_t* dst, int ldd, int M, hipStream_t st) {
+    const size_t total = (size_t)M * ldd;
+    if (!total) return CC_OK;
+    hipLaunchKernelGGL(k_f32_to_op16_pad, dim3((int)std::min<size_t>((total + 255) / 256, 8192)), dim3(256), 0, st, src, lds, V, dst, ldd, M);
+    return CC_OK;
 }
 int embed_bwd(const float* dx0, const long long* tokens, int cap, float* dwte, float* dwpe, int B, int L, int T, int D, hipStream_t st) {
     const size_t total = (size_t)B * T * D;

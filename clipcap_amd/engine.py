@@ -340,13 +340,16 @@ class Gpt2Engine:
         return ws
 
     # -- inference-style forward: logits for all rows (ClipCapModel.forward / language_model(inputs_embeds=...)) --
-    def logits(self, inputs_embeds: torch.Tensor) -> torch.Tensor:
-        """inputs_embeds fp32 (B,T,D) (no positional embedding) -> fp32 logits (B,T,V)."""
+    def logits(self, inputs_embeds: torch.Tensor, save_mode: int = 0) -> torch.Tensor:
+        """inputs_embeds fp32 (B,T,D) (no positional embedding) -> fp32 logits (B,T,V).  save_mode 1 / 2 keeps the activations for
+        logits_backward (1: gradient wrt inputs_embeds only, 2: + every GPT-2 weight gradient)."""
         _require_cuda(self.arena.w32, "Gpt2Engine.logits")
         l = _lib.lib()
         x = inputs_embeds.to(device=self.arena.device, dtype=torch.float32).contiguous()
         B, T, D = x.shape
-        shp = self.shape(B, T, T, 0, 0)
+        shp = self.shape(B, T, T, 0, 0) if not save_mode else self.shape(B, 0, T, T, save_mode)
+        if save_mode:
+            self._logits_pass = (shp, getattr(self, "_logits_pass", (None, 0))[1] + 1)
         ws = self.workspace(shp)
         self.arena.sync_bf16()
         st = _stream(self.arena.device)
@@ -357,6 +360,20 @@ class Gpt2Engine:
         out = torch.empty(B * T, Vp, dtype=torch.float32, device=a.device)
         check(l.cc_gpt2_logits(C.byref(self.cfg), C.byref(shp), _p(a.w32), _p(a.w16), _p(ws), _p(out), Vp, st), "cc_gpt2_logits")
         return out.view(B, T, Vp)[:, :, : self.dims["V"]]
+
+    def logits_backward(self, dlogits: torch.Tensor) -> torch.Tensor:
+        """d loss / d inputs_embeds (B,T,D) for the last logits(..., save_mode >= 1) pass; save_mode 2 also ACCUMULATES the GPT-2 weight
+        gradients into the arena's g32 (cc_gpt2_logits_bwd)."""
+        shp = self._logits_pass[0]
+        a = self.arena
+        dl = dlogits.to(device=a.device, dtype=torch.float32).contiguous()
+        B, T, V = dl.shape
+        assert (B, T) == (shp.B, shp.T) and V == self.dims["V"]
+        dx0 = torch.empty(B, T, self.dims["D"], dtype=torch.float32, device=a.device)
+        ws = self.workspace(shp)
+        check(_lib.lib().cc_gpt2_logits_bwd(C.byref(self.cfg), C.byref(shp), _p(a.w32), _p(a.w16), _p(ws), _p(dl), V, _p(dx0),
+                                            _p(a.grads()) if shp.mode == 2 else None, _stream(a.device)), "cc_gpt2_logits_bwd")
+        return dx0
 
 
 class ClipCapEngine:

@@ -23,6 +23,35 @@ from clipcap_amd.engine import Gpt2Engine
 from clipcap_amd.model.arena_module import ArenaModule
 
 
+class _LogitsFn(torch.autograd.Function):
+    """Autograd bridge for ``lm(inputs_embeds=...).logits`` (the fused trainer bypasses autograd): backward returns the gradient wrt
+    inputs_embeds (which flows on into the mapper / the token embeddings) and, when the parameters require grad, every GPT-2 weight
+    gradient computed by the HIP backward kernels (cc_gpt2_logits_bwd)."""
+
+    @staticmethod
+    def forward(ctx, module, x, train, *params):
+        ctx.module, ctx.train = module, train
+        out = module.engine.logits(x, save_mode=2 if train else 1)
+        ctx.serial = module.engine._logits_pass[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        eng = ctx.module.engine
+        if eng._logits_pass[1] != ctx.serial:
+            raise RuntimeError("GPT2LM.backward: the saved activations were overwritten by a later forward; call backward() first")
+        if not ctx.train:
+            return (None, eng.logits_backward(dlogits), None) + (None,) * len(ctx.module._arena_params)
+        g = eng.arena.grads()
+        keep = g.clone()
+        g.zero_()
+        dx0 = eng.logits_backward(dlogits)
+        views = eng.views(g)
+        grads = tuple(views[n].clone() for n in ctx.module._arena_params)
+        g.copy_(keep)
+        return (None, dx0, None) + grads
+
+
 class _Embedding(nn.Module):
     """wte lookup on the fp32 master (a gather; exact)."""
 
@@ -35,7 +64,7 @@ class _Embedding(nn.Module):
         return self._owner._arena_params["transformer.wte.weight"]
 
     def forward(self, ids: torch.Tensor) -> torch.Tensor:
-        w = self.weight.detach()
+        w = self.weight if (torch.is_grad_enabled() and self.weight.requires_grad) else self.weight.detach()
         return torch.nn.functional.embedding(ids.to(w.device), w)
 
 
@@ -137,4 +166,8 @@ class GPT2LM(ArenaModule):
             if input_ids is None:
                 raise ValueError("GPT2LM.forward needs inputs_embeds or input_ids")
             inputs_embeds = self._emb(input_ids)
+        if torch.is_grad_enabled():
+            train = any(p.requires_grad for p in self._arena_params.values())
+            if train or inputs_embeds.requires_grad:
+                return SimpleNamespace(logits=_LogitsFn.apply(self, inputs_embeds, train, *self._arena_params.values()))
         return SimpleNamespace(logits=self.engine.logits(inputs_embeds))

@@ -158,6 +158,13 @@ int cc_gpt2_fwd(const cc_gpt2_cfg* cfg, const cc_gpt2_shape* shp, const float* w
 int cc_gpt2_logits(const cc_gpt2_cfg* cfg, const cc_gpt2_shape* shp, const float* w32, const uint16_t* w16, void* ws, float* logits,
                    int64_t ldl, void* stream);
 
+/* autograd of cc_gpt2_logits for callers that differentiate `.logits` themselves (ClipCapModel.forward(...).logits.backward(), a
+ * custom loss): needs a pass run with shape L == 0 (so cap == T) and mode >= 1 — cc_gpt2_embed_from, cc_gpt2_fwd, cc_gpt2_logits —
+ * then this.  dlogits fp32 [B*T, ldl] (first V columns read); dx0 fp32 [B, T, D] (nullable) receives d loss / d inputs_embeds;
+ * mode 2 accumulates every GPT-2 weight gradient (tied wte through lm_head, wpe, blocks, ln_f) into g32. */
+int cc_gpt2_logits_bwd(const cc_gpt2_cfg* cfg, const cc_gpt2_shape* shp, const float* w32, const uint16_t* w16, void* ws,
+                       const float* dlogits, int64_t ldl, float* dx0, float* g32, void* stream);
+
 /* training loss of model.py:94-113 on rows L-1..T-2: fused ln_f + lm_head + softmax cross-entropy (ignore_index=0,
  * pads(-1)->0).  stats (2 device floats, zeroed by this call): [0] sum of kept-row losses, [1] number of kept rows. */
 int cc_lmhead_ce_fwd(const cc_gpt2_cfg* cfg, const cc_gpt2_shape* shp, const float* w32, const uint16_t* w16, void* ws,

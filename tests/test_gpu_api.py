@@ -34,7 +34,7 @@ def test_module_forward_logits_and_to_device():
     tokens = torch.from_numpy(g["in.tokens"])
     out = m(tokens.clamp_min(0).cuda(), torch.from_numpy(g["in.embeds"]).cuda(), tokens.ge(0).cuda())
     keep = np.concatenate([np.ones((tokens.shape[0], 3), bool), g["in.tokens"] >= 0], axis=1)
-    err = np.abs(out.logits.cpu().numpy()[keep] - g["logits0"][keep]).max()
+    err = np.abs(out.logits.detach().cpu().numpy()[keep] - g["logits0"][keep]).max()   # differentiable, like the reference's
     print("module forward: max |logits - reference fp32| =", err)
     assert out.logits.shape == g["logits0"].shape and err <= 3e-2
     pre = m.transformer_mapper(torch.from_numpy(g["in.embeds"]).cuda())
@@ -425,3 +425,57 @@ def test_mapper_forward_with_attention_matches_reference_probabilities():
             assert a.shape == ref.shape
             assert (a.cpu() - ref).abs().max().item() <= 5e-3, (name, i)
             assert (a.sum(dim=2) - 1).abs().max().item() <= 1e-5
+
+
+def test_language_model_logits_are_differentiable_vs_reference_gradients():
+    """``lm(inputs_embeds=x).logits`` under autograd (cc_gpt2_logits_bwd): gradient wrt the inputs and wrt every GPT-2 parameter of
+    loss = logits.square().mean() against the reference's own autograd (tests/golden/gpt2_tiny: grad.in.x, grad.*)."""
+    from clipcap_amd.model.gpt2 import GPT2LM
+    g = load_golden("gpt2_tiny")
+    D, n_layer, n_head, V, npos = [int(v) for v in g["cfg"]]
+    lm = GPT2LM(n_embd=D, n_layer=n_layer, n_head=n_head, vocab_size=V, n_positions=npos)
+    lm.load_state_dict(sd_of(g), strict=False)
+    lm = lm.to("cuda")
+    x = torch.from_numpy(g["in.x"]).cuda().requires_grad_(True)
+    logits = lm(inputs_embeds=x).logits
+    assert logits.requires_grad and (logits.detach().cpu() - torch.from_numpy(g["logits"])).abs().max().item() <= 3e-2
+    logits.square().mean().backward()
+    ref = torch.from_numpy(g["grad.in.x"])
+    assert float((x.grad.cpu() - ref).norm() / ref.norm()) <= 3e-2
+    n = 0
+    for k, p in lm.named_parameters():
+        if "grad." + k in g and "lm_head" not in k:
+            r = torch.from_numpy(g["grad." + k])
+            rel = float((p.grad.cpu() - r).norm() / r.norm().clamp_min(1e-12))
+            assert rel <= 6e-2, (k, rel)
+            n += 1
+    assert n >= 2 + 12 * n_layer + 2
+    # inputs only (frozen LM): no parameter gradients are produced, the input gradient is the same
+    lm.zero_grad()
+    lm.requires_grad_(False)
+    x2 = torch.from_numpy(g["in.x"]).cuda().requires_grad_(True)
+    lm(inputs_embeds=x2).logits.square().mean().backward()
+    assert torch.allclose(x2.grad, x.grad, rtol=1e-4, atol=1e-8) and all(p.grad is None for p in lm.parameters())
+
+
+def test_model_forward_logits_autograd_equals_fused_training_step():
+    """ClipCapModel.forward(...).logits -> the reference's loss expression in torch (model.py:103-109) -> backward(): the mapper
+    gradients equal the ones the fused kernel chain (training_step) produces for the same batch."""
+    m, g = _model_from_train_fixture("prefix_only")
+    m.train()
+    tokens, embeds = torch.from_numpy(g["in.tokens"]).cuda(), torch.from_numpy(g["in.embeds"]).cuda()
+    L = m.config.prefix_length
+    tk = tokens.clamp_min(0)
+    logits = m(tk, embeds, tokens.ge(0)).logits
+    loss = torch.nn.functional.cross_entropy(logits[:, L - 1:-1].reshape(-1, logits.shape[-1]), tk.flatten(), ignore_index=0)
+    loss.backward()
+    auto = {k: p.grad.clone() for k, p in m.transformer_mapper.named_parameters()}
+    assert abs(float(loss) - float(g["losses"][0])) <= 3e-2
+    m.zero_grad()
+    eng = m.engine
+    eng.zero_grad()
+    eng.forward_backward(tokens.clone(), embeds)
+    fused = m.transformer_mapper.engine.views(m.transformer_mapper.engine.arena.g32)
+    for k, v in auto.items():
+        rel = float((v - fused[k]).norm() / fused[k].norm().clamp_min(1e-12))
+        assert rel <= 3e-2, (k, rel)
