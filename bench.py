@@ -41,7 +41,9 @@ CONFIGS = {
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
 # Offline PMC measurements quoted in the JSON line (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 gfx950
 # correction; see the profile files).  They describe the build the profile was taken from; bench.py itself does not read counters.
-LMHEAD_TRAFFIC = {"bytes": (2 * 604061 + 1097837) * 1024, "source": "profiles/r01_i_pmc_fetch_write.md (offline PMC, round 1 build)"}
+LMHEAD_TRAFFIC = {"bytes": (2 * 643119 + 1097837) * 1024,
+                  "source": "offline PMC: FETCH_SIZE x2 from profiles/r02_d_pmc_fetch.md (this round's build), WRITE_SIZE from "
+                            "profiles/r01_i_pmc_fetch_write.md (same kernel, round 1)"}
 DECODE_TRAFFIC = {"bytes": 3.18e9, "source": "profiles/r01_p_decode_kernel_stats.md (offline PMC, round 1 build)"}
 
 
@@ -306,6 +308,8 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "16"], help="operand type: bf16 (default) or 16 = fp16 + loss scaling")
     ap.add_argument("--comm", default="torch", choices=["torch", "cabi"],
                     help="N>1 collectives: torch.distributed (backend nccl = RCCL) or the library's own C-ABI RCCL communicator")
+    ap.add_argument("--no-roofline-pass", action="store_true",
+                    help="skip the 25 extra event-bracketed steps (use under rocprofv3 --pmc, where every dispatch is serialised)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sub-benches", action="store_true", help="skip the mapper / decode sub-objects of the default N=1 line")
     ap.add_argument("--no-dropout", action="store_true", help="configs 3/4: run the full finetune without GPT-2 dropout")
@@ -408,7 +412,8 @@ def main():
     lib = _lib.lib()
     T, D, Mc, M = c["L"] + cap, c["D"], B * cap, B * (c["L"] + cap)
     S = c["P"] + c["L"]
-    if True:   # every rank runs the profiled extra steps (their collectives must match); rank 0 reports
+    roof = {}
+    if not args.no_roofline_pass:   # every rank runs the profiled extra steps (their collectives must match); rank 0 reports
         # ---- roofline of the dominant kernel family: every MFMA GEMM launch of the step (forward, dgrad, wgrad, lm_head), bracketed
         # with HIP events on the launch stream during 5 extra steps; achieved = sum of 2MNK / sum of launch durations ----
         n_prof = 5
@@ -417,7 +422,6 @@ def main():
         nxt += n_prof
         gemm_ms, gemm_fl = sum(ms), sum(fl)
         fam = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        roof = {}
         roof["roofline"] = {"bound": "mfma", "kernel": "bf16 MFMA GEMM family (gemm.hip.h: every NT / TT / lm_head launch of the step)",
                            "achieved": round(fam, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fam / PEAK_BF16_TFLOPS, 4),
                            "launches_per_step": len(ms) // n_prof, "avg_launch_ms": round(gemm_ms / max(1, len(ms)), 4),

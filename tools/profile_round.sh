@@ -1,0 +1,28 @@
+#!/bin/bash
+# Collects the per-round rocprofv3 evidence on a GPU box (run through gpurun from the repo root):
+#   tools/profile_round.sh r02     -> gpurun_out/<tag>_{train,mapper,decode}.md (kernel-trace stats) and <tag>_pmc_{fetch,write}.txt
+# Counters are collected in their own passes (one TCC counter per pass; never combined with other trace domains).
+set -u
+TAG=${1:-rXX}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+TRAIN="python $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-sub-benches"
+run_trace() {  # name, command...
+    local name=$1; shift
+    rm -rf $OUT/prof_$name
+    rocprofv3 --kernel-trace --output-format rocpd -d $OUT/prof_$name -- "$@" > $OUT/${TAG}_$name.log 2>&1
+    python $ROOT/tools/rocpd_stats.py $(find $OUT/prof_$name -name "*.db" | head -1) > $OUT/${TAG}_$name.md
+    rm -rf $OUT/prof_$name
+}
+run_trace train $TRAIN
+run_trace mapper python $ROOT/bench.py --mode mapper --steps 10 --warmup 3
+run_trace decode python $ROOT/bench.py --mode decode --steps 1 --warmup 1
+for ctr in FETCH_SIZE WRITE_SIZE; do
+    rm -rf $OUT/prof_pmc
+    rocprofv3 --kernel-trace --pmc $ctr --output-format rocpd -d $OUT/prof_pmc -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-sub-benches --no-roofline-pass > /dev/null 2>&1
+    python $ROOT/tools/rocpd_pmc.py $(find $OUT/prof_pmc -name "*.db" | head -1) > $OUT/${TAG}_pmc_$ctr.txt
+    rm -rf $OUT/prof_pmc
+done
+cd $ROOT
