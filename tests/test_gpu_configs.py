@@ -236,3 +236,40 @@ def test_beam_medium_width_tokens_vs_reference_and_oracle():
         assert np.array_equal(mine, want), (case, mine, want)
         exact_ref += int(np.array_equal(mine, g[case + ".best"]))
     assert exact_ref >= 3, exact_ref      # fp32 reference: exact unless a top-2 margin is below the bf16 noise
+
+
+def test_windowed_mapper_at_real_sequence_length():
+    """TransformerMapperWindowed at the reference's default window (window_size 16 -> 17 windows, model.py:28) and
+    config-2 width: sequence 17*10 + 10 = 180 rows per sample, D=768, H=8 (hd 96) — the MFMA attention kernels over six 32-row blocks,
+    forward and backward, against the like-for-like oracle (2 layers, B=2)."""
+    from tests import seeded
+    from clipcap_amd.engine import MapperEngine
+    E, D, P, L, H, N, W, B = 512, 768, 10, 10, 8, 2, 17, 2
+    msd = seeded.state_dict(seeded.mapper_shapes(E, D, P, L, N, W=W, use_pos=True), 4501)
+    sd = {k: torch.from_numpy(v) for k, v in msd.items()}
+    sd["pos_embeddings"] = sd["pos_embeddings"] * 0.1
+    eng = MapperEngine(E, D, L, P, H, N, window=W, use_pos=True, device="cuda")
+    for k, v in eng.views(eng.arena.w32).items():
+        v.copy_(sd[k])
+    x = torch.randn(B, W, E, generator=torch.Generator().manual_seed(3))
+    out = eng.forward(x.cuda(), save=True)
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.mapper_forward(sdr, x, projection_length=P, num_heads=H, num_layers=N, window=W, rb=True)
+    with torch.no_grad():
+        ref32 = O.mapper_forward(sd, x, projection_length=P, num_heads=H, num_layers=N, window=W)
+    scale = float(ref32.abs().max())
+    e_rb, e_32 = float((out.cpu() - ref.detach()).abs().max()), float((out.cpu() - ref32).abs().max())
+    print(f"windowed mapper S=180: |out|max {scale:.2f}; vs oracle(bf16 points) {e_rb:.3e}; vs fp32 oracle {e_32:.3e}")
+    assert e_rb <= 4e-3 * scale and e_32 <= 1e-2 * scale
+    ref.square().mean().backward()
+    eng.arena.grads().zero_()
+    eng.backward(2.0 * out / out.numel())
+    gv = eng.views(eng.arena.g32)
+    worst = ("", 0.0)
+    for k in sd:
+        r = _rel(gv[k].cpu(), sdr[k].grad)
+        worst = max(worst, (k, r), key=lambda t: t[1])
+        assert r <= 5e-2, (k, r)
+    print(f"windowed mapper S=180: worst relative gradient error {worst[1]:.3e} ({worst[0]})")
+    atts = eng.attention_probs(B)
+    assert atts[0].shape == (B, 180, 180, H) and float((atts[0].sum(dim=2) - 1).abs().max()) <= 1e-5

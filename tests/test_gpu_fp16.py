@@ -161,3 +161,34 @@ def test_fp16_full_size_step_and_decode():
     for t in range(10, 14):
         l = sess.forward(x[:, t:t + 1])
         assert (l - full[:, t]).abs().max().item() <= 2e-3 * scale, t
+
+
+def test_train_cli_fp_precision_16(tmp_path):
+    """``python -m clipcap_amd.train ... --fp-precision 16`` (reference flag, clipcap/train/args.py:30-34): the whole driver runs on the
+    fp16 build with loss scaling, the loss decreases and the written checkpoint loads and decodes."""
+    import argparse
+    import clipcap_amd
+    from clipcap_amd.inference import generate_beam
+    from clipcap_amd.model import add_model_args
+    from clipcap_amd.model.gpt2 import GPT2LM
+    from clipcap_amd.train import add_training_args, train
+    from tests.test_api_surface import FakeTokenizer, _write_dataset
+    _write_dataset(tmp_path / "ds", n=48, E=24, shards=(20, 28))
+    GPT2LM(n_embd=64, n_layer=2, n_head=4, vocab_size=157, n_positions=96).save_pretrained(str(tmp_path / "lm"))
+    args = add_model_args(add_training_args(argparse.ArgumentParser())).parse_args([
+        "--input-dataset", str(tmp_path / "ds"), "--output-folder", str(tmp_path / "out"), "--language-model", str(tmp_path / "lm"),
+        "--batch-size", "16", "--epochs", "4", "--optimizer-lr", "2e-3", "--scheduler-warmup-steps", "2", "--checkpoint-filename-prefix",
+        "h", "--prefix-length", "4", "--projection-length", "4", "--transformer-layers", "2", "--transformer-attention-heads", "4",
+        "--logging-frequency", "1", "--fp-precision", "16"])
+    tok = FakeTokenizer()
+    import contextlib
+    import io
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        assert train(args, tokenizer=tok) == 0
+    losses = [float(l.split("loss")[1]) for l in buf.getvalue().splitlines() if " loss " in l]
+    assert len(losses) == 12 and losses[-1] < losses[0] - 0.05 and all(np.isfinite(losses))
+    model, _ = clipcap_amd.load(str(tmp_path / "out" / "h_final.ckpt"), str(tmp_path / "out" / "h_config.yaml"), device="cuda",
+                                from_checkpoint=True, tokenizer=tok)
+    text = generate_beam(model, tok, model.transformer_mapper(torch.randn(1, 24, device="cuda")), beam_size=3, entry_length=6)
+    assert isinstance(text[0], str)
