@@ -273,3 +273,50 @@ def test_windowed_mapper_at_real_sequence_length():
     print(f"windowed mapper S=180: worst relative gradient error {worst[1]:.3e} ({worst[0]})")
     atts = eng.attention_probs(B)
     assert atts[0].shape == (B, 180, 180, H) and float((atts[0].sum(dim=2) - 1).abs().max()) <= 1e-5
+
+
+def test_reference_cli_default_shapes_gpt2_xl_width():
+    """The reference's CLI defaults (clipcap/model/args.py, train/args.py): --language-model gpt2-xl (D=1600, 25 heads of 64),
+    mapper heads 8 -> head dim 200 (no MFMA attention kernel: the LDS / VALU path), prefix = projection = 10; CLIP ViT-L/14
+    embeddings (E=768).  2 of 48 GPT-2 layers, 2 of 8 mapper layers, B=2, cap=24: loss, logits and mapper gradients against the
+    like-for-like oracle."""
+    from tests import seeded
+    E, D, P, L, H, N, n_head, NL, V, NPOS, cap, B = 768, 1600, 10, 10, 8, 2, 25, 2, 50257, 64, 24, 2
+    gsd = seeded.state_dict(seeded.gpt2_shapes(D, NL, V, NPOS), 4601)
+    msd = seeded.state_dict(seeded.mapper_shapes(E, D, P, L, N), 4602)
+    sd = {"language_model." + k: torch.from_numpy(v) for k, v in gsd.items()}
+    sd.update({"transformer_mapper." + k: torch.from_numpy(v) for k, v in msd.items()})
+    cfg = dict(projection_length=P, prefix_length=L, heads=H, layers=N, n_head=n_head, n_layer=NL)
+    dims = dict(E=E, D=D, P=P, L=L, H=H, N=N, n_head=n_head, NL=NL, V=V, NPOS=NPOS, full=False)
+    me, ge, eng = _engines(sd, dims)
+    gen = torch.Generator().manual_seed(5)
+    tokens = torch.randint(1, V, (B, cap), generator=gen)
+    tokens[1, cap - 5:] = -1
+    embeds = torch.randn(B, E, generator=gen)
+    eng.zero_grad()
+    loss = float(eng.forward_backward(tokens.cuda(), embeds.cuda()))
+    train = [k for k in sd if k.startswith("transformer_mapper.")]
+    sdr = {k: (v.clone().requires_grad_(True) if k in train else v) for k, v in sd.items()}
+    ref = O.clipcap_loss(sdr, tokens, embeds, cfg=cfg, rb=True)
+    ref.backward()
+    with torch.no_grad():
+        ref32 = float(O.clipcap_loss(sd, tokens, embeds, cfg=cfg))
+    print(f"gpt2-xl width: loss {loss:.6f}; oracle(bf16 points) {float(ref):.6f}; fp32 oracle {ref32:.6f}")
+    assert abs(loss - float(ref)) <= 2e-3 and abs(loss - ref32) <= 3e-3
+    gm = me.views(me.arena.g32)
+    worst = ("", 0.0)
+    for k in train:
+        r = _rel(gm[k[len("transformer_mapper."):]].cpu(), sdr[k].grad)
+        worst = max(worst, (k, r), key=lambda t: t[1])
+        assert r <= 6e-2, (k, r)
+    print(f"gpt2-xl width: worst relative mapper-gradient error {worst[1]:.3e} ({worst[0]})")
+    # KV-cached decode at this width
+    from clipcap_amd.engine import DecodeSession
+    x = torch.randn(5, 13, D, generator=gen).cuda() * 0.3
+    full = ge.logits(x)
+    sess = DecodeSession(ge, 5, 16)
+    l = sess.forward(x[:, :10]).clone()
+    scale = max(1.0, float(full.abs().max()))
+    assert float((l - full[:, 9]).abs().max()) <= 8e-3 * scale
+    for t in range(10, 13):
+        assert float((sess.forward(x[:, t:t + 1]) - full[:, t]).abs().max()) <= 8e-3 * scale, t
