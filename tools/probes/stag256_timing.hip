@@ -4,11 +4,11 @@
 #include "gemm.hip.h"
 #include <cstdio>
 #include <vector>
-using namespace cc;
+using namespace CC_NS;
 namespace cc { int g_gemm_tile_mode = -1, g_gemm_s64 = -1, g_gemm_small_x2 = 1; }
 template <int NJ>
 static void run(int M, int N, int K) {
-    bf16_t *A, *B; float* C;
+    op16_t *A, *B; float* C;
     hipMalloc(&A, (size_t)M * K * 2); hipMalloc(&B, (size_t)N * K * 2); hipMalloc(&C, (size_t)M * N * 4);
     hipMemset(A, 0, (size_t)M * K * 2); hipMemset(B, 0, (size_t)N * K * 2);
     GemmShape g;
