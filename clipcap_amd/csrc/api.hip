@@ -646,19 +646,17 @@ int CC_API(cc_gpt2_bwd_range)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, cons
     WgradBatch wb;          // full finetune: a layer's four weight gradients as one grouped launch + one slab reduce
     wb.defer = full;
     WgradBatch* wbp = full ? &wb : nullptr;
-    // bias gradients of the two c_proj's = column sums of the (dropout-masked) residual gradient copies.  Without residual dropout
-    // the LayerNorm backward that produces the copy sums its columns as well (ln_bwd dcol); with dropout the mask is applied
-    // afterwards, so the separate column-sum launch stays.
-    const bool fold = full && s->p_resid == 0.f;
+    // The 16-bit copy of the residual gradient that feeds a c_proj's backward GEMMs is the dropout-masked one, and the c_proj's bias
+    // gradient is its column sum.  Both are produced by the LayerNorm backward that writes the copy (ln_bwd dmask / dcol) — except for
+    // the top layer, whose copy comes from ln_f's row-mapped backward and is masked / summed by separate launches.
     for (int l = l_hi - 1; l >= l_lo; l--) {
         const auto& y = o.layer[l];
-        // residual dropout: the gradient entering a c_proj is the masked residual gradient (its 16-bit copy is only read by that
-        // c_proj's backward GEMMs, so it is masked in place; dx32, the residual stream's own gradient, stays unmasked)
-        CC_TRY(dropout_bf16(w.dx16, (size_t)M * D, make_drop(s->p_resid, s->drop_seed, DROP_RESID_MLP, l), st));
+        const bool top = l == c->NL - 1;
         // mlp.c_proj (Conv1D [4D, D]): y = hact W + b
+        if (top) CC_TRY(dropout_bf16(w.dx16, (size_t)M * D, make_drop(s->p_resid, s->drop_seed, DROP_RESID_MLP, l), st));
         if (full) {
             CC_TRY(gemm_wgrad(w.hact[l], D4, w.dx16, D, D4, D, M, g32 + y.p2w, D, w.wg_scratch, st, wbp));
-            if (!fold || l == c->NL - 1) CC_TRY(colsum_bf16(w.dx16, D, M, D, g32 + y.p2b, st));   // top layer: dx16 comes from ln_f's backward
+            if (top) CC_TRY(colsum_bf16(w.dx16, D, M, D, g32 + y.p2b, st));
         }
         CC_TRY(gemm_dact(0, 0, w.dx16, D, w16 + y.p2w, D, M, D4, D, w.du16, D4, w.u[l], 2, st));
         // mlp.c_fc (Conv1D [D, 4D])
@@ -668,13 +666,10 @@ int CC_API(cc_gpt2_bwd_range)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, cons
         }
         CC_TIMED(CC_SITE_GPT2_FC_DGRAD, st, gemm_bf16out(0, 0, w.du16, D4, w16 + y.fw, D4, M, D, D4, w.dxn16, D, nullptr, 0, nullptr, st));
         CC_TRY(ln_bwd(w.dxn16, w.x1[l], D, nullptr, w.mean2[l], w.rstd2[l], w32 + y.l2w, w.dx32, w.dx32, w.dx16b, full ? g32 + y.l2w : nullptr,
-                      full ? g32 + y.l2b : nullptr, M, D, st, fold ? g32 + y.pb : nullptr));
+                      full ? g32 + y.l2b : nullptr, M, D, st, full ? g32 + y.pb : nullptr,
+                      make_drop(s->p_resid, s->drop_seed, DROP_RESID_ATTN, l)));
         // attn.c_proj (Conv1D [D, D])
-        CC_TRY(dropout_bf16(w.dx16b, (size_t)M * D, make_drop(s->p_resid, s->drop_seed, DROP_RESID_ATTN, l), st));
-        if (full) {
-            CC_TRY(gemm_wgrad(w.att[l], D, w.dx16b, D, D, D, M, g32 + y.pw, D, w.wg_scratch, st, wbp));
-            if (!fold) CC_TRY(colsum_bf16(w.dx16b, D, M, D, g32 + y.pb, st));
-        }
+        if (full) CC_TRY(gemm_wgrad(w.att[l], D, w.dx16b, D, D, D, M, g32 + y.pw, D, w.wg_scratch, st, wbp));
         CC_TRY(gemm_bf16out(0, 0, w.dx16b, D, w16 + y.pw, D, M, D, D, w.datt16, D, nullptr, 0, nullptr, st));
         CC_TRY(attn_bwd(w.qkv[l], w.datt16, w.att[l], w.lse[l], w.adelta, s->B, s->T, H, hd, true, w.dqkv16, st,
                         make_drop(s->p_attn, s->drop_seed, DROP_ATTN, l)));
@@ -687,7 +682,8 @@ int CC_API(cc_gpt2_bwd_range)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, cons
         // deferred weight gradients: dx16 (masked layer-input gradient), du16, dx16b, dqkv16 are all still intact here
         if (full) CC_TRY(wgrad_flush(wb, st));
         CC_TRY(ln_bwd(w.dxn16, w.x[l], D, nullptr, w.mean1[l], w.rstd1[l], w32 + y.l1w, w.dx32, w.dx32, w.dx16, full ? g32 + y.l1w : nullptr,
-                      full ? g32 + y.l1b : nullptr, M, D, st, (fold && l > 0) ? g32 + o.layer[l - 1].p2b : nullptr));
+                      full ? g32 + y.l1b : nullptr, M, D, st, (full && l > 0) ? g32 + o.layer[l - 1].p2b : nullptr,
+                      l > 0 ? make_drop(s->p_resid, s->drop_seed, DROP_RESID_MLP, l - 1) : Drop()));
     }
     if (l_lo > 0) return CC_OK;
     CC_TRY(dropout_f32(w.dx32, (size_t)M * D, make_drop(s->p_embd, s->drop_seed, DROP_EMBD, 0), st));   // d(inputs + wpe)

@@ -27,7 +27,9 @@ int ln_fwd(const float* x, int ldx, const int* row_map, const float* gamma, cons
            float* rstd, int rows, int D, hipStream_t st);
 int ln_bwd(const op16_t* dy, const float* x, int ldx, const int* row_map, const float* mean, const float* rstd, const float* gamma,
            const float* dres, float* dx32, op16_t* dx16, float* dgamma, float* dbeta, int rows, int D, hipStream_t st,
-           float* dcol = nullptr);   // dcol (needs dgamma, dx16, no row_map): += column sums of the 16-bit dx16 (a bias gradient)
+           float* dcol = nullptr, Drop dmask = Drop());
+// dcol (needs dgamma, dx16, no row_map): += column sums of the 16-bit dx16 (a bias gradient).  dmask: dropout mask applied to the
+// 16-bit copy dx16 only (element index row * D + col; dx32 stays unmasked) — the residual dropout of the c_proj that consumes dx16.
 int colsum_bf16(const op16_t* X, int ld, int M, int N, float* out, hipStream_t st);
 
 int attn_probs(const op16_t* qkv, int B, int S, int H, int hd, float* out, hipStream_t st);

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(NW * 64) void k_ln_bwd(const op16_t* __restrict__ d
                                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                 const float* __restrict__ dres, float* __restrict__ dx32,
                                                 op16_t* __restrict__ dx16, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                float* __restrict__ dcol, int rows, int D) {
+                                                float* __restrict__ dcol, int rows, int D, Drop dmask) {
     extern __shared__ __attribute__((aligned(16))) float ln_red[];  // [2][NW][D] when dgamma
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float4 pg[DG ? NV : 1], pb[DG ? NV : 1], pc[DG ? NV : 1];
@@ -333,6 +333,10 @@ __global__ __launch_bounds__(NW * 64) void k_ln_bwd(const op16_t* __restrict__ d
                 o.x += rr[it].x; o.y += rr[it].y; o.z += rr[it].z; o.w += rr[it].w;
                 *reinterpret_cast<float4*>(dx32 + xr + c) = o;
                 if (dx16) {
+                    if (dmask.thresh) {          // residual dropout of the consumer c_proj: only its 16-bit operand copy is masked
+                        const unsigned e = (unsigned)(xr + c);
+                        o.x *= drop_mul(dmask, e); o.y *= drop_mul(dmask, e + 1); o.z *= drop_mul(dmask, e + 2); o.w *= drop_mul(dmask, e + 3);
+                    }
                     const uint2 pk = make_uint2(pack2op(o.x, o.y), pack2op(o.z, o.w));
                     *reinterpret_cast<uint2*>(dx16 + xr + c) = pk;
                     if constexpr (DG) {
@@ -385,8 +389,9 @@ __global__ __launch_bounds__(NW * 64) void k_ln_bwd(const op16_t* __restrict__ d
 }
 int ln_bwd(const op16_t* dy, const float* x, int ldx, const int* row_map, const float* mean, const float* rstd,
            const float* gamma, const float* dres, float* dx32, op16_t* dx16, float* dgamma, float* dbeta, int rows, int D,
-           hipStream_t st, float* dcol) {
-    if (D > LN_MAXV * 256 || (D & 3) || (ldx & 3) || (dcol && (!dgamma || !dx16 || row_map))) return CC_ERR_SHAPE;
+           hipStream_t st, float* dcol, Drop dmask) {
+    if (D > LN_MAXV * 256 || (D & 3) || (ldx & 3) || (dcol && (!dgamma || !dx16 || row_map)) || (dmask.thresh && (row_map || ldx != D)))
+        return CC_ERR_SHAPE;
     if (rows <= 0) return CC_OK;
     // with parameter gradients every block ends with 2*D fp32 atomics: keep the block count low (one per CU) so that the
     // atomic tail (measured: it dominated at 1024 blocks) stays ~0.4 M atomics per launch, and give those blocks 8 waves
@@ -394,7 +399,7 @@ int ln_bwd(const op16_t* dy, const float* x, int ldx, const int* row_map, const 
     static const int dg_grid = []() { const char* e = getenv("CC_LNBWD_GRID"); return e ? atoi(e) : 256; }();   // tuning knob
     const int grid = std::min((rows + nw - 1) / nw, dgamma ? dg_grid : 8192);
     const size_t sh = dgamma ? (size_t)2 * nw * D * sizeof(float) : 0;
-#define LN_BWD(NV, DG, NW) hipLaunchKernelGGL((k_ln_bwd<NV, DG, NW>), dim3(grid), dim3(NW * 64), sh, st, dy, x, ldx, row_map, mean, rstd, gamma, dres, dx32, dx16, dgamma, dbeta, dcol, rows, D)
+#define LN_BWD(NV, DG, NW) hipLaunchKernelGGL((k_ln_bwd<NV, DG, NW>), dim3(grid), dim3(NW * 64), sh, st, dy, x, ldx, row_map, mean, rstd, gamma, dres, dx32, dx16, dgamma, dbeta, dcol, rows, D, dmask)
 #define LN_BWD_D(DG, NW) { if (D <= 256) LN_BWD(1, DG, NW); else if (D <= 512) LN_BWD(2, DG, NW); else if (D <= 768) LN_BWD(3, DG, NW); else if (D <= 1024) LN_BWD(4, DG, NW); else LN_BWD(LN_MAXV, DG, NW); }
     if (dgamma && nw == 8) LN_BWD_D(true, 8) else if (dgamma) LN_BWD_D(true, 4) else LN_BWD_D(false, 4)
 #undef LN_BWD_D
