@@ -194,6 +194,10 @@ def decode_bench(args, device):
     dt = time.perf_counter() - t0
     steps_per_decode = toks.shape[2]
     wbytes = 2.0 * (lm.engine.arena.n - (lm.engine.dims["NPOS"] * 1024))     # bf16 weights read once per decode step
+    # + the KV cache rows every beam row attends to, 2 * n_layer * ctx * D * 2 B per row, averaged over the generated
+    # positions (upper bound: rows of one sample share ancestors, so part of it is the same memory)
+    ctx_avg = L + (steps_per_decode - 1) / 2.0
+    kvbytes = 2.0 * 24 * ctx_avg * 1024 * 2 * S * beam
     return {"metric": "decode tok/s (beam=5, GPT-2-medium, KV cache)", "value": round(gen / dt, 1), "unit": "tokens/s", "n_gpus": 1,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -204,11 +208,14 @@ def decode_bench(args, device):
                          "achieved": round(wbytes * steps_per_decode * args.steps / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(wbytes * steps_per_decode * args.steps / dt / 8e12, 4),
                          "algorithmic_bytes_per_position": int(wbytes),
+                         "kv_read_bytes_per_position_upper_bound": int(kvbytes),
+                         "achieved_incl_kv": round((wbytes + kvbytes) * steps_per_decode * args.steps / dt / 1e9, 1),
                          # fabric bytes per generated position from separate PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, summed over
                          # the step's kernels) — an OFFLINE measurement of an earlier build, quoted with its source, not of this run
                          "traffic": DECODE_TRAFFIC["bytes"] if S == 64 else None,
                          "traffic_source": DECODE_TRAFFIC["source"] if S == 64 else None,
-                         "traffic_over_algorithmic": round(DECODE_TRAFFIC["bytes"] / wbytes, 2) if S == 64 else None}}
+                         "traffic_over_algorithmic": round(DECODE_TRAFFIC["bytes"] / wbytes, 2) if S == 64 else None,
+                         "traffic_over_weights_plus_kv": round(DECODE_TRAFFIC["bytes"] / (wbytes + kvbytes), 2) if S == 64 else None}}
 
 
 def sample_bench(args, device):
