@@ -16,12 +16,15 @@ pytestmark = pytest.mark.gpu
 
 
 def _build(mode):
+    """mode "prefix_only" / "full" (bf16 operands) or "prefix_only_fp16" / "full_fp16" (fp16 operands + loss scale)."""
     from clipcap_amd.engine import ClipCapEngine, Gpt2Engine, MapperEngine
+    precision = 16 if mode.endswith("_fp16") else None
+    mode = mode.replace("_fp16", "")
     g = load_golden(f"train_{mode}")
     E, D, P, L, H, N, n_head, n_layer, V, npos = [int(v) for v in g["cfg"]]
     sd = sd_of(g)
-    me = MapperEngine(E, D, L, P, H, N, device="cuda")
-    ge = Gpt2Engine(D, n_head, n_layer, V, npos, device="cuda")
+    me = MapperEngine(E, D, L, P, H, N, device="cuda", precision=precision)
+    ge = Gpt2Engine(D, n_head, n_layer, V, npos, device="cuda", precision=precision)
     for k, v in me.views(me.arena.w32).items():
         v.copy_(sd["transformer_mapper." + k])
     for k, v in ge.views(ge.arena.w32).items():
@@ -40,7 +43,7 @@ def _worker(rank, world, port, mode, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from clipcap_amd.train.ddp import GradReducer, shard_batch
     eng, tokens, embeds = _build(mode)
-    arenas = [eng.mapper.arena] + ([eng.gpt2.arena] if mode == "full" else [])
+    arenas = eng.arenas()
     red = GradReducer([a.grads() for a in arenas])
     tk, em = shard_batch(tokens, embeds, rank, world)
     red.begin()
@@ -52,7 +55,7 @@ def _worker(rank, world, port, mode, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["prefix_only", "full"])
+@pytest.mark.parametrize("mode", ["prefix_only", "full", "full_fp16"])
 def test_two_rank_step_equals_single_process(tmp_path, mode):
     out = str(tmp_path / "ddp.npz")
     mp.spawn(_worker, args=(2, _free_port(), mode, out), nprocs=2, join=True)
@@ -61,9 +64,8 @@ def test_two_rank_step_equals_single_process(tmp_path, mode):
     loss = eng.forward_backward(tokens.cuda(), embeds.cuda())
     torch.cuda.synchronize()
     assert abs(float(loss) - float(res["loss"])) <= 1e-5
-    arenas = [eng.mapper.arena] + ([eng.gpt2.arena] if mode == "full" else [])
-    for i, a in enumerate(arenas):
-        ref = a.g32.cpu().numpy()
+    for i, a in enumerate(eng.arenas()):
+        ref = a.g32.cpu().numpy()       # fp16 operands: both sides carry the same initial loss scale
         rel = np.linalg.norm(res[f"g{i}"] - ref) / np.linalg.norm(ref)
         assert rel <= 2e-2, (i, rel)   # per-rank GEMMs see different M tiles / split-K slices: bf16-level agreement
 

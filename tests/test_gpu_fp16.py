@@ -192,3 +192,33 @@ def test_train_cli_fp_precision_16(tmp_path):
                                 from_checkpoint=True, tokenizer=tok)
     text = generate_beam(model, tok, model.transformer_mapper(torch.randn(1, 24, device="cuda")), beam_size=3, entry_length=6)
     assert isinstance(text[0], str)
+
+
+def test_fp16_beam_search_tokens_vs_oracle_and_reference():
+    """KV-cached beam search on the fp16 build: token-exact against the oracle evaluated with fp16 rounding points on every golden
+    beam fixture, and against the reference's own fp32 captions (fp16's 3 extra mantissa bits: every fixture, incl. the one whose
+    top-2 margin is below bf16 noise, is expected to match)."""
+    from types import SimpleNamespace
+    from clipcap_amd.inference import generate_beam_tokens
+    from clipcap_amd.model.gpt2 import GPT2LM
+    g = load_golden("beam_tiny")
+    D, n_layer, n_head, V, npos = [int(v) for v in g["cfg"]]
+    lm = GPT2LM(n_embd=D, n_layer=n_layer, n_head=n_head, vocab_size=V, n_positions=npos, precision=16)
+    lm.load_state_dict(sd_of(g), strict=False)
+    model = SimpleNamespace(language_model=lm.to("cuda"))
+    osd = {"language_model." + k: v for k, v in sd_of(g).items()}
+    exact_ref = 0
+    cases = [str(int(c)) for c in g["cases"]] + ["T"]
+    for c in cases:
+        eos, entry, beam = [int(v) for v in g[f"beam{c}.meta"]]
+        temp = 0.7 if c == "T" else 1.0
+        pref = torch.from_numpy(g[f"beam{c}.prefix"])
+        toks, scores, lens = generate_beam_tokens(model, pref.cuda(), beam, entry, temp, eos)
+        b = int(scores[0].argmax())
+        best = toks[0, b, : int(lens[0, b])].cpu().numpy()
+        ot, osc, ol, oo = O.generate_beam_tokens(osd, pref, n_head=n_head, n_layer=n_layer, beam_size=beam, entry_length=entry,
+                                                 temperature=temp, stop_token=eos, rb="fp16")
+        assert np.array_equal(best, ot[oo[0]][: int(ol[oo[0]])].numpy()), c
+        exact_ref += int(np.array_equal(best, g[f"beam{c}.best"]))
+    print(f"fp16 beam search: {exact_ref}/{len(cases)} captions identical to the reference's fp32 run")
+    assert exact_ref >= len(cases) - 1
