@@ -74,6 +74,12 @@ class CAbiComm:
             self._lib.lib().cc_comm_destroy(self._comm)
             self._comm = self._C.c_void_p()
 
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # interpreter shutdown: the library may already be gone
+            pass
+
 
 class GradReducer:
     """Bucketed SUM all-reduce of flat gradient arenas plus the loss-statistics reduction.  Collectives go through torch.distributed
