@@ -27,6 +27,19 @@ constexpr int MAX_LAYERS = 96;
         if (_e != CC_OK) return _e;              \
     } while (0)
 
+// tuning knob (environment, read once): force a GEMM tile kernel at ONE call-site class for A/B measurements —
+// CC_TILE_FC = c_fc forward (gelu epilogue, two outputs), CC_TILE_DACT = its activation-gradient dgrad.  Unset = the chooser.
+struct TileScope {
+    int old;
+    bool on;
+    explicit TileScope(int mode) : old(cc_shared::g_gemm_tile_mode), on(mode != -2) { if (on) cc_shared::g_gemm_tile_mode = mode; }
+    ~TileScope() { if (on) cc_shared::g_gemm_tile_mode = old; }
+};
+inline int env_tile(const char* name) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : -2;
+}
+
 struct Carver {
     char* base;
     size_t off = 0;
@@ -537,8 +550,12 @@ int CC_API(cc_gpt2_fwd)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const floa
                           make_drop(s->p_resid, s->drop_seed, DROP_RESID_ATTN, l)));
         // x = x1 + c_proj(gelu_new(c_fc(ln_2 x1)))   (hf :229-243)
         CC_TRY(ln_fwd(w.x1[l], D, nullptr, w32 + y.l2w, w32 + y.l2b, w.xn2[l], nullptr, w.mean2[l], w.rstd2[l], M, D, st));
-        CC_TIMED(CC_SITE_GPT2_FC_FWD, st, gemm_bf16out(0, 0, w.xn2[l], D, w16t + y.fw, D, M, 4 * D, D, w.hact[l], 4 * D, w32 + y.fb, 2,
-                                                        s->mode >= 1 ? w.u[l] : nullptr, st));
+        {
+            static const int tile_fc = env_tile("CC_TILE_FC");
+            TileScope ts(tile_fc);
+            CC_TIMED(CC_SITE_GPT2_FC_FWD, st, gemm_bf16out(0, 0, w.xn2[l], D, w16t + y.fw, D, M, 4 * D, D, w.hact[l], 4 * D, w32 + y.fb, 2,
+                                                            s->mode >= 1 ? w.u[l] : nullptr, st));
+        }
         CC_TIMED(CC_SITE_GPT2_PROJ2_FWD, st, gemm_resid(0, 0, w.hact[l], 4 * D, w16t + y.p2w, 4 * D, M, D, 4 * D, w.x[l + 1], w.x1[l], D, w32 + y.p2b, st,
                                                        make_drop(s->p_resid, s->drop_seed, DROP_RESID_MLP, l)));
     }
@@ -658,7 +675,11 @@ int CC_API(cc_gpt2_bwd_range)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, cons
             CC_TRY(gemm_wgrad(w.hact[l], D4, w.dx16, D, D4, D, M, g32 + y.p2w, D, w.wg_scratch, st, wbp));
             if (top) CC_TRY(colsum_bf16(w.dx16, D, M, D, g32 + y.p2b, st));
         }
-        CC_TRY(gemm_dact(0, 0, w.dx16, D, w16 + y.p2w, D, M, D4, D, w.du16, D4, w.u[l], 2, st));
+        {
+            static const int tile_dact = env_tile("CC_TILE_DACT");
+            TileScope ts(tile_dact);
+            CC_TRY(gemm_dact(0, 0, w.dx16, D, w16 + y.p2w, D, M, D4, D, w.du16, D4, w.u[l], 2, st));
+        }
         // mlp.c_fc (Conv1D [D, 4D])
         if (full) {
             CC_TRY(gemm_wgrad(w.xn2[l], D, w.du16, D4, D, D4, M, g32 + y.fw, D4, w.wg_scratch, st, wbp));

@@ -34,6 +34,7 @@ struct GemmShape {
     int lda, ldb;
     int k_chunk;  // K extent handled by one blockIdx.z slice (multiple of 64); == K rounded up when no split
     int group_m;  // m-tiles per band of the tile order (tile_coords)
+    int stagger;  // 128 x 128 two-blocks-per-CU kernel: s_sleep units (64 cycles) the second block of every CU waits before its first tile
 };
 
 __device__ __forceinline__ int g_lds_off(int row, int chunk) {
@@ -379,6 +380,12 @@ __global__ __launch_bounds__(G_THREADS, 2) void gemm_nt_glds_kernel(const op16_t
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // Two blocks share a CU.  Launched together they run in lockstep — both in the MFMA loop, then both in the (VALU) epilogue — so the
+    // two pipes never overlap.  The blocks of the odd 256-block dispatch waves start a fraction of a tile late, which keeps one block's
+    // epilogue under the other's main loop for the rest of the launch.
+    if (g.stagger > 0 && ((blockIdx.x >> 8) & 1)) {
+        for (int s_ = g.stagger; s_ > 0; s_ -= 64) __builtin_amdgcn_s_sleep(64);
+    }
     glds_tile(A, g.lda, g.M, m0, kbeg, smem, wave, lane);
     glds_tile(B, g.ldb, g.N, n0, kbeg, smem + G_TILE_BYTES, wave, lane);
     const int frow = lane & 15, fchunk = lane >> 4;
@@ -1430,6 +1437,8 @@ inline int launch_gemm(int al, int bl, const op16_t* A, int lda, const op16_t* B
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
     static const int env_group = []() { const char* e = getenv("CC_GROUP_M"); return e ? atoi(e) : 0; }();
     g.group_m = env_group > 0 ? env_group : 8;
+    static const int env_stagger = []() { const char* e = getenv("CC_GEMM_STAGGER"); return e ? atoi(e) : 0; }();   // tuning knob
+    g.stagger = env_stagger;
     if (ksplit < 1) ksplit = 1;
     int kt = (K + G_BK - 1) / G_BK;
     int per = (kt + ksplit - 1) / ksplit;
@@ -1506,6 +1515,7 @@ inline int launch_gemm_s64(const op16_t* A, int lda, const op16_t* B, int ldb, i
     GemmShape g;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
     g.group_m = 8;
+    g.stagger = 0;
     if (ksplit < 1) ksplit = 1;
     const int kt = K / G_BK;
     const int per = (kt + ksplit - 1) / ksplit;
@@ -1541,6 +1551,7 @@ inline int launch_gemm_tt256(const op16_t* A, int lda, const op16_t* B, int ldb,
     GemmShape g;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
     g.group_m = 8;
+    g.stagger = 0;
     if (ksplit < 1) ksplit = 1;
     const int kt = (K + G_BK - 1) / G_BK;
     const int per = (kt + ksplit - 1) / ksplit;
@@ -1621,6 +1632,7 @@ inline int launch_gemm_tt128(const op16_t* A, int lda, const op16_t* B, int ldb,
     GemmShape g;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
     g.group_m = 8;
+    g.stagger = 0;
     if (ksplit < 1) ksplit = 1;
     const int kt = K / G_BK;
     const int per = (kt + ksplit - 1) / ksplit;

@@ -89,7 +89,7 @@ static int wgrad_launch_group(WgradBatch& b, hipStream_t st) {
         float* sc = b.scratch + b.used / sizeof(float);
         const int tiles = ((d.Mw + best_tile - 1) / best_tile) * ((d.Nw + best_tile - 1) / best_tile);
         grp.A[i] = d.X; grp.B[i] = d.Y;
-        grp.g[i] = GemmShape{d.Mw, d.Nw, d.K, d.ldx, d.ldy, per64 * G_BK, 8};
+        grp.g[i] = GemmShape{d.Mw, d.Nw, d.K, d.ldx, d.ldy, per64 * G_BK, 8, 0};
         grp.slab[i] = sc; grp.zstride[i] = slab;
         grp.first[i] = first;
         first += tiles * ks;
