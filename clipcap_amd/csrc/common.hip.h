@@ -91,7 +91,10 @@ __device__ __forceinline__ float gelu_new_grad(float x) {
 
 // ---- dropout (GPT-2 full finetune in train mode: embd / attention-probability / residual dropout, hf modeling_gpt2.py) --------
 // Counter-based: keep(element) is a hash of (seed, stream = site * 256 + layer, element index), so the backward pass regenerates the
-// forward's mask instead of storing it.  thresh = p * 2^32 (0 = dropout off); kept values are scaled by 1 / (1 - p).
+// forward's mask instead of storing it.  One 32-bit hash serves TWO neighbouring elements (idx >> 1; low / high 16 bits), so the vector
+// call sites (drop_mul_pair) pay half a hash per element — the hash's three 32-bit multiplies are quarter-rate VALU operations and
+// made the residual-dropout epilogues as expensive as a gelu.  thresh = p * 2^16 (0 = dropout off, p is honoured to 1.5e-5); kept
+// values are scaled by 1 / (1 - p).
 struct Drop {
     unsigned thresh = 0, seed_lo = 0, seed_hi = 0, stream = 0;
     float scale = 1.0f;
@@ -104,15 +107,24 @@ __host__ __device__ __forceinline__ unsigned drop_hash(unsigned seed_lo, unsigne
     x *= 0x27D4EB2Fu; x ^= x >> 16;
     return x;
 }
-__device__ __forceinline__ bool drop_keep(const Drop& d, unsigned idx) { return drop_hash(d.seed_lo, d.seed_hi, d.stream, idx) >= d.thresh; }
+__device__ __forceinline__ bool drop_keep(const Drop& d, unsigned idx) {
+    const unsigned h = drop_hash(d.seed_lo, d.seed_hi, d.stream, idx >> 1);
+    return ((idx & 1u) ? (h >> 16) : (h & 0xffffu)) >= d.thresh;
+}
 // multiplier of element idx: 0 or 1 / (1 - p)
 __device__ __forceinline__ float drop_mul(const Drop& d, unsigned idx) { return drop_keep(d, idx) ? d.scale : 0.f; }
+// multipliers of elements idx_even, idx_even + 1 (idx_even must be even) from ONE hash
+__device__ __forceinline__ void drop_mul_pair(const Drop& d, unsigned idx_even, float& m0, float& m1) {
+    const unsigned h = drop_hash(d.seed_lo, d.seed_hi, d.stream, idx_even >> 1);
+    m0 = (h & 0xffffu) >= d.thresh ? d.scale : 0.f;
+    m1 = (h >> 16) >= d.thresh ? d.scale : 0.f;
+}
 enum { DROP_EMBD = 0, DROP_ATTN = 1, DROP_RESID_ATTN = 2, DROP_RESID_MLP = 3 };
 inline Drop make_drop(float p, unsigned long long seed, unsigned site, unsigned layer) {
     Drop d;
     if (p > 0.f) {
-        const double t = (double)p * 4294967296.0;
-        d.thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+        const double t = (double)p * 65536.0 + 0.5;
+        d.thresh = t >= 65535.0 ? 65535u : (unsigned)t;
         d.scale = 1.0f / (1.0f - p);
         d.seed_lo = (unsigned)seed; d.seed_hi = (unsigned)(seed >> 32); d.stream = site * 256u + layer;
     }

@@ -1191,7 +1191,11 @@ struct EpiResid {
         float y[8] = {v[0] + b0.x, v[1] + b0.y, v[2] + b0.z, v[3] + b0.w, v[4] + b1.x, v[5] + b1.y, v[6] + b1.z, v[7] + b1.w};
         if (drop.thresh) {
 #pragma unroll
-            for (int e = 0; e < 8; e++) y[e] *= drop_mul(drop, (unsigned)o + e);
+            for (int e = 0; e < 8; e += 2) {
+                float m0, m1;
+                drop_mul_pair(drop, (unsigned)o + e, m0, m1);
+                y[e] *= m0; y[e + 1] *= m1;
+            }
         }
         *reinterpret_cast<float4*>(out + o) = make_float4(r0.x + y[0], r0.y + y[1], r0.z + y[2], r0.w + y[3]);
         *reinterpret_cast<float4*>(out + o + 4) = make_float4(r1.x + y[4], r1.y + y[5], r1.z + y[6], r1.w + y[7]);
@@ -1204,10 +1208,13 @@ struct EpiResid {
         if (drop.thresh) {
             float4 b = make_float4(0, 0, 0, 0);
             if (bias) b = *reinterpret_cast<const float4*>(bias + col);
-            a[0] = r.x + drop_mul(drop, (unsigned)o) * (a[0] + b.x);
-            a[1] = r.y + drop_mul(drop, (unsigned)o + 1) * (a[1] + b.y);
-            a[2] = r.z + drop_mul(drop, (unsigned)o + 2) * (a[2] + b.z);
-            a[3] = r.w + drop_mul(drop, (unsigned)o + 3) * (a[3] + b.w);
+            float m0, m1, m2, m3;
+            drop_mul_pair(drop, (unsigned)o, m0, m1);
+            drop_mul_pair(drop, (unsigned)o + 2, m2, m3);
+            a[0] = r.x + m0 * (a[0] + b.x);
+            a[1] = r.y + m1 * (a[1] + b.y);
+            a[2] = r.z + m2 * (a[2] + b.z);
+            a[3] = r.w + m3 * (a[3] + b.w);
             return;
         }
         a[0] += r.x; a[1] += r.y; a[2] += r.z; a[3] += r.w;

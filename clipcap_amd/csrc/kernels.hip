@@ -335,7 +335,10 @@ __global__ __launch_bounds__(NW * 64) void k_ln_bwd(const op16_t* __restrict__ d
                 if (dx16) {
                     if (dmask.thresh) {          // residual dropout of the consumer c_proj: only its 16-bit operand copy is masked
                         const unsigned e = (unsigned)(xr + c);
-                        o.x *= drop_mul(dmask, e); o.y *= drop_mul(dmask, e + 1); o.z *= drop_mul(dmask, e + 2); o.w *= drop_mul(dmask, e + 3);
+                        float m0, m1, m2, m3;
+                        drop_mul_pair(dmask, e, m0, m1);
+                        drop_mul_pair(dmask, e + 2, m2, m3);
+                        o.x *= m0; o.y *= m1; o.z *= m2; o.w *= m3;
                     }
                     const uint2 pk = make_uint2(pack2op(o.x, o.y), pack2op(o.z, o.w));
                     *reinterpret_cast<uint2*>(dx16 + xr + c) = pk;
@@ -1159,7 +1162,10 @@ __global__ void k_dropout_f32(float* __restrict__ x, size_t n4, Drop d) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 v = reinterpret_cast<float4*>(x)[i];
         const unsigned e = (unsigned)(i * 4);
-        v.x *= drop_mul(d, e); v.y *= drop_mul(d, e + 1); v.z *= drop_mul(d, e + 2); v.w *= drop_mul(d, e + 3);
+        float m0, m1, m2, m3;
+        drop_mul_pair(d, e, m0, m1);
+        drop_mul_pair(d, e + 2, m2, m3);
+        v.x *= m0; v.y *= m1; v.z *= m2; v.w *= m3;
         reinterpret_cast<float4*>(x)[i] = v;
     }
 }
@@ -1169,7 +1175,11 @@ __global__ void k_dropout_bf16(op16_t* __restrict__ x, size_t n8, Drop d) {
         unpack8(reinterpret_cast<const uint4*>(x)[i], f);
         const unsigned e = (unsigned)(i * 8);
 #pragma unroll
-        for (int k = 0; k < 8; k++) f[k] *= drop_mul(d, e + k);
+        for (int k = 0; k < 8; k += 2) {
+            float m0, m1;
+            drop_mul_pair(d, e + k, m0, m1);
+            f[k] *= m0; f[k + 1] *= m1;
+        }
         reinterpret_cast<uint4*>(x)[i] = pack8(f);
     }
 }

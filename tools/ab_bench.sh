@@ -8,7 +8,7 @@ for r in 1 2 3; do
   for v in old new; do
     cp /tmp/$v.so clipcap_amd/libclipcap_hip.so
     line="$v:"
-    for a in "$@"; do line="$line  [$a] $(python bench.py $a --no-cpu-baseline --steps 20 2>&1 | tail -1 | grep -o '"ms_per_step": [0-9.]*' | cut -d' ' -f2)"; done
+    for a in "$@"; do line="$line  [$a] $(python bench.py $a --no-cpu-baseline --no-sub-benches --no-roofline-pass --steps 60 --warmup 10 2>&1 | tail -1 | grep -o '"ms_per_step": [0-9.]*' | cut -d' ' -f2)"; done
     echo "$line"
   done
 done
