@@ -315,6 +315,8 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "16"], help="operand type: bf16 (default) or 16 = fp16 + loss scaling")
     ap.add_argument("--comm", default="torch", choices=["torch", "cabi"],
                     help="N>1 collectives: torch.distributed (backend nccl = RCCL) or the library's own C-ABI RCCL communicator")
+    ap.add_argument("--grad-wire", default="fp32", choices=["fp32", "bf16"],
+                    help="N>1: dtype of the gradient slices on the wire (bf16 halves the all-reduce bytes; fp32 arena stays the accumulator)")
     ap.add_argument("--no-roofline-pass", action="store_true",
                     help="skip the 25 extra event-bracketed steps (use under rocprofv3 --pmc, where every dispatch is serialised)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -365,7 +367,8 @@ def main():
     if world > 1 and args.comm == "cabi":
         from clipcap_amd.train.ddp import CAbiComm
         comm = CAbiComm.from_process_group(device)
-    reducer = GradReducer([a.grads() for a in arenas], comm=comm) if world > 1 else None
+    reducer = GradReducer([a.grads() for a in arenas], comm=comm,
+                          wire_dtype=torch.bfloat16 if args.grad_wire == "bf16" else torch.float32) if world > 1 else None
     total_steps = args.steps + args.warmup
     base_lr, warm = 2e-5, 2
     sched = linear_warmup_decay(warm, 4 * total_steps + 64)
@@ -475,7 +478,8 @@ def main():
         out["rccl_ranks"] = world if backend == "nccl" else 0
         out["collective_backend"] = "rccl (C ABI cc_allreduce_bucket)" if comm is not None else ("rccl" if backend == "nccl" else backend)
         out["allreduce_exposed_ms"] = round(exposed_ms, 3)
-        out["gradient_payload_bytes"] = int(sum(a.n for a in arenas) * 4)
+        out["gradient_payload_bytes"] = int(sum(a.n for a in arenas) * (2 if args.grad_wire == "bf16" else 4))
+        out["gradient_wire_dtype"] = args.grad_wire
     out.update(roof)
     if world == 1:
         if not args.no_sub_benches:

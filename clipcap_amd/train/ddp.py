@@ -85,10 +85,18 @@ class GradReducer:
     """Bucketed SUM all-reduce of flat gradient arenas plus the loss-statistics reduction.  Collectives go through torch.distributed
     (backend "nccl" = RCCL) or, with ``comm=CAbiComm(...)``, through the library's own C-ABI communicator."""
 
-    def __init__(self, flats: Sequence[torch.Tensor], bucket_bytes: int = 256 << 20, group=None, comm: Optional[CAbiComm] = None):
+    def __init__(self, flats: Sequence[torch.Tensor], bucket_bytes: int = 256 << 20, group=None, comm: Optional[CAbiComm] = None,
+                 wire_dtype: torch.dtype = torch.float32):
+        """wire_dtype torch.bfloat16: every slice travels as bf16 (half the bytes over xGMI) — cast into a staging arena, SUM
+        all-reduce in bf16, widened back into the fp32 gradient arena, which stays the accumulator and what AdamW reads
+        (the frozen-LM step has only the mapper backward, ~2 ms, to hide 167 MB of fp32 gradients under)."""
         self.flats = list(flats)
         self.group = group
         self.comm = comm
+        assert wire_dtype in (torch.float32, torch.bfloat16)
+        self.wire_dtype = wire_dtype
+        self.stage = [torch.empty_like(f, dtype=wire_dtype) for f in self.flats] if wire_dtype != torch.float32 else None
+        self._pending = []       # (arena, lo, hi, work) of bf16 slices still to be widened back
         self.buckets: List[torch.Tensor] = []
         for f in self.flats:
             assert f.dim() == 1 and f.is_contiguous()
@@ -104,6 +112,12 @@ class GradReducer:
 
     def all_reduce(self) -> None:
         """Non-overlapped form: everything at once, after backward."""
+        if self.stage is not None:
+            self.begin()
+            for i, f in enumerate(self.flats):
+                self.on_grads_ready(i, 0, f.numel())
+            self.finish()
+            return
         if self.comm is not None:
             for b in self.buckets:
                 self.comm.all_reduce_(b)
@@ -115,6 +129,7 @@ class GradReducer:
     # ---- overlapped form: slices are reduced as backward finishes them ------------------------------------------
     def begin(self) -> None:
         self._works = []
+        self._pending = []
         self._covered = [0] * len(self.flats)
 
     def on_grads_ready(self, arena: int, lo: int, hi: int) -> None:
@@ -122,6 +137,19 @@ class GradReducer:
         ordered after those kernels (ProcessGroupNCCL waits on the current stream) and runs on RCCL's own stream, i.e. under
         the backward kernels of the layers below."""
         if hi <= lo:
+            return
+        if self.stage is not None:
+            st = self.stage[arena][lo:hi]
+            st.copy_(self.flats[arena][lo:hi])                                   # fp32 -> bf16 on the compute stream
+            if self.comm is not None:
+                side = self.comm.stream
+                side.wait_stream(torch.cuda.current_stream(self.comm.device))
+                self.comm.all_reduce_(st, side)
+                work = None
+            else:
+                work = dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._pending.append((arena, lo, hi, work))
+            self._covered[arena] += hi - lo
             return
         if self.comm is not None:
             side = self.comm.stream
@@ -138,6 +166,11 @@ class GradReducer:
             w.wait()
         if self.comm is not None:
             torch.cuda.current_stream(self.comm.device).wait_stream(self.comm.stream)
+        for arena, lo, hi, work in self._pending:                                # widen the reduced bf16 slices back into fp32
+            if work is not None:
+                work.wait()
+            self.flats[arena][lo:hi].copy_(self.stage[arena][lo:hi])
+        self._pending = []
         for f, c in zip(self.flats, self._covered):
             assert c == f.numel(), f"overlapped all-reduce covered {c} of {f.numel()} gradient elements"
         self._works = []

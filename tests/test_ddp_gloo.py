@@ -47,7 +47,7 @@ def _grads_flat(sd, names, tokens, embeds, cfg, denom):
     return torch.cat([sd[k].grad.reshape(-1) for k in names]), float(loss.detach())
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, wire="fp32"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -59,7 +59,7 @@ def _worker(rank, world, port, out):
     kept = float(((tk > 0)).sum())
     stats = torch.tensor([0.0, kept])
     flat = torch.zeros(sum(sd[k].numel() for k in names))
-    red = GradReducer([flat], bucket_bytes=1 << 16)
+    red = GradReducer([flat], bucket_bytes=1 << 16, wire_dtype=torch.bfloat16 if wire == "bf16" else torch.float32)
     assert len(red.buckets) > 1
     red.reduce_stats(stats)                      # global kept-token count
     g, local_sum = _grads_flat(sd, names, tk, em, cfg, denom=float(stats[1]))
@@ -90,6 +90,20 @@ def test_two_rank_gradients_equal_single_process(tmp_path):
     assert abs(res[-1] - ref_loss) <= 1e-5
     err = np.abs(res[:-1] - ref.numpy()).max()
     assert err <= 1e-6 * max(1.0, float(ref.abs().max())), err
+
+
+def test_two_rank_gradients_bf16_on_the_wire(tmp_path):
+    """wire_dtype=bf16: slices are cast to bf16, summed in bf16 across the ranks and widened back into the fp32 arena — the
+    single-process gradient to bf16 precision (two roundings: the cast and the 2-rank sum)."""
+    out = str(tmp_path / "ddp16.npy")
+    mp.spawn(_worker, args=(2, _free_port(), out, "bf16"), nprocs=2, join=True)
+    res = np.load(out)
+    cfg, sd, tokens, embeds = _setup()
+    names = sorted(k for k in sd if k.startswith("transformer_mapper."))
+    ref, ref_loss = _grads_flat(sd, names, tokens, embeds, cfg, denom=None)
+    assert abs(res[-1] - ref_loss) <= 1e-5
+    rel = np.linalg.norm(res[:-1] - ref.numpy()) / np.linalg.norm(ref.numpy())
+    assert 1e-5 < rel <= 8e-3, rel          # really went through bf16, and no worse than two bf16 roundings
 
 
 def test_shard_range_covers_batch():
