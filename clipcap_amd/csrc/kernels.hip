@@ -398,13 +398,26 @@ int ln_bwd(const op16_t* dy, const float* x, int ldx, const int* row_map, const 
     if (rows <= 0) return CC_OK;
     // with parameter gradients every block ends with 2*D fp32 atomics: keep the block count low (one per CU) so that the
     // atomic tail (measured: it dominated at 1024 blocks) stays ~0.4 M atomics per launch, and give those blocks 8 waves
-    const int nw = (dgamma && (size_t)16 * D * sizeof(float) <= 65536) ? 8 : 4;      // 8-wave reduction buffer within the 64 KiB default
+    static const int dg_waves = []() { const char* e = getenv("CC_LNBWD_WAVES"); return e ? atoi(e) : 8; }();       // tuning knob: 8 or 16
+    int nw = (dgamma && (size_t)16 * D * sizeof(float) <= 65536) ? 8 : 4;      // 8-wave reduction buffer within the 64 KiB default
+    if (dgamma && nw == 8 && dg_waves == 16 && (size_t)32 * D * sizeof(float) <= 160 * 1024) nw = 16;
     static const int dg_grid = []() { const char* e = getenv("CC_LNBWD_GRID"); return e ? atoi(e) : 256; }();   // tuning knob
     const int grid = std::min((rows + nw - 1) / nw, dgamma ? dg_grid : 8192);
     const size_t sh = dgamma ? (size_t)2 * nw * D * sizeof(float) : 0;
 #define LN_BWD(NV, DG, NW) hipLaunchKernelGGL((k_ln_bwd<NV, DG, NW>), dim3(grid), dim3(NW * 64), sh, st, dy, x, ldx, row_map, mean, rstd, gamma, dres, dx32, dx16, dgamma, dbeta, dcol, rows, D, dmask)
 #define LN_BWD_D(DG, NW) { if (D <= 256) LN_BWD(1, DG, NW); else if (D <= 512) LN_BWD(2, DG, NW); else if (D <= 768) LN_BWD(3, DG, NW); else if (D <= 1024) LN_BWD(4, DG, NW); else LN_BWD(LN_MAXV, DG, NW); }
-    if (dgamma && nw == 8) LN_BWD_D(true, 8) else if (dgamma) LN_BWD_D(true, 4) else LN_BWD_D(false, 4)
+    if (dgamma && nw == 16) {
+        static bool attr16 = false;
+        if (!attr16) {
+            (void)hipFuncSetAttribute((const void*)k_ln_bwd<1, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_ln_bwd<2, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_ln_bwd<3, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_ln_bwd<4, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_ln_bwd<LN_MAXV, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr16 = true;
+        }
+        LN_BWD_D(true, 16)
+    } else if (dgamma && nw == 8) LN_BWD_D(true, 8) else if (dgamma) LN_BWD_D(true, 4) else LN_BWD_D(false, 4)
 #undef LN_BWD_D
 #undef LN_BWD
     return CC_OK;
