@@ -41,10 +41,8 @@ CONFIGS = {
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
 # Offline PMC measurements quoted in the JSON line (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 gfx950
 # correction; see the profile files).  They describe the build the profile was taken from; bench.py itself does not read counters.
-LMHEAD_TRAFFIC = {"bytes": (2 * 643119 + 1097837) * 1024,
-                  "source": "offline PMC: FETCH_SIZE x2 from profiles/r02_d_pmc_fetch.md (this round's build), WRITE_SIZE from "
-                            "profiles/r01_i_pmc_fetch_write.md (same kernel, round 1)"}
-DECODE_TRAFFIC = {"bytes": 3.18e9, "source": "profiles/r01_p_decode_kernel_stats.md (offline PMC, round 1 build)"}
+LMHEAD_TRAFFIC = {"bytes": (2 * 608364 + 1098505) * 1024, "source": "profiles/r02_g_pmc_fetch_write_train.md (offline PMC, this round's build)"}
+DECODE_TRAFFIC = {"bytes": 3.31e9, "source": "profiles/r02_h_pmc_fetch_write_decode.md (offline PMC, this round's build)"}
 
 
 def mapper_flops_fwd(c):   # 2*E*P*D + N*[S*2*D*(D+2D+D+rD+rD) + 4*S^2*D], r=2
