@@ -691,9 +691,9 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void k_attn_fwd_mfma(const o
             pf[t] = __builtin_bit_cast(op16x8, v);
         }
 #pragma unroll
-        for (int nb = 0; nb < NB; nb++)
+        for (int t = 0; t < 2; t++)          // t outer: consecutive MFMAs go to different accumulators (no back-to-back RAW stall)
 #pragma unroll
-            for (int t = 0; t < 2; t++) o[nb] = CC_MFMA_32x32x16(frag_tr<HD>(vs, nb, t, lane), pf[t], o[nb]);
+            for (int nb = 0; nb < NB; nb++) o[nb] = CC_MFMA_32x32x16(frag_tr<HD>(vs, nb, t, lane), pf[t], o[nb]);
 #pragma unroll
         for (int kk = 0; kk < KK; kk++) kq[kk] = kn[kk];
 #pragma unroll
@@ -845,9 +845,9 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void k_attn_bwd_dkv(const op
         const op16x8 pf[2] = {pack_frag(p), pack_frag(p + 8)};
         const op16x8 dsf[2] = {pack_frag(ds), pack_frag(ds + 8)};
 #pragma unroll
-        for (int nb = 0; nb < NB; nb++)
+        for (int t = 0; t < 2; t++)
 #pragma unroll
-            for (int t = 0; t < 2; t++) {
+            for (int nb = 0; nb < NB; nb++) {
                 dv[nb] = CC_MFMA_32x32x16(frag_tr<HD>(dsm[wave], nb, t, lane), pf[t], dv[nb]);
                 dk[nb] = CC_MFMA_32x32x16(frag_tr<HD>(qsm[wave], nb, t, lane), dsf[t], dk[nb]);
             }
@@ -950,9 +950,9 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : (HD == 96 ? 2 : 1)) void k_attn
         }
         const op16x8 dsf[2] = {pack_frag(ds), pack_frag(ds + 8)};
 #pragma unroll
-        for (int nb = 0; nb < NB; nb++)
+        for (int t = 0; t < 2; t++)
 #pragma unroll
-            for (int t = 0; t < 2; t++)
+            for (int nb = 0; nb < NB; nb++)
                 dq[nb] = CC_MFMA_32x32x16(frag_tr<HD>(ksm[wave], nb, t, lane), dsf[t], dq[nb]);
 #pragma unroll
         for (int kk = 0; kk < KK; kk++) { kf[kk] = kn[kk]; vf[kk] = vn[kk]; }
