@@ -337,6 +337,9 @@ class Gpt2Engine:
             self._ws.pop(shp.mode, None)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=self.arena.device)
             self._ws[shp.mode] = ws
+        # every hand-out of a mode's buffer may overwrite the activations a differentiable .logits pass left in it: the autograd
+        # bridge compares this counter (logits(save_mode) / logits_backward)
+        self._ws_uses = getattr(self, "_ws_uses", 0) + 1
         return ws
 
     # -- inference-style forward: logits for all rows (ClipCapModel.forward / language_model(inputs_embeds=...)) --
@@ -349,7 +352,7 @@ class Gpt2Engine:
         B, T, D = x.shape
         shp = self.shape(B, T, T, 0, 0) if not save_mode else self.shape(B, 0, T, T, save_mode)
         if save_mode:
-            self._logits_pass = (shp, getattr(self, "_logits_pass", (None, 0))[1] + 1)
+            self._logits_pass = (shp, getattr(self, "_logits_pass", (None, 0, 0))[1] + 1, 0)
         ws = self.workspace(shp)
         self.arena.sync_bf16()
         st = _stream(self.arena.device)
@@ -359,12 +362,17 @@ class Gpt2Engine:
         Vp = self.dims["Vp"]
         out = torch.empty(B * T, Vp, dtype=torch.float32, device=a.device)
         check(l.cc_gpt2_logits(C.byref(self.cfg), C.byref(shp), _p(a.w32), _p(a.w16), _p(ws), _p(out), Vp, st), "cc_gpt2_logits")
+        if save_mode:
+            self._logits_pass = (shp, self._logits_pass[1], self._ws_uses)
         return out.view(B, T, Vp)[:, :, : self.dims["V"]]
 
     def logits_backward(self, dlogits: torch.Tensor) -> torch.Tensor:
         """d loss / d inputs_embeds (B,T,D) for the last logits(..., save_mode >= 1) pass; save_mode 2 also ACCUMULATES the GPT-2 weight
         gradients into the arena's g32 (cc_gpt2_logits_bwd)."""
-        shp = self._logits_pass[0]
+        shp, _, uses = self._logits_pass
+        if uses != self._ws_uses:
+            raise RuntimeError("Gpt2Engine.logits_backward: another pass has used the activation workspace since the forward; "
+                               "call backward() before running the language model again")
         a = self.arena
         dl = dlogits.to(device=a.device, dtype=torch.float32).contiguous()
         B, T, V = dl.shape

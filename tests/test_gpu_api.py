@@ -450,6 +450,11 @@ def test_language_model_logits_are_differentiable_vs_reference_gradients():
             assert rel <= 6e-2, (k, rel)
             n += 1
     assert n >= 2 + 12 * n_layer + 2
+    # a graph whose activations another training-mode pass has overwritten refuses to run backward
+    stale = lm(inputs_embeds=x.detach().requires_grad_(True)).logits
+    lm(inputs_embeds=x.detach().requires_grad_(True))
+    with pytest.raises(RuntimeError, match="backward"):
+        stale.sum().backward()
     # inputs only (frozen LM): no parameter gradients are produced, the input gradient is the same
     lm.zero_grad()
     lm.requires_grad_(False)
