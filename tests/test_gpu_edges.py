@@ -10,11 +10,12 @@ from oracle import clipcap_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def _build(E, D, P, L, H, N, n_head, n_layer, V, npos, seed=0):
+def _build(E, D, P, L, H, N, n_head, n_layer, V, npos, seed=0, prec=None):
+    """prec None = bf16 operands, 16 = fp16 operands (the gradients in the arena then carry the engine's loss scale)."""
     from clipcap_amd.engine import ClipCapEngine, Gpt2Engine, MapperEngine
     torch.manual_seed(seed)
-    me = MapperEngine(E, D, L, P, H, N, device="cuda")
-    ge = Gpt2Engine(D, n_head, n_layer, V, npos, device="cuda")
+    me = MapperEngine(E, D, L, P, H, N, device="cuda", precision=prec)
+    ge = Gpt2Engine(D, n_head, n_layer, V, npos, device="cuda", precision=prec)
     sd = {}
     for pre, eng in (("transformer_mapper.", me), ("language_model.", ge)):
         for k, v in eng.views(eng.arena.w32).items():
@@ -40,24 +41,28 @@ def _check(eng, sd, cfg, tokens, embeds, tol=2e-3):
         assert float(loss) == 0.0 and float(eng.stats[1]) == 0.0
         assert torch.count_nonzero(eng.mapper.arena.g32) == 0
         return
-    ref = O.clipcap_loss(sdr, tokens, embeds, cfg=cfg, rb=True)
+    fp16 = eng.scaler is not None
+    ref = O.clipcap_loss(sdr, tokens, embeds, cfg=cfg, rb="fp16" if fp16 else True)
     ref.backward()
     assert abs(float(loss) - float(ref)) <= tol, (float(loss), float(ref))
+    unscale = 1.0 / float(eng.scaler.scale) if fp16 else 1.0
     gv = eng.mapper.views(eng.mapper.arena.g32)
     for k, v in gv.items():
         r = sdr["transformer_mapper." + k].grad
-        assert ((v.cpu() - r).norm() / r.norm().clamp_min(1e-12)).item() <= 6e-2, k
+        assert ((v.cpu() * unscale - r).norm() / r.norm().clamp_min(1e-12)).item() <= 6e-2, k
 
 
+@pytest.mark.parametrize("prec", [None, 16])
 @pytest.mark.parametrize("B,cap,P,L", [(1, 1, 1, 1), (1, 5, 2, 3), (3, 2, 4, 1), (2, 9, 1, 6)])
-def test_smallest_shapes(B, cap, P, L):
-    eng, sd, cfg = _build(16, 64, P, L, 4, 1, 4, 1, 97, 32)
+def test_smallest_shapes(B, cap, P, L, prec):
+    eng, sd, cfg = _build(16, 64, P, L, 4, 1, 4, 1, 97, 32, prec=prec)
     torch.manual_seed(B * 10 + cap)
     _check(eng, sd, cfg, torch.randint(1, 97, (B, cap)), torch.randn(B, 16))
 
 
-def test_ragged_pads_zero_ids_and_fully_padded_rows():
-    eng, sd, cfg = _build(24, 64, 2, 3, 4, 2, 4, 2, 157, 40)
+@pytest.mark.parametrize("prec", [None, 16])
+def test_ragged_pads_zero_ids_and_fully_padded_rows(prec):
+    eng, sd, cfg = _build(24, 64, 2, 3, 4, 2, 4, 2, 157, 40, prec=prec)
     torch.manual_seed(4)
     tokens = torch.randint(1, 157, (5, 8))
     tokens[0, 3:] = -1
@@ -69,9 +74,10 @@ def test_ragged_pads_zero_ids_and_fully_padded_rows():
     _check(eng, sd, cfg, torch.full((2, 4), -1), torch.randn(2, 24))      # nothing kept at all: loss 0, zero gradients
 
 
-def test_widths_that_are_multiples_of_8_but_not_of_64():
+@pytest.mark.parametrize("prec", [None, 16])
+def test_widths_that_are_multiples_of_8_but_not_of_64(prec):
     # D = 40*... : K of the GEMMs not a multiple of 64 -> generic register-staged kernel instead of the direct-to-LDS one
-    eng, sd, cfg = _build(40, 96, 3, 2, 4, 1, 4, 1, 203, 24)      # hd = 24, Hm = 192, E = 40
+    eng, sd, cfg = _build(40, 96, 3, 2, 4, 1, 4, 1, 203, 24, prec=prec)      # hd = 24, Hm = 192, E = 40
     torch.manual_seed(9)
     _check(eng, sd, cfg, torch.randint(1, 203, (3, 6)), torch.randn(3, 40), tol=3e-3)
 
