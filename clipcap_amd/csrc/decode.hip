@@ -8,6 +8,13 @@
 
 using namespace CC_NS;
 
+#ifndef CC_DEC_SCU
+#define CC_DEC_SCU 4   // K rows (score phase) / V rows (PV phase) a lane keeps in flight in k_decode_attn
+#endif
+#ifndef CC_DEC_PVU
+#define CC_DEC_PVU 4
+#endif
+
 #define CC_TRY(expr)                 \
     do {                             \
         int _e = (expr);             \
@@ -69,7 +76,7 @@ __global__ __launch_bounds__(256) void k_decode_attn(const op16_t* __restrict__ 
     if ((nchunk & (nchunk - 1)) == 0 && nchunk <= 16) {
         // lane = (key group, 16-B chunk of the head slice): one load instruction covers 64 / nchunk whole K rows (full 128-B lines for
         // hd = 64) instead of 16 B of 64 different rows, SC_U of them in flight; the chunk dot products meet by xor-shuffles
-        constexpr int SC_U = 4;
+        constexpr int SC_U = CC_DEC_SCU;
         const int kgs = 64 / nchunk, skg = lane / nchunk, sdc = lane - skg * nchunk;
         float qf[8];
         unpack8(*reinterpret_cast<const uint4*>(q + sdc * 8), qf);
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(256) void k_decode_attn(const op16_t* __restrict__ 
     const int kg = lane / nchunk, dc = lane - kg * nchunk;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (kg < kgroups) {
-        constexpr int PV_U = 4;                                // V rows in flight per lane
+        constexpr int PV_U = CC_DEC_PVU;                       // V rows in flight per lane
         for (int j0 = kg; j0 < nkeys; j0 += kgroups * PV_U) {
             uint4 vv[PV_U];
             float pj[PV_U];
