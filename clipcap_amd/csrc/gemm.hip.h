@@ -797,6 +797,9 @@ __global__ __launch_bounds__(G_THREADS, 2) void gemm_nt_s64kw_kernel(const op16_
 // spill 90 registers).  TT = true is the weight-gradient form (both operands K-strided), see H_ISSUE / h_tt_read.
 // NT LDS image [row][32 k] (64-B rows) with the bank-group-exact XOR key h_swz below.
 // ------------------------------------------------------------------------------------------------
+#ifndef CC_STAG_READ_FIRST
+#define CC_STAG_READ_FIRST 1   // fragment reads of tile t are issued before the DMA of tile t+3: the DMA issue stalls (queue back-pressure) then cover the read latency; +1-2 % on the K <= 4096 shapes, A/B in DESIGN 4.5
+#endif
 constexpr int H_BM = 256, H_BN = 256, H_BK = 32, H_NS = 4, H_STAGE = (H_BM + H_BN) * H_BK * 2;   // 32 KiB per stage, 128 KiB total (5 stages = all 160 KiB measured 2-3 % slower)
 // The B tile may be narrower: NJ MFMA column tiles per wave -> block tile 256 x (64 NJ); NJ = 3 gives 256 x 192 for N = 768-like widths.
 // 64-B rows, 4 chunks of 16 B.  ds_read_b128 is serviced in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (guide, LDS
@@ -944,9 +947,16 @@ __device__ __forceinline__ void gemm_stag256_body(const op16_t* __restrict__ A, 
         H_SEGEND();
         H_STAMP(0)                                     // prologue
         for (int t = 0; t < nk; t++) {
+#if CC_STAG_READ_FIRST
+            H_LOADF(t);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + H_NS - 1 < nk) H_ISSUE(t + H_NS - 1, true);
+            H_STAMP(1)
+#else
             if (t + H_NS - 1 < nk) H_ISSUE(t + H_NS - 1, true);      // that buffer held tile t-1, last read (by group 1) in segment 2t-1
             H_STAMP(1)                                 // DMA issue
             H_LOADF(t);
+#endif
 #ifdef CC_STAMP
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -974,9 +984,16 @@ __device__ __forceinline__ void gemm_stag256_body(const op16_t* __restrict__ A, 
             H_STAMP(4)
             H_SEGEND();
             H_STAMP(6)
+#if CC_STAG_READ_FIRST
+            H_LOADF(t);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + H_NS - 1 < nk) H_ISSUE(t + H_NS - 1, false);
+            H_STAMP(1)
+#else
             if (t + H_NS - 1 < nk) H_ISSUE(t + H_NS - 1, false);     // one segment after group 0's half of the same tile
             H_STAMP(1)
             H_LOADF(t);
+#endif
 #ifdef CC_STAMP
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif

@@ -970,14 +970,215 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : (HD == 96 ? 2 : 1)) void k_attn
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// One-pass backward for S <= 64 (the training shapes: 10 + 40 GPT-2 positions, 20 mapper rows): one wave per (sample, head) holds the
+// Q / dO fragments of both 32-row blocks, computes delta itself, and walks the (key block j, query block i) pairs once — per pair the
+// score / dP tiles in BOTH orientations (the packed P / dS registers are B fragments only along their register axis, see above), so
+// dQ, dK and dV come out of one read of qkv / dO / O and one launch instead of two.  NBLK = number of 32-row blocks (1 or 2).
+// ------------------------------------------------------------------------------------------------------------
+template <int HD, bool CAUSAL, bool DROP, int NBLK>
+__global__ __launch_bounds__(256, 1) void k_attn_bwd_fused(const op16_t* __restrict__ qkv, const op16_t* __restrict__ dout, const op16_t* __restrict__ o,
+                                                           const float* __restrict__ lse, int B, int S, int H, float scale,
+                                                           op16_t* __restrict__ dqkv, Drop drop = Drop()) {
+    constexpr int KK = HD / 16, NB = HD / 32, LD = AttLd<HD>::v;
+    __shared__ __attribute__((aligned(16))) op16_t ksm[4][32 * LD];
+    __shared__ __attribute__((aligned(16))) op16_t qsm[4][32 * LD];
+    __shared__ __attribute__((aligned(16))) op16_t dsm[4][32 * LD];
+    __shared__ __attribute__((aligned(16))) float ldsm[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= B * H) return;          // wave-uniform; only wave-private LDS below, no block barrier
+    const int h = item % H, b = item / H;
+    const int D = H * HD;
+    const size_t rs = (size_t)3 * D;
+    const op16_t* base = qkv + (size_t)b * S * rs + h * HD;
+    const op16_t* dbase = dout + (size_t)b * S * D + h * HD;
+    const op16_t* obase = o + (size_t)b * S * D + h * HD;
+    const float* lrow = lse + ((size_t)b * H + h) * S;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    // query side of every block: Q, dO fragments (row l31 of the block, columns 16 kk + 8 half .. + 7), lse, delta = sum_d dO O
+    op16x8 qf[NBLK][KK], dof[NBLK][KK];
+    float my_lse[NBLK], my_delta[NBLK];
+#pragma unroll
+    for (int i = 0; i < NBLK; i++) {
+        const int q = i * 32 + l31, qc = min(q, S - 1);
+        my_lse[i] = lrow[qc];
+        float acc = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++) {
+            qf[i][kk] = load_frag(base + (size_t)qc * rs + kk * 16 + half * 8, q < S);
+            dof[i][kk] = load_frag(dbase + (size_t)qc * D + kk * 16 + half * 8, q < S);
+            const op16x8 of = load_frag(obase + (size_t)qc * D + kk * 16 + half * 8, q < S);
+            float x[8], y[8];
+            unpack8(__builtin_bit_cast(uint4, dof[i][kk]), x);
+            unpack8(__builtin_bit_cast(uint4, of), y);
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc += x[e] * y[e];
+        }
+        my_delta[i] = acc + __shfl_xor(acc, 32, 64);
+    }
+    f32x16 dq[NBLK][NB];
+#pragma unroll
+    for (int i = 0; i < NBLK; i++)
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) dq[i][nb][r] = 0.f;
+
+#pragma unroll
+    for (int j = 0; j < NBLK; j++) {
+        const int key = j * 32 + l31, kc = min(key, S - 1);
+        op16x8 kf[KK], vf[KK];
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++) {
+            kf[kk] = load_frag(base + D + (size_t)kc * rs + kk * 16 + half * 8, key < S);
+            vf[kk] = load_frag(base + 2 * D + (size_t)kc * rs + kk * 16 + half * 8, key < S);
+        }
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++) *reinterpret_cast<op16x8*>(ksm[wave] + l31 * LD + kk * 16 + half * 8) = kf[kk];
+        f32x16 dk[NB], dv[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) { dk[nb][r] = 0.f; dv[nb][r] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < NBLK; i++) {
+            if (CAUSAL && i < j) continue;
+            const int q = i * 32 + l31;
+            // ---- S^T orientation (lane <-> query): dQ_i^T += K_j^T dS^T
+            {
+                f32x16 st, dpt;
+#pragma unroll
+                for (int r = 0; r < 16; r++) { st[r] = 0.f; dpt[r] = 0.f; }
+#pragma unroll
+                for (int kk = 0; kk < KK; kk++) {
+                    st = CC_MFMA_32x32x16(kf[kk], qf[i][kk], st);
+                    dpt = CC_MFMA_32x32x16(vf[kk], dof[i][kk], dpt);
+                }
+                float ds[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int kr = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const bool ok = kr < S && q < S && (!CAUSAL || kr <= q);
+                    const float p = ok ? __expf(st[r] * scale - my_lse[i]) : 0.f;
+                    const float mk = DROP ? drop_mul(drop, ((unsigned)(b * H + h) * S + min(q, S - 1)) * S + min(kr, S - 1)) : 1.0f;
+                    ds[r] = p * (mk * dpt[r] - my_delta[i]) * scale;
+                }
+                const op16x8 dsf[2] = {pack_frag(ds), pack_frag(ds + 8)};
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++) dq[i][nb] = CC_MFMA_32x32x16(frag_tr<HD>(ksm[wave], nb, t, lane), dsf[t], dq[i][nb]);
+            }
+            // ---- S orientation (lane <-> key): dV_j^T += dO_i^T P,  dK_j^T += Q_i^T dS
+            {
+#pragma unroll
+                for (int kk = 0; kk < KK; kk++) {
+                    *reinterpret_cast<op16x8*>(qsm[wave] + l31 * LD + kk * 16 + half * 8) = qf[i][kk];
+                    *reinterpret_cast<op16x8*>(dsm[wave] + l31 * LD + kk * 16 + half * 8) = dof[i][kk];
+                }
+                ldsm[wave][lane] = half ? my_delta[i] : my_lse[i];          // [0,32): lse, [32,64): delta of block i's queries
+                f32x16 s, dp;
+#pragma unroll
+                for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+                for (int kk = 0; kk < KK; kk++) {
+                    s = CC_MFMA_32x32x16(qf[i][kk], kf[kk], s);
+                    dp = CC_MFMA_32x32x16(dof[i][kk], vf[kk], dp);
+                }
+                float lq[16], dl[16];
+#pragma unroll
+                for (int g4 = 0; g4 < 4; g4++) {
+                    const float4 a = *reinterpret_cast<const float4*>(&ldsm[wave][4 * half + 8 * g4]);
+                    const float4 c = *reinterpret_cast<const float4*>(&ldsm[wave][32 + 4 * half + 8 * g4]);
+                    lq[g4 * 4 + 0] = a.x; lq[g4 * 4 + 1] = a.y; lq[g4 * 4 + 2] = a.z; lq[g4 * 4 + 3] = a.w;
+                    dl[g4 * 4 + 0] = c.x; dl[g4 * 4 + 1] = c.y; dl[g4 * 4 + 2] = c.z; dl[g4 * 4 + 3] = c.w;
+                }
+                float p[16], ds[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int qr = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const bool ok = qr < S && key < S && (!CAUSAL || key <= qr);
+                    p[r] = ok ? __expf(s[r] * scale - lq[r]) : 0.f;
+                    if (DROP) {
+                        const float mk = drop_mul(drop, ((unsigned)(b * H + h) * S + min(qr, S - 1)) * S + min(key, S - 1));
+                        ds[r] = p[r] * (mk * dp[r] - dl[r]) * scale;
+                        p[r] *= mk;
+                    } else {
+                        ds[r] = p[r] * (dp[r] - dl[r]) * scale;
+                    }
+                }
+                const op16x8 pf[2] = {pack_frag(p), pack_frag(p + 8)};
+                const op16x8 dsf[2] = {pack_frag(ds), pack_frag(ds + 8)};
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++) {
+                        dv[nb] = CC_MFMA_32x32x16(frag_tr<HD>(dsm[wave], nb, t, lane), pf[t], dv[nb]);
+                        dk[nb] = CC_MFMA_32x32x16(frag_tr<HD>(qsm[wave], nb, t, lane), dsf[t], dk[nb]);
+                    }
+            }
+        }
+        if (key < S) {
+            op16_t* orow = dqkv + ((size_t)b * S + key) * rs + h * HD;
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int d0 = nb * 32 + 8 * g + 4 * half;
+                    *reinterpret_cast<uint2*>(orow + D + d0) =
+                        make_uint2(pack2op(dk[nb][g * 4 + 0], dk[nb][g * 4 + 1]), pack2op(dk[nb][g * 4 + 2], dk[nb][g * 4 + 3]));
+                    *reinterpret_cast<uint2*>(orow + 2 * D + d0) =
+                        make_uint2(pack2op(dv[nb][g * 4 + 0], dv[nb][g * 4 + 1]), pack2op(dv[nb][g * 4 + 2], dv[nb][g * 4 + 3]));
+                }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NBLK; i++) {
+        const int q = i * 32 + l31;
+        if (q < S) {
+            op16_t* orow = dqkv + ((size_t)b * S + q) * rs + h * HD;
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int d0 = nb * 32 + 8 * g + 4 * half;
+                    *reinterpret_cast<uint2*>(orow + d0) =
+                        make_uint2(pack2op(dq[i][nb][g * 4 + 0], dq[i][nb][g * 4 + 1]), pack2op(dq[i][nb][g * 4 + 2], dq[i][nb][g * 4 + 3]));
+                }
+        }
+    }
+}
+
+template <int HD, int NBLK>
+static void attn_bwd_fused_launch(const op16_t* qkv, const op16_t* dout, const op16_t* o, const float* lse, int B, int S, int H, bool causal,
+                                  op16_t* dqkv, hipStream_t st, Drop drop, float scale) {
+    const dim3 grid((B * H + 3) / 4), blk(256);
+    if (drop.thresh) hipLaunchKernelGGL((k_attn_bwd_fused<HD, true, true, NBLK>), grid, blk, 0, st, qkv, dout, o, lse, B, S, H, scale, dqkv, drop);
+    else if (causal) hipLaunchKernelGGL((k_attn_bwd_fused<HD, true, false, NBLK>), grid, blk, 0, st, qkv, dout, o, lse, B, S, H, scale, dqkv, drop);
+    else hipLaunchKernelGGL((k_attn_bwd_fused<HD, false, false, NBLK>), grid, blk, 0, st, qkv, dout, o, lse, B, S, H, scale, dqkv, drop);
+}
+
 template <int HD>
 static int attn_bwd_mfma_launch(const op16_t* qkv, const op16_t* dout, const op16_t* o, const float* lse, float* delta, int B, int S, int H,
                                 bool causal, op16_t* dqkv, hipStream_t st, Drop drop) {
     const int items = B * H * ((S + 31) / 32);
     const float scale = 1.0f / sqrtf((float)HD);
+    if (drop.thresh && !causal) return CC_ERR_SHAPE;
+    static const int fused = []() { const char* e = getenv("CC_ATTN_BWD_FUSED"); return e ? atoi(e) : 1; }();   // A/B switch (0 = two-kernel path)
+    if (fused && S <= 32) {
+        attn_bwd_fused_launch<HD, 1>(qkv, dout, o, lse, B, S, H, causal, dqkv, st, drop, scale);
+        return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+    }
+    if constexpr (HD < 128) {      // two blocks at head dim 128 do not fit the register file (spills)
+        if (fused && S <= 64) {
+            attn_bwd_fused_launch<HD, 2>(qkv, dout, o, lse, B, S, H, causal, dqkv, st, drop, scale);
+            return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+        }
+    }
     // dQ first: it also produces delta, which the dK/dV kernel reads
     if (drop.thresh) {
-        if (!causal) return CC_ERR_SHAPE;
         hipLaunchKernelGGL((k_attn_bwd_dq<HD, true, true>), dim3((items + 3) / 4), dim3(256), 0, st, qkv, dout, o, lse, delta, B, S, H, scale, dqkv, drop);
         hipLaunchKernelGGL((k_attn_bwd_dkv<HD, true, true>), dim3((items + 3) / 4), dim3(256), 0, st, qkv, dout, lse, delta, B, S, H, scale, dqkv, drop);
     } else if (causal) {
@@ -1044,10 +1245,10 @@ int attn_fwd(const op16_t* qkv, int B, int S, int H, int hd, bool causal, op16_t
     if (sh > 160 * 1024) return CC_ERR_SHAPE;
     const float scale = 1.0f / sqrtf((float)hd);
     if (causal) {
-        if (sh > 64 * 1024) hipFuncSetAttribute((const void*)k_attn_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        if (sh > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_attn_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         hipLaunchKernelGGL(k_attn_fwd<true>, dim3(B * H), dim3(256), sh, st, qkv, S, H, hd, scale, out, lse);
     } else {
-        if (sh > 64 * 1024) hipFuncSetAttribute((const void*)k_attn_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        if (sh > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_attn_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         hipLaunchKernelGGL(k_attn_fwd<false>, dim3(B * H), dim3(256), sh, st, qkv, S, H, hd, scale, out, lse);
     }
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
@@ -1155,10 +1356,10 @@ int attn_bwd(const op16_t* qkv, const op16_t* dout, const op16_t* o, const float
     if (sh > 160 * 1024) return CC_ERR_SHAPE;
     const float scale = 1.0f / sqrtf((float)hd);
     if (causal) {
-        if (sh > 64 * 1024) hipFuncSetAttribute((const void*)k_attn_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        if (sh > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_attn_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         hipLaunchKernelGGL(k_attn_bwd<true>, dim3(B * H), dim3(256), sh, st, qkv, dout, lse, S, H, hd, scale, dqkv);
     } else {
-        if (sh > 64 * 1024) hipFuncSetAttribute((const void*)k_attn_bwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        if (sh > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_attn_bwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         hipLaunchKernelGGL(k_attn_bwd<false>, dim3(B * H), dim3(256), sh, st, qkv, dout, lse, S, H, hd, scale, dqkv);
     }
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;

@@ -182,10 +182,12 @@ def _attn_ref(qkv, B, S, H, hd, causal):
 
 
 @pytest.mark.parametrize("B,S,H,hd,causal", [(3, 20, 8, 96, 0), (2, 50, 12, 64, 1), (2, 74, 4, 64, 1), (1, 7, 2, 8, 0), (2, 33, 2, 128, 1),
-                                             (2, 64, 2, 64, 0), (1, 97, 2, 64, 1), (2, 32, 3, 96, 1)])
+                                             (2, 64, 2, 64, 0), (1, 97, 2, 64, 1), (2, 32, 3, 96, 1), (2, 20, 4, 128, 0), (2, 40, 2, 96, 1),
+                                             (1, 64, 2, 64, 1), (5, 17, 3, 64, 1)])
 @pytest.mark.parametrize("mfma_bwd", [0, 1])
 def test_attention_fwd_bwd(B, S, H, hd, causal, mfma_bwd):
-    """hd in {64,96,128}: MFMA forward (and, with mfma_bwd, the MFMA delta/dKV/dQ backward); otherwise the LDS/VALU kernels.
+    """hd in {64,96,128}: MFMA forward (and, with mfma_bwd, the MFMA backward: the one-pass kernel for S <= 64 (S <= 32 at hd 128), the
+    dQ + dK/dV pair beyond); otherwise the LDS/VALU kernels.
     Reference: fp32 torch math on the same bf16 inputs; P is bf16-rounded before PV like the kernels do."""
     if not mfma_bwd and S > 80:
         pytest.skip("the LDS/VALU backward keeps whole S x S tiles in LDS (S <= ~80); longer sequences use the MFMA kernels")
