@@ -971,20 +971,65 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : (HD == 96 ? 2 : 1)) void k_attn
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// One-pass backward for S <= 64 (the training shapes: 10 + 40 GPT-2 positions, 20 mapper rows): one wave per (sample, head) holds the
-// Q / dO fragments of both 32-row blocks, computes delta itself, and walks the (key block j, query block i) pairs once — per pair the
-// score / dP tiles in BOTH orientations (the packed P / dS registers are B fragments only along their register axis, see above), so
-// dQ, dK and dV come out of one read of qkv / dO / O and one launch instead of two.  NBLK = number of 32-row blocks (1 or 2).
+// One-pass backward for S <= 64 (the training shapes: 10 + 40 GPT-2 positions, 20 mapper rows): one wave per (sample, head) computes
+// delta itself and walks the (key block j, query block i) pairs once, in the "S orientation" only (lane <-> key): bf16(P) and
+// bf16(dS) are the B fragments of the dV / dK products as in k_attn_bwd_dkv, and dS goes through a wave-private [32 key][32 query]
+// LDS tile whose transpose read is the B fragment of dQ_i^T[d][q] += K_j^T[d][key] dS^T[key][q] (same k-slot order as frag_tr's A
+// fragments of the K copy).  One read of qkv / dO / O and one launch instead of two, no second score / exp pass.
+// NBLK = number of 32-row blocks (1 or 2).  Q / dO of the next pair and K / V of the next key block are requested as soon as the
+// current pair's score MFMAs have consumed their registers.
 // ------------------------------------------------------------------------------------------------------------
-template <int HD, bool CAUSAL, bool DROP, int NBLK>
-__global__ __launch_bounds__(256, 1) void k_attn_bwd_fused(const op16_t* __restrict__ qkv, const op16_t* __restrict__ dout, const op16_t* __restrict__ o,
-                                                           const float* __restrict__ lse, int B, int S, int H, float scale,
-                                                           op16_t* __restrict__ dqkv, Drop drop = Drop()) {
+#ifndef CC_ATTN_FUSED_OCC
+#define CC_ATTN_FUSED_OCC 2
+#endif
+template <int LD>
+__device__ __forceinline__ op16x8 frag_tr_ld(const op16_t* blk, int nb, int t, int lane) {
+    typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+    typedef __attribute__((address_space(3))) s16x4_t* lp_t;
+    const int half = lane >> 5, j = lane & 15, dsub = (lane >> 4) & 1;
+    const op16_t* p = blk + (16 * t + 4 * half + (j >> 2)) * LD + nb * 32 + 16 * dsub + 4 * (j & 3);
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)p);
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(p + 8 * LD));
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(op16x8, v);
+}
+
+// Accumulator tile (C layout: lane <-> row of the output block, registers <-> 16 of its HD columns) -> global rows, through a
+// wave-private row-major LDS tile so that the stores are whole 16-B chunks of consecutive lanes (8 lanes per 128-B row at head
+// dim 64) instead of 8-B pieces 4.5 KB apart: the scattered form cost 15 of the kernel's 40 us.
+template <int HD>
+__device__ __forceinline__ void attn_store_tile(op16_t* T, const f32x16 (&acc)[HD / 32], op16_t* gblock, size_t gstride, int rows_left, int lane) {
+    constexpr int LD = AttLd<HD>::v, C8 = HD / 8;
+    const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int nb = 0; nb < HD / 32; nb++)
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+            *reinterpret_cast<uint2*>(T + l31 * LD + nb * 32 + 8 * g + 4 * half) =
+                make_uint2(pack2op(acc[nb][g * 4 + 0], acc[nb][g * 4 + 1]), pack2op(acc[nb][g * 4 + 2], acc[nb][g * 4 + 3]));
+#pragma unroll
+    for (int it = 0; it < C8 / 2; it++) {
+        const int idx = lane + 64 * it, row = idx / C8, chunk = idx % C8;
+        const uint4 v = *reinterpret_cast<const uint4*>(T + row * LD + chunk * 8);
+        if (row < rows_left) *reinterpret_cast<uint4*>(gblock + (size_t)row * gstride + chunk * 8) = v;
+    }
+}
+
+template <int HD, bool CAUSAL, bool DROP, int NBLK, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_attn_bwd_fused(const op16_t* __restrict__ qkv, const op16_t* __restrict__ dout, const op16_t* __restrict__ o,
+                                                             const float* __restrict__ lse, int B, int S, int H, float scale,
+                                                             op16_t* __restrict__ dqkv, Drop drop = Drop()) {
+    // the dS^T tile lives in the 32 spare columns of the K copy's rows when there are any (row pitch 96 / 160 for head dim 64 / 128),
+    // otherwise in its own tile with 64-B rows (the 4 rows of a transpose read fall into 4 different bank slots either way)
     constexpr int KK = HD / 16, NB = HD / 32, LD = AttLd<HD>::v;
+    constexpr bool SPARE = LD >= HD + 32;
+    constexpr int LT = SPARE ? LD : 32;
     __shared__ __attribute__((aligned(16))) op16_t ksm[4][32 * LD];
     __shared__ __attribute__((aligned(16))) op16_t qsm[4][32 * LD];
     __shared__ __attribute__((aligned(16))) op16_t dsm[4][32 * LD];
-    __shared__ __attribute__((aligned(16))) float ldsm[4][64];
+    __shared__ __attribute__((aligned(16))) op16_t dtx[SPARE ? 1 : 4][SPARE ? 8 : 32 * 32];
+    __shared__ __attribute__((aligned(16))) float ldsm[4][NBLK][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int item = blockIdx.x * 4 + wave;
     if (item >= B * H) return;          // wave-uniform; only wave-private LDS below, no block barrier
@@ -996,47 +1041,53 @@ __global__ __launch_bounds__(256, 1) void k_attn_bwd_fused(const op16_t* __restr
     const op16_t* obase = o + (size_t)b * S * D + h * HD;
     const float* lrow = lse + ((size_t)b * H + h) * S;
     const int half = lane >> 5, l31 = lane & 31;
+    const int coff = half * 8;
+    op16_t* dtm = SPARE ? ksm[wave] + HD : dtx[SPARE ? 0 : wave];
 
-    // query side of every block: Q, dO fragments (row l31 of the block, columns 16 kk + 8 half .. + 7), lse, delta = sum_d dO O
-    op16x8 qf[NBLK][KK], dof[NBLK][KK];
-    float my_lse[NBLK], my_delta[NBLK];
+    op16x8 qf[KK], dof[KK], kf[KK], vf[KK];
+    auto load_q = [&](int i) {
+        const int q = i * 32 + l31, qc = min(q, S - 1);
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++) {
+            qf[kk] = load_frag(base + (size_t)qc * rs + kk * 16 + coff, q < S);
+            dof[kk] = load_frag(dbase + (size_t)qc * D + kk * 16 + coff, q < S);
+        }
+    };
+    auto load_k = [&](int j) {
+        const int key = j * 32 + l31, kc = min(key, S - 1);
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++) {
+            kf[kk] = load_frag(base + D + (size_t)kc * rs + kk * 16 + coff, key < S);
+            vf[kk] = load_frag(base + 2 * D + (size_t)kc * rs + kk * 16 + coff, key < S);
+        }
+    };
+    load_k(0);
+    load_q(0);
+    // lse and delta = sum_d dO O of every query, row layout (lane <-> query, half <-> column half) -> LDS rows read back per pair
 #pragma unroll
     for (int i = 0; i < NBLK; i++) {
         const int q = i * 32 + l31, qc = min(q, S - 1);
-        my_lse[i] = lrow[qc];
         float acc = 0.f;
 #pragma unroll
         for (int kk = 0; kk < KK; kk++) {
-            qf[i][kk] = load_frag(base + (size_t)qc * rs + kk * 16 + half * 8, q < S);
-            dof[i][kk] = load_frag(dbase + (size_t)qc * D + kk * 16 + half * 8, q < S);
-            const op16x8 of = load_frag(obase + (size_t)qc * D + kk * 16 + half * 8, q < S);
+            const op16x8 df = load_frag(dbase + (size_t)qc * D + kk * 16 + coff, q < S);
+            const op16x8 of = load_frag(obase + (size_t)qc * D + kk * 16 + coff, q < S);
             float x[8], y[8];
-            unpack8(__builtin_bit_cast(uint4, dof[i][kk]), x);
+            unpack8(__builtin_bit_cast(uint4, df), x);
             unpack8(__builtin_bit_cast(uint4, of), y);
 #pragma unroll
             for (int e = 0; e < 8; e++) acc += x[e] * y[e];
         }
-        my_delta[i] = acc + __shfl_xor(acc, 32, 64);
+        acc += __shfl_xor(acc, 32, 64);
+        ldsm[wave][i][lane] = half ? acc : lrow[qc];          // [0,32): lse, [32,64): delta
     }
     f32x16 dq[NBLK][NB];
-#pragma unroll
-    for (int i = 0; i < NBLK; i++)
-#pragma unroll
-        for (int nb = 0; nb < NB; nb++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) dq[i][nb][r] = 0.f;
 
 #pragma unroll
     for (int j = 0; j < NBLK; j++) {
-        const int key = j * 32 + l31, kc = min(key, S - 1);
-        op16x8 kf[KK], vf[KK];
+        const int key = j * 32 + l31;
 #pragma unroll
-        for (int kk = 0; kk < KK; kk++) {
-            kf[kk] = load_frag(base + D + (size_t)kc * rs + kk * 16 + half * 8, key < S);
-            vf[kk] = load_frag(base + 2 * D + (size_t)kc * rs + kk * 16 + half * 8, key < S);
-        }
-#pragma unroll
-        for (int kk = 0; kk < KK; kk++) *reinterpret_cast<op16x8*>(ksm[wave] + l31 * LD + kk * 16 + half * 8) = kf[kk];
+        for (int kk = 0; kk < KK; kk++) *reinterpret_cast<op16x8*>(ksm[wave] + l31 * LD + kk * 16 + coff) = kf[kk];
         f32x16 dk[NB], dv[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; nb++)
@@ -1045,108 +1096,89 @@ __global__ __launch_bounds__(256, 1) void k_attn_bwd_fused(const op16_t* __restr
 #pragma unroll
         for (int i = 0; i < NBLK; i++) {
             if (CAUSAL && i < j) continue;
-            const int q = i * 32 + l31;
-            // ---- S^T orientation (lane <-> query): dQ_i^T += K_j^T dS^T
-            {
-                f32x16 st, dpt;
-#pragma unroll
-                for (int r = 0; r < 16; r++) { st[r] = 0.f; dpt[r] = 0.f; }
+            const int ifirst = CAUSAL ? j : 0;
+            // qf / dof hold block i here; the LDS copies are still valid if the previous pair had the same i
+            if (!(j > 0 && i == ifirst && i == NBLK - 1)) {
 #pragma unroll
                 for (int kk = 0; kk < KK; kk++) {
-                    st = CC_MFMA_32x32x16(kf[kk], qf[i][kk], st);
-                    dpt = CC_MFMA_32x32x16(vf[kk], dof[i][kk], dpt);
+                    *reinterpret_cast<op16x8*>(qsm[wave] + l31 * LD + kk * 16 + coff) = qf[kk];
+                    *reinterpret_cast<op16x8*>(dsm[wave] + l31 * LD + kk * 16 + coff) = dof[kk];
                 }
-                float ds[16];
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int kr = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const bool ok = kr < S && q < S && (!CAUSAL || kr <= q);
-                    const float p = ok ? __expf(st[r] * scale - my_lse[i]) : 0.f;
-                    const float mk = DROP ? drop_mul(drop, ((unsigned)(b * H + h) * S + min(q, S - 1)) * S + min(kr, S - 1)) : 1.0f;
-                    ds[r] = p * (mk * dpt[r] - my_delta[i]) * scale;
-                }
-                const op16x8 dsf[2] = {pack_frag(ds), pack_frag(ds + 8)};
-#pragma unroll
-                for (int t = 0; t < 2; t++)
-#pragma unroll
-                    for (int nb = 0; nb < NB; nb++) dq[i][nb] = CC_MFMA_32x32x16(frag_tr<HD>(ksm[wave], nb, t, lane), dsf[t], dq[i][nb]);
             }
-            // ---- S orientation (lane <-> key): dV_j^T += dO_i^T P,  dK_j^T += Q_i^T dS
-            {
+            f32x16 s, dp;
 #pragma unroll
-                for (int kk = 0; kk < KK; kk++) {
-                    *reinterpret_cast<op16x8*>(qsm[wave] + l31 * LD + kk * 16 + half * 8) = qf[i][kk];
-                    *reinterpret_cast<op16x8*>(dsm[wave] + l31 * LD + kk * 16 + half * 8) = dof[i][kk];
-                }
-                ldsm[wave][lane] = half ? my_delta[i] : my_lse[i];          // [0,32): lse, [32,64): delta of block i's queries
-                f32x16 s, dp;
+            for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-                for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
+            for (int kk = 0; kk < KK; kk++) {
+                s = CC_MFMA_32x32x16(qf[kk], kf[kk], s);
+                dp = CC_MFMA_32x32x16(dof[kk], vf[kk], dp);
+            }
+            // next operands
+            if (i + 1 < NBLK) {
+                load_q(i + 1);
+            } else if (j + 1 < NBLK) {
+                const int ni = CAUSAL ? j + 1 : 0;
+                if (ni != i) load_q(ni);
+                load_k(j + 1);
+            }
+            if (j == 0) {
 #pragma unroll
-                for (int kk = 0; kk < KK; kk++) {
-                    s = CC_MFMA_32x32x16(qf[i][kk], kf[kk], s);
-                    dp = CC_MFMA_32x32x16(dof[i][kk], vf[kk], dp);
-                }
-                float lq[16], dl[16];
+                for (int nb = 0; nb < NB; nb++)
 #pragma unroll
-                for (int g4 = 0; g4 < 4; g4++) {
-                    const float4 a = *reinterpret_cast<const float4*>(&ldsm[wave][4 * half + 8 * g4]);
-                    const float4 c = *reinterpret_cast<const float4*>(&ldsm[wave][32 + 4 * half + 8 * g4]);
-                    lq[g4 * 4 + 0] = a.x; lq[g4 * 4 + 1] = a.y; lq[g4 * 4 + 2] = a.z; lq[g4 * 4 + 3] = a.w;
-                    dl[g4 * 4 + 0] = c.x; dl[g4 * 4 + 1] = c.y; dl[g4 * 4 + 2] = c.z; dl[g4 * 4 + 3] = c.w;
-                }
-                float p[16], ds[16];
+                    for (int r = 0; r < 16; r++) dq[i][nb][r] = 0.f;
+            }
+            float p[16], ds[16];
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int qr = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            for (int g4 = 0; g4 < 4; g4++) {
+                const float4 lq = *reinterpret_cast<const float4*>(&ldsm[wave][i][4 * half + 8 * g4]);
+                const float4 dl = *reinterpret_cast<const float4*>(&ldsm[wave][i][32 + 4 * half + 8 * g4]);
+                const float lqa[4] = {lq.x, lq.y, lq.z, lq.w}, dla[4] = {dl.x, dl.y, dl.z, dl.w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int r = g4 * 4 + e;
+                    const int qr = i * 32 + e + 8 * g4 + 4 * half;
                     const bool ok = qr < S && key < S && (!CAUSAL || key <= qr);
-                    p[r] = ok ? __expf(s[r] * scale - lq[r]) : 0.f;
+                    p[r] = ok ? __expf(s[r] * scale - lqa[e]) : 0.f;
                     if (DROP) {
                         const float mk = drop_mul(drop, ((unsigned)(b * H + h) * S + min(qr, S - 1)) * S + min(key, S - 1));
-                        ds[r] = p[r] * (mk * dp[r] - dl[r]) * scale;
+                        ds[r] = p[r] * (mk * dp[r] - dla[e]) * scale;
                         p[r] *= mk;
                     } else {
-                        ds[r] = p[r] * (dp[r] - dl[r]) * scale;
+                        ds[r] = p[r] * (dp[r] - dla[e]) * scale;
                     }
                 }
-                const op16x8 pf[2] = {pack_frag(p), pack_frag(p + 8)};
-                const op16x8 dsf[2] = {pack_frag(ds), pack_frag(ds + 8)};
+            }
+            const op16x8 pf[2] = {pack_frag(p), pack_frag(p + 8)};
+            const op16x8 dsf[2] = {pack_frag(ds), pack_frag(ds + 8)};
+            // dS^T tile: row = key (this lane), columns = queries 8 g + 4 half + 0..3 (the register order of the accumulator layout)
 #pragma unroll
-                for (int t = 0; t < 2; t++)
+            for (int t = 0; t < 2; t++) {
+                const uint4 w = __builtin_bit_cast(uint4, dsf[t]);
+                *reinterpret_cast<uint2*>(dtm + l31 * LT + 16 * t + 4 * half) = make_uint2(w.x, w.y);
+                *reinterpret_cast<uint2*>(dtm + l31 * LT + 16 * t + 8 + 4 * half) = make_uint2(w.z, w.w);
+            }
 #pragma unroll
-                    for (int nb = 0; nb < NB; nb++) {
-                        dv[nb] = CC_MFMA_32x32x16(frag_tr<HD>(dsm[wave], nb, t, lane), pf[t], dv[nb]);
-                        dk[nb] = CC_MFMA_32x32x16(frag_tr<HD>(qsm[wave], nb, t, lane), dsf[t], dk[nb]);
-                    }
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) {
+                    dv[nb] = CC_MFMA_32x32x16(frag_tr<HD>(dsm[wave], nb, t, lane), pf[t], dv[nb]);
+                    dk[nb] = CC_MFMA_32x32x16(frag_tr<HD>(qsm[wave], nb, t, lane), dsf[t], dk[nb]);
+                }
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const op16x8 dst = frag_tr_ld<LT>(dtm, 0, t, lane);
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) dq[i][nb] = CC_MFMA_32x32x16(frag_tr<HD>(ksm[wave], nb, t, lane), dst, dq[i][nb]);
+            }
+            if (j == (CAUSAL ? i : NBLK - 1)) {        // last key block that reaches query block i
+                // block i's Q copy is dead here (the next pair, if any, has another i and rewrites it): stage dQ_i through it
+                attn_store_tile<HD>(qsm[wave], dq[i], dqkv + ((size_t)b * S + i * 32) * rs + h * HD, rs, S - i * 32, lane);
             }
         }
-        if (key < S) {
-            op16_t* orow = dqkv + ((size_t)b * S + key) * rs + h * HD;
-#pragma unroll
-            for (int nb = 0; nb < NB; nb++)
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const int d0 = nb * 32 + 8 * g + 4 * half;
-                    *reinterpret_cast<uint2*>(orow + D + d0) =
-                        make_uint2(pack2op(dk[nb][g * 4 + 0], dk[nb][g * 4 + 1]), pack2op(dk[nb][g * 4 + 2], dk[nb][g * 4 + 3]));
-                    *reinterpret_cast<uint2*>(orow + 2 * D + d0) =
-                        make_uint2(pack2op(dv[nb][g * 4 + 0], dv[nb][g * 4 + 1]), pack2op(dv[nb][g * 4 + 2], dv[nb][g * 4 + 3]));
-                }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < NBLK; i++) {
-        const int q = i * 32 + l31;
-        if (q < S) {
-            op16_t* orow = dqkv + ((size_t)b * S + q) * rs + h * HD;
-#pragma unroll
-            for (int nb = 0; nb < NB; nb++)
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const int d0 = nb * 32 + 8 * g + 4 * half;
-                    *reinterpret_cast<uint2*>(orow + d0) =
-                        make_uint2(pack2op(dq[i][nb][g * 4 + 0], dq[i][nb][g * 4 + 1]), pack2op(dq[i][nb][g * 4 + 2], dq[i][nb][g * 4 + 3]));
-                }
+        {      // the K copy is dead until the next j rewrites it
+            op16_t* gblk = dqkv + ((size_t)b * S + j * 32) * rs + h * HD;
+            attn_store_tile<HD>(ksm[wave], dk, gblk + D, rs, S - j * 32, lane);
+            attn_store_tile<HD>(ksm[wave], dv, gblk + 2 * D, rs, S - j * 32, lane);
         }
     }
 }
@@ -1154,10 +1186,11 @@ __global__ __launch_bounds__(256, 1) void k_attn_bwd_fused(const op16_t* __restr
 template <int HD, int NBLK>
 static void attn_bwd_fused_launch(const op16_t* qkv, const op16_t* dout, const op16_t* o, const float* lse, int B, int S, int H, bool causal,
                                   op16_t* dqkv, hipStream_t st, Drop drop, float scale) {
+    constexpr int OCC = CC_ATTN_FUSED_OCC;
     const dim3 grid((B * H + 3) / 4), blk(256);
-    if (drop.thresh) hipLaunchKernelGGL((k_attn_bwd_fused<HD, true, true, NBLK>), grid, blk, 0, st, qkv, dout, o, lse, B, S, H, scale, dqkv, drop);
-    else if (causal) hipLaunchKernelGGL((k_attn_bwd_fused<HD, true, false, NBLK>), grid, blk, 0, st, qkv, dout, o, lse, B, S, H, scale, dqkv, drop);
-    else hipLaunchKernelGGL((k_attn_bwd_fused<HD, false, false, NBLK>), grid, blk, 0, st, qkv, dout, o, lse, B, S, H, scale, dqkv, drop);
+    if (drop.thresh) hipLaunchKernelGGL((k_attn_bwd_fused<HD, true, true, NBLK, 1>), grid, blk, 0, st, qkv, dout, o, lse, B, S, H, scale, dqkv, drop);
+    else if (causal) hipLaunchKernelGGL((k_attn_bwd_fused<HD, true, false, NBLK, (HD == 64 ? OCC : 1)>), grid, blk, 0, st, qkv, dout, o, lse, B, S, H, scale, dqkv, drop);
+    else hipLaunchKernelGGL((k_attn_bwd_fused<HD, false, false, NBLK, 1>), grid, blk, 0, st, qkv, dout, o, lse, B, S, H, scale, dqkv, drop);
 }
 
 template <int HD>
