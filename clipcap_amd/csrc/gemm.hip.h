@@ -818,10 +818,10 @@ __device__ __forceinline__ int h_lds_off(int row, int chunk) { return row * 64 +
 __device__ __forceinline__ int h_tt_g(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
 #define H_ISSUE(T, IS_A)                                                                                                 \
     {                                                                                                                    \
-        char* st_ = smem + ((T) % H_NS) * H_STAGE + ((IS_A) ? 0 : H_BM * H_BK * 2);                                      \
+        char* st_ = smem + ((T) % H_NS) * SSTAGE + ((IS_A) ? 0 : SBM * H_BK * 2);                                      \
         const int k0_ = kbeg + (T)*H_BK;                                                                                 \
-        _Pragma("unroll") for (int i_ = 0; i_ < ((IS_A) ? 4 : NJ); i_++) {                                              \
-            const int seg = wn + 4 * i_;                        /* 16 (A) or 4 NJ (B) segments of 1 KiB */                \
+        _Pragma("unroll") for (int i_ = 0; i_ < ((IS_A) ? NI / 2 : NJ); i_++) {                                              \
+            const int seg = wn + 4 * i_;                        /* 2 NI (A) or 4 NJ (B) segments of 1 KiB */                \
             const op16_t* src;                                                                                           \
             if constexpr (TT) {                                                                                          \
                 const int kr = seg * 2 + (lane >> 5);           /* 2 k-rows of 512 B per segment */                       \
@@ -857,24 +857,24 @@ __device__ __forceinline__ op16x8 h_tt_oper(const HTTFrag& f) {
 }
 #define H_LOADF(T)                                                                                                       \
     {                                                                                                                    \
-        const char* ca_ = smem + ((T) % H_NS) * H_STAGE;                                                                 \
-        const char* cb_ = ca_ + H_BM * H_BK * 2;                                                                         \
+        const char* ca_ = smem + ((T) % H_NS) * SSTAGE;                                                                 \
+        const char* cb_ = ca_ + SBM * H_BK * 2;                                                                         \
         if constexpr (TT) {                                                                                              \
-            _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) taf[i_] = h_tt_read(ca_, tt_base, ((grp * 16 + 2 * i_) ^ tt_gx) << 4);  \
+            _Pragma("unroll") for (int i_ = 0; i_ < NI; i_++) taf[i_] = h_tt_read(ca_, tt_base, ((grp * 16 + 2 * i_) ^ tt_gx) << 4);  \
             _Pragma("unroll") for (int j_ = 0; j_ < NJ; j_++) tbf[j_] = h_tt_read(cb_, tt_base, ((wn * 8 + 2 * j_) ^ tt_gx) << 4);  \
         } else {                                                                                                         \
-            _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) af[i_] = *reinterpret_cast<const op16x8*>(ca_ + h_lds_off(arow + i_ * 16 + frow, fchunk)); \
+            _Pragma("unroll") for (int i_ = 0; i_ < NI; i_++) af[i_] = *reinterpret_cast<const op16x8*>(ca_ + h_lds_off(arow + i_ * 16 + frow, fchunk)); \
             _Pragma("unroll") for (int j_ = 0; j_ < NJ; j_++) bfr[j_] = *reinterpret_cast<const op16x8*>(cb_ + h_lds_off(bcol + j_ * 16 + frow, fchunk)); \
         }                                                                                                                \
     }
 #define H_MFMA()                                                                                                         \
     {                                                                                                      \
         if constexpr (TT) {                                                                                              \
-            _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) af[i_] = h_tt_oper(taf[i_]);                                 \
+            _Pragma("unroll") for (int i_ = 0; i_ < NI; i_++) af[i_] = h_tt_oper(taf[i_]);                                 \
             _Pragma("unroll") for (int j_ = 0; j_ < NJ; j_++) bfr[j_] = h_tt_oper(tbf[j_]);                               \
         }                                                                                                                \
         __builtin_amdgcn_s_setprio(1);                                                                                   \
-        _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) _Pragma("unroll") for (int j_ = 0; j_ < NJ; j_++)                \
+        _Pragma("unroll") for (int i_ = 0; i_ < NI; i_++) _Pragma("unroll") for (int j_ = 0; j_ < NJ; j_++)                \
             acc[i_][j_] = CC_MFMA_16x16x32(bfr[j_], af[i_], acc[i_][j_]);                \
         __builtin_amdgcn_s_setprio(0);                                                                                   \
     }
@@ -885,15 +885,14 @@ __device__ __forceinline__ op16x8 h_tt_oper(const HTTFrag& f) {
         __builtin_amdgcn_s_barrier();                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
     }
-// tile t+1 must have landed; tiles t+2 .. t+H_NS-1 (CNT DMA instructions per wave each: 4 in group 0, NJ in group 1) may stay in flight
-#define H_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+// tile t+1 must have landed; tiles t+2 .. t+H_NS-1 (CNT DMA instructions per wave each: NI / 2 in group 0, NJ in group 1) may stay in flight
 #define H_WAIT(T, CNT)                                                                                                   \
     {                                                                                                                    \
         const int rem_ = min(nk - 1, (T) + H_NS - 1) - ((T) + 1);                                                        \
-        if (rem_ >= 3) { if ((CNT) == 4) H_VMCNT(12); else if ((CNT) == 3) H_VMCNT(9); else H_VMCNT(6); }                \
-        else if (rem_ == 2) { if ((CNT) == 4) H_VMCNT(8); else if ((CNT) == 3) H_VMCNT(6); else H_VMCNT(4); }            \
-        else if (rem_ == 1) { if ((CNT) == 4) H_VMCNT(4); else if ((CNT) == 3) H_VMCNT(3); else H_VMCNT(2); }            \
-        else H_VMCNT(0);                                                                                                 \
+        if (rem_ >= 3) s_wait_vm<3 * (CNT)>();                                                                           \
+        else if (rem_ == 2) s_wait_vm<2 * (CNT)>();                                                                      \
+        else if (rem_ == 1) s_wait_vm<(CNT)>();                                                                          \
+        else s_wait_vm<0>();                                                                                             \
     }
 // tools/probes/stag256_timing.hip compiles this header with CC_STAMP: cycle counts per phase of the main loop, wave 0 of either group
 #ifdef CC_STAMP
@@ -908,29 +907,29 @@ __device__ unsigned long long cc_stamp_buf[2 * 8];
 #endif
 // body shared by the single-problem kernels and the grouped weight-gradient kernel: `tile` = logical tile of this block inside its
 // problem (XCD remap applied by the caller), `zslice` = its K slice
-template <class Epi, int NJ, bool TT>
+template <class Epi, int NJ, bool TT, int NI = 8>
 __device__ __forceinline__ void gemm_stag256_body(const op16_t* __restrict__ A, const op16_t* __restrict__ B, const GemmShape& g, const Epi& epi,
                                                   int tile, int zslice, char* smem) {
-    static_assert(NJ >= 2 && NJ <= 4, "wave tile is 128 x (16 NJ)");
-    static_assert(!TT || NJ == 4, "the K-strided image is laid out for 256-column tiles");
-    constexpr int BN = 64 * NJ;
+    static_assert(NJ >= 2 && NJ <= 4 && (NI == 8 || NI == 10), "wave tile is (16 NI) x (16 NJ)");
+    static_assert(!TT || (NJ == 4 && NI == 8), "the K-strided image is laid out for 256 x 256 tiles");
+    constexpr int BN = 64 * NJ, SBM = 32 * NI, SSTAGE = (SBM + H_BN) * H_BK * 2;      // NI = 10: 320-row tiles, 36 KiB stages
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wn = wave & 3;
-    const int arow = grp * 128, bcol = wn * (16 * NJ);
-    const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + H_BM - 1) / H_BM;
+    const int arow = grp * (16 * NI), bcol = wn * (16 * NJ);
+    const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + SBM - 1) / SBM;
     int tm, tn;
     tile_coords(tile, tiles_m, tiles_n, g.group_m, tm, tn);
-    const int m0 = tm * H_BM, n0 = tn * BN;
+    const int m0 = tm * SBM, n0 = tn * BN;
     const int kbeg = zslice * g.k_chunk;                      // split-K slice (k_chunk is a multiple of 64)
     const int nk = (min(g.K, kbeg + g.k_chunk) - kbeg) / H_BK;
-    f32x4 acc[8][NJ];
+    f32x4 acc[NI][NJ];
 #pragma unroll
-    for (int i = 0; i < 8; i++)
+    for (int i = 0; i < NI; i++)
 #pragma unroll
         for (int j = 0; j < NJ; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    op16x8 af[8], bfr[NJ];
-    HTTFrag taf[TT ? 8 : 1], tbf[TT ? NJ : 1];
+    op16x8 af[NI], bfr[NJ];
+    HTTFrag taf[TT ? NI : 1], tbf[TT ? NJ : 1];
     (void)taf; (void)tbf;
     const int frow = lane & 15, fchunk = lane >> 4;
     // TT fragment addressing: k row 8 fchunk + (frow >> 2), byte 16 ((frow & 3) >> 1) + 8 (frow & 1) inside the 32-B slot
@@ -943,7 +942,7 @@ __device__ __forceinline__ void gemm_stag256_body(const op16_t* __restrict__ A, 
         if (nk > 1) H_ISSUE(1, true);
         if (nk > 2) H_ISSUE(2, true);
         if (H_NS > 4 && nk > 3) H_ISSUE(3, true);
-        H_WAIT(-1, 4);
+        H_WAIT(-1, NI / 2);
         H_SEGEND();
         H_STAMP(0)                                     // prologue
         for (int t = 0; t < nk; t++) {
@@ -965,7 +964,7 @@ __device__ __forceinline__ void gemm_stag256_body(const op16_t* __restrict__ A, 
             H_STAMP(3)                                 // barrier (end of read segment)
             H_MFMA();
             H_STAMP(4)                                 // MFMA issue
-            H_WAIT(t, 4);
+            H_WAIT(t, NI / 2);
             H_STAMP(5)                                 // vmcnt wait
             H_SEGEND();
             H_STAMP(6)                                 // barrier (end of MFMA segment)
@@ -1006,14 +1005,14 @@ __device__ __forceinline__ void gemm_stag256_body(const op16_t* __restrict__ A, 
         H_MFMA(); H_SEGEND();
     }
     H_STAMP(0)
-    gemm_epilogue_regs<Epi, 8, NJ>(acc, lane, m0 + arow, n0 + bcol, epi);
+    gemm_epilogue_regs<Epi, NI, NJ>(acc, lane, m0 + arow, n0 + bcol, epi);
     H_STAMP(7)                                         // epilogue
     H_STAMP_OUT
 }
-template <class Epi, int NJ, bool TT = false>
+template <class Epi, int NJ, bool TT = false, int NI = 8>
 __global__ __launch_bounds__(512, 1) void gemm_nt_stag256_kernel(const op16_t* __restrict__ A, const op16_t* __restrict__ B, GemmShape g, Epi epi) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    gemm_stag256_body<Epi, NJ, TT>(A, B, g, epi, xcd_remap(blockIdx.x, gridDim.x), (int)blockIdx.z, smem);
+    gemm_stag256_body<Epi, NJ, TT, NI>(A, B, g, epi, xcd_remap(blockIdx.x, gridDim.x), (int)blockIdx.z, smem);
 }
 #undef H_STAMP_DECL
 #undef H_STAMP
@@ -1023,7 +1022,6 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_stag256_kernel(const op16_t* _
 #undef H_MFMA
 #undef H_SEGEND
 #undef H_WAIT
-#undef H_VMCNT
 
 // ------------------------------------------------------------------------------------------------
 // TT 128 x 128 kernel (both operands K-strided, weight gradients below the 256-row kernel's break-even): the 4-stage small-grid
@@ -1472,30 +1470,37 @@ inline int launch_gemm(int al, int bl, const op16_t* A, int lda, const op16_t* B
     // Tile choice for NT launches.  The 256-row kernel moves 1/2 (256 wide) or 2/3 (192 wide) of the 128 x 128 kernel's L2->LDS
     // bytes per flop and runs ~1.2x / ~1.15x its rate on full waves, but holds one block per CU, so wave quantisation decides:
     // cost = rounds x tile area / rate, the 128 x 128 kernel counted with 2 co-resident blocks per CU (measured table: DESIGN.md 4.1).
-    // g_gemm_tile_mode (cc_gemm_tile_mode / CC_GEMM_S256) = 0 (never) / 3 / 4 (force) overrides it for tests and tools/gemm_bench.py.
+    // The 320 x 256 form (10 row tiles per wave, 36-KiB stages) does 1.25x the MFMAs per K-step at 1.13-1.27x the step time: it wins
+    // where it saves a round (12800 x 3072: 480 tiles = 2 rounds instead of 3; the lm_head: 25 instead of 31).
+    // g_gemm_tile_mode (cc_gemm_tile_mode / CC_GEMM_S256) = 0 (never) / 3 / 4 / 5 (force 256x192 / 256x256 / 320x256) overrides it for
+    // tests and tools/gemm_tiles.py.
     const int s256 = g_gemm_tile_mode;
-    int nj = 0;
+    int nj = 0, ni = 8;
     if (al == 0 && bl == 0 && (K % H_BK) == 0 && ksplit == 1 && s256 != 0) {
         const long tm = (M + H_BM - 1) / H_BM, t128 = (long)grid.x;
-        const long t256 = tm * ((N + 255) / 256), t192 = tm * ((N + 191) / 192);
+        const long t256 = tm * ((N + 255) / 256), t192 = tm * ((N + 191) / 192), t320 = (long)((M + 319) / 320) * ((N + 255) / 256);
         const double c128 = t128 <= 256 ? 16384.0 / 0.75 : (double)((t128 + 511) / 512) * 32768.0;
         const double c256 = (double)((t256 + 255) / 256) * 65536.0 / 1.2, c192 = (double)((t192 + 255) / 256) * 49152.0 / 1.15;
+        const double c320 = (double)((t320 + 255) / 256) * 81920.0 / 1.3;
         constexpr bool can192 = !std::is_same<Epi, EpiLMHead>::value;   // its partials assume 64-column wave strips
-        if (s256 == 4 || (s256 < 0 && c256 < 0.98 * c128 && (!can192 || c256 <= c192))) nj = 4;
+        if (s256 == 5 || (s256 < 0 && c320 < 0.98 * c128 && c320 < c256 && (!can192 || c320 < c192))) { nj = 4; ni = 10; }
+        else if (s256 == 4 || (s256 < 0 && c256 < 0.98 * c128 && (!can192 || c256 <= c192))) nj = 4;
         else if (can192 && (s256 == 3 || (s256 < 0 && c192 < 0.98 * c128))) nj = 3;
     }
     if (nj) {
-        constexpr size_t sh = (size_t)H_NS * H_STAGE;
-        const dim3 gr((unsigned)(((M + H_BM - 1) / H_BM) * ((N + 64 * nj - 1) / (64 * nj))));
-        if (nj == 4) {
-            static bool attr4 = false;
-            if (!attr4) { (void)hipFuncSetAttribute((const void*)gemm_nt_stag256_kernel<Epi, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr4 = true; }
-            hipLaunchKernelGGL((gemm_nt_stag256_kernel<Epi, 4>), gr, dim3(512), sh, st, A, B, g, epi);
-        } else if constexpr (!std::is_same<Epi, EpiLMHead>::value) {
-            static bool attr3 = false;
-            if (!attr3) { (void)hipFuncSetAttribute((const void*)gemm_nt_stag256_kernel<Epi, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr3 = true; }
-            hipLaunchKernelGGL((gemm_nt_stag256_kernel<Epi, 3>), gr, dim3(512), sh, st, A, B, g, epi);
-        }
+        const int bm = 32 * ni;
+        const size_t sh = (size_t)H_NS * (bm + H_BN) * H_BK * 2;
+        const dim3 gr((unsigned)(((M + bm - 1) / bm) * ((N + 64 * nj - 1) / (64 * nj))));
+#define CC_LAUNCH_STAG(NJ_, NI_)                                                                                         \
+    {                                                                                                                    \
+        static bool attr_ = false;                                                                                       \
+        if (!attr_) { (void)hipFuncSetAttribute((const void*)gemm_nt_stag256_kernel<Epi, NJ_, false, NI_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr_ = true; } \
+        hipLaunchKernelGGL((gemm_nt_stag256_kernel<Epi, NJ_, false, NI_>), gr, dim3(512), sh, st, A, B, g, epi);        \
+    }
+        if (nj == 4 && ni == 8) CC_LAUNCH_STAG(4, 8)
+        else if (nj == 4) CC_LAUNCH_STAG(4, 10)
+        else if constexpr (!std::is_same<Epi, EpiLMHead>::value) CC_LAUNCH_STAG(3, 8)
+#undef CC_LAUNCH_STAG
     } else
 #ifdef CC_GEMM_ABLATION
     static const int abl = []() { const char* e = getenv("CC_GEMM_ABL"); return e ? atoi(e) : 0; }();

@@ -88,7 +88,7 @@ struct Rccl {
         ok = get_uid && init_rank && all_reduce && destroy;
     }
 };
-Rccl& rccl() {
+extern "C++" Rccl& rccl() {
     static Rccl r;
     return r;
 }

@@ -131,3 +131,20 @@ def test_decode_row_count_paths_agree():
             d = (a - b[half]).float()
             scale = max(1.0, b.abs().max().item())
             assert d.abs().max().item() <= 8e-3 * scale and d.pow(2).mean().sqrt().item() <= 2e-3 * scale
+
+
+@pytest.mark.parametrize("mode", [0, 3, 4, 5])
+def test_whole_step_under_every_forced_gemm_tile(mode):
+    """The NT tile chooser picks by size, so small tests never reach the 256- / 320-row kernels through the model: force each tile
+    (cc_gemm_tile_mode) for every NT GEMM of a training step — residual, gelu', lm_head + cross-entropy epilogues included — and
+    check loss and mapper gradients against the oracle."""
+    from clipcap_amd import _lib
+    eng, sd, cfg = _build(32, 128, 3, 5, 4, 2, 4, 2, 1000, 64)
+    torch.manual_seed(mode)
+    tokens = torch.randint(1, 1000, (6, 11))
+    tokens[1, 7:] = -1
+    old = _lib.lib().cc_gemm_tile_mode(mode)
+    try:
+        _check(eng, sd, cfg, tokens, torch.randn(6, 32))
+    finally:
+        _lib.lib().cc_gemm_tile_mode(old)

@@ -56,10 +56,10 @@ def test_gemm_layouts(al, bl, M, N, K):
     assert torch.isnan(Cm[:, N:]).all()   # nothing written outside the N columns
 
 
-@pytest.mark.parametrize("mode", [3, 4])
-@pytest.mark.parametrize("M,N,K", [(256, 256, 32), (8, 8, 32), (520, 200, 96), (1000, 392, 1024), (300, 776, 160)])
+@pytest.mark.parametrize("mode", [3, 4, 5])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 32), (8, 8, 32), (520, 200, 96), (1000, 392, 1024), (300, 776, 160), (640, 512, 64), (330, 248, 128)])
 def test_gemm_nt_256_row_tiles(mode, M, N, K):
-    """the 256 x 192 / 256 x 256 group-staggered NT kernels (forced: the chooser would pick 128 x 128 at these sizes)"""
+    """the 256 x 192 / 256 x 256 / 320 x 256 group-staggered NT kernels (forced: the chooser would pick 128 x 128 at these sizes)"""
     torch.manual_seed(M + N + K + mode)
     dev = "cuda"
     A = _bf(torch.randn(M, K, device=dev))
