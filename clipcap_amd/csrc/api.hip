@@ -610,7 +610,13 @@ int CC_API(cc_lmhead_ce_bwd)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const
     const bool full = s->mode == 2;
     CC_TRY(ce_dlogits(w.logits16, c->Vp, c->V, w.target, w.lse_row, denom, loss_scale, Mc, st));
     // d hf = dlogits · wte   ([Mc,Vp] x [Vp(k), D(n)])
-    CC_TIMED(CC_SITE_LMHEAD_DGRAD, st, gemm_bf16out(0, 0, w.logits16, c->Vp, w16 + o.total + o.wte, c->Vp, Mc, D, c->Vp, w.dhf16, D, nullptr, 0, nullptr, st));
+    // K = Vp is deep and the output narrow: K slices over the idle CUs, slabs parked in du16 (free until the first layer's backward)
+    const auto lm_dgrad = [&]() {
+        const int rc = gemm_nt_deepk(w.logits16, c->Vp, w16 + o.total + o.wte, c->Vp, Mc, D, c->Vp, w.dhf16, D, reinterpret_cast<float*>(w.du16),
+                                     (size_t)M * 4 * D * sizeof(op16_t), st);
+        return rc != CC_ERR_SHAPE ? rc : gemm_bf16out(0, 0, w.logits16, c->Vp, w16 + o.total + o.wte, c->Vp, Mc, D, c->Vp, w.dhf16, D, nullptr, 0, nullptr, st);
+    };
+    CC_TIMED(CC_SITE_LMHEAD_DGRAD, st, lm_dgrad());
     if (full) CC_TRY(gemm_wgrad(w.logits16, c->Vp, w.hf16, D, c->Vp, D, Mc, g32 + o.wte, D, w.wg_scratch, st));  // tied lm_head: d wte += dlogits^T hf
     if (hipMemsetAsync(w.dx32, 0, (size_t)M * D * sizeof(float), st) != hipSuccess) return CC_ERR_LAUNCH;
     if (hipMemsetAsync(w.dx16, 0, (size_t)M * D * sizeof(op16_t), st) != hipSuccess) return CC_ERR_LAUNCH;

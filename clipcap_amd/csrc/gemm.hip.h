@@ -1444,7 +1444,7 @@ inline int launch_gemm_s64(const op16_t* A, int lda, const op16_t* B, int ldb, i
                            hipStream_t st);
 template <class Epi>
 inline int launch_gemm(int al, int bl, const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K,
-                       int ksplit, const Epi& epi, hipStream_t st) {
+                       int ksplit, const Epi& epi, hipStream_t st, int tile = -2) {      // tile: -2 = process-wide mode / chooser, else as cc_gemm_tile_mode
     if (M <= 0 || N <= 0 || K <= 0) return CC_OK;
     if ((lda & 7) || (ldb & 7) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return CC_ERR_SHAPE;
     if (al == 0 && (K & 7)) return CC_ERR_SHAPE;
@@ -1474,23 +1474,28 @@ inline int launch_gemm(int al, int bl, const op16_t* A, int lda, const op16_t* B
     // where it saves a round (12800 x 3072: 480 tiles = 2 rounds instead of 3; the lm_head: 25 instead of 31).
     // g_gemm_tile_mode (cc_gemm_tile_mode / CC_GEMM_S256) = 0 (never) / 3 / 4 / 5 (force 256x192 / 256x256 / 320x256) overrides it for
     // tests and tools/gemm_tiles.py.
-    const int s256 = g_gemm_tile_mode;
+    const int s256 = tile != -2 ? tile : g_gemm_tile_mode;
     int nj = 0, ni = 8;
-    if (al == 0 && bl == 0 && (K % H_BK) == 0 && ksplit == 1 && s256 != 0) {
+    // K slices (blockIdx.z) on the 256-row kernels only for the slab-writing fp32 epilogue and only when the caller names the tile
+    constexpr bool zsplit_ok = std::is_same<Epi, EpiF32>::value;
+    if (al == 0 && bl == 0 && (K % H_BK) == 0 && (ksplit == 1 || (zsplit_ok && tile > 0)) && s256 != 0) {
         const long tm = (M + H_BM - 1) / H_BM, t128 = (long)grid.x;
         const long t256 = tm * ((N + 255) / 256), t192 = tm * ((N + 191) / 192), t320 = (long)((M + 319) / 320) * ((N + 255) / 256);
         const double c128 = t128 <= 256 ? 16384.0 / 0.75 : (double)((t128 + 511) / 512) * 32768.0;
         const double c256 = (double)((t256 + 255) / 256) * 65536.0 / 1.2, c192 = (double)((t192 + 255) / 256) * 49152.0 / 1.15;
         const double c320 = (double)((t320 + 255) / 256) * 81920.0 / 1.3;
         constexpr bool can192 = !std::is_same<Epi, EpiLMHead>::value;   // its partials assume 64-column wave strips
-        if (s256 == 5 || (s256 < 0 && c320 < 0.98 * c128 && c320 < c256 && (!can192 || c320 < c192))) { nj = 4; ni = 10; }
+        // the activation-gradient epilogue (aux tile read + gelu' + store) is not hidden at one block per CU: 12800 x 3072 x 768 measured
+        // 106.6 us on 320 x 256 vs 97.3 on 128 x 128 (two co-resident blocks), while the plain / gelu-forward epilogues gain (90 -> 78 us)
+        constexpr bool can320 = !std::is_same<Epi, EpiDAct>::value;
+        if (s256 == 5 || (can320 && s256 < 0 && c320 < 0.98 * c128 && c320 < c256 && (!can192 || c320 < c192))) { nj = 4; ni = 10; }
         else if (s256 == 4 || (s256 < 0 && c256 < 0.98 * c128 && (!can192 || c256 <= c192))) nj = 4;
         else if (can192 && (s256 == 3 || (s256 < 0 && c192 < 0.98 * c128))) nj = 3;
     }
     if (nj) {
         const int bm = 32 * ni;
         const size_t sh = (size_t)H_NS * (bm + H_BN) * H_BK * 2;
-        const dim3 gr((unsigned)(((M + bm - 1) / bm) * ((N + 64 * nj - 1) / (64 * nj))));
+        const dim3 gr((unsigned)(((M + bm - 1) / bm) * ((N + 64 * nj - 1) / (64 * nj))), 1, (unsigned)ksplit);
 #define CC_LAUNCH_STAG(NJ_, NI_)                                                                                         \
     {                                                                                                                    \
         static bool attr_ = false;                                                                                       \

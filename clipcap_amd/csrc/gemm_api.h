@@ -5,7 +5,7 @@
 
 namespace CC_NS {
 // NT tile choice (cc_shared::g_gemm_tile_mode): -1 chooser (default; CC_GEMM_S256 in the environment presets it), 0 = 128 x 128 only,
-// 3 / 4 = force the 256 x 192 / 256 x 256 kernel wherever it is legal.  g_gemm_s64 > 0: route NT GEMMs with M <= 1024 through the 64-row
+// 3 / 4 / 5 = force the 256 x 192 / 256 x 256 / 320 x 256 kernel wherever it is legal.  g_gemm_s64 > 0: route NT GEMMs with M <= 1024 through the 64-row
 // skinny kernel (env CC_GEMM_S64); g_gemm_small_x2: small-grid NT GEMMs on the 8-wave kernel (env CC_GEMM_X2, default 1).  All three
 // are test / microbenchmark hooks living in shared.cpp.
 // al/bl: 0 = K-contiguous operand ([rows][K]), 1 = K-strided operand ([K][rows]).  See gemm.hip.h.
@@ -60,6 +60,11 @@ struct SkinnyFuse {
 int gemm_nt_skinny(const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, const float* bias, int act, const float* res,
                    float* out32, op16_t* out16, int ldo, float* scratch, size_t scratch_bytes, hipStream_t st,
                    const SkinnyFuse* fuse = nullptr);
+// Narrow output, very deep K (the lm_head input gradient: [B*cap, Vp] x [Vp, D] -> 10240 x 768 over K = 50304): the 256 x 256 kernel on
+// 120 tiles leaves half the chip idle, so K is cut into as many slices as fill the CUs (fp32 slabs in `scratch`), and one elementwise
+// pass sums the slabs into the 16-bit output.  Returns CC_ERR_SHAPE when the shape does not call for it (caller then uses gemm_bf16out).
+int gemm_nt_deepk(const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, op16_t* out16, int ldo, float* scratch,
+                  size_t scratch_bytes, hipStream_t st);
 int skinny_single_min_tiles();   // grids of at least this many 128 x 128 tiles skip split-K (CC_SKINNY_SINGLE; tuning knob)
 // whether gemm_nt_skinny will take the slab + row-finish path for this problem (the only path that supports SkinnyFuse)
 bool gemm_nt_skinny_can_fuse(int M, int N, int K, size_t scratch_bytes);

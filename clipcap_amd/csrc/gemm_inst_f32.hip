@@ -341,6 +341,29 @@ bool gemm_nt_skinny_can_fuse(int M, int N, int K, size_t scratch_bytes) {
     return M > 0 && N > 0 && (N & 7) == 0 && N <= 3072 && (K % G_BK) == 0 && scratch_bytes >= (size_t)M * N * sizeof(float);
 }
 
+int gemm_nt_deepk(const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, op16_t* out16, int ldo, float* scratch,
+                  size_t scratch_bytes, hipStream_t st) {
+    static const int knob = []() { const char* e = getenv("CC_DEEPK"); return e ? atoi(e) : -1; }();   // 0 = off, n > 0 = force n slices
+    if (knob == 0 || g_gemm_tile_mode == 0 || !scratch || (N & 7) || (ldo & 7) || (K % 64) || (lda & 7) || (ldb & 7)) return CC_ERR_SHAPE;
+    const long tiles = (long)((M + H_BM - 1) / H_BM) * ((N + H_BN - 1) / H_BN);
+    const size_t slab = (size_t)M * N;
+    int ks = knob > 0 ? knob : (int)(256 / (tiles > 0 ? tiles : 1));
+    const size_t fit = scratch_bytes / (slab * sizeof(float));
+    if ((size_t)ks > fit) ks = (int)fit;
+    if (ks > K / 2048) ks = K / 2048;                      // slices of at least 64 K-steps: below that the slab pass costs what the idle CUs gain
+    if (ks < 2 || tiles > 128) return CC_ERR_SHAPE;
+    cc_shared::ProfScope _all(cc_shared::SITE_ALL_GEMMS, st, 2.0 * M * N * (double)K);
+    EpiF32 e{scratch, nullptr, N, M, N, 3, 1.0f};
+    e.zstride = slab;
+    const int rc = launch_gemm(0, 0, A, lda, B, ldb, M, N, K, ks, e, st, 4);
+    if (rc != CC_OK) return rc;
+    const int kt = K / G_BK, per = (kt + ks - 1) / ks, ks_eff = (kt + per - 1) / per;
+    const size_t n8 = (size_t)M * (N >> 3);
+    hipLaunchKernelGGL(k_splitk_finish, dim3((int)std::min<size_t>((n8 + 255) / 256, 2048)), dim3(256), 0, st, scratch, slab, ks_eff, M, N, nullptr, 0,
+                       nullptr, nullptr, out16, ldo);
+    return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+}
+
 int gemm_nt_skinny(const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, const float* bias, int act, const float* res,
                    float* out32, op16_t* out16, int ldo, float* scratch, size_t scratch_bytes, hipStream_t st, const SkinnyFuse* fuse) {
     cc_shared::ProfScope _all(cc_shared::SITE_ALL_GEMMS, st, 2.0 * M * N * (double)K);
