@@ -28,7 +28,8 @@ constexpr int MAX_LAYERS = 96;
     } while (0)
 
 // tuning knob (environment, read once): force a GEMM tile kernel at ONE call-site class for A/B measurements —
-// CC_TILE_FC = c_fc forward (gelu epilogue, two outputs), CC_TILE_DACT = its activation-gradient dgrad.  Unset = the chooser.
+// CC_TILE_FC = c_fc forward (gelu epilogue, two outputs), CC_TILE_DACT = its activation-gradient dgrad, CC_TILE_PROJ / CC_TILE_PROJ2 = the
+// two residual-epilogue c_proj forwards.  Unset = the chooser.
 struct TileScope {
     int old;
     bool on;
@@ -546,8 +547,12 @@ int CC_API(cc_gpt2_fwd)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const floa
         CC_TRY(ln_fwd(w.x[l], D, nullptr, w32 + y.l1w, w32 + y.l1b, w.xn1[l], nullptr, w.mean1[l], w.rstd1[l], M, D, st));
         CC_TRY(gemm_bf16out(0, 0, w.xn1[l], D, w16t + y.aw, D, M, 3 * D, D, w.qkv[l], 3 * D, w32 + y.ab, 0, nullptr, st));
         CC_TRY(attn_fwd(w.qkv[l], s->B, s->T, H, hd, true, w.att[l], w.lse[l], st, make_drop(s->p_attn, s->drop_seed, DROP_ATTN, l)));
-        CC_TRY(gemm_resid(0, 0, w.att[l], D, w16t + y.pw, D, M, D, D, w.x1[l], w.x[l], D, w32 + y.pb, st,
-                          make_drop(s->p_resid, s->drop_seed, DROP_RESID_ATTN, l)));
+        {
+            static const int tile_proj = env_tile("CC_TILE_PROJ");
+            TileScope ts(tile_proj);
+            CC_TRY(gemm_resid(0, 0, w.att[l], D, w16t + y.pw, D, M, D, D, w.x1[l], w.x[l], D, w32 + y.pb, st,
+                              make_drop(s->p_resid, s->drop_seed, DROP_RESID_ATTN, l)));
+        }
         // x = x1 + c_proj(gelu_new(c_fc(ln_2 x1)))   (hf :229-243)
         CC_TRY(ln_fwd(w.x1[l], D, nullptr, w32 + y.l2w, w32 + y.l2b, w.xn2[l], nullptr, w.mean2[l], w.rstd2[l], M, D, st));
         {
@@ -556,8 +561,12 @@ int CC_API(cc_gpt2_fwd)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const floa
             CC_TIMED(CC_SITE_GPT2_FC_FWD, st, gemm_bf16out(0, 0, w.xn2[l], D, w16t + y.fw, D, M, 4 * D, D, w.hact[l], 4 * D, w32 + y.fb, 2,
                                                             s->mode >= 1 ? w.u[l] : nullptr, st));
         }
-        CC_TIMED(CC_SITE_GPT2_PROJ2_FWD, st, gemm_resid(0, 0, w.hact[l], 4 * D, w16t + y.p2w, 4 * D, M, D, 4 * D, w.x[l + 1], w.x1[l], D, w32 + y.p2b, st,
-                                                       make_drop(s->p_resid, s->drop_seed, DROP_RESID_MLP, l)));
+        {
+            static const int tile_proj2 = env_tile("CC_TILE_PROJ2");
+            TileScope ts(tile_proj2);
+            CC_TIMED(CC_SITE_GPT2_PROJ2_FWD, st, gemm_resid(0, 0, w.hact[l], 4 * D, w16t + y.p2w, 4 * D, M, D, 4 * D, w.x[l + 1], w.x1[l], D, w32 + y.p2b, st,
+                                                           make_drop(s->p_resid, s->drop_seed, DROP_RESID_MLP, l)));
+        }
     }
     return CC_OK;
 }
