@@ -1444,7 +1444,7 @@ inline int launch_gemm_s64(const op16_t* A, int lda, const op16_t* B, int ldb, i
                            hipStream_t st);
 template <class Epi>
 inline int launch_gemm(int al, int bl, const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K,
-                       int ksplit, const Epi& epi, hipStream_t st, int tile = -2) {      // tile: -2 = process-wide mode / chooser, else as cc_gemm_tile_mode
+                       int ksplit, const Epi& epi, hipStream_t st, int tile = -2, int group_m = 0) {   // tile: -2 = process-wide mode / chooser, else as cc_gemm_tile_mode; group_m: row tiles per ordering group (0 = default)
     if (M <= 0 || N <= 0 || K <= 0) return CC_OK;
     if ((lda & 7) || (ldb & 7) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return CC_ERR_SHAPE;
     if (al == 0 && (K & 7)) return CC_ERR_SHAPE;
@@ -1458,7 +1458,7 @@ inline int launch_gemm(int al, int bl, const op16_t* A, int lda, const op16_t* B
     GemmShape g;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
     static const int env_group = []() { const char* e = getenv("CC_GROUP_M"); return e ? atoi(e) : 0; }();
-    g.group_m = env_group > 0 ? env_group : 8;
+    g.group_m = env_group > 0 ? env_group : (group_m > 0 ? group_m : 8);
     static const int env_stagger = []() { const char* e = getenv("CC_GEMM_STAGGER"); return e ? atoi(e) : 0; }();   // tuning knob
     g.stagger = env_stagger;
     if (ksplit < 1) ksplit = 1;

@@ -355,7 +355,11 @@ int gemm_nt_deepk(const op16_t* A, int lda, const op16_t* B, int ldb, int M, int
     cc_shared::ProfScope _all(cc_shared::SITE_ALL_GEMMS, st, 2.0 * M * N * (double)K);
     EpiF32 e{scratch, nullptr, N, M, N, 3, 1.0f};
     e.zstride = slab;
-    const int rc = launch_gemm(0, 0, A, lda, B, ldb, M, N, K, ks, e, st, 4);
+    // tile order: an XCD's share of the grid (tiles / 8 consecutive logical tiles per K slice) should hold whole row panels, so that the
+    // column tiles of a panel run side by side on one L2 and the deep A panel is fetched once, not once per column tile
+    const int tiles_n = (N + H_BN - 1) / H_BN;
+    const int gm = std::max(1, (int)((tiles + 7) / 8) / tiles_n);
+    const int rc = launch_gemm(0, 0, A, lda, B, ldb, M, N, K, ks, e, st, 4, gm);
     if (rc != CC_OK) return rc;
     const int kt = K / G_BK, per = (kt + ks - 1) / ks, ks_eff = (kt + per - 1) / per;
     const size_t n8 = (size_t)M * (N >> 3);
