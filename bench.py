@@ -447,7 +447,7 @@ def main():
         ach = site_flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         default_site = args.site == "lmhead_fwd" and args.config == "2" and not args.batch
         roof["roofline_lmhead" if args.site == "lmhead_fwd" else "roofline_site"] = {
-            "bound": "mfma", "kernel": ("gemm_nt_stag256_kernel<EpiLMHead,4>" if args.site == "lmhead_fwd" else "NT GEMM") + f" @ {args.site}",
+            "bound": "mfma", "kernel": ("gemm_nt_stag256_kernel<EpiLMHead,4,false,10> (320x256 tiles)" if args.site == "lmhead_fwd" else "NT GEMM") + f" @ {args.site}",
             "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
             "avg_launch_ms": round(avg_ms, 4), "launches": len(ms), "time_share_of_step": round(avg_ms * per_step / ms_per_step, 3),
             "traffic": LMHEAD_TRAFFIC["bytes"] if default_site else None, "traffic_source": LMHEAD_TRAFFIC["source"] if default_site else None,
