@@ -297,22 +297,50 @@ __global__ __launch_bounds__(NW * 64) void k_ln_bwd(const op16_t* __restrict__ d
     float4 pg[DG ? NV : 1], pb[DG ? NV : 1], pc[DG ? NV : 1];
 #pragma unroll
     for (int it = 0; it < (DG ? NV : 1); it++) pg[it] = pb[it] = pc[it] = make_float4(0, 0, 0, 0);
-    for (int row = blockIdx.x * NW + wave; row < rows; row += gridDim.x * NW) {
-        const size_t xr = (size_t)(row_map ? row_map[row] : row) * ldx;
-        const float mu = mean[row], rs = rstd[row];
+    // the row loop is a chain of dependent HBM round trips when a wave owns several rows (the parameter-gradient form keeps the grid
+    // at one block per CU): the next row's operands are requested before the current row is reduced
+    float4 gmv[NV];
+#pragma unroll
+    for (int it = 0; it < NV; it++) {
+        const int c = lane * 4 + it * 256;
+        gmv[it] = c < D ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(0, 0, 0, 0);
+    }
+    struct RowIn { uint2 d[NV]; float4 xv[NV], rr[NV]; float mu, rs; size_t xr; };
+    auto fetch = [&](int row, RowIn& r) {
+        r.xr = (size_t)(row_map ? row_map[row] : row) * ldx;
+        r.mu = mean[row]; r.rs = rstd[row];
+#pragma unroll
+        for (int it = 0; it < NV; it++) {
+            const int c = lane * 4 + it * 256;
+            if (c < D) {
+                r.d[it] = *reinterpret_cast<const uint2*>(dy + (size_t)row * D + c);
+                r.xv[it] = *reinterpret_cast<const float4*>(x + r.xr + c);
+                r.rr[it] = dres ? *reinterpret_cast<const float4*>(dres + r.xr + c) : make_float4(0, 0, 0, 0);
+            }
+        }
+    };
+    const int rstep = gridDim.x * NW;
+    int row = blockIdx.x * NW + wave;
+    RowIn cur;
+    if (row < rows) fetch(row, cur);
+    for (; row < rows; row += rstep) {
+        RowIn nxt;
+        const bool more = DG && row + rstep < rows;      // the plain form runs one row per wave (grid covers the rows): no second register set
+        if constexpr (DG) { if (more) fetch(row + rstep, nxt); }
+        const size_t xr = cur.xr;
+        const float mu = cur.mu, rs = cur.rs;
         float4 g[NV], xh[NV], rr[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int it = 0; it < NV; it++) {
             const int c = lane * 4 + it * 256;
             if (c < D) {
-                const uint2 d = *reinterpret_cast<const uint2*>(dy + (size_t)row * D + c);
                 float d0, d1, d2, d3;
-                unpack2(d.x, d0, d1);
-                unpack2(d.y, d2, d3);
-                const float4 xv = *reinterpret_cast<const float4*>(x + xr + c);
-                const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
-                rr[it] = dres ? *reinterpret_cast<const float4*>(dres + xr + c) : make_float4(0, 0, 0, 0);   // fetched with the row, not after the reductions
+                unpack2(cur.d[it].x, d0, d1);
+                unpack2(cur.d[it].y, d2, d3);
+                const float4 xv = cur.xv[it];
+                const float4 gm = gmv[it];
+                rr[it] = cur.rr[it];
                 xh[it] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
                 g[it] = make_float4(d0 * gm.x, d1 * gm.y, d2 * gm.z, d3 * gm.w);
                 s1 += g[it].x + g[it].y + g[it].z + g[it].w;
@@ -353,6 +381,7 @@ __global__ __launch_bounds__(NW * 64) void k_ln_bwd(const op16_t* __restrict__ d
                 }
             }
         }
+        if constexpr (DG) { if (more) cur = nxt; } else { if (row + rstep < rows) fetch(row + rstep, cur); }
     }
     if constexpr (DG) {
         float* rg = ln_red;
@@ -398,26 +427,13 @@ int ln_bwd(const op16_t* dy, const float* x, int ldx, const int* row_map, const 
     if (rows <= 0) return CC_OK;
     // with parameter gradients every block ends with 2*D fp32 atomics: keep the block count low (one per CU) so that the
     // atomic tail (measured: it dominated at 1024 blocks) stays ~0.4 M atomics per launch, and give those blocks 8 waves
-    static const int dg_waves = []() { const char* e = getenv("CC_LNBWD_WAVES"); return e ? atoi(e) : 8; }();       // tuning knob: 8 or 16
-    int nw = (dgamma && (size_t)16 * D * sizeof(float) <= 65536) ? 8 : 4;      // 8-wave reduction buffer within the 64 KiB default
-    if (dgamma && nw == 8 && dg_waves == 16 && (size_t)32 * D * sizeof(float) <= 160 * 1024) nw = 16;
+    const int nw = (dgamma && (size_t)16 * D * sizeof(float) <= 65536) ? 8 : 4;      // 8-wave reduction buffer within the 64 KiB default
     static const int dg_grid = []() { const char* e = getenv("CC_LNBWD_GRID"); return e ? atoi(e) : 256; }();   // tuning knob
     const int grid = std::min((rows + nw - 1) / nw, dgamma ? dg_grid : 8192);
     const size_t sh = dgamma ? (size_t)2 * nw * D * sizeof(float) : 0;
 #define LN_BWD(NV, DG, NW) hipLaunchKernelGGL((k_ln_bwd<NV, DG, NW>), dim3(grid), dim3(NW * 64), sh, st, dy, x, ldx, row_map, mean, rstd, gamma, dres, dx32, dx16, dgamma, dbeta, dcol, rows, D, dmask)
 #define LN_BWD_D(DG, NW) { if (D <= 256) LN_BWD(1, DG, NW); else if (D <= 512) LN_BWD(2, DG, NW); else if (D <= 768) LN_BWD(3, DG, NW); else if (D <= 1024) LN_BWD(4, DG, NW); else LN_BWD(LN_MAXV, DG, NW); }
-    if (dgamma && nw == 16) {
-        static bool attr16 = false;
-        if (!attr16) {
-            (void)hipFuncSetAttribute((const void*)k_ln_bwd<1, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)k_ln_bwd<2, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)k_ln_bwd<3, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)k_ln_bwd<4, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)k_ln_bwd<LN_MAXV, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr16 = true;
-        }
-        LN_BWD_D(true, 16)
-    } else if (dgamma && nw == 8) LN_BWD_D(true, 8) else if (dgamma) LN_BWD_D(true, 4) else LN_BWD_D(false, 4)
+    if (dgamma && nw == 8) LN_BWD_D(true, 8) else if (dgamma) LN_BWD_D(true, 4) else LN_BWD_D(false, 4)
 #undef LN_BWD_D
 #undef LN_BWD
     return CC_OK;
