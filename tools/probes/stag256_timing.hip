@@ -6,7 +6,7 @@
 #include <vector>
 using namespace CC_NS;
 namespace cc { int g_gemm_tile_mode = -1, g_gemm_s64 = -1, g_gemm_small_x2 = 1; }
-template <int NJ>
+template <int NJ, int NI = 8>
 static void run(int M, int N, int K) {
     op16_t *A, *B; float* C;
     hipMalloc(&A, (size_t)M * K * 2); hipMalloc(&B, (size_t)N * K * 2); hipMalloc(&C, (size_t)M * N * 4);
@@ -14,15 +14,15 @@ static void run(int M, int N, int K) {
     GemmShape g;
     g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.k_chunk = K; g.group_m = 8;
     EpiF32 e{C, nullptr, N, M, N, 0, 1.0f};
-    constexpr size_t sh = (size_t)H_NS * H_STAGE;
-    hipFuncSetAttribute((const void*)gemm_nt_stag256_kernel<EpiF32, NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    const dim3 gr((unsigned)(((M + 255) / 256) * ((N + 64 * NJ - 1) / (64 * NJ))));
+    constexpr size_t sh = (size_t)H_NS * (32 * NI + H_BN) * H_BK * 2;
+    hipFuncSetAttribute((const void*)gemm_nt_stag256_kernel<EpiF32, NJ, false, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    const dim3 gr((unsigned)(((M + 32 * NI - 1) / (32 * NI)) * ((N + 64 * NJ - 1) / (64 * NJ))));
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
-    for (int it = 0; it < 3; it++) hipLaunchKernelGGL((gemm_nt_stag256_kernel<EpiF32, NJ>), gr, dim3(512), sh, 0, A, B, g, e);
+    for (int it = 0; it < 3; it++) hipLaunchKernelGGL((gemm_nt_stag256_kernel<EpiF32, NJ, false, NI>), gr, dim3(512), sh, 0, A, B, g, e);
     hipDeviceSynchronize();
     hipEventRecord(a);
-    for (int it = 0; it < 10; it++) hipLaunchKernelGGL((gemm_nt_stag256_kernel<EpiF32, NJ>), gr, dim3(512), sh, 0, A, B, g, e);
+    for (int it = 0; it < 10; it++) hipLaunchKernelGGL((gemm_nt_stag256_kernel<EpiF32, NJ, false, NI>), gr, dim3(512), sh, 0, A, B, g, e);
     hipEventRecord(b);
     hipEventSynchronize(b);
     float ms;
@@ -31,7 +31,7 @@ static void run(int M, int N, int K) {
     hipMemcpyFromSymbol(h, HIP_SYMBOL(cc_stamp_buf), sizeof(h));
     const int nk = K / 32;
     const char* names[8] = {"prologue+tail", "dma issue", "frag reads+wait", "barrier after reads", "mfma issue", "vmcnt wait", "barrier after mfma", "epilogue"};
-    printf("M=%d N=%d K=%d tile 256x%d: %.1f us, %.0f TFLOP/s (with stamps); cycles per K-step, group 0 | group 1\n", M, N, K, 64 * NJ, ms * 100,
+    printf("M=%d N=%d K=%d tile %dx%d: %.1f us, %.0f TFLOP/s (with stamps); cycles per K-step, group 0 | group 1\n", M, N, K, 32 * NI, 64 * NJ, ms * 100,
            2.0 * M * N * K / (ms / 10 * 1e-3) / 1e12);
     double t0 = 0, t1 = 0;
     for (int i = 1; i <= 6; i++) {
@@ -45,6 +45,8 @@ static void run(int M, int N, int K) {
 int main() {
     run<4>(8192, 8192, 8192);
     run<4>(10240, 50304, 768);
+    run<4, 10>(10240, 50304, 768);
+    run<4, 10>(12800, 3072, 768);
     run<3>(12800, 768, 3072);
     return 0;
 }
