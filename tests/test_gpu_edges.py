@@ -148,3 +148,28 @@ def test_whole_step_under_every_forced_gemm_tile(mode):
         _check(eng, sd, cfg, tokens, torch.randn(6, 32))
     finally:
         _lib.lib().cc_gemm_tile_mode(old)
+
+
+def test_lm_head_gradient_k_slices_equal_the_single_pass():
+    """The lm_head input gradient runs as K slices on the 256 x 256 kernel + a slab pass from K = 4096 (vocabulary) columns up
+    (gemm_nt_deepk); cc_gemm_tile_mode(0) takes the single-pass 128 x 128 path instead.  Same step, both paths, at the real vocabulary
+    width: loss identical, mapper gradients equal up to the 16-bit rounding of the one tensor that differs in summation order."""
+    from clipcap_amd import _lib
+    eng, sd, cfg = _build(64, 256, 4, 4, 4, 1, 4, 1, 50257, 64, seed=3)
+    torch.manual_seed(1)
+    tokens = torch.randint(1, 50257, (6, 20)).cuda()
+    tokens[2, 11:] = -1
+    embeds = torch.randn(6, 64).cuda()
+    eng.zero_grad()
+    l_deep = float(eng.forward_backward(tokens, embeds))
+    g_deep = eng.mapper.arena.g32.clone()
+    old = _lib.lib().cc_gemm_tile_mode(0)
+    try:
+        eng.zero_grad()
+        l_flat = float(eng.forward_backward(tokens, embeds))
+        g_flat = eng.mapper.arena.g32.clone()
+    finally:
+        _lib.lib().cc_gemm_tile_mode(old)
+    assert abs(l_deep - l_flat) <= 1e-6 * abs(l_flat)
+    assert torch.isfinite(g_deep).all() and g_flat.abs().max() > 0
+    assert ((g_deep - g_flat).norm() / g_flat.norm()).item() <= 5e-3
