@@ -142,6 +142,14 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// XCD-aware block order: the dispatcher places block b on XCD b%8; give each XCD a contiguous run of logical blocks (bijective for any
+// grid size), so that neighbours in the logical order — GEMM tiles sharing an A row panel, the beams of one caption in the decode
+// attention — meet in the same L2.
+__device__ __forceinline__ int xcd_remap(int b, int nb) {
+    const int q = nb >> 3, r = nb & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
 }  // namespace CC_NS
 
 // status codes returned across the C ABI (same values as include/clipcap_hip.h)

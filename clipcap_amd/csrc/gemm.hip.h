@@ -118,12 +118,7 @@ __device__ __forceinline__ void l_store(const StageRegs& s, char* lds, int tid) 
         l_store_ks(s, lds, tid);
 }
 
-// XCD-aware tile order: the dispatcher places block b on XCD b%8; give each XCD a contiguous run of tiles
-// (bijective for any grid size) so neighbouring tiles that share an A row-panel hit the same L2.
-__device__ __forceinline__ int xcd_remap(int b, int nb) {
-    const int q = nb >> 3, r = nb & 7, x = b & 7;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-}
+// xcd_remap (XCD-aware block order) lives in common.hip.h
 
 // Functors whose epilogue reads a second tensor (dgrad-through-activation: the activation input) can hand it over in the strip
 // layout before the first store: Epi::StripAux / load_aux(row, col) / operator()(row, col, v, aux).  Otherwise every such load sits
