@@ -1204,7 +1204,7 @@ static void attn_bwd_fused_launch(const op16_t* qkv, const op16_t* dout, const o
                                   op16_t* dqkv, hipStream_t st, Drop drop, float scale) {
     constexpr int OCC = CC_ATTN_FUSED_OCC;
     const dim3 grid((B * H + 3) / 4), blk(256);
-    if (drop.thresh) hipLaunchKernelGGL((k_attn_bwd_fused<HD, true, true, NBLK, 1>), grid, blk, 0, st, qkv, dout, o, lse, B, S, H, scale, dqkv, drop);
+    if (drop.thresh) hipLaunchKernelGGL((k_attn_bwd_fused<HD, true, true, NBLK, (HD == 64 ? OCC : 1)>), grid, blk, 0, st, qkv, dout, o, lse, B, S, H, scale, dqkv, drop);
     else if (causal) hipLaunchKernelGGL((k_attn_bwd_fused<HD, true, false, NBLK, (HD == 64 ? OCC : 1)>), grid, blk, 0, st, qkv, dout, o, lse, B, S, H, scale, dqkv, drop);
     else hipLaunchKernelGGL((k_attn_bwd_fused<HD, false, false, NBLK, 1>), grid, blk, 0, st, qkv, dout, o, lse, B, S, H, scale, dqkv, drop);
 }
