@@ -1551,13 +1551,31 @@ __global__ __launch_bounds__(256) void k_ce_rows(const float* __restrict__ pmax,
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    float m = -INFINITY;
-    for (int p = lane; p < npart; p += 64) m = fmaxf(m, pmax[(size_t)row * npart + p]);
-    m = wave_max(m);
-    float s = 0.f;
-    for (int p = lane; p < npart; p += 64) {
-        const float pm = pmax[(size_t)row * npart + p];
-        if (pm != -INFINITY) s += psum[(size_t)row * npart + p] * __expf(pm - m);
+    float m = -INFINITY, s = 0.f;
+    if (npart <= 64 * 16) {
+        // all partials of the row are requested at once (one round trip instead of one per 64 partials, and no second read of the maxima)
+        float pm[16], ps[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int p = lane + 64 * i;
+            const bool ok = p < npart;
+            const size_t at = (size_t)row * npart + min(p, npart - 1);      // clamped address + select: the loads stay one batch
+            const float a = pmax[at], b = psum[at];
+            pm[i] = ok ? a : -INFINITY;
+            ps[i] = ok ? b : 0.f;
+            m = fmaxf(m, pm[i]);
+        }
+        m = wave_max(m);
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            if (pm[i] != -INFINITY) s += ps[i] * __expf(pm[i] - m);
+    } else {
+        for (int p = lane; p < npart; p += 64) m = fmaxf(m, pmax[(size_t)row * npart + p]);
+        m = wave_max(m);
+        for (int p = lane; p < npart; p += 64) {
+            const float pm = pmax[(size_t)row * npart + p];
+            if (pm != -INFINITY) s += psum[(size_t)row * npart + p] * __expf(pm - m);
+        }
     }
     s = wave_sum(s);
     if (lane == 0) {
