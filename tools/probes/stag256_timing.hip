@@ -48,5 +48,9 @@ int main() {
     run<4, 10>(10240, 50304, 768);
     run<4, 10>(12800, 3072, 768);
     run<3>(12800, 768, 3072);
+    // epilogue cost against the number of CUs storing at once (K = 768: 24 K-steps per tile)
+    run<4>(4096, 4096, 768);
+    run<4>(2048, 2048, 768);
+    run<4>(512, 512, 768);
     return 0;
 }
