@@ -41,7 +41,7 @@ CONFIGS = {
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
 # Offline PMC measurements quoted in the JSON line (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 gfx950
 # correction; see the profile files).  They describe the build the profile was taken from; bench.py itself does not read counters.
-LMHEAD_TRAFFIC = {"bytes": (2 * 555418 + 1097102) * 1024, "source": "profiles/r02_k_pmc_fetch_write_train.md (offline PMC, this round's build)"}
+LMHEAD_TRAFFIC = {"bytes": (2 * 555411 + 1097446) * 1024, "source": "profiles/r02_k_pmc_fetch_write_train.md (offline PMC, this round's build)"}
 DECODE_TRAFFIC = {"bytes": 3.31e9, "source": "profiles/r02_h_pmc_fetch_write_decode.md (offline PMC, this round's build)"}
 
 
