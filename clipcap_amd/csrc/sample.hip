@@ -26,9 +26,16 @@ struct SmRow {
     bool use_rep;
     __device__ __forceinline__ float xform(int i, float v) const {
         if (use_rep && ((bitmap[i >> 5] >> (i & 31)) & 1u)) v = v < 0.f ? v * rep_pen : v / rep_pen;   // utils.py:33-37, before temperature
-        return v * inv_temp;
+        float t = v * inv_temp;
+        asm volatile("" : "+v"(t));      // the ROUNDED product is the element's value everywhere: nothing downstream may fuse with this multiply (see lb)
+        return t;
     }
     __device__ __forceinline__ float val(int i) const { return xform(i, x[i]); }
+    // Every pass of a selection must put an element into the SAME bucket.  With `v = x * inv_temp` visible to the optimiser, it was free
+    // to contract x * inv_temp - xmin into one fma at one inlined call site and not at another (-ffp-contract=fast; HIP's __fsub_rn /
+    // __fmul_rn are plain operators and do not prevent it): an element within 1e-7 of a bucket boundary then left the crossing bucket
+    // between the histogram pass and the radix passes, the crossing was not found, and the row fell back to "keep everything" — once
+    // in ~10^4 rows (found by tools/fuzz_decode_steps.py).  xform() now hands out the product behind an optimisation barrier.
     __device__ __forceinline__ int lb(float v) const { return (int)fminf(fmaxf((v - xmin) * xscale, 0.f), (float)(SM_NB - 1)); }
 };
 
@@ -131,6 +138,9 @@ __device__ unsigned sm_select(const SmRow& r, int V, unsigned long long target, 
             red[SM_T / 64] = before + (b == b0 ? 0 : w0);
         }
         __syncthreads();
+#ifdef CC_SAMPLE_DEBUG
+        if (bcast[0] == 0xffffffffu && threadIdx.x == 0) printf("sm_select: linear pass found no crossing: target %llu total %llu\n", target, tot);
+#endif
         if (bcast[0] == 0xffffffffu) { *gt = 0; *ties_w = 0; *ties_n = 0; __syncthreads(); return 0u; }
         lbsel = (int)bcast[0];
         acc = red[SM_T / 64];
@@ -163,6 +173,9 @@ __device__ unsigned sm_select(const SmRow& r, int V, unsigned long long target, 
             red[SM_T / 64] = before + (b == b0 ? 0 : w0);          // weight strictly above bucket b
         }
         __syncthreads();
+#ifdef CC_SAMPLE_DEBUG
+        if (bcast[0] == 0xffffffffu && threadIdx.x == 0) printf("sm_select: radix pass %d found no crossing: target %llu acc %llu bucket total %llu lbsel %d prefix %08x\n", pass, target, acc, tot, lbsel, prefix);
+#endif
         if (bcast[0] == 0xffffffffu) { none = true; break; }
         acc = red[SM_T / 64];
         prefix |= bcast[0] << sh;

@@ -48,7 +48,12 @@ def test_beam_step_matches_oracle(beam, V, ld):
         assert torch.equal(nt.cpu().long(), ont), step
         if step > 0:
             assert torch.equal(sr.cpu().long(), osr), step
-        assert torch.allclose(scores.cpu(), o_scores, rtol=1e-5, atol=1e-5), step
+        # the oracle follows the reference's fp32 `softmax(-1).log()`, which is itself only good to ~1e-5 (a random sweep found a 1.2e-5
+        # row); the kernel's first-step scores are checked against fp64 below
+        assert torch.allclose(scores.cpu(), o_scores, rtol=1e-5, atol=3e-5), step
+        if step == 0:
+            exact = torch.log_softmax(lg.double().cpu()[::beam] / temp, -1).topk(beam, -1).values.reshape(-1)
+            assert (scores.cpu().double() - exact).abs().max().item() <= 2e-6
         assert torch.equal(seql.cpu(), o_seql) and torch.equal(stopped.cpu().bool(), o_stopped), step
     assert o_stopped.any()
 

@@ -199,3 +199,12 @@ def test_generate_variants_step_distributions_vs_reference(case, monkeypatch):
         lg, hist = logit_rec[3]
         nopen = oracle.no_beam_step_distribution(lg, hist, top_p=top_p, top_k=int(top_k), temperature=temp, repetition_penalty=1.0)
         assert np.abs(nopen.numpy() - got[3]).max() > 1e-3
+
+
+@pytest.mark.parametrize("V,scale,top_p,top_k,temperature", [(1106, 1.5494166708685264, 0.211, None, 1.28), (41153, 3.2492567638160006, 0.4, None, 1.49)])
+def test_selection_passes_bucket_an_element_identically(V, scale, top_p, top_k, temperature):
+    """Regression (found by tools/fuzz_decode_steps.py): the threshold element of one row of these draws sits within 1e-7 of a boundary
+    of the sampler's linear pre-buckets; with the temperature multiply contracted into the bucket computation at one call site and
+    not at another, the element changed bucket between the histogram pass and the radix passes, no crossing was found and the row
+    kept all V tokens instead of its 30 / 285-token nucleus."""
+    test_nucleus_distribution_matches_reference_semantics(V, scale, top_p, top_k, temperature)
