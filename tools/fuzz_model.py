@@ -101,6 +101,61 @@ def classify(eng, sd, cfg, tokens, embeds):
     return "; ".join(bad) if bad else None
 
 
+def one_full(rng):
+    """full finetune (GPT-2 gradients too), half of the cases with the three dropout sites active: the kernels' counter-based masks are
+    read back through cc_dropout_mask and handed to the oracle (the check of tests/test_gpu_dropout.py)"""
+    from oracle import clipcap_oracle as O
+    from tests import test_gpu_dropout as TD
+    hd = rng.choice([16, 32, 64, 64])            # 64: the MFMA attention kernels (the only ones with attention dropout)
+    n_head = rng.choice([1, 2, 3])
+    D = hd * n_head
+    H = rng.choice([h for h in (1, 2, 4) if D % h == 0 and (D // h) % 8 == 0])
+    P, L, N, n_layer = rng.randint(1, 4), rng.randint(1, 4), rng.randint(1, 2), rng.randint(1, 2)
+    E_, V, B, cap = 8 * rng.randint(1, 8), rng.randint(60, 900), rng.randint(1, 5), rng.randint(1, 10)
+    use_drop = hd == 64 and rng.random() < 0.6
+    mode = rng.choice([-1, -1, 0, 3, 4, 5])
+    args = dict(full=True, E=E_, D=D, P=P, L=L, H=H, N=N, n_head=n_head, n_layer=n_layer, V=V, B=B, cap=cap, drop=use_drop, tile=mode)
+    LAST.update(args=args)
+    eng, sd, cfg = TD._build(E_, D, P, L, H, N, n_head, n_layer, V, L + cap + 2, seed=rng.randint(0, 999))
+    torch.manual_seed(rng.randint(0, 1 << 30))
+    tokens, embeds = torch.randint(1, V, (B, cap)), torch.randn(B, E_)
+    if rng.random() < 0.4:
+        tokens[rng.randint(0, B - 1), rng.randint(0, cap):] = -1
+    T = L + cap
+    drop = None
+    kw = {}
+    if use_drop:
+        p_e, p_a, p_r, seed = round(rng.uniform(0.05, 0.3), 2), round(rng.uniform(0.05, 0.3), 2), round(rng.uniform(0.05, 0.3), 2), rng.randrange(1 << 40)
+        kw = dict(dropout=(p_e, p_a, p_r, seed))
+        drop = {"p_embd": p_e, "p_attn": p_a, "p_resid": p_r, "embd": TD._mask(seed, 0, 0, p_e, (B, T, D)),
+                "attn": [TD._mask(seed, 1, l, p_a, (B, n_head, T, T)) for l in range(n_layer)],
+                "resid_attn": [TD._mask(seed, 2, l, p_r, (B, T, D)) for l in range(n_layer)],
+                "resid_mlp": [TD._mask(seed, 3, l, p_r, (B, T, D)) for l in range(n_layer)]}
+    old = _lib.lib().cc_gemm_tile_mode(mode)
+    try:
+        loss = float(eng.forward_backward(tokens.cuda(), embeds.cuda(), **kw))
+    finally:
+        _lib.lib().cc_gemm_tile_mode(old)
+    kept = int((tokens > 0).sum())
+    if kept == 0:
+        assert loss == 0.0
+        return args
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.clipcap_loss(sdr, tokens, embeds, cfg=cfg, rb=True, drop=drop)
+    ref.backward()
+    assert abs(loss - float(ref.detach())) <= max(4e-3, 1e-3 * abs(float(ref.detach()))), (loss, float(ref.detach()))
+    for pre, e in (("transformer_mapper.", eng.mapper), ("language_model.", eng.gpt2)):
+        for k, v in e.views(e.arena.g32).items():
+            r = sdr[pre + k].grad
+            if "lm_head" in k or r is None:
+                continue
+            err = ((v.cpu() - r).norm() / r.norm().clamp_min(1e-12)).item()
+            relu = (".mlp.fc1." in k or ".norm2." in k) and pre.startswith("transformer_mapper")      # ReLU-mask flips, see classify(); one flip weighs more the fewer rows there are
+            lim = (0.4 if B * (P + L) <= 8 else 0.25) if relu else 8e-2
+            assert err <= lim, (pre + k, err)
+    return args
+
+
 def one_decode(rng):
     from clipcap_amd.engine import DecodeSession
     from clipcap_amd.model.gpt2 import GPT2LM
@@ -128,7 +183,8 @@ def one_decode(rng):
 def main():
     if len(sys.argv) > 2 and sys.argv[1] == "--case":          # re-run one case by its seed, verbosely
         rng = random.Random(int(sys.argv[2]))
-        fn = one_step if rng.random() < 0.7 else one_decode
+        x = rng.random()
+        fn = one_step if x < 0.55 else (one_full if x < 0.8 else one_decode)
         VERBOSE.append(1)
         print(fn.__name__, fn(rng), "ok")
         return
@@ -138,7 +194,8 @@ def main():
     while time.time() - t0 < budget:
         case = master.randrange(1 << 30)
         rng = random.Random(case)
-        fn = one_step if rng.random() < 0.7 else one_decode
+        x = rng.random()
+        fn = one_step if x < 0.55 else (one_full if x < 0.8 else one_decode)
         try:
             if fn(rng) is not None:
                 n += 1
