@@ -42,6 +42,7 @@ PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (/opt/skills/guides/MI
 # Offline PMC measurements quoted in the JSON line (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 gfx950
 # correction; see the profile files).  They describe the build the profile was taken from; bench.py itself does not read counters.
 LMHEAD_TRAFFIC = {"bytes": (2 * 555411 + 1097446) * 1024, "source": "profiles/r02_k_pmc_fetch_write_train.md (offline PMC, this round's build)"}
+GEMM_TRAFFIC = {"bytes": int((2 * 9740151.8 + 7588918.7) * 1024), "source": "profiles/r02_k_pmc_fetch_write_train.md (offline PMC: sum over the gemm_* kernels of one step)"}
 DECODE_TRAFFIC = {"bytes": 3.31e9, "source": "profiles/r02_h_pmc_fetch_write_decode.md (offline PMC, this round's build)"}
 
 
@@ -425,6 +426,7 @@ def main():
         # ---- roofline of the dominant kernel family: every MFMA GEMM launch of the step (forward, dgrad, wgrad, lm_head), bracketed
         # with HIP events on the launch stream during 5 extra steps; achieved = sum of 2MNK / sum of launch durations ----
         n_prof = 5
+        default_cfg = args.config == "2" and not args.batch and args.precision == "bf16"
         per_step_cap = 64 + 24 * c["N"] + 16 * c["n_layer"]
         ms, fl = profile_sites(lib, one_step, sync, n_prof, "all_gemms", per_step_cap, nxt)
         nxt += n_prof
@@ -434,7 +436,9 @@ def main():
                            "achieved": round(fam, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fam / PEAK_BF16_TFLOPS, 4),
                            "launches_per_step": len(ms) // n_prof, "avg_launch_ms": round(gemm_ms / max(1, len(ms)), 4),
                            "time_share_of_step": round(gemm_ms / n_prof / ms_per_step, 3),
-                           "flops_per_step": gemm_fl / n_prof, "traffic": None}
+                           "flops_per_step": gemm_fl / n_prof,
+                           "traffic": GEMM_TRAFFIC["bytes"] if default_cfg else None, "traffic_source": GEMM_TRAFFIC["source"] if default_cfg else None,
+                           "traffic_note": "HBM bytes of all GEMM launches of one step (per step, not per launch)"}
         # ---- second entry: the largest single launch (lm_head forward) at its own call site, 20 extra steps ----
         per_step = {"lmhead_fwd": 1, "lmhead_dgrad": 1, "gpt2_fc_fwd": c["n_layer"], "gpt2_proj2_fwd": c["n_layer"], "gpt2_fc_dgrad": c["n_layer"],
                     "mapper_fc1_fwd": c["N"], "mapper_qkv_fwd": c["N"], "mapper_wgrad_fc2": c["N"]}[args.site]
