@@ -138,9 +138,6 @@ __device__ unsigned sm_select(const SmRow& r, int V, unsigned long long target, 
             red[SM_T / 64] = before + (b == b0 ? 0 : w0);
         }
         __syncthreads();
-#ifdef CC_SAMPLE_DEBUG
-        if (bcast[0] == 0xffffffffu && threadIdx.x == 0) printf("sm_select: linear pass found no crossing: target %llu total %llu\n", target, tot);
-#endif
         if (bcast[0] == 0xffffffffu) { *gt = 0; *ties_w = 0; *ties_n = 0; __syncthreads(); return 0u; }
         lbsel = (int)bcast[0];
         acc = red[SM_T / 64];
@@ -173,9 +170,6 @@ __device__ unsigned sm_select(const SmRow& r, int V, unsigned long long target, 
             red[SM_T / 64] = before + (b == b0 ? 0 : w0);          // weight strictly above bucket b
         }
         __syncthreads();
-#ifdef CC_SAMPLE_DEBUG
-        if (bcast[0] == 0xffffffffu && threadIdx.x == 0) printf("sm_select: radix pass %d found no crossing: target %llu acc %llu bucket total %llu lbsel %d prefix %08x\n", pass, target, acc, tot, lbsel, prefix);
-#endif
         if (bcast[0] == 0xffffffffu) { none = true; break; }
         acc = red[SM_T / 64];
         prefix |= bcast[0] << sh;
