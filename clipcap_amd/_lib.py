@@ -59,7 +59,9 @@ SIGNATURES = {
     "cc_mapper_param_offsets": (_I, [_MC, C.POINTER(_L)]),
     "cc_mapper_ws_bytes": (_L, [_MC, _I, _I]),
     "cc_mapper_sync_weights": (_I, [_MC, _P, _P, _P]),
+    "cc_mapper_transpose_weights": (_I, [_MC, _P, _P]),
     "cc_gpt2_sync_weights": (_I, [_GC, _P, _P, _P]),
+    "cc_gpt2_transpose_weights": (_I, [_GC, _P, _P]),
     "cc_mapper_fwd": (_I, [_MC, _I, _P, _P, _P, _P, _P, _I, _P]),
     "cc_mapper_attention_probs": (_I, [_MC, _I, _P, _I, _P, _P]),
     "cc_mapper_bwd": (_I, [_MC, _I, _P, _P, _P, _P, _P, _P]),
@@ -84,6 +86,7 @@ SIGNATURES = {
     "cc_embed_tokens": (_I, [_GC, _I, _P, _P, _P, _P]),
     "cc_beam_advance": (_I, [_GC, _I, _I, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P]),
     "cc_adamw_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P, _P, _P]),
+    "cc_adamw_step_cast": (_I, [_I, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P, _P, _P, _P]),
     "cc_cast_op16": (_I, [_I, _P, _P, _L, _P]),
     "cc_grad_nonfinite": (_I, [_P, _L, _P, _P]),
     "cc_loss_scale_update": (_I, [_P, _P, _F, _F, _I, _P]),

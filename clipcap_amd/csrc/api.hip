@@ -315,12 +315,9 @@ int64_t CC_API(cc_mapper_ws_bytes)(const cc_mapper_cfg* cfg, int32_t B, int32_t 
     return (int64_t)w.bytes;
 }
 
-int CC_API(cc_mapper_sync_weights)(const cc_mapper_cfg* c, const float* w32, uint16_t* w16, void* stream) {
-    if (!mapper_cfg_ok(c) || !w32 || !w16) return CC_ERR_ARG;
-    hipStream_t st = S_(stream);
+static int mapper_transposes(const cc_mapper_cfg* c, uint16_t* w16, hipStream_t st) {
     MapperOff o;
     mapper_offsets(c, o);
-    CC_TRY(f32_to_bf16(w32, w16, (size_t)o.total, st));
     op16_t* t = w16 + o.total;
     const int D = c->D, Hm = c->Hm;
     TransposeBatch tb;                      // 8 layers x 4 matrices: one launch per 32 matrices instead of one each
@@ -334,6 +331,20 @@ int CC_API(cc_mapper_sync_weights)(const cc_mapper_cfg* c, const float* w32, uin
     }
     CC_TRY(transpose_bf16_multi(tb, st));
     return CC_OK;
+}
+
+int CC_API(cc_mapper_sync_weights)(const cc_mapper_cfg* c, const float* w32, uint16_t* w16, void* stream) {
+    if (!mapper_cfg_ok(c) || !w32 || !w16) return CC_ERR_ARG;
+    hipStream_t st = S_(stream);
+    MapperOff o;
+    mapper_offsets(c, o);
+    CC_TRY(f32_to_bf16(w32, w16, (size_t)o.total, st));
+    return mapper_transposes(c, w16, st);
+}
+
+int CC_API(cc_mapper_transpose_weights)(const cc_mapper_cfg* c, uint16_t* w16, void* stream) {
+    if (!mapper_cfg_ok(c) || !w16) return CC_ERR_ARG;
+    return mapper_transposes(c, w16, S_(stream));
 }
 
 int CC_API(cc_mapper_fwd)(const cc_mapper_cfg* c, int32_t B, const float* w32, const uint16_t* w16, const float* emb, void* ws, float* out,
@@ -480,12 +491,9 @@ int64_t CC_API(cc_gpt2_ws_bytes)(const cc_gpt2_cfg* cfg, const cc_gpt2_shape* s)
     return (int64_t)w.bytes;
 }
 
-int CC_API(cc_gpt2_sync_weights)(const cc_gpt2_cfg* c, const float* w32, uint16_t* w16, void* stream) {
-    if (!gpt2_cfg_ok(c) || !w32 || !w16) return CC_ERR_ARG;
-    hipStream_t st = S_(stream);
+static int gpt2_transposes(const cc_gpt2_cfg* c, uint16_t* w16, hipStream_t st) {
     Gpt2Off o;
     gpt2_offsets(c, o);
-    CC_TRY(f32_to_bf16(w32, w16, (size_t)o.total, st));
     op16_t* t = w16 + o.total;
     const int D = c->D;
     CC_TRY(transpose_bf16(w16 + o.wte, t + o.wte, c->Vp, D, st));     // [Vp, D] -> [D, Vp]  (lm_head dgrad)
@@ -500,6 +508,20 @@ int CC_API(cc_gpt2_sync_weights)(const cc_gpt2_cfg* c, const float* w32, uint16_
     }
     CC_TRY(transpose_bf16_multi(tb, st));
     return CC_OK;
+}
+
+int CC_API(cc_gpt2_sync_weights)(const cc_gpt2_cfg* c, const float* w32, uint16_t* w16, void* stream) {
+    if (!gpt2_cfg_ok(c) || !w32 || !w16) return CC_ERR_ARG;
+    hipStream_t st = S_(stream);
+    Gpt2Off o;
+    gpt2_offsets(c, o);
+    CC_TRY(f32_to_bf16(w32, w16, (size_t)o.total, st));
+    return gpt2_transposes(c, w16, st);
+}
+
+int CC_API(cc_gpt2_transpose_weights)(const cc_gpt2_cfg* c, uint16_t* w16, void* stream) {
+    if (!gpt2_cfg_ok(c) || !w16) return CC_ERR_ARG;
+    return gpt2_transposes(c, w16, S_(stream));
 }
 
 // GPT-2 dropout (full finetune in train mode) is part of the pass's cc_gpt2_shape: embed / fwd / bwd(_range) of one pass read the
@@ -734,6 +756,12 @@ int CC_API(cc_adamw_step)(float* p32, const float* g32, float* m, float* v, int6
                   float weight_decay, int32_t step, float grad_scale, const float* loss_scale, const float* found_inf, void* stream) {
     if (!p32 || !g32 || !m || !v || n < 0 || step < 1) return CC_ERR_ARG;
     return adamw(p32, g32, m, v, (size_t)n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, loss_scale, found_inf, S_(stream));
+}
+
+int CC_API(cc_adamw_step_cast)(float* p32, const float* g32, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, int32_t step, float grad_scale, const float* loss_scale, const float* found_inf, uint16_t* w16, void* stream) {
+    if (!p32 || !g32 || !m || !v || !w16 || n < 0 || step < 1) return CC_ERR_ARG;
+    return adamw(p32, g32, m, v, (size_t)n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, loss_scale, found_inf, S_(stream), w16);
 }
 
 int CC_API(cc_cast_op16)(const float* src, uint16_t* dst, int64_t n, void* stream) {

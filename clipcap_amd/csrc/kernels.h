@@ -57,7 +57,7 @@ int sample_rows(const float* logits, int R, int V, int ld, float temperature, in
 int ce_targets(const long long* tokens, int* target, int* row_map, int B, int cap, int L, int T, hipStream_t st);
 
 int adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd, int step, float gscale,
-          const float* loss_scale, const float* found_inf, hipStream_t st);
+          const float* loss_scale, const float* found_inf, hipStream_t st, op16_t* w16 = nullptr);   // w16: also store the 16-bit copy of the updated parameters
 int grad_nonfinite(const float* g, size_t n, float* found_inf, hipStream_t st);
 int loss_scale_update(float* state, float* found_inf, float growth, float backoff, int interval, hipStream_t st);
 

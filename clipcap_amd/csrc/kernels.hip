@@ -1665,7 +1665,7 @@ int ce_targets(const long long* tokens, int* target, int* row_map, int B, int ca
 __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                float* __restrict__ v, size_t n4, float lr, float b1, float b2, float eps, float wd, float bc1,
                                                float bc2_sqrt, float gscale, const float* __restrict__ loss_scale,
-                                               const float* __restrict__ found_inf) {
+                                               const float* __restrict__ found_inf, op16_t* __restrict__ w16) {
     if (found_inf && found_inf[0] != 0.f) return;
     if (loss_scale) gscale /= loss_scale[0];
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -1684,17 +1684,19 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const floa
         reinterpret_cast<float4*>(p)[i] = P;
         reinterpret_cast<float4*>(m)[i] = M;
         reinterpret_cast<float4*>(v)[i] = V;
+        // the 16-bit operand copy of the updated parameters, while they are in registers: saves the separate cast pass over the arena
+        if (w16) reinterpret_cast<uint2*>(w16)[i] = make_uint2(pack2op(P.x, P.y), pack2op(P.z, P.w));
     }
 }
 int adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd, int step, float gscale,
-          const float* loss_scale, const float* found_inf, hipStream_t st) {
+          const float* loss_scale, const float* found_inf, hipStream_t st, op16_t* w16) {
     if (n & 3) return CC_ERR_SHAPE;
     if (!n) return CC_OK;
     const float bc1 = 1.0f - powf(b1, (float)step);
     const float bc2s = sqrtf(1.0f - powf(b2, (float)step));
     const size_t n4 = n >> 2;
     hipLaunchKernelGGL(k_adamw, dim3((int)std::min<size_t>((n4 + 255) / 256, 4096)), dim3(256), 0, st, p, g, m, v, n4, lr, b1, b2, eps, wd,
-                       bc1, bc2s, gscale, loss_scale, found_inf);
+                       bc1, bc2s, gscale, loss_scale, found_inf, w16);
     return CC_OK;
 }
 

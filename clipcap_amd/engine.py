@@ -10,6 +10,7 @@ PyTorch is used for device memory and streams only; all arithmetic runs in the H
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -44,7 +45,7 @@ class _Arena:
     def __init__(self, n: int, device, sync_fn=None, op_dtype: int = OP_BF16):
         self.n = n
         self.device = torch.device(device)
-        self.sync_fn = sync_fn   # (w32_ptr, w16_ptr, stream) -> rc : cast + transposed GEMM-weight copies
+        self.sync_fn = sync_fn   # (w32_ptr or None, w16_ptr, stream) -> rc : cast + transposed GEMM-weight copies (None: transposed copies only)
         self.op_dtype = op_dtype
         self.w32 = torch.zeros(n, dtype=torch.float32, device=self.device)
         # [0,n): 16-bit cast of the master (bf16 or fp16, cfg.op_dtype); [n,2n): transposed copies of the GEMM weights
@@ -106,10 +107,25 @@ class _Arena:
         if self.m is None:
             self.m = torch.zeros_like(self.w32)
             self.v = torch.zeros_like(self.w32)
-        check(_lib.lib().cc_adamw_step(_p(self.w32), _p(self.grads()), _p(self.m), _p(self.v), self.n, lr, betas[0], betas[1], eps,
-                                       weight_decay, step, grad_scale, _p(scaler.scale) if scaler is not None else None,
-                                       _p(scaler.found_inf) if scaler is not None else None, _stream(self.device)), "cc_adamw_step")
-        self.refresh_bf16()
+        # The step also stores the 16-bit cast of every updated parameter (cc_adamw_step_cast), so the operand arena only needs its
+        # transposed half rebuilt.  One corner keeps the full refresh: a step that may be SKIPPED on the device (fp16 overflow) leaves
+        # the cast untouched, which is only right if the cast was current before the step.
+        if os.environ.get("CC_ADAMW_TWO_PASS"):          # A/B switch: the separate-cast form
+            check(_lib.lib().cc_adamw_step(_p(self.w32), _p(self.grads()), _p(self.m), _p(self.v), self.n, lr, betas[0], betas[1], eps,
+                                           weight_decay, step, grad_scale, _p(scaler.scale) if scaler is not None else None,
+                                           _p(scaler.found_inf) if scaler is not None else None, _stream(self.device)), "cc_adamw_step")
+            self.refresh_bf16()
+            return
+        current = self._stamp() == self._w16_version
+        check(_lib.lib().cc_adamw_step_cast(self.op_dtype, _p(self.w32), _p(self.grads()), _p(self.m), _p(self.v), self.n, lr, betas[0],
+                                            betas[1], eps, weight_decay, step, grad_scale, _p(scaler.scale) if scaler is not None else None,
+                                            _p(scaler.found_inf) if scaler is not None else None, _p(self.w16), _stream(self.device)),
+              "cc_adamw_step_cast")
+        if scaler is None or current:
+            check(self.sync_fn(None, _p(self.w16), _stream(self.device)), "cc_*_transpose_weights")
+            self._w16_version = self._stamp()
+        else:
+            self.refresh_bf16()
 
 
 class LossScaler:
@@ -158,6 +174,8 @@ class MapperEngine:
         self._ws: Dict[Tuple[int, int], torch.Tensor] = {}
 
     def _sync(self, w32, w16, st):
+        if w32 is None:          # the cast half is current (written by the optimizer step): transposed copies only
+            return _lib.lib().cc_mapper_transpose_weights(C.byref(self.cfg), w16, st)
         return _lib.lib().cc_mapper_sync_weights(C.byref(self.cfg), w32, w16, st)
 
     # ---- named views (reference state-dict names / layouts) ----
@@ -298,6 +316,8 @@ class Gpt2Engine:
         self._ws: Dict[int, torch.Tensor] = {}
 
     def _sync(self, w32, w16, st):
+        if w32 is None:
+            return _lib.lib().cc_gpt2_transpose_weights(C.byref(self.cfg), w16, st)
         return _lib.lib().cc_gpt2_sync_weights(C.byref(self.cfg), w32, w16, st)
 
     def shapes(self) -> List[Tuple[str, int, Tuple[int, ...]]]:

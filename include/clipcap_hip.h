@@ -82,6 +82,8 @@ int64_t cc_mapper_ws_bytes(const cc_mapper_cfg* cfg, int32_t B, int32_t save);
 
 /* w16[0:count] = bf16(w32); w16[count:2*count] = per-tensor transposes of the GEMM weights (see Conventions) */
 int cc_mapper_sync_weights(const cc_mapper_cfg* cfg, const float* w32, uint16_t* w16, void* stream);
+/* only the second half: w16[count:2*count] from w16[0:count] — for callers whose optimizer already wrote the cast (cc_adamw_step_cast) */
+int cc_mapper_transpose_weights(const cc_mapper_cfg* cfg, uint16_t* w16, void* stream);
 
 /* replaces model.transformer_mapper(embeddings) (mapper.py:122-130; callers model.py:46, inference/generate.py:31,
  * docs/inference.md:24).  emb fp32 [B, W, E]; out fp32 [B, L, D]. */
@@ -143,6 +145,7 @@ int cc_gpt2_param_offsets(const cc_gpt2_cfg* cfg, int64_t* offsets);
 int64_t cc_gpt2_ws_bytes(const cc_gpt2_cfg* cfg, const cc_gpt2_shape* shp);
 
 int cc_gpt2_sync_weights(const cc_gpt2_cfg* cfg, const float* w32, uint16_t* w16, void* stream);
+int cc_gpt2_transpose_weights(const cc_gpt2_cfg* cfg, uint16_t* w16, void* stream);   /* as cc_mapper_transpose_weights */
 
 /* x0[b,t,:] = (t<L ? prefix[b,t,:] : wte[max(tok[b,t-L],0),:]) + wpe[t,:]  — model.py:45-49 + hf :571-577.
  * prefix fp32 [B,L,D]; tokens int64 [B, cap] (may be NULL when L == T).  Writes the workspace's layer-0 input. */
@@ -225,6 +228,11 @@ int cc_beam_advance(const cc_gpt2_cfg* cfg, int32_t R, int32_t beam, const float
  * ------------------------------------------------------------------------------------------------------------ */
 int cc_adamw_step(float* p32, const float* g32, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int32_t step, float grad_scale, const float* loss_scale, const float* found_inf, void* stream);
+/* cc_adamw_step that also stores w16[0:n] = cast of the updated parameters to op_dtype (untouched when the step is skipped), so that
+ * the refresh of the operand arena after a step is cc_*_transpose_weights alone: one pass over the arena less per step. */
+int cc_adamw_step_cast(int32_t op_dtype, float* p32, const float* g32, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                       float eps, float weight_decay, int32_t step, float grad_scale, const float* loss_scale, const float* found_inf,
+                       uint16_t* w16, void* stream);
 /* dst = cast of src to the 16-bit operand type op_dtype */
 int cc_cast_op16(int32_t op_dtype, const float* src, uint16_t* dst, int64_t n, void* stream);
 /* Dynamic loss scaling for CC_OP_FP16 training (torch.cuda.amp.GradScaler semantics; what Lightning wraps around the reference's

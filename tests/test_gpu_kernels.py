@@ -261,3 +261,40 @@ def test_adamw_matches_torch_and_loss_scaling_rules():
     for i in range(3):     # growth after `interval` consecutive good steps
         assert l.cc_loss_scale_update(_p(scale), _p(found), 2.0, 0.5, 3, _st()) == 0
         assert float(scale[0]) == (s0 if i < 2 else 2 * s0) and float(scale[1]) == (i + 1 if i < 2 else 0)
+
+
+def test_adamw_step_cast_and_transpose_only_sync_equal_the_two_pass_form():
+    """cc_adamw_step_cast = cc_adamw_step + the 16-bit cast of the updated parameters in the same pass (bit-identical to cc_cast_op16 of
+    the result; untouched when found_inf skips the step), and cc_*_transpose_weights after it = cc_*_sync_weights: the whole operand
+    arena (cast half and transposed half) is bit-identical either way."""
+    from clipcap_amd import _lib as L
+    l = _lib()
+    torch.manual_seed(3)
+    cfg = L.Gpt2Cfg(64, 4, 2, 97, 128, 16, OP[0])
+    n = l.cc_gpt2_param_count(C.byref(cfg))
+    mcfg = L.MapperCfg(E=32, D=64, P=3, L=2, H=4, N=2, Hm=128, W=1, use_pos=0, op_dtype=OP[0])
+    nm = l.cc_mapper_param_count(C.byref(mcfg))
+    for count, sync, transp, c in ((n, l.cc_gpt2_sync_weights, l.cc_gpt2_transpose_weights, cfg), (nm, l.cc_mapper_sync_weights, l.cc_mapper_transpose_weights, mcfg)):
+        p0 = torch.randn(count, device="cuda")
+        g = torch.randn(count, device="cuda")
+        pa, pb = p0.clone(), p0.clone()
+        ma, va, mb, vb = (torch.zeros(count, device="cuda") for _ in range(4))
+        wa = torch.zeros(2 * count, dtype=OP[1], device="cuda")
+        wb = torch.full((2 * count,), 7.0, dtype=OP[1], device="cuda")
+        assert l.cc_adamw_step(_p(pa), _p(g), _p(ma), _p(va), count, 1e-2, 0.9, 0.999, 1e-8, 0.01, 1, 1.0, None, None, _st()) == 0
+        assert sync(C.byref(c), _p(pa), _p(wa), _st()) == 0
+        assert l.cc_adamw_step_cast(OP[0], _p(pb), _p(g), _p(mb), _p(vb), count, 1e-2, 0.9, 0.999, 1e-8, 0.01, 1, 1.0, None, None, _p(wb), _st()) == 0
+        assert transp(C.byref(c), _p(wb), _st()) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+        assert torch.equal(wa[:count].view(torch.int16), wb[:count].view(torch.int16))
+        # the transposed half: every GEMM weight's slot is rewritten by both forms; slots of 1-D tensors are never read or written
+        gemm = wa[count:].float() != 0
+        assert torch.equal(wa[count:][gemm].view(torch.int16), wb[count:][gemm].view(torch.int16)) and gemm.any()
+        # a skipped step leaves the cast untouched
+        found = torch.ones(1, device="cuda")
+        scale = torch.tensor([8.0, 0.0], device="cuda")
+        before = wb.clone()
+        assert l.cc_adamw_step_cast(OP[0], _p(pb), _p(g), _p(mb), _p(vb), count, 1e-2, 0.9, 0.999, 1e-8, 0.01, 2, 1.0, _p(scale), _p(found), _p(wb), _st()) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(pa, pb) and torch.equal(before.view(torch.int16), wb.view(torch.int16))
