@@ -43,6 +43,7 @@ extern "C" {
 #define CC_ERR_LAUNCH (-3)
 #define CC_ERR_STATE (-4)
 
+/* bumped when an existing entry point changes; entry points ADDED since 2: cc_adamw_step_cast, cc_mapper_transpose_weights, cc_gpt2_transpose_weights */
 #define CC_ABI_VERSION 2
 int cc_abi_version(void);
 
