@@ -23,17 +23,27 @@ class CCError(RuntimeError):
     pass
 
 
-OP_BF16, OP_FP16 = 0, 1      # CC_OP_BF16 / CC_OP_FP16: operand type of a model's 16-bit tensors (cfg.op_dtype)
+OP_BF16, OP_FP16, OP_X3 = 0, 1, 2      # CC_OP_BF16 / CC_OP_FP16 / CC_OP_BF16X3: operand mode of a model (cfg.op_dtype)
 
 
 def op_dtype_of(precision) -> int:
-    """--fp-precision of the reference (clipcap/train/args.py:30-34) -> operand type: 16 = fp16 operands (+ loss scaling);
-    32 / 64 / "bf16" = bf16 operands.  Accumulation and master weights are fp32 either way."""
-    if precision in (OP_BF16, "bf16", 32, 64, None):
+    """--fp-precision of the reference (clipcap/train/args.py:30-34, handed to pl.Trainer at train.py:82) -> operand mode:
+
+    * 32 (the reference's default) / 64 / "32" / "bf16x3": split bf16 operands — every GEMM as three bf16 MFMA terms
+      (hi*hi + hi*lo + lo*hi), fp32 activations and attention: logits within 1e-3 of the fp32 reference at full depth, about a third
+      of the GEMM rate.  MI355X has no fp32 / fp64 matrix path, so 64 runs the same mode.
+    * 16 / "fp16": IEEE fp16 operands + dynamic loss scaling (what Lightning gives the reference for --fp-precision 16).
+    * "bf16" (or None, the engines' own default = BASELINE.json's bf16 configurations): bf16 operands, the throughput mode.
+
+    Accumulation, master weights, residual streams, LayerNorm statistics, loss and optimizer are fp32 in all three."""
+    if precision in ("bf16", None) or (precision == OP_BF16 and not isinstance(precision, bool)):
         return OP_BF16
-    if precision in (16, "fp16", "16"):
+    if precision in (16, "fp16", "16", OP_FP16):
         return OP_FP16
-    raise ValueError(f"unsupported precision {precision!r}: use 16 (fp16 operands), 32 / 64 or 'bf16' (bf16 operands)")
+    if precision in (32, 64, "32", "64", "bf16x3", "fp32", OP_X3):
+        return OP_X3
+    raise ValueError(f"unsupported precision {precision!r}: use 32 / 64 (split-bf16 operands, the reference default), 16 (fp16 operands) "
+                     "or 'bf16' (bf16 operands)")
 
 
 class MapperCfg(C.Structure):

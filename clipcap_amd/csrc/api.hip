@@ -57,6 +57,20 @@ struct Carver {
 inline hipStream_t S_(void* s) { return static_cast<hipStream_t>(s); }
 inline int rup(int x, int m) { return (x + m - 1) / m * m; }
 
+// Operand arena addressing.  16-bit builds: w16[off] is the cast of w32[off], w16[total + off] the transposed copy.  bf16x3 build: every
+// 2-D GEMM weight [R][C] at element offset off owns 3*R*C operand elements at 3*off — rows [hi | lo | hi] of 3C (the B-operand image,
+// common.hip.h) — and its transposed image [C][3R] at 3*(total + off); the arena has 6*total elements (1-D tensors leave holes).
+constexpr int PL = kX3 ? 3 : 1;
+inline const uint16_t* W16(const uint16_t* w16, int64_t off) { return w16 + (size_t)PL * off; }
+inline uint16_t* W16(uint16_t* w16, int64_t off) { return w16 + (size_t)PL * off; }
+// bf16x3: bytes of operand-image scratch for GEMMs whose largest A image is rows x depth (x3_operand rounds each image up to 256 B)
+inline size_t x3_img(size_t rows, size_t depth) { return ((rows * 3 * depth * sizeof(op16_t)) + 255) & ~size_t(255); }
+#if CC_OP == 2
+#define X3_SCRATCH(w) x3_set_scratch((w).x3, (w).x3_bytes)
+#else
+#define X3_SCRATCH(w) (void)0
+#endif
+
 // ------------------------------------------------------------------------------------------------------------
 // mapper
 // ------------------------------------------------------------------------------------------------------------
@@ -99,17 +113,19 @@ void mapper_offsets(const cc_mapper_cfg* c, MapperOff& o) {
 }
 
 struct MapperWS {
-    op16_t* emb16;
+    act_t* emb16;
     float* lin_tmp;
     float* x[MAX_LAYERS + 1];
     float* x1[MAX_LAYERS];
-    op16_t *xn1[MAX_LAYERS], *xn2[MAX_LAYERS], *qkv[MAX_LAYERS], *att[MAX_LAYERS], *h[MAX_LAYERS];
+    act_t *xn1[MAX_LAYERS], *xn2[MAX_LAYERS], *qkv[MAX_LAYERS], *att[MAX_LAYERS], *h[MAX_LAYERS];
     float *lse[MAX_LAYERS], *mean1[MAX_LAYERS], *rstd1[MAX_LAYERS], *mean2[MAX_LAYERS], *rstd2[MAX_LAYERS];
     // backward scratch
     float* dx32;
-    op16_t *dx16, *dx16b, *dh16, *dxn16, *datt16, *dqkv16, *dlin16;
+    act_t *dx16, *dx16b, *dh16, *dxn16, *datt16, *dqkv16, *dlin16;
     float* wg_scratch;
     float* adelta;
+    char* x3;          // bf16x3 build: operand-image scratch of the GEMM in flight (gemm_api.h)
+    size_t x3_bytes;
     size_t bytes;
 };
 
@@ -117,7 +133,7 @@ void mapper_carve(const cc_mapper_cfg* c, int B, int save, void* ws, MapperWS& w
     Carver cv(ws);
     const int S = c->W * c->P + c->L;
     const size_t M = (size_t)B * S, D = c->D;
-    w.emb16 = cv.take<op16_t>((size_t)B * c->W * c->E);
+    w.emb16 = cv.take<act_t>((size_t)B * c->W * c->E);
     w.lin_tmp = c->W > 1 ? cv.take<float>((size_t)B * c->W * c->P * D) : nullptr;
     const int nx = save ? c->N + 1 : 2;
     float* xb[MAX_LAYERS + 1];
@@ -129,11 +145,11 @@ void mapper_carve(const cc_mapper_cfg* c, int B, int save, void* ws, MapperWS& w
         const int s = fresh ? l : 0;
         if (fresh) {
             w.x1[l] = cv.take<float>(M * D);
-            w.xn1[l] = cv.take<op16_t>(M * D);
-            w.xn2[l] = cv.take<op16_t>(M * D);
-            w.qkv[l] = cv.take<op16_t>(M * 3 * D);
-            w.att[l] = cv.take<op16_t>(M * D);
-            w.h[l] = cv.take<op16_t>(M * c->Hm);
+            w.xn1[l] = cv.take<act_t>(M * D);
+            w.xn2[l] = cv.take<act_t>(M * D);
+            w.qkv[l] = cv.take<act_t>(M * 3 * D);
+            w.att[l] = cv.take<act_t>(M * D);
+            w.h[l] = cv.take<act_t>(M * c->Hm);
             w.lse[l] = cv.take<float>((size_t)B * c->H * S);
             w.mean1[l] = cv.take<float>(M);
             w.rstd1[l] = cv.take<float>(M);
@@ -146,18 +162,30 @@ void mapper_carve(const cc_mapper_cfg* c, int B, int save, void* ws, MapperWS& w
     }
     if (save) {
         w.dx32 = cv.take<float>(M * D);
-        w.dx16 = cv.take<op16_t>(M * D);
-        w.dx16b = cv.take<op16_t>(M * D);       // gradient after the LN2 backward: a second buffer so that the layer's four weight
+        w.dx16 = cv.take<act_t>(M * D);
+        w.dx16b = cv.take<act_t>(M * D);        // gradient after the LN2 backward: a second buffer so that the layer's four weight
                                                 // gradients can run as one grouped launch once all their operands exist
-        w.dh16 = cv.take<op16_t>(M * c->Hm);
-        w.dxn16 = cv.take<op16_t>(M * D);
-        w.datt16 = cv.take<op16_t>(M * D);
-        w.dqkv16 = cv.take<op16_t>(M * 3 * D);
-        w.dlin16 = cv.take<op16_t>((size_t)B * c->W * c->P * D);
+        w.dh16 = cv.take<act_t>(M * c->Hm);
+        w.dxn16 = cv.take<act_t>(M * D);
+        w.datt16 = cv.take<act_t>(M * D);
+        w.dqkv16 = cv.take<act_t>(M * 3 * D);
+        w.dlin16 = cv.take<act_t>((size_t)B * c->W * c->P * D);
         w.wg_scratch = cv.take<float>(WGRAD_SCRATCH_BYTES / sizeof(float));
         w.adelta = cv.take<float>((size_t)B * c->H * S);
     } else {
         w.dx32 = nullptr; w.dx16 = w.dx16b = w.dh16 = w.dxn16 = w.datt16 = w.dqkv16 = w.dlin16 = nullptr; w.wg_scratch = nullptr; w.adelta = nullptr;
+    }
+    w.x3 = nullptr; w.x3_bytes = 0;
+    if (kX3) {
+        const size_t Hm = c->Hm, Mb = (size_t)B * c->W, PD = (size_t)c->P * D;
+        size_t need = std::max(x3_img(Mb, c->E), x3_img(M, std::max(D, Hm)));                          // forward A images
+        if (save) {
+            need = std::max(need, x3_img(M, 3 * D));                                                     // dgrad through the fused QKV weight
+            need = std::max(need, std::max(x3_img(M, D) + x3_img(M, Hm), x3_img(M, 3 * D) + x3_img(M, D)));   // weight-gradient pairs
+            need = std::max(need, x3_img(Mb, PD) + x3_img(Mb, c->E));
+        }
+        w.x3_bytes = need;
+        w.x3 = cv.take<char>(need);
     }
     w.bytes = (cv.off + 255) & ~size_t(255);
 }
@@ -206,19 +234,21 @@ void gpt2_offsets(const cc_gpt2_cfg* c, Gpt2Off& o) {
 struct Gpt2WS {
     float* x[MAX_LAYERS + 1];
     float* x1[MAX_LAYERS];
-    op16_t *xn1[MAX_LAYERS], *xn2[MAX_LAYERS], *qkv[MAX_LAYERS], *att[MAX_LAYERS], *u[MAX_LAYERS], *hact[MAX_LAYERS];
+    act_t *xn1[MAX_LAYERS], *xn2[MAX_LAYERS], *qkv[MAX_LAYERS], *att[MAX_LAYERS], *u[MAX_LAYERS], *hact[MAX_LAYERS];
     float *lse[MAX_LAYERS], *mean1[MAX_LAYERS], *rstd1[MAX_LAYERS], *mean2[MAX_LAYERS], *rstd2[MAX_LAYERS];
     // lm head / loss
-    op16_t* hf16;      // [Mh, D]   ln_f output rows (Mh = max(B*cap, B*T) so the parity API can use it too)
+    act_t* hf16;       // [Mh, D]   ln_f output rows (Mh = max(B*cap, B*T) so the parity API can use it too)
     float *meanf, *rstdf;
     int *target, *row_map;
-    op16_t* logits16;  // [B*cap, Vp]
+    act_t* logits16;   // [B*cap, Vp]
     float *pmax, *psum, *tgt_logit, *lse_row, *row_loss;
     // backward
     float* dx32;
-    op16_t *dx16, *dx16b, *dhf16, *du16, *dxn16, *datt16, *dqkv16;
+    act_t *dx16, *dx16b, *dhf16, *du16, *dxn16, *datt16, *dqkv16;
     float* wg_scratch;
     float* adelta;
+    char* x3;          // bf16x3 build: operand-image scratch
+    size_t x3_bytes;
     size_t bytes;
 };
 
@@ -233,46 +263,54 @@ void gpt2_carve(const cc_gpt2_cfg* c, int B, int T, int cap, int mode, void* ws,
     for (int l = 0; l < c->NL; l++) {
         const bool k0 = keep || l == 0, f0 = full || l == 0;
         w.x1[l] = k0 ? cv.take<float>(M * D) : w.x1[0];
-        w.qkv[l] = k0 ? cv.take<op16_t>(M * 3 * D) : w.qkv[0];
-        w.u[l] = k0 ? cv.take<op16_t>(M * 4 * D) : w.u[0];
+        w.qkv[l] = k0 ? cv.take<act_t>(M * 3 * D) : w.qkv[0];
+        w.u[l] = k0 ? cv.take<act_t>(M * 4 * D) : w.u[0];
         w.lse[l] = k0 ? cv.take<float>((size_t)B * c->H * T) : w.lse[0];
         w.mean1[l] = k0 ? cv.take<float>(M) : w.mean1[0];
         w.rstd1[l] = k0 ? cv.take<float>(M) : w.rstd1[0];
         w.mean2[l] = k0 ? cv.take<float>(M) : w.mean2[0];
         w.rstd2[l] = k0 ? cv.take<float>(M) : w.rstd2[0];
-        w.xn1[l] = f0 ? cv.take<op16_t>(M * D) : w.xn1[0];
-        w.xn2[l] = f0 ? cv.take<op16_t>(M * D) : w.xn2[0];
-        w.att[l] = k0 ? cv.take<op16_t>(M * D) : w.att[0];   // attention output: needed by the backward's delta = rowsum(dO*O)
-        w.hact[l] = f0 ? cv.take<op16_t>(M * 4 * D) : w.hact[0];
+        w.xn1[l] = f0 ? cv.take<act_t>(M * D) : w.xn1[0];
+        w.xn2[l] = f0 ? cv.take<act_t>(M * D) : w.xn2[0];
+        w.att[l] = k0 ? cv.take<act_t>(M * D) : w.att[0];    // attention output: needed by the backward's delta = rowsum(dO*O)
+        w.hact[l] = f0 ? cv.take<act_t>(M * 4 * D) : w.hact[0];
     }
     const size_t Mh = std::max(M, Mc);
-    w.hf16 = cv.take<op16_t>(Mh * D);
+    w.hf16 = cv.take<act_t>(Mh * D);
     w.meanf = cv.take<float>(Mh);
     w.rstdf = cv.take<float>(Mh);
     w.target = cv.take<int>(Mh);
     w.row_map = cv.take<int>(Mh);
     if (keep) {
         const int npart = c->Vp / 64;
-        w.logits16 = cv.take<op16_t>(Mc * c->Vp);
+        w.logits16 = cv.take<act_t>(Mc * c->Vp);
         w.pmax = cv.take<float>(Mc * npart);
         w.psum = cv.take<float>(Mc * npart);
         w.tgt_logit = cv.take<float>(Mc);
         w.lse_row = cv.take<float>(Mc);
         w.row_loss = cv.take<float>(Mc);
         w.dx32 = cv.take<float>(M * D);
-        w.dx16 = cv.take<op16_t>(M * D);
-        w.dx16b = full ? cv.take<op16_t>(M * D) : w.dx16;   // full finetune: second copy so a layer's weight gradients can run grouped
-        w.dhf16 = cv.take<op16_t>(Mc * D);
-        w.du16 = cv.take<op16_t>(M * 4 * D);
-        w.dxn16 = cv.take<op16_t>(M * D);
-        w.datt16 = cv.take<op16_t>(M * D);
-        w.dqkv16 = cv.take<op16_t>(M * 3 * D);
+        w.dx16 = cv.take<act_t>(M * D);
+        w.dx16b = full ? cv.take<act_t>(M * D) : w.dx16;    // full finetune: second copy so a layer's weight gradients can run grouped
+        w.dhf16 = cv.take<act_t>(Mc * D);
+        w.du16 = cv.take<act_t>(M * 4 * D);
+        w.dxn16 = cv.take<act_t>(M * D);
+        w.datt16 = cv.take<act_t>(M * D);
+        w.dqkv16 = cv.take<act_t>(M * 3 * D);
         w.wg_scratch = full ? cv.take<float>(WGRAD_SCRATCH_BYTES / sizeof(float)) : nullptr;
         w.adelta = cv.take<float>((size_t)B * c->H * T);
     } else {
         w.wg_scratch = nullptr; w.adelta = nullptr;
         w.logits16 = nullptr; w.pmax = w.psum = w.tgt_logit = w.lse_row = w.row_loss = nullptr;
         w.dx32 = nullptr; w.dx16 = w.dx16b = w.dhf16 = w.du16 = w.dxn16 = w.datt16 = w.dqkv16 = nullptr;
+    }
+    w.x3 = nullptr; w.x3_bytes = 0;
+    if (kX3) {
+        size_t need = x3_img(Mh, 4 * D);                                                       // forward A images (mlp.c_proj is the deepest)
+        if (keep) need = std::max(need, x3_img(Mc, c->Vp));                                    // lm_head input gradient: A = dlogits
+        if (full) need = std::max(need, std::max(x3_img(M, D) + x3_img(M, 4 * D), x3_img(Mc, c->Vp) + x3_img(Mc, D)));   // weight-gradient pairs
+        w.x3_bytes = need;
+        w.x3 = cv.take<char>(need);
     }
     w.bytes = (cv.off + 255) & ~size_t(255);
 }
@@ -315,7 +353,30 @@ int64_t CC_API(cc_mapper_ws_bytes)(const cc_mapper_cfg* cfg, int32_t B, int32_t 
     return (int64_t)w.bytes;
 }
 
+#if CC_OP == 2
+// bf16x3: [hi | lo | hi] images of every GEMM weight and of its transpose, straight from the fp32 master (W16 layout above)
+static int mapper_sync_x3(const cc_mapper_cfg* c, const float* w32, uint16_t* w16, hipStream_t st) {
+    MapperOff o;
+    mapper_offsets(c, o);
+    const int D = c->D, Hm = c->Hm;
+    X3SplitBatch sb;
+    sb.add(w32 + o.lin_w, W16(w16, o.lin_w), c->P * D, c->E, 0, 1);
+    for (int l = 0; l < c->N; l++) {
+        const auto& y = o.layer[l];
+        const int64_t off[4] = {y.wq, y.wp, y.w1, y.w2};
+        const int R[4] = {3 * D, D, Hm, D}, C[4] = {D, D, D, Hm};
+        for (int i = 0; i < 4; i++) {
+            if (sb.n + 2 > 32) { CC_TRY(x3_split_multi(sb, st)); sb.n = 0; }
+            sb.add(w32 + off[i], W16(w16, off[i]), R[i], C[i], 0, 1);
+            sb.add(w32 + off[i], W16(w16, o.total + off[i]), R[i], C[i], 1, 1);
+        }
+    }
+    return x3_split_multi(sb, st);
+}
+#endif
+
 static int mapper_transposes(const cc_mapper_cfg* c, uint16_t* w16, hipStream_t st) {
+    if (kX3) return CC_ERR_ARG;      // the operand images are made from the fp32 master (cc_mapper_sync_weights)
     MapperOff o;
     mapper_offsets(c, o);
     op16_t* t = w16 + o.total;
@@ -336,10 +397,14 @@ static int mapper_transposes(const cc_mapper_cfg* c, uint16_t* w16, hipStream_t 
 int CC_API(cc_mapper_sync_weights)(const cc_mapper_cfg* c, const float* w32, uint16_t* w16, void* stream) {
     if (!mapper_cfg_ok(c) || !w32 || !w16) return CC_ERR_ARG;
     hipStream_t st = S_(stream);
+#if CC_OP == 2
+    return mapper_sync_x3(c, w32, w16, st);
+#else
     MapperOff o;
     mapper_offsets(c, o);
     CC_TRY(f32_to_bf16(w32, w16, (size_t)o.total, st));
     return mapper_transposes(c, w16, st);
+#endif
 }
 
 int CC_API(cc_mapper_transpose_weights)(const cc_mapper_cfg* c, uint16_t* w16, void* stream) {
@@ -355,14 +420,15 @@ int CC_API(cc_mapper_fwd)(const cc_mapper_cfg* c, int32_t B, const float* w32, c
     mapper_offsets(c, o);
     MapperWS w;
     mapper_carve(c, B, save, ws, w);
+    X3_SCRATCH(w);
     const int D = c->D, PP = c->W * c->P, S = PP + c->L, M = B * S, H = c->H, hd = D / H, Hm = c->Hm;
     const int PD = c->P * D;
     // linear (mapper.py:123): [B*W, E] x [P*D, E]^T + b -> rows 0..PP-1 of every sample of x[0]
-    CC_TRY(f32_to_bf16(emb, w.emb16, (size_t)B * c->W * c->E, st));
+    CC_TRY(f32_to_act(emb, w.emb16, (size_t)B * c->W * c->E, st));
     if (c->W == 1) {
-        CC_TRY(gemm_f32out(0, 0, w.emb16, c->E, w16 + o.lin_w, c->E, B, PD, c->E, w.x[0], S * D, w32 + o.lin_b, 0, 1.0f, 1, st));
+        CC_TRY(gemm_f32out(0, 0, w.emb16, c->E, W16(w16, o.lin_w), c->E, B, PD, c->E, w.x[0], S * D, w32 + o.lin_b, 0, 1.0f, 1, st));
     } else {
-        CC_TRY(gemm_f32out(0, 0, w.emb16, c->E, w16 + o.lin_w, c->E, B * c->W, PD, c->E, w.lin_tmp, PD, w32 + o.lin_b, 0, 1.0f, 1, st));
+        CC_TRY(gemm_f32out(0, 0, w.emb16, c->E, W16(w16, o.lin_w), c->E, B * c->W, PD, c->E, w.lin_tmp, PD, w32 + o.lin_b, 0, 1.0f, 1, st));
         CC_TRY(copy_rows(w.lin_tmp, (size_t)PP * D, w.x[0], (size_t)S * D, PP * D, B, st));
         if (o.pos >= 0) CC_TRY(add_rows(w.x[0], (size_t)S * D, w32 + o.pos, PP * D, B, st));
     }
@@ -372,13 +438,13 @@ int CC_API(cc_mapper_fwd)(const cc_mapper_cfg* c, int32_t B, const float* w32, c
         const auto& y = o.layer[l];
         // x1 = x + project(attn(LN1 x))  (mapper.py:108, attention.py:17-43)
         CC_TRY(ln_fwd(w.x[l], D, nullptr, w32 + y.n1w, w32 + y.n1b, w.xn1[l], nullptr, w.mean1[l], w.rstd1[l], M, D, st));
-        CC_TIMED(CC_SITE_MAPPER_QKV_FWD, st, gemm_bf16out(0, 0, w.xn1[l], D, w16 + y.wq, D, M, 3 * D, D, w.qkv[l], 3 * D, nullptr, 0, nullptr, st));
+        CC_TIMED(CC_SITE_MAPPER_QKV_FWD, st, gemm_bf16out(0, 0, w.xn1[l], D, W16(w16, y.wq), D, M, 3 * D, D, w.qkv[l], 3 * D, nullptr, 0, nullptr, st));
         CC_TRY(attn_fwd(w.qkv[l], B, S, H, hd, false, w.att[l], w.lse[l], st));
-        CC_TRY(gemm_resid(0, 0, w.att[l], D, w16 + y.wp, D, M, D, D, w.x1[l], w.x[l], D, w32 + y.bp, st));
+        CC_TRY(gemm_resid(0, 0, w.att[l], D, W16(w16, y.wp), D, M, D, D, w.x1[l], w.x[l], D, w32 + y.bp, st));
         // x = x1 + fc2(relu(fc1(LN2 x1)))  (mapper.py:109, :82-88)
         CC_TRY(ln_fwd(w.x1[l], D, nullptr, w32 + y.n2w, w32 + y.n2b, w.xn2[l], nullptr, w.mean2[l], w.rstd2[l], M, D, st));
-        CC_TIMED(CC_SITE_MAPPER_FC1_FWD, st, gemm_bf16out(0, 0, w.xn2[l], D, w16 + y.w1, D, M, Hm, D, w.h[l], Hm, w32 + y.b1, 1, nullptr, st));
-        CC_TRY(gemm_resid(0, 0, w.h[l], Hm, w16 + y.w2, Hm, M, D, Hm, w.x[l + 1], w.x1[l], D, w32 + y.b2, st));
+        CC_TIMED(CC_SITE_MAPPER_FC1_FWD, st, gemm_bf16out(0, 0, w.xn2[l], D, W16(w16, y.w1), D, M, Hm, D, w.h[l], Hm, w32 + y.b1, 1, nullptr, st));
+        CC_TRY(gemm_resid(0, 0, w.h[l], Hm, W16(w16, y.w2), Hm, M, D, Hm, w.x[l + 1], w.x1[l], D, w32 + y.b2, st));
     }
     // out = rows [PP:] (mapper.py:128)
     CC_TRY(copy_rows(w.x[c->N] + (size_t)PP * D, (size_t)S * D, out, (size_t)c->L * D, c->L * D, B, st));
@@ -407,13 +473,14 @@ int CC_API(cc_mapper_bwd_range)(const cc_mapper_cfg* c, int32_t B, const float* 
     mapper_offsets(c, o);
     MapperWS w;
     mapper_carve(c, B, 1, ws, w);
+    X3_SCRATCH(w);
     const int D = c->D, PP = c->W * c->P, S = PP + c->L, M = B * S, H = c->H, hd = D / H, Hm = c->Hm;
     const int PD = c->P * D;
-    const uint16_t* w16t = w16 + o.total;   // transposed weight copies: dgrad GEMMs are NT
+    const uint16_t* w16t = W16(w16, o.total);   // transposed weight copies: dgrad GEMMs are NT
     if (l_hi == c->N) {   // seed: d x[N][:, PP:, :] = dout, rows [0:PP] = 0
         if (hipMemsetAsync(w.dx32, 0, (size_t)M * D * sizeof(float), st) != hipSuccess) return CC_ERR_LAUNCH;
         CC_TRY(copy_rows(dout, (size_t)c->L * D, w.dx32 + (size_t)PP * D, (size_t)S * D, c->L * D, B, st));
-        CC_TRY(f32_to_bf16(w.dx32, w.dx16, (size_t)M * D, st));
+        CC_TRY(f32_to_act(w.dx32, w.dx16, (size_t)M * D, st));
     }
     WgradBatch wb;          // per layer: its four weight gradients as ONE grouped GEMM launch + ONE slab reduce (wgrad_flush)
     wb.defer = true;
@@ -424,20 +491,20 @@ int CC_API(cc_mapper_bwd_range)(const cc_mapper_cfg* c, int32_t B, const float* 
         // fc2.bias gradient = column sums of dx16: for every layer but the top one the LN1 backward of the layer above produced
         // them together with dx16 (ln_bwd dcol); the top layer's dx16 comes from the seed
         if (l == c->N - 1) CC_TRY(colsum_bf16(w.dx16, D, M, D, g32 + y.b2, st));
-        CC_TRY(gemm_dact(0, 0, w.dx16, D, w16t + y.w2, D, M, Hm, D, w.dh16, Hm, w.h[l], 1, st));          // W2^T [Hm, D]
+        CC_TRY(gemm_dact(0, 0, w.dx16, D, W16(w16t, y.w2), D, M, Hm, D, w.dh16, Hm, w.h[l], 1, st));          // W2^T [Hm, D]
         // fc1
         CC_TRY(gemm_wgrad(w.dh16, Hm, w.xn2[l], D, Hm, D, M, g32 + y.w1, D, w.wg_scratch, st, &wb));
         CC_TRY(colsum_bf16(w.dh16, Hm, M, Hm, g32 + y.b1, st));
-        CC_TRY(gemm_bf16out(0, 0, w.dh16, Hm, w16t + y.w1, Hm, M, D, Hm, w.dxn16, D, nullptr, 0, nullptr, st));   // W1^T [D, Hm]
+        CC_TRY(gemm_bf16out(0, 0, w.dh16, Hm, W16(w16t, y.w1), Hm, M, D, Hm, w.dxn16, D, nullptr, 0, nullptr, st));   // W1^T [D, Hm]
         CC_TRY(ln_bwd(w.dxn16, w.x1[l], D, nullptr, w.mean2[l], w.rstd2[l], w32 + y.n2w, w.dx32, w.dx32, w.dx16b, g32 + y.n2w,
                       g32 + y.n2b, M, D, st, g32 + y.bp));         // + project.bias gradient (column sums of dx16b)
         // project
         CC_TRY(gemm_wgrad(w.dx16b, D, w.att[l], D, D, D, M, g32 + y.wp, D, w.wg_scratch, st, &wb));
-        CC_TRY(gemm_bf16out(0, 0, w.dx16b, D, w16t + y.wp, D, M, D, D, w.datt16, D, nullptr, 0, nullptr, st));     // Wp^T
+        CC_TRY(gemm_bf16out(0, 0, w.dx16b, D, W16(w16t, y.wp), D, M, D, D, w.datt16, D, nullptr, 0, nullptr, st));     // Wp^T
         CC_TRY(attn_bwd(w.qkv[l], w.datt16, w.att[l], w.lse[l], w.adelta, B, S, H, hd, false, w.dqkv16, st));
         // fused q/kv projection (to_queries.weight ++ to_keys_values.weight = [3D, D])
         CC_TRY(gemm_wgrad(w.dqkv16, 3 * D, w.xn1[l], D, 3 * D, D, M, g32 + y.wq, D, w.wg_scratch, st, &wb));
-        CC_TRY(gemm_bf16out(0, 0, w.dqkv16, 3 * D, w16t + y.wq, 3 * D, M, D, 3 * D, w.dxn16, D, nullptr, 0, nullptr, st));  // Wqkv^T [D, 3D]
+        CC_TRY(gemm_bf16out(0, 0, w.dqkv16, 3 * D, W16(w16t, y.wq), 3 * D, M, D, 3 * D, w.dxn16, D, nullptr, 0, nullptr, st));  // Wqkv^T [D, 3D]
         // the deferred weight gradients read dx16 (layer input gradient), dh16, dx16b, dqkv16: all still intact here — run them
         // before the LN1 backward overwrites dx16 with the next layer's input gradient
         CC_TRY(wgrad_flush(wb, st));
@@ -491,7 +558,32 @@ int64_t CC_API(cc_gpt2_ws_bytes)(const cc_gpt2_cfg* cfg, const cc_gpt2_shape* s)
     return (int64_t)w.bytes;
 }
 
+#if CC_OP == 2
+static int gpt2_sync_x3(const cc_gpt2_cfg* c, const float* w32, uint16_t* w16, hipStream_t st) {
+    Gpt2Off o;
+    gpt2_offsets(c, o);
+    const int D = c->D;
+    X3SplitBatch sb;
+    sb.add(w32 + o.wte, W16(w16, o.wte), c->Vp, D, 0, 1);                       // lm_head forward / logits / decode
+    sb.add(w32 + o.wte, W16(w16, o.total + o.wte), c->Vp, D, 1, 1);             // [D][3 Vp]: lm_head input gradient
+    CC_TRY(x3_split_multi(sb, st));
+    sb.n = 0;
+    for (int l = 0; l < c->NL; l++) {
+        const auto& y = o.layer[l];
+        const int64_t off[4] = {y.aw, y.pw, y.fw, y.p2w};
+        const int R[4] = {D, D, D, 4 * D}, C[4] = {3 * D, D, 4 * D, D};          // Conv1D [in][out]
+        for (int i = 0; i < 4; i++) {
+            if (sb.n + 2 > 32) { CC_TRY(x3_split_multi(sb, st)); sb.n = 0; }
+            sb.add(w32 + off[i], W16(w16, off[i]), R[i], C[i], 0, 1);
+            sb.add(w32 + off[i], W16(w16, o.total + off[i]), R[i], C[i], 1, 1);
+        }
+    }
+    return x3_split_multi(sb, st);
+}
+#endif
+
 static int gpt2_transposes(const cc_gpt2_cfg* c, uint16_t* w16, hipStream_t st) {
+    if (kX3) return CC_ERR_ARG;      // the operand images are made from the fp32 master (cc_gpt2_sync_weights)
     Gpt2Off o;
     gpt2_offsets(c, o);
     op16_t* t = w16 + o.total;
@@ -513,10 +605,14 @@ static int gpt2_transposes(const cc_gpt2_cfg* c, uint16_t* w16, hipStream_t st) 
 int CC_API(cc_gpt2_sync_weights)(const cc_gpt2_cfg* c, const float* w32, uint16_t* w16, void* stream) {
     if (!gpt2_cfg_ok(c) || !w32 || !w16) return CC_ERR_ARG;
     hipStream_t st = S_(stream);
+#if CC_OP == 2
+    return gpt2_sync_x3(c, w32, w16, st);
+#else
     Gpt2Off o;
     gpt2_offsets(c, o);
     CC_TRY(f32_to_bf16(w32, w16, (size_t)o.total, st));
     return gpt2_transposes(c, w16, st);
+#endif
 }
 
 int CC_API(cc_gpt2_transpose_weights)(const cc_gpt2_cfg* c, uint16_t* w16, void* stream) {
@@ -561,18 +657,19 @@ int CC_API(cc_gpt2_fwd)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const floa
     gpt2_offsets(c, o);
     Gpt2WS w;
     gpt2_carve(c, s->B, s->T, s->T - s->L, s->mode, ws, w);
+    X3_SCRATCH(w);
     const int D = c->D, M = s->B * s->T, H = c->H, hd = D / H;
-    const uint16_t* w16t = w16 + o.total;   // Conv1D weights transposed to [out,in]: every forward GEMM is NT
+    const uint16_t* w16t = W16(w16, o.total);   // Conv1D weights transposed to [out,in]: every forward GEMM is NT
     for (int l = 0; l < c->NL; l++) {
         const auto& y = o.layer[l];
         // hf :262-310: x1 = x + c_proj(attn(c_attn(ln_1 x)))
         CC_TRY(ln_fwd(w.x[l], D, nullptr, w32 + y.l1w, w32 + y.l1b, w.xn1[l], nullptr, w.mean1[l], w.rstd1[l], M, D, st));
-        CC_TRY(gemm_bf16out(0, 0, w.xn1[l], D, w16t + y.aw, D, M, 3 * D, D, w.qkv[l], 3 * D, w32 + y.ab, 0, nullptr, st));
+        CC_TRY(gemm_bf16out(0, 0, w.xn1[l], D, W16(w16t, y.aw), D, M, 3 * D, D, w.qkv[l], 3 * D, w32 + y.ab, 0, nullptr, st));
         CC_TRY(attn_fwd(w.qkv[l], s->B, s->T, H, hd, true, w.att[l], w.lse[l], st, make_drop(s->p_attn, s->drop_seed, DROP_ATTN, l)));
         {
             static const int tile_proj = env_tile("CC_TILE_PROJ");
             TileScope ts(tile_proj);
-            CC_TRY(gemm_resid(0, 0, w.att[l], D, w16t + y.pw, D, M, D, D, w.x1[l], w.x[l], D, w32 + y.pb, st,
+            CC_TRY(gemm_resid(0, 0, w.att[l], D, W16(w16t, y.pw), D, M, D, D, w.x1[l], w.x[l], D, w32 + y.pb, st,
                               make_drop(s->p_resid, s->drop_seed, DROP_RESID_ATTN, l)));
         }
         // x = x1 + c_proj(gelu_new(c_fc(ln_2 x1)))   (hf :229-243)
@@ -580,13 +677,13 @@ int CC_API(cc_gpt2_fwd)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const floa
         {
             static const int tile_fc = env_tile("CC_TILE_FC");
             TileScope ts(tile_fc);
-            CC_TIMED(CC_SITE_GPT2_FC_FWD, st, gemm_bf16out(0, 0, w.xn2[l], D, w16t + y.fw, D, M, 4 * D, D, w.hact[l], 4 * D, w32 + y.fb, 2,
+            CC_TIMED(CC_SITE_GPT2_FC_FWD, st, gemm_bf16out(0, 0, w.xn2[l], D, W16(w16t, y.fw), D, M, 4 * D, D, w.hact[l], 4 * D, w32 + y.fb, 2,
                                                             s->mode >= 1 ? w.u[l] : nullptr, st));
         }
         {
             static const int tile_proj2 = env_tile("CC_TILE_PROJ2");
             TileScope ts(tile_proj2);
-            CC_TIMED(CC_SITE_GPT2_PROJ2_FWD, st, gemm_resid(0, 0, w.hact[l], 4 * D, w16t + y.p2w, 4 * D, M, D, 4 * D, w.x[l + 1], w.x1[l], D, w32 + y.p2b, st,
+            CC_TIMED(CC_SITE_GPT2_PROJ2_FWD, st, gemm_resid(0, 0, w.hact[l], 4 * D, W16(w16t, y.p2w), 4 * D, M, D, 4 * D, w.x[l + 1], w.x1[l], D, w32 + y.p2b, st,
                                                            make_drop(s->p_resid, s->drop_seed, DROP_RESID_MLP, l)));
         }
     }
@@ -603,9 +700,10 @@ int CC_API(cc_gpt2_logits)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const f
     gpt2_offsets(c, o);
     Gpt2WS w;
     gpt2_carve(c, s->B, s->T, s->T - s->L, s->mode, ws, w);
+    X3_SCRATCH(w);
     const int D = c->D, M = s->B * s->T;
     CC_TRY(ln_fwd(w.x[c->NL], D, nullptr, w32 + o.lnf_w, w32 + o.lnf_b, w.hf16, nullptr, w.meanf, w.rstdf, M, D, st));
-    return gemm_f32out(0, 0, w.hf16, D, w16 + o.wte, D, M, Ns, D, logits, (int)ldl, nullptr, 0, 1.0f, 1, st);
+    return gemm_f32out(0, 0, w.hf16, D, W16(w16, o.wte), D, M, Ns, D, logits, (int)ldl, nullptr, 0, 1.0f, 1, st);
 }
 
 int CC_API(cc_lmhead_ce_fwd)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const float* w32, const uint16_t* w16, void* ws, const int64_t* tokens,
@@ -617,13 +715,14 @@ int CC_API(cc_lmhead_ce_fwd)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const
     Gpt2WS w;
     const int cap = s->T - s->L;
     gpt2_carve(c, s->B, s->T, cap, s->mode, ws, w);
+    X3_SCRATCH(w);
     const int D = c->D, Mc = s->B * cap, npart = c->Vp / 64;
     if (cap != s->cap) return CC_ERR_SHAPE;  // the loss consumes every token column (model.py:108-109)
     if (hipMemsetAsync(stats, 0, 2 * sizeof(float), st) != hipSuccess) return CC_ERR_LAUNCH;
     CC_TRY(ce_targets(reinterpret_cast<const long long*>(tokens), w.target, w.row_map, s->B, cap, s->L, s->T, st));
     // ln_f only on the rows the loss reads: L-1 .. T-2 of every sample (model.py:108)
     CC_TRY(ln_fwd(w.x[c->NL], D, w.row_map, w32 + o.lnf_w, w32 + o.lnf_b, w.hf16, nullptr, w.meanf, w.rstdf, Mc, D, st));
-    CC_TIMED(CC_SITE_LMHEAD_FWD, st, gemm_lmhead(w.hf16, D, w16 + o.wte, D, Mc, c->Vp, c->V, D, w.logits16, c->Vp, w.pmax, w.psum, npart, w.target, w.tgt_logit, st));
+    CC_TIMED(CC_SITE_LMHEAD_FWD, st, gemm_lmhead(w.hf16, D, W16(w16, o.wte), D, Mc, c->Vp, c->V, D, w.logits16, c->Vp, w.pmax, w.psum, npart, w.target, w.tgt_logit, st));
     CC_TRY(ce_rows(w.pmax, w.psum, npart, w.target, w.tgt_logit, w.lse_row, w.row_loss, stats, Mc, st));
     return CC_OK;
 }
@@ -637,20 +736,21 @@ int CC_API(cc_lmhead_ce_bwd)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const
     Gpt2WS w;
     const int cap = s->T - s->L;
     gpt2_carve(c, s->B, s->T, cap, s->mode, ws, w);
+    X3_SCRATCH(w);
     const int D = c->D, Mc = s->B * cap, M = s->B * s->T;
     const bool full = s->mode == 2;
     CC_TRY(ce_dlogits(w.logits16, c->Vp, c->V, w.target, w.lse_row, denom, loss_scale, Mc, st));
     // d hf = dlogits · wte   ([Mc,Vp] x [Vp(k), D(n)])
     // K = Vp is deep and the output narrow: K slices over the idle CUs, slabs parked in du16 (free until the first layer's backward)
     const auto lm_dgrad = [&]() {
-        const int rc = gemm_nt_deepk(w.logits16, c->Vp, w16 + o.total + o.wte, c->Vp, Mc, D, c->Vp, w.dhf16, D, reinterpret_cast<float*>(w.du16),
-                                     (size_t)M * 4 * D * sizeof(op16_t), st);
-        return rc != CC_ERR_SHAPE ? rc : gemm_bf16out(0, 0, w.logits16, c->Vp, w16 + o.total + o.wte, c->Vp, Mc, D, c->Vp, w.dhf16, D, nullptr, 0, nullptr, st);
+        const int rc = gemm_nt_deepk(w.logits16, c->Vp, W16(w16, o.total + o.wte), c->Vp, Mc, D, c->Vp, w.dhf16, D, reinterpret_cast<float*>(w.du16),
+                                     (size_t)M * 4 * D * sizeof(act_t), st);
+        return rc != CC_ERR_SHAPE ? rc : gemm_bf16out(0, 0, w.logits16, c->Vp, W16(w16, o.total + o.wte), c->Vp, Mc, D, c->Vp, w.dhf16, D, nullptr, 0, nullptr, st);
     };
     CC_TIMED(CC_SITE_LMHEAD_DGRAD, st, lm_dgrad());
     if (full) CC_TRY(gemm_wgrad(w.logits16, c->Vp, w.hf16, D, c->Vp, D, Mc, g32 + o.wte, D, w.wg_scratch, st));  // tied lm_head: d wte += dlogits^T hf
     if (hipMemsetAsync(w.dx32, 0, (size_t)M * D * sizeof(float), st) != hipSuccess) return CC_ERR_LAUNCH;
-    if (hipMemsetAsync(w.dx16, 0, (size_t)M * D * sizeof(op16_t), st) != hipSuccess) return CC_ERR_LAUNCH;
+    if (hipMemsetAsync(w.dx16, 0, (size_t)M * D * sizeof(act_t), st) != hipSuccess) return CC_ERR_LAUNCH;
     CC_TRY(ln_bwd(w.dhf16, w.x[c->NL], D, w.row_map, w.meanf, w.rstdf, w32 + o.lnf_w, nullptr, w.dx32, w.dx16, full ? g32 + o.lnf_w : nullptr,
                   full ? g32 + o.lnf_b : nullptr, Mc, D, st));
     return CC_OK;
@@ -665,11 +765,12 @@ int CC_API(cc_gpt2_logits_bwd)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, con
     gpt2_offsets(c, o);
     Gpt2WS w;
     gpt2_carve(c, s->B, s->T, s->T, s->mode, ws, w);      // L == 0: the loss-side buffers are sized for all B*T rows
+    X3_SCRATCH(w);
     const int D = c->D, M = s->B * s->T;
     const bool full = s->mode == 2;
     CC_TRY(f32_to_op16_pad(dlogits, ldl, c->V, w.logits16, c->Vp, M, st));
     // d hf = dlogits · wte ([M,Vp] x [Vp(k), D(n)]); tied lm_head: d wte += dlogits^T hf (hf16 = the rows cc_gpt2_logits normalised)
-    CC_TRY(gemm_bf16out(0, 0, w.logits16, c->Vp, w16 + o.total + o.wte, c->Vp, M, D, c->Vp, w.dhf16, D, nullptr, 0, nullptr, st));
+    CC_TRY(gemm_bf16out(0, 0, w.logits16, c->Vp, W16(w16, o.total + o.wte), c->Vp, M, D, c->Vp, w.dhf16, D, nullptr, 0, nullptr, st));
     if (full) CC_TRY(gemm_wgrad(w.logits16, c->Vp, w.hf16, D, c->Vp, D, M, g32 + o.wte, D, w.wg_scratch, st));
     if (hipMemsetAsync(w.dx32, 0, (size_t)M * D * sizeof(float), st) != hipSuccess) return CC_ERR_LAUNCH;
     CC_TRY(ln_bwd(w.dhf16, w.x[c->NL], D, nullptr, w.meanf, w.rstdf, w32 + o.lnf_w, nullptr, w.dx32, w.dx16, full ? g32 + o.lnf_w : nullptr,
@@ -695,6 +796,7 @@ int CC_API(cc_gpt2_bwd_range)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, cons
     gpt2_offsets(c, o);
     Gpt2WS w;
     gpt2_carve(c, s->B, s->T, s->T - s->L, s->mode, ws, w);
+    X3_SCRATCH(w);
     const int D = c->D, M = s->B * s->T, H = c->H, hd = D / H, D3 = 3 * D, D4 = 4 * D;
     const bool full = s->mode == 2;
     WgradBatch wb;          // full finetune: a layer's four weight gradients as one grouped launch + one slab reduce
@@ -715,20 +817,20 @@ int CC_API(cc_gpt2_bwd_range)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, cons
         {
             static const int tile_dact = env_tile("CC_TILE_DACT");
             TileScope ts(tile_dact);
-            CC_TRY(gemm_dact(0, 0, w.dx16, D, w16 + y.p2w, D, M, D4, D, w.du16, D4, w.u[l], 2, st));
+            CC_TRY(gemm_dact(0, 0, w.dx16, D, W16(w16, y.p2w), D, M, D4, D, w.du16, D4, w.u[l], 2, st));
         }
         // mlp.c_fc (Conv1D [D, 4D])
         if (full) {
             CC_TRY(gemm_wgrad(w.xn2[l], D, w.du16, D4, D, D4, M, g32 + y.fw, D4, w.wg_scratch, st, wbp));
             CC_TRY(colsum_bf16(w.du16, D4, M, D4, g32 + y.fb, st));
         }
-        CC_TIMED(CC_SITE_GPT2_FC_DGRAD, st, gemm_bf16out(0, 0, w.du16, D4, w16 + y.fw, D4, M, D, D4, w.dxn16, D, nullptr, 0, nullptr, st));
+        CC_TIMED(CC_SITE_GPT2_FC_DGRAD, st, gemm_bf16out(0, 0, w.du16, D4, W16(w16, y.fw), D4, M, D, D4, w.dxn16, D, nullptr, 0, nullptr, st));
         CC_TRY(ln_bwd(w.dxn16, w.x1[l], D, nullptr, w.mean2[l], w.rstd2[l], w32 + y.l2w, w.dx32, w.dx32, w.dx16b, full ? g32 + y.l2w : nullptr,
                       full ? g32 + y.l2b : nullptr, M, D, st, full ? g32 + y.pb : nullptr,
                       make_drop(s->p_resid, s->drop_seed, DROP_RESID_ATTN, l)));
         // attn.c_proj (Conv1D [D, D])
         if (full) CC_TRY(gemm_wgrad(w.att[l], D, w.dx16b, D, D, D, M, g32 + y.pw, D, w.wg_scratch, st, wbp));
-        CC_TRY(gemm_bf16out(0, 0, w.dx16b, D, w16 + y.pw, D, M, D, D, w.datt16, D, nullptr, 0, nullptr, st));
+        CC_TRY(gemm_bf16out(0, 0, w.dx16b, D, W16(w16, y.pw), D, M, D, D, w.datt16, D, nullptr, 0, nullptr, st));
         CC_TRY(attn_bwd(w.qkv[l], w.datt16, w.att[l], w.lse[l], w.adelta, s->B, s->T, H, hd, true, w.dqkv16, st,
                         make_drop(s->p_attn, s->drop_seed, DROP_ATTN, l)));
         // attn.c_attn (Conv1D [D, 3D])
@@ -736,7 +838,7 @@ int CC_API(cc_gpt2_bwd_range)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, cons
             CC_TRY(gemm_wgrad(w.xn1[l], D, w.dqkv16, D3, D, D3, M, g32 + y.aw, D3, w.wg_scratch, st, wbp));
             CC_TRY(colsum_bf16(w.dqkv16, D3, M, D3, g32 + y.ab, st));
         }
-        CC_TRY(gemm_bf16out(0, 0, w.dqkv16, D3, w16 + y.aw, D3, M, D, D3, w.dxn16, D, nullptr, 0, nullptr, st));
+        CC_TRY(gemm_bf16out(0, 0, w.dqkv16, D3, W16(w16, y.aw), D3, M, D, D3, w.dxn16, D, nullptr, 0, nullptr, st));
         // deferred weight gradients: dx16 (masked layer-input gradient), du16, dx16b, dqkv16 are all still intact here
         if (full) CC_TRY(wgrad_flush(wb, st));
         CC_TRY(ln_bwd(w.dxn16, w.x[l], D, nullptr, w.mean1[l], w.rstd1[l], w32 + y.l1w, w.dx32, w.dx32, w.dx16, full ? g32 + y.l1w : nullptr,
@@ -761,11 +863,12 @@ int CC_API(cc_adamw_step)(float* p32, const float* g32, float* m, float* v, int6
 int CC_API(cc_adamw_step_cast)(float* p32, const float* g32, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                        float weight_decay, int32_t step, float grad_scale, const float* loss_scale, const float* found_inf, uint16_t* w16, void* stream) {
     if (!p32 || !g32 || !m || !v || !w16 || n < 0 || step < 1) return CC_ERR_ARG;
+    if (kX3) return CC_ERR_ARG;      // bf16x3: the operand images are per-matrix row images, not a flat cast (use cc_adamw_step + cc_*_sync_weights)
     return adamw(p32, g32, m, v, (size_t)n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, loss_scale, found_inf, S_(stream), w16);
 }
 
 int CC_API(cc_cast_op16)(const float* src, uint16_t* dst, int64_t n, void* stream) {
-    if (!src || !dst || n < 0) return CC_ERR_ARG;
+    if (!src || !dst || n < 0 || kX3) return CC_ERR_ARG;
     return f32_to_bf16(src, dst, (size_t)n, S_(stream));
 }
 
@@ -781,8 +884,8 @@ int CC_API(cc_loss_scale_update)(float* state, float* found_inf, float growth, f
 
 int CC_API(cc_gemm_op16_f32)(int32_t al, int32_t bl, const uint16_t* A, int32_t lda, const uint16_t* B, int32_t ldb, int32_t M, int32_t N, int32_t K,
                      float* C, int32_t ldc, const float* bias, int32_t ksplit, void* stream) {
-    if (!A || !B || !C) return CC_ERR_ARG;
-    return gemm_f32out(al, bl, A, lda, B, ldb, M, N, K, C, ldc, ksplit > 1 ? nullptr : bias, ksplit > 1 ? 2 : 0, 1.0f, ksplit, S_(stream));
+    if (!A || !B || !C || kX3) return CC_ERR_ARG;      // (bf16x3 GEMMs need a workspace for their operand images: no bare hook)
+    return gemm_f32out(al, bl, reinterpret_cast<const act_t*>(A), lda, B, ldb, M, N, K, C, ldc, ksplit > 1 ? nullptr : bias, ksplit > 1 ? 2 : 0, 1.0f, ksplit, S_(stream));
 }
 
 int CC_API(cc_sample_step)(const float* logits, int32_t R, int32_t V, int32_t ld, float temperature, int32_t top_k, float top_p, int32_t mode,
@@ -797,25 +900,26 @@ int64_t CC_API(cc_wgrad_scratch_bytes)(void) { return (int64_t)WGRAD_SCRATCH_BYT
 
 int CC_API(cc_gemm_wgrad)(const uint16_t* X, int32_t ldx, const uint16_t* Y, int32_t ldy, int32_t Mw, int32_t Nw, int32_t K, float* dW, int32_t ldw,
                   float* scratch, void* stream) {
-    if (!X || !Y || !dW) return CC_ERR_ARG;
-    return gemm_wgrad(X, ldx, Y, ldy, Mw, Nw, K, dW, ldw, scratch, S_(stream));
+    if (!X || !Y || !dW || kX3) return CC_ERR_ARG;
+    return gemm_wgrad(reinterpret_cast<const act_t*>(X), ldx, reinterpret_cast<const act_t*>(Y), ldy, Mw, Nw, K, dW, ldw, scratch, S_(stream));
 }
 
 int CC_API(cc_layernorm_fwd)(const float* x, const float* gamma, const float* beta, uint16_t* y, float* mean, float* rstd, int32_t rows, int32_t D,
                      void* stream) {
     if (!x || !gamma || !beta || !y) return CC_ERR_ARG;
-    return ln_fwd(x, D, nullptr, gamma, beta, y, nullptr, mean, rstd, rows, D, S_(stream));
+    return ln_fwd(x, D, nullptr, gamma, beta, reinterpret_cast<act_t*>(y), nullptr, mean, rstd, rows, D, S_(stream));
 }
 
 int CC_API(cc_attention_fwd)(const uint16_t* qkv, int32_t B, int32_t S, int32_t H, int32_t hd, int32_t causal, uint16_t* out, float* lse, void* stream) {
     if (!qkv || !out) return CC_ERR_ARG;
-    return attn_fwd(qkv, B, S, H, hd, causal != 0, out, lse, S_(stream));
+    return attn_fwd(reinterpret_cast<const act_t*>(qkv), B, S, H, hd, causal != 0, reinterpret_cast<act_t*>(out), lse, S_(stream));
 }
 
 int CC_API(cc_attention_bwd)(const uint16_t* qkv, const uint16_t* dout, const uint16_t* o, const float* lse, float* delta_ws, int32_t B, int32_t S,
                      int32_t H, int32_t hd, int32_t causal, uint16_t* dqkv, void* stream) {
     if (!qkv || !dout || !lse || !dqkv) return CC_ERR_ARG;
-    return attn_bwd(qkv, dout, o, lse, delta_ws, B, S, H, hd, causal != 0, dqkv, S_(stream));
+    return attn_bwd(reinterpret_cast<const act_t*>(qkv), reinterpret_cast<const act_t*>(dout), reinterpret_cast<const act_t*>(o), lse, delta_ws, B, S, H, hd,
+                    causal != 0, reinterpret_cast<act_t*>(dqkv), S_(stream));
 }
 
 }  // extern "C"

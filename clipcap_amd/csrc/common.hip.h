@@ -15,6 +15,16 @@
 #if CC_OP == 1
 #define CC_NS cc_f16
 #define CC_API(name) name##_f16
+#elif CC_OP == 2
+// CC_OP = 2, "bf16x3" (namespace cc_x3, <name>_x3): the reference's DEFAULT precision (`--fp-precision 32`, clipcap/train/args.py:30-34,
+// train.py:82).  gfx950 has no fp32 / xf32 MFMA, so every GEMM operand x is split into bf16 hi = bf16(x) and lo = bf16(x - hi) and a
+// product runs as three bf16 MFMA terms hi*hi + hi*lo + lo*hi with fp32 accumulation (~16 mantissa bits per operand, 1/3 of the bf16
+// MFMA rate).  Realised without touching the GEMM main loops: the A operand is laid out [hi | hi | lo] and the B operand [hi | lo | hi]
+// along K, i.e. the same NT kernels run with K' = 3K (gemm_x3.hip.h).  Activations between kernels are stored as fp32 (act_t) and split
+// at the GEMM boundary; attention runs on the fp32 VALU kernels.  This is the parity mode (logits within 1e-3 of the fp32 reference at
+// full depth), not the throughput mode.
+#define CC_NS cc_x3
+#define CC_API(name) name##_x3
 #else
 #define CC_NS cc_bf16
 #define CC_API(name) name##_bf16
@@ -33,6 +43,16 @@ using cc_shared::g_gemm_small_x2;
 using cc_shared::g_gemm_tile_mode;
 
 typedef unsigned short op16_t;  // raw 16-bit operand storage (bf16 or fp16 bit pattern); conversions are round-to-nearest-even like torch
+// act_t: element type of the activations the kernels hand each other through HBM (normalised rows, qkv, attention output, MLP hidden,
+// their gradients, the logits kept for the backward, the KV cache).  16-bit operand storage in the bf16 / fp16 builds; fp32 in the
+// bf16x3 build, where the 16-bit hi / lo operand pair is made at the GEMM boundary.
+#if CC_OP == 2
+constexpr bool kX3 = true;
+typedef float act_t;
+#else
+constexpr bool kX3 = false;
+typedef op16_t act_t;
+#endif
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2_hw;
 #if CC_OP == 1
@@ -69,6 +89,51 @@ __device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
 __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
     return make_uint4(pack2op(f[0], f[1]), pack2op(f[2], f[3]), pack2op(f[4], f[5]), pack2op(f[6], f[7]));
 }
+
+// ---- stored activations (act_t): 8 / 4 consecutive elements <-> floats.  One 16-B (8-B) vector in the 16-bit builds, two (one)
+// 16-B vectors in the bf16x3 build.  p must be aligned to the vector size.
+#if CC_OP == 2
+struct act_raw8 { float4 a, b; };          // raw register image of 8 stored elements (loaded early, unpacked late)
+struct act_raw4 { float4 a; };
+__device__ __forceinline__ float act2f(act_t v) { return v; }
+__device__ __forceinline__ act_t f2act(float f) { return f; }
+__device__ __forceinline__ float act_round(float f) { return f; }      // value a stored activation takes: no rounding here
+__device__ __forceinline__ act_raw8 act_ldraw8(const act_t* p) {
+    return act_raw8{*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4)};
+}
+__device__ __forceinline__ act_raw8 act_zero8() { return act_raw8{make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)}; }
+__device__ __forceinline__ void act_unpack8(const act_raw8& r, float (&f)[8]) {
+    f[0] = r.a.x; f[1] = r.a.y; f[2] = r.a.z; f[3] = r.a.w; f[4] = r.b.x; f[5] = r.b.y; f[6] = r.b.z; f[7] = r.b.w;
+}
+__device__ __forceinline__ void act_straw8(act_t* p, const act_raw8& r) {
+    *reinterpret_cast<float4*>(p) = r.a; *reinterpret_cast<float4*>(p + 4) = r.b;
+}
+__device__ __forceinline__ act_raw8 act_pack8(const float (&f)[8]) {
+    return act_raw8{make_float4(f[0], f[1], f[2], f[3]), make_float4(f[4], f[5], f[6], f[7])};
+}
+__device__ __forceinline__ act_raw4 act_ldraw4(const act_t* p) { return act_raw4{*reinterpret_cast<const float4*>(p)}; }
+__device__ __forceinline__ void act_unpack4(const act_raw4& r, float& a, float& b, float& c, float& d) { a = r.a.x; b = r.a.y; c = r.a.z; d = r.a.w; }
+__device__ __forceinline__ act_raw4 act_pack4(float a, float b, float c, float d) { return act_raw4{make_float4(a, b, c, d)}; }
+__device__ __forceinline__ void act_straw4(act_t* p, const act_raw4& r) { *reinterpret_cast<float4*>(p) = r.a; }
+#else
+struct act_raw8 { uint4 a; };
+struct act_raw4 { uint2 a; };
+__device__ __forceinline__ float act2f(act_t v) { return op2f(v); }
+__device__ __forceinline__ act_t f2act(float f) { return f2op(f); }
+__device__ __forceinline__ float act_round(float f) { return op2f(f2op(f)); }
+__device__ __forceinline__ act_raw8 act_ldraw8(const act_t* p) { return act_raw8{*reinterpret_cast<const uint4*>(p)}; }
+__device__ __forceinline__ act_raw8 act_zero8() { return act_raw8{make_uint4(0, 0, 0, 0)}; }
+__device__ __forceinline__ void act_unpack8(const act_raw8& r, float (&f)[8]) { unpack8(r.a, f); }
+__device__ __forceinline__ void act_straw8(act_t* p, const act_raw8& r) { *reinterpret_cast<uint4*>(p) = r.a; }
+__device__ __forceinline__ act_raw8 act_pack8(const float (&f)[8]) { return act_raw8{pack8(f)}; }
+__device__ __forceinline__ act_raw4 act_ldraw4(const act_t* p) { return act_raw4{*reinterpret_cast<const uint2*>(p)}; }
+__device__ __forceinline__ void act_unpack4(const act_raw4& r, float& a, float& b, float& c, float& d) { unpack2(r.a.x, a, b); unpack2(r.a.y, c, d); }
+__device__ __forceinline__ act_raw4 act_pack4(float a, float b, float c, float d) { return act_raw4{make_uint2(pack2op(a, b), pack2op(c, d))}; }
+__device__ __forceinline__ void act_straw4(act_t* p, const act_raw4& r) { *reinterpret_cast<uint2*>(p) = r.a; }
+#endif
+__device__ __forceinline__ void act_ld8(const act_t* p, float (&f)[8]) { act_unpack8(act_ldraw8(p), f); }
+__device__ __forceinline__ void act_st8(act_t* p, const float (&f)[8]) { act_straw8(p, act_pack8(f)); }
+__device__ __forceinline__ void act_st4(act_t* p, float a, float b, float c, float d) { act_straw4(p, act_pack4(a, b, c, d)); }
 
 // gelu_new (tanh approximation) and its derivative — transformers.activations.NewGELUActivation, in the sigmoid form
 //   0.5 (1 + tanh u) = 1 / (1 + exp(-2u)) = s,   u = k0 (x + k1 x^3)   =>   gelu = x s,   gelu' = s + x s (1 - s) 2 k0 (1 + 3 k1 x^2)

@@ -43,8 +43,8 @@ __global__ void k_add_wpe(const float* __restrict__ xin, const float* __restrict
 // APPEND: the wave also writes its own (row, head, new position) K / V slice into the cache (instead of a separate append launch)
 // and reads the keys / values of the NEW positions straight from qkv — other waves' cache writes are not ordered with its reads.
 template <bool APPEND>
-__global__ __launch_bounds__(256) void k_decode_attn(const op16_t* __restrict__ qkv, op16_t* __restrict__ kc,
-                                                     op16_t* __restrict__ vc, const int* __restrict__ row_map, op16_t* __restrict__ out,
+__global__ __launch_bounds__(256) void k_decode_attn(const act_t* __restrict__ qkv, act_t* __restrict__ kc,
+                                                     act_t* __restrict__ vc, const int* __restrict__ row_map, act_t* __restrict__ out,
                                                      int R, int Tn, int H, int hd, int pos0, int ctx_max, float scale) {
     extern __shared__ float psm[];  // per wave: p[ctx_max] | srow[ctx_max] | red[8][hd]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -56,20 +56,20 @@ __global__ __launch_bounds__(256) void k_decode_attn(const op16_t* __restrict__ 
     float* p = psm + wave * per_wave;
     int* srow = reinterpret_cast<int*>(p + ctx_max);
     float* red = p + 2 * ctx_max;
-    const op16_t* q = qkv + ((size_t)r * Tn + t) * 3 * D + h * hd;
+    const act_t* q = qkv + ((size_t)r * Tn + t) * 3 * D + h * hd;
     // position j of row r lives in cache row row_map[r*ctx_max + j] (beam ancestry table; identity when null)
-    const op16_t* kb = kc + h * hd;
-    const op16_t* vb = vc + h * hd;
+    const act_t* kb = kc + h * hd;
+    const act_t* vb = vc + h * hd;
     if (APPEND) {
         const int c8 = hd >> 3;                            // 16-B chunks per head slice
         if (lane < 2 * c8) {
             const int which = lane / c8, c = lane - which * c8;
-            const uint4 v = *reinterpret_cast<const uint4*>(q + (which + 1) * D + c * 8);
-            op16_t* dst = (which ? vc : kc) + ((size_t)r * ctx_max + pos0 + t) * D + h * hd + c * 8;
-            *reinterpret_cast<uint4*>(dst) = v;
+            const act_raw8 v = act_ldraw8(q + (which + 1) * D + c * 8);
+            act_t* dst = (which ? vc : kc) + ((size_t)r * ctx_max + pos0 + t) * D + h * hd + c * 8;
+            act_straw8(dst, v);
         }
     }
-    const op16_t* knew = qkv + (size_t)r * Tn * 3 * D + D + h * hd;        // K of new position u: knew + u * 3D  (V: + D)
+    const act_t* knew = qkv + (size_t)r * Tn * 3 * D + D + h * hd;        // K of new position u: knew + u * 3D  (V: + D)
     for (int j = lane; j < nkeys; j += 64) srow[j] = row_map ? row_map[(size_t)r * ctx_max + j] : r;
     float m = -INFINITY;
     const int nchunk = hd >> 3;
@@ -79,19 +79,19 @@ __global__ __launch_bounds__(256) void k_decode_attn(const op16_t* __restrict__ 
         constexpr int SC_U = CC_DEC_SCU;
         const int kgs = 64 / nchunk, skg = lane / nchunk, sdc = lane - skg * nchunk;
         float qf[8];
-        unpack8(*reinterpret_cast<const uint4*>(q + sdc * 8), qf);
+        act_ld8(q + sdc * 8, qf);
         for (int j0 = 0; j0 < nkeys; j0 += kgs * SC_U) {
-            uint4 kv[SC_U];
+            act_raw8 kv[SC_U];
 #pragma unroll
             for (int u = 0; u < SC_U; u++) {
                 const int j = min(j0 + u * kgs + skg, nkeys - 1);
-                const op16_t* krow = (APPEND && j >= pos0) ? knew + (size_t)(j - pos0) * 3 * D : kb + ((size_t)srow[j] * ctx_max + j) * D;
-                kv[u] = *reinterpret_cast<const uint4*>(krow + sdc * 8);
+                const act_t* krow = (APPEND && j >= pos0) ? knew + (size_t)(j - pos0) * 3 * D : kb + ((size_t)srow[j] * ctx_max + j) * D;
+                kv[u] = act_ldraw8(krow + sdc * 8);
             }
 #pragma unroll
             for (int u = 0; u < SC_U; u++) {
                 float b[8], sc = 0.f;
-                unpack8(kv[u], b);
+                act_unpack8(kv[u], b);
 #pragma unroll
                 for (int e = 0; e < 8; e++) sc += qf[e] * b[e];
                 for (int o = 1; o < nchunk; o <<= 1) sc += __shfl_xor(sc, o);
@@ -106,11 +106,11 @@ __global__ __launch_bounds__(256) void k_decode_attn(const op16_t* __restrict__ 
     } else {
         for (int j = lane; j < nkeys; j += 64) {
             float s = 0.f;
-            const op16_t* krow = (APPEND && j >= pos0) ? knew + (size_t)(j - pos0) * 3 * D : kb + ((size_t)srow[j] * ctx_max + j) * D;
+            const act_t* krow = (APPEND && j >= pos0) ? knew + (size_t)(j - pos0) * 3 * D : kb + ((size_t)srow[j] * ctx_max + j) * D;
             for (int d = 0; d < hd; d += 8) {
                 float a[8], b[8];
-                unpack8(*reinterpret_cast<const uint4*>(q + d), a);
-                unpack8(*reinterpret_cast<const uint4*>(krow + d), b);
+                act_ld8(q + d, a);
+                act_ld8(krow + d, b);
 #pragma unroll
                 for (int e = 0; e < 8; e++) s += a[e] * b[e];
             }
@@ -135,19 +135,19 @@ __global__ __launch_bounds__(256) void k_decode_attn(const op16_t* __restrict__ 
     if (kg < kgroups) {
         constexpr int PV_U = CC_DEC_PVU;                       // V rows in flight per lane
         for (int j0 = kg; j0 < nkeys; j0 += kgroups * PV_U) {
-            uint4 vv[PV_U];
+            act_raw8 vv[PV_U];
             float pj[PV_U];
 #pragma unroll
             for (int u = 0; u < PV_U; u++) {
                 const int j = min(j0 + u * kgroups, nkeys - 1);
-                const op16_t* vrow = (APPEND && j >= pos0) ? knew + D + (size_t)(j - pos0) * 3 * D : vb + ((size_t)srow[j] * ctx_max + j) * D;
-                vv[u] = *reinterpret_cast<const uint4*>(vrow + dc * 8);
+                const act_t* vrow = (APPEND && j >= pos0) ? knew + D + (size_t)(j - pos0) * 3 * D : vb + ((size_t)srow[j] * ctx_max + j) * D;
+                vv[u] = act_ldraw8(vrow + dc * 8);
                 pj[u] = j0 + u * kgroups < nkeys ? p[j] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < PV_U; u++) {
                 float v[8];
-                unpack8(vv[u], v);
+                act_unpack8(vv[u], v);
 #pragma unroll
                 for (int e = 0; e < 8; e++) acc[e] += pj[u] * v[e];
             }
@@ -158,13 +158,13 @@ __global__ __launch_bounds__(256) void k_decode_attn(const op16_t* __restrict__ 
     for (int d = lane; d < hd; d += 64) {
         float o = 0.f;
         for (int g = 0; g < kgroups; g++) o += red[g * hd + d];
-        out[((size_t)r * Tn + t) * D + h * hd + d] = f2op(o * inv);
+        out[((size_t)r * Tn + t) * D + h * hd + d] = f2act(o * inv);
     }
 }
 
-__global__ void k_kv_reorder(const op16_t* __restrict__ src, op16_t* __restrict__ dst, const int* __restrict__ map, int R_src, int R_dst,
+__global__ void k_kv_reorder(const act_t* __restrict__ src, act_t* __restrict__ dst, const int* __restrict__ map, int R_src, int R_dst,
                              int ctx, int ctx_max, int D, int NL2) {
-    const int d8n = D >> 3;
+    const int d8n = D * (int)sizeof(act_t) / 16;      // 16-B vectors per cache row
     const size_t per_row = (size_t)ctx * d8n;
     const size_t total = (size_t)NL2 * R_dst * per_row;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -530,11 +530,13 @@ __global__ __launch_bounds__(64) void k_beam_final(int beam, int V, int first, i
 
 struct DecWS {
     float *x, *x1;
-    op16_t *xn, *qkv, *att, *hact, *hf;
+    act_t *xn, *qkv, *att, *hact, *hf;
     float *meanf, *rstdf;
     int* last;
     float* scratch;
     size_t scratch_bytes;
+    char* x3;              // bf16x3 build: operand-image scratch (gemm_api.h)
+    size_t x3_bytes;
     size_t bytes;
 };
 void dec_carve(const cc_gpt2_cfg* c, int R, int Tn, void* ws, DecWS& w) {
@@ -549,16 +551,18 @@ void dec_carve(const cc_gpt2_cfg* c, int R, int Tn, void* ws, DecWS& w) {
     const size_t M = (size_t)R * Tn, D = c->D;
     w.x = (float*)take(M * D * 4);
     w.x1 = (float*)take(M * D * 4);
-    w.xn = (op16_t*)take(M * D * 2);
-    w.qkv = (op16_t*)take(M * 3 * D * 2);
-    w.att = (op16_t*)take(M * D * 2);
-    w.hact = (op16_t*)take(M * 4 * D * 2);
-    w.hf = (op16_t*)take((size_t)R * D * 2);
+    w.xn = (act_t*)take(M * D * sizeof(act_t));
+    w.qkv = (act_t*)take(M * 3 * D * sizeof(act_t));
+    w.att = (act_t*)take(M * D * sizeof(act_t));
+    w.hact = (act_t*)take(M * 4 * D * sizeof(act_t));
+    w.hf = (act_t*)take((size_t)R * D * sizeof(act_t));
     w.meanf = (float*)take((size_t)R * 4);
     w.rstdf = (float*)take((size_t)R * 4);
     w.last = (int*)take((size_t)R * 4);
     w.scratch_bytes = (size_t)8 * M * 4 * D * 4;   // up to 8 K-slices of the widest (4D) output
     w.scratch = (float*)take(w.scratch_bytes);
+    w.x3_bytes = kX3 ? ((M * 3 * 4 * D * sizeof(op16_t) + 255) & ~size_t(255)) : 0;      // the deepest A image: mlp.c_proj, K = 4D
+    w.x3 = kX3 ? take(w.x3_bytes) : nullptr;
     w.bytes = (off + 255) & ~size_t(255);
 }
 
@@ -587,6 +591,10 @@ int CC_API(cc_decode_fwd)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t p
     hipStream_t st = S_(stream);
     DecWS w;
     dec_carve(c, R, Tn, ws, w);
+#if CC_OP == 2
+    x3_set_scratch(w.x3, w.x3_bytes);
+#endif
+    constexpr int PL = kX3 ? 3 : 1;          // operand-arena addressing as in api.hip (W16): bf16x3 weights own 3x the elements at 3x the offset
     const int D = c->D, M = R * Tn, H = c->H, hd = D / H;
     // arena offsets (same order as api.hip::gpt2_offsets)
     int64_t p = 0;
@@ -598,7 +606,7 @@ int CC_API(cc_decode_fwd)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t p
     }
     const size_t cache_layer = (size_t)2 * R * ctx_max * D;
     const int64_t total = (int64_t)c->Vp * D + (int64_t)c->NPOS * D + (int64_t)c->NL * (12 * (int64_t)D * D + 13 * (int64_t)D) + 2 * D;
-    const uint16_t* w16t = w16 + total;   // transposed Conv1D weights (cc_gpt2_sync_weights): forward GEMMs are NT
+    const uint16_t* w16t = w16 + (size_t)PL * total;   // transposed Conv1D weights (cc_gpt2_sync_weights): forward GEMMs are NT
     const float scale = 1.0f / sqrtf((float)hd);
     bool xn_ready = false;
     for (int l = 0; l < c->NL; l++) {
@@ -614,8 +622,8 @@ int CC_API(cc_decode_fwd)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t p
         const int64_t fb = p; p += 4 * D;
         const int64_t p2w = p; p += (int64_t)4 * D * D;
         const int64_t p2b = p; p += D;
-        op16_t* kc = kv + (size_t)l * cache_layer;
-        op16_t* vc = kc + (size_t)R * ctx_max * D;
+        act_t* kc = reinterpret_cast<act_t*>(kv) + (size_t)l * cache_layer;     // (bf16x3: the cache holds fp32, twice the bytes)
+        act_t* vc = kc + (size_t)R * ctx_max * D;
         // xn = ln_1(x): produced by the previous layer's fused finish when possible
         if (!xn_ready) CC_TRY(ln_fwd(w.x, D, nullptr, w32 + l1w, w32 + l1b, w.xn, nullptr, nullptr, nullptr, M, D, st));
         // c_attn (+ fused KV append into the cache)
@@ -623,7 +631,7 @@ int CC_API(cc_decode_fwd)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t p
                            ((M + 127) / 128) * ((3 * D + 127) / 128) < skinny_single_min_tiles();
         SkinnyFuse fq;
         fq.kcache = kc; fq.vcache = vc; fq.Tn = Tn; fq.pos0 = pos0; fq.ctx_max = ctx_max;
-        CC_TRY(gemm_nt_skinny(w.xn, D, w16t + aw, D, M, 3 * D, D, w32 + ab, 0, nullptr, nullptr, w.qkv, 3 * D, w.scratch, w.scratch_bytes, st,
+        CC_TRY(gemm_nt_skinny(w.xn, D, w16t + (size_t)PL * aw, D, M, 3 * D, D, w32 + ab, 0, nullptr, nullptr, w.qkv, 3 * D, w.scratch, w.scratch_bytes, st,
                               f_qkv ? &fq : nullptr));
         {
             const int nw = R * H * Tn;
@@ -637,21 +645,21 @@ int CC_API(cc_decode_fwd)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t p
         const bool f_d = gemm_nt_skinny_can_fuse(M, D, D, w.scratch_bytes) && gemm_nt_skinny_can_fuse(M, D, 4 * D, w.scratch_bytes);
         SkinnyFuse f2;
         f2.ln_gamma = w32 + l2w; f2.ln_beta = w32 + l2b; f2.ln_out16 = w.xn;
-        CC_TRY(gemm_nt_skinny(w.att, D, w16t + pw, D, M, D, D, w32 + pb, 0, w.x, w.x1, nullptr, D, w.scratch, w.scratch_bytes, st, f_d ? &f2 : nullptr));
+        CC_TRY(gemm_nt_skinny(w.att, D, w16t + (size_t)PL * pw, D, M, D, D, w32 + pb, 0, w.x, w.x1, nullptr, D, w.scratch, w.scratch_bytes, st, f_d ? &f2 : nullptr));
         if (!f_d) CC_TRY(ln_fwd(w.x1, D, nullptr, w32 + l2w, w32 + l2b, w.xn, nullptr, nullptr, nullptr, M, D, st));
-        CC_TRY(gemm_nt_skinny(w.xn, D, w16t + fw, D, M, 4 * D, D, w32 + fb, 2, nullptr, nullptr, w.hact, 4 * D, w.scratch, w.scratch_bytes, st));
+        CC_TRY(gemm_nt_skinny(w.xn, D, w16t + (size_t)PL * fw, D, M, 4 * D, D, w32 + fb, 2, nullptr, nullptr, w.hact, 4 * D, w.scratch, w.scratch_bytes, st));
         // mlp.c_proj + residual (+ fused ln_1 of the next layer: its parameters sit right behind this layer's in the arena)
         const bool f_next = f_d && l + 1 < c->NL;
         SkinnyFuse f1;
         f1.ln_gamma = w32 + p; f1.ln_beta = w32 + p + D; f1.ln_out16 = w.xn;       // p now points at layer l+1's ln_1.weight
-        CC_TRY(gemm_nt_skinny(w.hact, 4 * D, w16t + p2w, 4 * D, M, D, 4 * D, w32 + p2b, 0, w.x1, w.x, nullptr, D, w.scratch, w.scratch_bytes, st,
+        CC_TRY(gemm_nt_skinny(w.hact, 4 * D, w16t + (size_t)PL * p2w, 4 * D, M, D, 4 * D, w32 + p2b, 0, w.x1, w.x, nullptr, D, w.scratch, w.scratch_bytes, st,
                               f_next ? &f1 : nullptr));
         xn_ready = f_next;
     }
     const int64_t lnf_w = p, lnf_b = p + D;
     hipLaunchKernelGGL(k_last_rows, dim3((R + 255) / 256), dim3(256), 0, st, w.last, R, Tn);
     CC_TRY(ln_fwd(w.x, D, w.last, w32 + lnf_w, w32 + lnf_b, w.hf, nullptr, w.meanf, w.rstdf, R, D, st));
-    CC_TRY(gemm_f32out(0, 0, w.hf, D, w16 + wte, D, R, Ns, D, logits, (int)ldl, nullptr, 0, 1.0f, 1, st));
+    CC_TRY(gemm_f32out(0, 0, w.hf, D, w16 + (size_t)PL * wte, D, R, Ns, D, logits, (int)ldl, nullptr, 0, 1.0f, 1, st));
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
 
@@ -659,8 +667,9 @@ int CC_API(cc_decode_reorder)(const cc_gpt2_cfg* c, int32_t R_src, int32_t R_dst
                       const int32_t* src, void* stream) {
     if (!cfg_ok(c) || R_src <= 0 || R_dst <= 0 || ctx < 0 || ctx > ctx_max || !kv_src || !kv_dst || !src || kv_src == kv_dst) return CC_ERR_ARG;
     if (ctx == 0) return CC_OK;
-    const size_t total = (size_t)c->NL * 2 * R_dst * ctx * (c->D >> 3);
-    hipLaunchKernelGGL(k_kv_reorder, dim3((int)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, S_(stream), kv_src, kv_dst, src, R_src,
+    const size_t total = (size_t)c->NL * 2 * R_dst * ctx * (c->D * sizeof(act_t) / 16);
+    hipLaunchKernelGGL(k_kv_reorder, dim3((int)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, S_(stream),
+                       reinterpret_cast<const act_t*>(kv_src), reinterpret_cast<act_t*>(kv_dst), src, R_src,
                        R_dst, ctx, ctx_max, c->D, c->NL * 2);
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }

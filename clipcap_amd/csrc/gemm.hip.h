@@ -1136,8 +1136,8 @@ __device__ __forceinline__ void load_bias8(const float* bias, int col, int Ns, f
 }
 
 struct EpiBF16 {
-    op16_t* C;
-    op16_t* pre;        // nullable
+    act_t* C;
+    act_t* pre;         // nullable
     const float* bias;  // nullable
     int ldc, M, Ns;     // Ns: columns to store (multiple of 8)
     int act;            // 0 none, 1 relu, 2 gelu_new
@@ -1148,7 +1148,7 @@ struct EpiBF16 {
             const float4 b1 = *reinterpret_cast<const float4*>(bias + col + 4);
             v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
         }
-        if (pre) *reinterpret_cast<uint4*>(pre + (size_t)row * ldc + col) = pack8(v);
+        if (pre) act_st8(pre + (size_t)row * ldc + col, v);
         if (act == 1) {
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
@@ -1156,7 +1156,7 @@ struct EpiBF16 {
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] = gelu_new_f(v[e]);
         }
-        *reinterpret_cast<uint4*>(C + (size_t)row * ldc + col) = pack8(v);
+        act_st8(C + (size_t)row * ldc + col, v);
     }
     // Split form for the 256-row kernels (see gemm_nt_stag256_kernel): every global LOAD of the epilogue happens before its first
     // STORE — with loads and stores both pending on the one vmcnt counter the compiler must wait vmcnt(0), i.e. drain the store
@@ -1169,7 +1169,7 @@ struct EpiBF16 {
         if (row >= M || col >= Ns) return;
 #pragma unroll
         for (int e = 0; e < 8; e++) v[e] += b[e];
-        if (pre) *reinterpret_cast<uint4*>(pre + (size_t)row * ldc + col) = pack8(v);
+        if (pre) act_st8(pre + (size_t)row * ldc + col, v);
         if (act == 1) {
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
@@ -1177,7 +1177,7 @@ struct EpiBF16 {
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] = gelu_new_f(v[e]);
         }
-        *reinterpret_cast<uint4*>(C + (size_t)row * ldc + col) = pack8(v);
+        act_st8(C + (size_t)row * ldc + col, v);
     }
 };
 
@@ -1292,15 +1292,15 @@ struct EpiF32 {
 
 // C(bf16) = acc * act'(aux)   (dgrad through relu: aux = post-activation h; through gelu_new: aux = pre-activation u)
 struct EpiDAct {
-    op16_t* C;
-    const op16_t* aux;
+    act_t* C;
+    const act_t* aux;
     int ldc, M, Ns;
     int act;  // 1 relu, 2 gelu_new
     __device__ __forceinline__ void operator()(int row, int col, float (&v)[8]) const {
         if (row >= M || col >= Ns) return;
         const size_t o = (size_t)row * ldc + col;
         float a[8];
-        unpack8(*reinterpret_cast<const uint4*>(aux + o), a);
+        act_ld8(aux + o, a);
         if (act == 1) {
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] = a[e] > 0.f ? v[e] : 0.f;
@@ -1308,16 +1308,16 @@ struct EpiDAct {
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] *= gelu_new_grad(a[e]);
         }
-        *reinterpret_cast<uint4*>(C + o) = pack8(v);
+        act_st8(C + o, v);
     }
-    typedef uint4 StripAux;                                                           // 128 x 128 strip epilogue: aux fetched up front
-    __device__ __forceinline__ uint4 load_aux(int row, int col) const {
-        return (row < M && col < Ns) ? *reinterpret_cast<const uint4*>(aux + (size_t)row * ldc + col) : make_uint4(0, 0, 0, 0);
+    typedef act_raw8 StripAux;                                                        // 128 x 128 strip epilogue: aux fetched up front
+    __device__ __forceinline__ act_raw8 load_aux(int row, int col) const {
+        return (row < M && col < Ns) ? act_ldraw8(aux + (size_t)row * ldc + col) : act_zero8();
     }
-    __device__ __forceinline__ void operator()(int row, int col, float (&v)[8], const uint4& ax) const {
+    __device__ __forceinline__ void operator()(int row, int col, float (&v)[8], const act_raw8& ax) const {
         if (row >= M || col >= Ns) return;
         float a[8];
-        unpack8(ax, a);
+        act_unpack8(ax, a);
         if (act == 1) {
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] = a[e] > 0.f ? v[e] : 0.f;
@@ -1325,15 +1325,13 @@ struct EpiDAct {
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] *= gelu_new_grad(a[e]);
         }
-        *reinterpret_cast<uint4*>(C + (size_t)row * ldc + col) = pack8(v);
+        act_st8(C + (size_t)row * ldc + col, v);
     }
     static constexpr bool kPre = true;
     __device__ __forceinline__ void pre4(int row, int col, f32x4& a) const {        // acc *= act'(aux)
         if (row >= M || col >= Ns) return;
-        const uint2 u = *reinterpret_cast<const uint2*>(aux + (size_t)row * ldc + col);
         float x[4];
-        unpack2(u.x, x[0], x[1]);
-        unpack2(u.y, x[2], x[3]);
+        act_unpack4(act_ldraw4(aux + (size_t)row * ldc + col), x[0], x[1], x[2], x[3]);
 #pragma unroll
         for (int e = 0; e < 4; e++) a[e] = act == 1 ? (x[e] > 0.f ? a[e] : 0.f) : a[e] * gelu_new_grad(x[e]);
     }
@@ -1343,13 +1341,13 @@ struct EpiDAct {
     }
     __device__ __forceinline__ void fin(int row, int col, float (&v)[8], const float (&)[8]) const {
         if (row >= M || col >= Ns) return;
-        *reinterpret_cast<uint4*>(C + (size_t)row * ldc + col) = pack8(v);
+        act_st8(C + (size_t)row * ldc + col, v);
     }
 };
 
 // lm_head: bf16 logits + per-(row, 64-column block) softmax partials from the fp32 accumulators + exact target logit.
 struct EpiLMHead {
-    op16_t* C;
+    act_t* C;
     float* pmax;
     float* psum;           // [M][npart]
     const int* target;     // [M] token id per row (>=0)
@@ -1380,7 +1378,7 @@ struct EpiLMHead {
         }
         const int t = target[row] - col;
         if (t >= 0 && t < 8) tgt_logit[row] = v[t];
-        *reinterpret_cast<uint4*>(C + (size_t)row * ldc + col) = pack8(v);
+        act_st8(C + (size_t)row * ldc + col, v);
     }
     // 256-row kernels: the lane holds columns ca..ca+7 and cb..cb+7 of `row`; lanes l, l^16, l^32, l^48 together hold the row's
     // aligned 64-column block (all lanes of the wave must call this).
@@ -1421,11 +1419,11 @@ struct EpiLMHead {
         }
         if (ca < ldc) {
             if (t >= ca && t < ca + 8) tgt_logit[row] = va[t - ca];
-            *reinterpret_cast<uint4*>(C + (size_t)row * ldc + ca) = pack8(va);
+            act_st8(C + (size_t)row * ldc + ca, va);
         }
         if (cb < ldc) {
             if (t >= cb && t < cb + 8) tgt_logit[row] = vb[t - cb];
-            *reinterpret_cast<uint4*>(C + (size_t)row * ldc + cb) = pack8(vb);
+            act_st8(C + (size_t)row * ldc + cb, vb);
         }
     }
 };

@@ -9,17 +9,43 @@ namespace CC_NS {
 // skinny kernel (env CC_GEMM_S64); g_gemm_small_x2: small-grid NT GEMMs on the 8-wave kernel (env CC_GEMM_X2, default 1).  All three
 // are test / microbenchmark hooks living in shared.cpp.
 // al/bl: 0 = K-contiguous operand ([rows][K]), 1 = K-strided operand ([K][rows]).  See gemm.hip.h.
-int gemm_bf16out(int al, int bl, const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, op16_t* C, int ldc,
-                 const float* bias, int act, op16_t* pre, hipStream_t st);
-int gemm_resid(int al, int bl, const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, float* out, const float* res,
+//
+// Operand types.  A is an ACTIVATION (act_t), B a WEIGHT from the 16-bit operand arena, C / pre / aux activations again.  In the bf16 /
+// fp16 builds act_t is the 16-bit operand type and the calls are what they say.  In the bf16x3 build (common.hip.h) activations are
+// fp32: every wrapper below first splits A into its [hi | hi | lo] operand image in the call's scratch (x3_set_scratch, set by the
+// C-ABI entry point from its workspace), B is the pre-split [hi | lo | hi] image the weight sync left in the operand arena
+// (row stride 3 * ldb), and the unchanged NT kernels run with K' = 3 K.  Callers pass the LOGICAL lda / ldb / K in every build.
+// Only al = bl = 0 is supported there.
+int gemm_bf16out(int al, int bl, const act_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, act_t* C, int ldc,
+                 const float* bias, int act, act_t* pre, hipStream_t st);
+int gemm_resid(int al, int bl, const act_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, float* out, const float* res,
                int ld, const float* bias, hipStream_t st, Drop drop = Drop());
 // mode 0 store (+bias), 1 add, 2 atomic add (required when ksplit > 1)
-int gemm_f32out(int al, int bl, const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, float* C, int ldc,
+int gemm_f32out(int al, int bl, const act_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, float* C, int ldc,
                 const float* bias, int mode, float alpha, int ksplit, hipStream_t st);
-int gemm_dact(int al, int bl, const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, op16_t* C, int ldc,
-              const op16_t* aux, int act, hipStream_t st);
-int gemm_lmhead(const op16_t* A, int lda, const op16_t* B, int ldb, int M, int Vp, int V, int K, op16_t* C, int ldc, float* pmax,
+int gemm_dact(int al, int bl, const act_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, act_t* C, int ldc,
+              const act_t* aux, int act, hipStream_t st);
+int gemm_lmhead(const act_t* A, int lda, const op16_t* B, int ldb, int M, int Vp, int V, int K, act_t* C, int ldc, float* pmax,
                 float* psum, int npart, const int* target, float* tgt_logit, hipStream_t st);
+
+#if CC_OP == 2
+// bf16x3: scratch for the operand images of the GEMM being launched (stream order makes reuse by the next GEMM safe).  Thread-local:
+// the C ABI stays re-entrant across host threads / streams; every compute entry point sets it from its own workspace.
+void x3_set_scratch(void* base, size_t bytes);
+// split `rows` x `width` fp32 (row stride ld) into the scratch: form 0 = [hi | hi | lo] (A side), 1 = [hi | lo | hi] (B side).
+// first = true restarts the scratch (one GEMM's operands live there at a time).  Returns nullptr (rc set) when it does not fit.
+const op16_t* x3_operand(const float* src, size_t ld, int rows, int width, int form, bool first, hipStream_t st, int* rc);
+#define CC_X3_NT(A, lda, ldb, M, K, A16, al, bl, st)                                      \
+    {                                                                                     \
+        if ((al) || (bl)) return CC_ERR_ARG;                                              \
+        int rc_ = CC_OK;                                                                  \
+        A16 = x3_operand(A, (size_t)(lda), M, K, 0, true, st, &rc_);                      \
+        if (!A16) return rc_;                                                             \
+        lda = 3 * (K); ldb = 3 * (ldb); K = 3 * (K);                                      \
+    }
+#else
+#define CC_X3_NT(A, lda, ldb, M, K, A16, al, bl, st) A16 = A;
+#endif
 // weight gradient dW[Mw][Nw] += X^T Y with X stored [K][Mw], Y stored [K][Nw].  Split-K for occupancy: the K slices
 // write fp32 slabs into `scratch` (plain stores) and a second kernel folds them into dW — fp32 atomics on the same
 // tile from 7-14 concurrent blocks measured 3x slower than the whole GEMM (profiles/r01_b_gemm_microbench.md).
@@ -36,13 +62,13 @@ struct WgradBatch {
     // and run by wgrad_flush as ONE grouped launch (gemm_tt_glds4_group_kernel) + one slab reduce.  The caller must keep every
     // operand unchanged until the flush.
     bool defer = false;
-    struct Deferred { const op16_t* X; const op16_t* Y; int ldx, ldy, Mw, Nw, K; float* dW; int ldw; };
+    struct Deferred { const op16_t* X; const op16_t* Y; int ldx, ldy, Mw, Nw, K; float* dW; int ldw; };      // (never used in the bf16x3 build: operands are split per call)
     Deferred d[4];
     int nd = 0;
     float* scratch = nullptr;
 };
 int wgrad_flush(WgradBatch& b, hipStream_t st);
-int gemm_wgrad(const op16_t* X, int ldx, const op16_t* Y, int ldy, int Mw, int Nw, int K, float* dW, int ldw, float* scratch,
+int gemm_wgrad(const act_t* X, int ldx, const act_t* Y, int ldy, int Mw, int Nw, int K, float* dW, int ldw, float* scratch,
                hipStream_t st, WgradBatch* batch = nullptr);
 // Skinny-M NT GEMMs (KV-cached decode: M = beams x samples, a handful of 128x128 tiles): split K over blockIdx.z so every CU
 // streams a distinct slice of the weights, fp32 slabs in `scratch`, then ONE finishing kernel sums the slabs and applies the
@@ -52,18 +78,18 @@ int gemm_wgrad(const op16_t* X, int ldx, const op16_t* Y, int ldy, int Mw, int N
 struct SkinnyFuse {
     const float* ln_gamma = nullptr;   // LayerNorm over the N columns of (acc + bias + res): out -> ln_out16 [M, N]
     const float* ln_beta = nullptr;
-    op16_t* ln_out16 = nullptr;
-    op16_t* kcache = nullptr;          // qkv rows (N == 3*D): columns [D,2D) -> kcache, [2D,3D) -> vcache at (r*ctx_max + pos0 + t)*D
-    op16_t* vcache = nullptr;
+    act_t* ln_out16 = nullptr;
+    act_t* kcache = nullptr;           // qkv rows (N == 3*D): columns [D,2D) -> kcache, [2D,3D) -> vcache at (r*ctx_max + pos0 + t)*D
+    act_t* vcache = nullptr;
     int Tn = 1, pos0 = 0, ctx_max = 0;
 };
-int gemm_nt_skinny(const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, const float* bias, int act, const float* res,
-                   float* out32, op16_t* out16, int ldo, float* scratch, size_t scratch_bytes, hipStream_t st,
+int gemm_nt_skinny(const act_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, const float* bias, int act, const float* res,
+                   float* out32, act_t* out16, int ldo, float* scratch, size_t scratch_bytes, hipStream_t st,
                    const SkinnyFuse* fuse = nullptr);
 // Narrow output, very deep K (the lm_head input gradient: [B*cap, Vp] x [Vp, D] -> 10240 x 768 over K = 50304): the 256 x 256 kernel on
 // 120 tiles leaves half the chip idle, so K is cut into as many slices as fill the CUs (fp32 slabs in `scratch`), and one elementwise
 // pass sums the slabs into the 16-bit output.  Returns CC_ERR_SHAPE when the shape does not call for it (caller then uses gemm_bf16out).
-int gemm_nt_deepk(const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, op16_t* out16, int ldo, float* scratch,
+int gemm_nt_deepk(const act_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, act_t* out16, int ldo, float* scratch,
                   size_t scratch_bytes, hipStream_t st);
 int skinny_single_min_tiles();   // grids of at least this many 128 x 128 tiles skip split-K (CC_SKINNY_SINGLE; tuning knob)
 // whether gemm_nt_skinny will take the slab + row-finish path for this problem (the only path that supports SkinnyFuse)

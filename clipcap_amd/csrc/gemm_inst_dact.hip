@@ -1,11 +1,13 @@
 #include "gemm.hip.h"
 #include "gemm_api.h"
 namespace CC_NS {
-int gemm_dact(int al, int bl, const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, op16_t* C, int ldc,
-              const op16_t* aux, int act, hipStream_t st) {
+int gemm_dact(int al, int bl, const act_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, act_t* C, int ldc,
+              const act_t* aux, int act, hipStream_t st) {
     cc_shared::ProfScope _all(cc_shared::SITE_ALL_GEMMS, st, 2.0 * M * N * (double)K);
     if ((ldc & 7) || (N & 7)) return CC_ERR_SHAPE;
+    const op16_t* A16;
+    CC_X3_NT(A, lda, ldb, M, K, A16, al, bl, st);
     EpiDAct e{C, aux, ldc, M, N, act};
-    return launch_gemm(al, bl, A, lda, B, ldb, M, N, K, 1, e, st);
+    return launch_gemm(al, bl, A16, lda, B, ldb, M, N, K, 1, e, st);
 }
 }  // namespace CC_NS

@@ -4,13 +4,20 @@
 #include <algorithm>
 #include "gemm_api.h"
 namespace CC_NS {
-int gemm_f32out(int al, int bl, const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, float* C, int ldc,
-                const float* bias, int mode, float alpha, int ksplit, hipStream_t st) {
-    cc_shared::ProfScope _all(cc_shared::SITE_ALL_GEMMS, st, 2.0 * M * N * (double)K);
+// both operands already in the 16-bit operand form (in the bf16x3 build: their hi / lo images, K = 3 x the logical depth)
+static int gemm_f32out_op(int al, int bl, const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, float* C, int ldc,
+                          const float* bias, int mode, float alpha, int ksplit, hipStream_t st) {
     if ((ldc & 3) || (N & 7)) return CC_ERR_SHAPE;
     if (ksplit > 1 && mode != 2) return CC_ERR_ARG;  // slab mode (3) is reached through gemm_wgrad only
     EpiF32 e{C, bias, ldc, M, N, mode, alpha};
     return launch_gemm(al, bl, A, lda, B, ldb, M, N, K, ksplit, e, st);
+}
+int gemm_f32out(int al, int bl, const act_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, float* C, int ldc,
+                const float* bias, int mode, float alpha, int ksplit, hipStream_t st) {
+    cc_shared::ProfScope _all(cc_shared::SITE_ALL_GEMMS, st, 2.0 * M * N * (double)K);
+    const op16_t* A16;
+    CC_X3_NT(A, lda, ldb, M, K, A16, al, bl, st);
+    return gemm_f32out_op(al, bl, A16, lda, B, ldb, M, N, K, C, ldc, bias, mode, alpha, ksplit, st);
 }
 __global__ __launch_bounds__(256) void k_slab_reduce(const float* __restrict__ slabs, size_t slab_elems, int ks, int Nw, float* __restrict__ dW,
                                                      int ldw, size_t n4) {
@@ -129,9 +136,27 @@ static int wgrad_reduce(const float* slabs, size_t slab, int ks, int Nw, float* 
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
 
-int gemm_wgrad(const op16_t* X, int ldx, const op16_t* Y, int ldy, int Mw, int Nw, int K, float* dW, int ldw, float* scratch,
+int gemm_wgrad(const act_t* Xa, int ldx, const act_t* Ya, int ldy, int Mw, int Nw, int K, float* dW, int ldw, float* scratch,
                hipStream_t st, WgradBatch* batch) {
     if ((Nw & 7) || (ldw & 3)) return CC_ERR_SHAPE;
+    const double flops = 2.0 * Mw * Nw * (double)K;
+#if CC_OP == 2
+    // bf16x3: dW = X^T Y = Xhi^T Yhi + Xhi^T Ylo + Xlo^T Yhi.  The [K][3 Mw] image [hi | hi | lo] of X, read as a [3K][Mw] matrix, has
+    // rows (hi, hi, lo) per source row, the [hi | lo | hi] image of Y rows (hi, lo, hi): the unchanged kernels contract over K' = 3K.
+    // The images live in the call's scratch, so nothing can be deferred to a grouped launch.
+    if (Mw & 7) return CC_ERR_SHAPE;
+    int rcx = CC_OK;
+    const op16_t* X = x3_operand(Xa, (size_t)ldx, K, Mw, 0, true, st, &rcx);
+    if (!X) return rcx;
+    const op16_t* Y = x3_operand(Ya, (size_t)ldy, K, Nw, 1, false, st, &rcx);
+    if (!Y) return rcx;
+    ldx = Mw; ldy = Nw; K *= 3;
+    const bool may_defer = false;
+#else
+    const op16_t* X = Xa;
+    const op16_t* Y = Ya;
+    const bool may_defer = true;
+#endif
     const size_t slab = (size_t)Mw * Nw;
     // the DMA-staged TT kernels need 16-B aligned operands and row strides; anything else takes the register-staged kernel
     const bool tt_ok = (Mw & 7) == 0 && (ldx & 7) == 0 && (ldy & 7) == 0 && ((uintptr_t)X & 15) == 0 && ((uintptr_t)Y & 15) == 0;
@@ -141,14 +166,14 @@ int gemm_wgrad(const op16_t* X, int ldx, const op16_t* Y, int ldy, int Mw, int N
         if (rcf != CC_OK) return rcf;
     }
     // grouped path: park the problem; wgrad_flush launches the layer's gradients together (one tail, one launch floor)
-    if (batch && batch->defer && g_gemm_tile_mode != 0 && tt_ok && scratch && (K % G_BK) == 0 && K >= 1024 && (slab & 3) == 0 &&
+    if (may_defer && batch && batch->defer && g_gemm_tile_mode != 0 && tt_ok && scratch && (K % G_BK) == 0 && K >= 1024 && (slab & 3) == 0 &&
         (batch->nd == 0 || batch->d[0].K == K)) {
         if (batch->nd == 4 || batch->n + batch->nd >= 8) { const int rcf = wgrad_flush(*batch, st); if (rcf != CC_OK) return rcf; }
         batch->scratch = scratch;
         batch->d[batch->nd++] = WgradBatch::Deferred{X, Y, ldx, ldy, Mw, Nw, K, dW, ldw};
         return CC_OK;
     }
-    cc_shared::ProfScope _all(cc_shared::SITE_ALL_GEMMS, st, 2.0 * Mw * Nw * (double)K);
+    cc_shared::ProfScope _all(cc_shared::SITE_ALL_GEMMS, st, flops);
     const size_t used = (batch && scratch) ? batch->used : 0;
     float* sc = scratch ? scratch + used / sizeof(float) : nullptr;
     const size_t fit = scratch ? (WGRAD_SCRATCH_BYTES - used) / (slab * sizeof(float)) : 1;
@@ -189,7 +214,7 @@ int gemm_wgrad(const op16_t* X, int ldx, const op16_t* Y, int ldy, int Mw, int N
     const int kmax = (K + 255) / 256;  // at least 4 K-steps per slice
     if (ks > kmax) ks = kmax;
     if (scratch) { if ((size_t)ks > fit) ks = (int)fit; } else ks = 1;
-    if (ks <= 1) return gemm_f32out(1, 1, X, ldx, Y, ldy, Mw, Nw, K, dW, ldw, nullptr, 1, 1.0f, 1, st);
+    if (ks <= 1) return gemm_f32out_op(1, 1, X, ldx, Y, ldy, Mw, Nw, K, dW, ldw, nullptr, 1, 1.0f, 1, st);
     // slices z write slab z (EpiF32 store mode; C pointer advanced per z inside the kernel via blockIdx.z * slab)
     EpiF32 e{sc, nullptr, Nw, Mw, Nw, 3, 1.0f};
     e.zstride = slab;
@@ -203,7 +228,7 @@ int gemm_wgrad(const op16_t* X, int ldx, const op16_t* Y, int ldy, int Mw, int N
 
 __global__ __launch_bounds__(256) void k_splitk_finish(const float* __restrict__ slabs, size_t slab_elems, int ks, int M, int N,
                                                        const float* __restrict__ bias, int act, const float* __restrict__ res,
-                                                       float* __restrict__ out32, op16_t* __restrict__ out16, int ldo) {
+                                                       float* __restrict__ out32, act_t* __restrict__ out16, int ldo) {
     const size_t n8 = (size_t)M * (N >> 3);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
         const int row = (int)(i / (N >> 3)), col = (int)(i % (N >> 3)) * 8;
@@ -234,7 +259,7 @@ __global__ __launch_bounds__(256) void k_splitk_finish(const float* __restrict__
             *reinterpret_cast<float4*>(out32 + o) = make_float4(v[0], v[1], v[2], v[3]);
             *reinterpret_cast<float4*>(out32 + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
         }
-        if (out16) *reinterpret_cast<uint4*>(out16 + o) = pack8(v);
+        if (out16) act_st8(out16 + o, v);
     }
 }
 
@@ -251,7 +276,7 @@ __device__ __forceinline__ float block_sum256(float v, float* red) {
 
 __global__ __launch_bounds__(256) void k_splitk_finish_row(const float* __restrict__ slabs, size_t slab_elems, int ks, int M, int N,
                                                            const float* __restrict__ bias, int act, const float* __restrict__ res,
-                                                           float* __restrict__ out32, op16_t* __restrict__ out16, int ldo, SkinnyFuse f) {
+                                                           float* __restrict__ out32, act_t* __restrict__ out16, int ldo, SkinnyFuse f) {
     __shared__ float red[4];
     const int row = blockIdx.x;
     constexpr int MAXV = 3;                // float4 per thread -> N <= 3072
@@ -298,14 +323,14 @@ __global__ __launch_bounds__(256) void k_splitk_finish_row(const float* __restri
             const size_t o = (size_t)row * ldo + c;
             a.x += rr.x; a.y += rr.y; a.z += rr.z; a.w += rr.w;
             if (out32) *reinterpret_cast<float4*>(out32 + o) = a;
-            const uint2 pk = make_uint2(pack2op(a.x, a.y), pack2op(a.z, a.w));
-            if (out16) *reinterpret_cast<uint2*>(out16 + o) = pk;
+            const act_raw4 pk = act_pack4(a.x, a.y, a.z, a.w);
+            if (out16) act_straw4(out16 + o, pk);
             if (f.kcache) {                   // N == 3*D
                 const int D = N / 3, which = c / D, cc_ = c - which * D;
                 if (which > 0) {
                     const int r = row / f.Tn, t = row - r * f.Tn;
-                    op16_t* dst = (which == 1 ? f.kcache : f.vcache) + ((size_t)r * f.ctx_max + f.pos0 + t) * D + cc_;
-                    *reinterpret_cast<uint2*>(dst) = pk;
+                    act_t* dst = (which == 1 ? f.kcache : f.vcache) + ((size_t)r * f.ctx_max + f.pos0 + t) * D + cc_;
+                    act_straw4(dst, pk);
                 }
             }
             v[it] = a;
@@ -326,9 +351,8 @@ __global__ __launch_bounds__(256) void k_splitk_finish_row(const float* __restri
         const int c = threadIdx.x * 4 + it * 1024;
         if (c < N) {
             const float4 g = lg_[it], b = lb_[it];
-            *reinterpret_cast<uint2*>(f.ln_out16 + (size_t)row * N + c) =
-                make_uint2(pack2op((v[it].x - mu) * rs * g.x + b.x, (v[it].y - mu) * rs * g.y + b.y),
-                           pack2op((v[it].z - mu) * rs * g.z + b.z, (v[it].w - mu) * rs * g.w + b.w));
+            act_st4(f.ln_out16 + (size_t)row * N + c, (v[it].x - mu) * rs * g.x + b.x, (v[it].y - mu) * rs * g.y + b.y,
+                    (v[it].z - mu) * rs * g.z + b.z, (v[it].w - mu) * rs * g.w + b.w);
         }
     }
 }
@@ -341,7 +365,7 @@ bool gemm_nt_skinny_can_fuse(int M, int N, int K, size_t scratch_bytes) {
     return M > 0 && N > 0 && (N & 7) == 0 && N <= 3072 && (K % G_BK) == 0 && scratch_bytes >= (size_t)M * N * sizeof(float);
 }
 
-int gemm_nt_deepk(const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, op16_t* out16, int ldo, float* scratch,
+int gemm_nt_deepk(const act_t* Aa, int lda, const op16_t* B, int ldb, int M, int N, int K, act_t* out16, int ldo, float* scratch,
                   size_t scratch_bytes, hipStream_t st) {
     static const int knob = []() { const char* e = getenv("CC_DEEPK"); return e ? atoi(e) : -1; }();   // 0 = off, n > 0 = force n slices
     if (knob == 0 || g_gemm_tile_mode == 0 || !scratch || (N & 7) || (ldo & 7) || (K % 64) || (lda & 7) || (ldb & 7)) return CC_ERR_SHAPE;
@@ -353,6 +377,8 @@ int gemm_nt_deepk(const op16_t* A, int lda, const op16_t* B, int ldb, int M, int
     if (ks > K / 2048) ks = K / 2048;                      // slices of at least 64 K-steps: below that the slab pass costs what the idle CUs gain
     if (ks < 2 || tiles > 128) return CC_ERR_SHAPE;
     cc_shared::ProfScope _all(cc_shared::SITE_ALL_GEMMS, st, 2.0 * M * N * (double)K);
+    const op16_t* A;
+    CC_X3_NT(Aa, lda, ldb, M, K, A, 0, 0, st);
     EpiF32 e{scratch, nullptr, N, M, N, 3, 1.0f};
     e.zstride = slab;
     // tile order: an XCD's share of the grid (tiles / 8 consecutive logical tiles per K slice) should hold whole row panels, so that the
@@ -368,10 +394,12 @@ int gemm_nt_deepk(const op16_t* A, int lda, const op16_t* B, int ldb, int M, int
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
 
-int gemm_nt_skinny(const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, const float* bias, int act, const float* res,
-                   float* out32, op16_t* out16, int ldo, float* scratch, size_t scratch_bytes, hipStream_t st, const SkinnyFuse* fuse) {
+int gemm_nt_skinny(const act_t* Aa, int lda, const op16_t* B, int ldb, int M, int N, int K, const float* bias, int act, const float* res,
+                   float* out32, act_t* out16, int ldo, float* scratch, size_t scratch_bytes, hipStream_t st, const SkinnyFuse* fuse) {
     cc_shared::ProfScope _all(cc_shared::SITE_ALL_GEMMS, st, 2.0 * M * N * (double)K);
     if ((N & 7) || (ldo & 7)) return CC_ERR_SHAPE;
+    const op16_t* A;
+    CC_X3_NT(Aa, lda, ldb, M, K, A, 0, 0, st);
     const int tiles = ((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
     const size_t slab = (size_t)M * N;
     const bool can_slab = scratch && slab && (K % G_BK) == 0 && scratch_bytes >= slab * sizeof(float);

@@ -1,11 +1,13 @@
 #include "gemm.hip.h"
 #include "gemm_api.h"
 namespace CC_NS {
-int gemm_resid(int al, int bl, const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, float* out, const float* res,
+int gemm_resid(int al, int bl, const act_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, float* out, const float* res,
                int ld, const float* bias, hipStream_t st, Drop drop) {
     cc_shared::ProfScope _all(cc_shared::SITE_ALL_GEMMS, st, 2.0 * M * N * (double)K);
     if ((ld & 7) || (N & 7)) return CC_ERR_SHAPE;
+    const op16_t* A16;
+    CC_X3_NT(A, lda, ldb, M, K, A16, al, bl, st);
     EpiResid e{out, res, bias, ld, M, N, drop};
-    return launch_gemm(al, bl, A, lda, B, ldb, M, N, K, 1, e, st);
+    return launch_gemm(al, bl, A16, lda, B, ldb, M, N, K, 1, e, st);
 }
 }  // namespace CC_NS

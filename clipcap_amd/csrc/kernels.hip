@@ -2,6 +2,7 @@
 // embedding assembly, softmax-cross-entropy pieces, column sums, AdamW, KV-cached decode attention and beam update.
 // All are wave64 code; memory accesses are 16-B vectors wherever the layout allows.
 #include "kernels.h"
+#include "gemm_api.h"
 
 namespace CC_NS {
 
@@ -24,8 +25,17 @@ int f32_to_bf16(const float* src, op16_t* dst, size_t n, hipStream_t st) {
     return CC_OK;
 }
 
+int f32_to_act(const float* src, act_t* dst, size_t n, hipStream_t st) {
+    if constexpr (kX3) {
+        if (!n) return CC_OK;
+        return hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st) == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+    } else {
+        return f32_to_bf16(src, reinterpret_cast<op16_t*>(dst), n, st);
+    }
+}
+
 // dst[b*dst_stride + i] = (bf16) src[b*src_stride + i], i < len (len % 8 == 0)
-__global__ void k_slice_f32_to_bf16(const float* __restrict__ src, size_t src_stride, op16_t* __restrict__ dst,
+__global__ void k_slice_f32_to_bf16(const float* __restrict__ src, size_t src_stride, act_t* __restrict__ dst,
                                     size_t dst_stride, int len8, int B) {
     const size_t total = (size_t)len8 * B;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -33,10 +43,10 @@ __global__ void k_slice_f32_to_bf16(const float* __restrict__ src, size_t src_st
         const float* s = src + b * src_stride + (size_t)c * 8;
         const float4 x = *reinterpret_cast<const float4*>(s), y = *reinterpret_cast<const float4*>(s + 4);
         float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
-        *reinterpret_cast<uint4*>(dst + b * dst_stride + (size_t)c * 8) = pack8(v);
+        act_st8(dst + b * dst_stride + (size_t)c * 8, v);
     }
 }
-int slice_f32_to_bf16(const float* src, size_t src_stride, op16_t* dst, size_t dst_stride, int len, int B, hipStream_t st) {
+int slice_f32_to_bf16(const float* src, size_t src_stride, act_t* dst, size_t dst_stride, int len, int B, hipStream_t st) {
     if (len & 7) return CC_ERR_SHAPE;
     const size_t total = (size_t)(len >> 3) * B;
     if (!total) return CC_OK;
@@ -207,7 +217,7 @@ constexpr int LN_MAXV = 8;  // float4 per lane -> D <= 2048
 template <int NV>   // float4 per lane actually used: D <= 256 NV (a run-time bound of 8 kept 8 x 4 registers live per array)
 __global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ x, int ldx, const int* __restrict__ row_map,
                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                op16_t* __restrict__ y, float* __restrict__ y32, float* __restrict__ mean,
+                                                act_t* __restrict__ y, float* __restrict__ y32, float* __restrict__ mean,
                                                 float* __restrict__ rstd, int rows, int D, float eps) {
     constexpr int R = NV <= 4 ? 2 : 1;       // rows per wave, loaded together: one row per wave is a chain of exposed round trips
     const int lane = threadIdx.x & 63;
@@ -262,13 +272,13 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ x, int
             if (c < D) {
                 const float o0 = (v[r][it].x - mu[r]) * rs[r] * g[it].x + bt[it].x, o1 = (v[r][it].y - mu[r]) * rs[r] * g[it].y + bt[it].y;
                 const float o2 = (v[r][it].z - mu[r]) * rs[r] * g[it].z + bt[it].z, o3 = (v[r][it].w - mu[r]) * rs[r] * g[it].w + bt[it].w;
-                if (y) *reinterpret_cast<uint2*>(y + (size_t)row * D + c) = make_uint2(pack2op(o0, o1), pack2op(o2, o3));
+                if (y) act_st4(y + (size_t)row * D + c, o0, o1, o2, o3);
                 if (y32) *reinterpret_cast<float4*>(y32 + (size_t)row * D + c) = make_float4(o0, o1, o2, o3);
             }
         }
     }
 }
-int ln_fwd(const float* x, int ldx, const int* row_map, const float* gamma, const float* beta, op16_t* y, float* y32,
+int ln_fwd(const float* x, int ldx, const int* row_map, const float* gamma, const float* beta, act_t* y, float* y32,
            float* mean, float* rstd, int rows, int D, hipStream_t st) {
     if (D > LN_MAXV * 256 || (D & 3) || (ldx & 3)) return CC_ERR_SHAPE;
     if (rows <= 0) return CC_OK;
@@ -286,11 +296,11 @@ int ln_fwd(const float* x, int ldx, const int* row_map, const float* gamma, cons
 // (column sums of the 16-bit values, exactly what k_colsum_bf16 on dx16 gives): one launch less per bias.
 // Each wave walks rows  row = blockIdx*4 + wave + k*gridDim*4.
 template <int NV, bool DG, int NW>   // NV as in k_ln_fwd; DG: accumulate dgamma / dbeta; NW waves per block
-__global__ __launch_bounds__(NW * 64) void k_ln_bwd(const op16_t* __restrict__ dy, const float* __restrict__ x, int ldx,
+__global__ __launch_bounds__(NW * 64) void k_ln_bwd(const act_t* __restrict__ dy, const float* __restrict__ x, int ldx,
                                                 const int* __restrict__ row_map, const float* __restrict__ mean,
                                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                 const float* __restrict__ dres, float* __restrict__ dx32,
-                                                op16_t* __restrict__ dx16, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                act_t* __restrict__ dx16, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                 float* __restrict__ dcol, int rows, int D, Drop dmask) {
     extern __shared__ __attribute__((aligned(16))) float ln_red[];  // [2][NW][D] when dgamma
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -305,7 +315,7 @@ __global__ __launch_bounds__(NW * 64) void k_ln_bwd(const op16_t* __restrict__ d
         const int c = lane * 4 + it * 256;
         gmv[it] = c < D ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(0, 0, 0, 0);
     }
-    struct RowIn { uint2 d[NV]; float4 xv[NV], rr[NV]; float mu, rs; size_t xr; };
+    struct RowIn { act_raw4 d[NV]; float4 xv[NV], rr[NV]; float mu, rs; size_t xr; };
     auto fetch = [&](int row, RowIn& r) {
         r.xr = (size_t)(row_map ? row_map[row] : row) * ldx;
         r.mu = mean[row]; r.rs = rstd[row];
@@ -313,7 +323,7 @@ __global__ __launch_bounds__(NW * 64) void k_ln_bwd(const op16_t* __restrict__ d
         for (int it = 0; it < NV; it++) {
             const int c = lane * 4 + it * 256;
             if (c < D) {
-                r.d[it] = *reinterpret_cast<const uint2*>(dy + (size_t)row * D + c);
+                r.d[it] = act_ldraw4(dy + (size_t)row * D + c);
                 r.xv[it] = *reinterpret_cast<const float4*>(x + r.xr + c);
                 r.rr[it] = dres ? *reinterpret_cast<const float4*>(dres + r.xr + c) : make_float4(0, 0, 0, 0);
             }
@@ -336,8 +346,7 @@ __global__ __launch_bounds__(NW * 64) void k_ln_bwd(const op16_t* __restrict__ d
             const int c = lane * 4 + it * 256;
             if (c < D) {
                 float d0, d1, d2, d3;
-                unpack2(cur.d[it].x, d0, d1);
-                unpack2(cur.d[it].y, d2, d3);
+                act_unpack4(cur.d[it], d0, d1, d2, d3);
                 const float4 xv = cur.xv[it];
                 const float4 gm = gmv[it];
                 rr[it] = cur.rr[it];
@@ -368,13 +377,12 @@ __global__ __launch_bounds__(NW * 64) void k_ln_bwd(const op16_t* __restrict__ d
                         drop_mul_pair(dmask, e + 2, m2, m3);
                         o.x *= m0; o.y *= m1; o.z *= m2; o.w *= m3;
                     }
-                    const uint2 pk = make_uint2(pack2op(o.x, o.y), pack2op(o.z, o.w));
-                    *reinterpret_cast<uint2*>(dx16 + xr + c) = pk;
+                    const act_raw4 pk = act_pack4(o.x, o.y, o.z, o.w);
+                    act_straw4(dx16 + xr + c, pk);
                     if constexpr (DG) {
                         if (dcol) {
                             float r0, r1, r2, r3;
-                            unpack2(pk.x, r0, r1);
-                            unpack2(pk.y, r2, r3);
+                            act_unpack4(pk, r0, r1, r2, r3);
                             pc[it].x += r0; pc[it].y += r1; pc[it].z += r2; pc[it].w += r3;
                         }
                     }
@@ -419,8 +427,8 @@ __global__ __launch_bounds__(NW * 64) void k_ln_bwd(const op16_t* __restrict__ d
         }
     }
 }
-int ln_bwd(const op16_t* dy, const float* x, int ldx, const int* row_map, const float* mean, const float* rstd,
-           const float* gamma, const float* dres, float* dx32, op16_t* dx16, float* dgamma, float* dbeta, int rows, int D,
+int ln_bwd(const act_t* dy, const float* x, int ldx, const int* row_map, const float* mean, const float* rstd,
+           const float* gamma, const float* dres, float* dx32, act_t* dx16, float* dgamma, float* dbeta, int rows, int D,
            hipStream_t st, float* dcol, Drop dmask) {
     if (D > LN_MAXV * 256 || (D & 3) || (ldx & 3) || (dcol && (!dgamma || !dx16 || row_map)) || (dmask.thresh && (row_map || ldx != D)))
         return CC_ERR_SHAPE;
@@ -442,7 +450,7 @@ int ln_bwd(const op16_t* dy, const float* x, int ldx, const int* row_map, const 
 // ------------------------------------------------------------------------------------------------------------
 // Column sums of a bf16 matrix (bias gradients): out[n] += sum_m X[m][n].  Block = 64 columns x a row slice.
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_colsum_bf16(const op16_t* __restrict__ X, int ld, int M, int N, float* __restrict__ out,
+__global__ __launch_bounds__(256) void k_colsum_bf16(const act_t* __restrict__ X, int ld, int M, int N, float* __restrict__ out,
                                                      int rows_per_slice) {
     __shared__ float red[32][65];
     const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
@@ -452,7 +460,7 @@ __global__ __launch_bounds__(256) void k_colsum_bf16(const op16_t* __restrict__ 
     if (col < N) {
         for (int r = r0 + rl; r < r1; r += 32) {
             float f[8];
-            unpack8(*reinterpret_cast<const uint4*>(X + (size_t)r * ld + col), f);
+            act_ld8(X + (size_t)r * ld + col, f);
 #pragma unroll
             for (int e = 0; e < 8; e++) acc[e] += f[e];
         }
@@ -468,7 +476,7 @@ __global__ __launch_bounds__(256) void k_colsum_bf16(const op16_t* __restrict__ 
         if (c < N) __hip_atomic_fetch_add(out + c, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-int colsum_bf16(const op16_t* X, int ld, int M, int N, float* out, hipStream_t st) {
+int colsum_bf16(const act_t* X, int ld, int M, int N, float* out, hipStream_t st) {
     if ((N & 7) || (ld & 7)) return CC_ERR_SHAPE;
     if (M <= 0 || N <= 0) return CC_OK;
     const int cb = (N + 63) / 64;
@@ -485,12 +493,12 @@ int colsum_bf16(const op16_t* X, int ld, int M, int N, float* out, hipStream_t s
 // wave's b128 reads of consecutive rows are conflict-free).  qkv is [B*S][3*D] = [q | k | v], head h at h*hd.
 // Saves the log-sum-exp per (b,h,row) for the backward pass (probabilities are recomputed there).
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void load_head_rows(float* dst, int hdp, const op16_t* src, size_t ld, int S, int hd) {
+__device__ __forceinline__ void load_head_rows(float* dst, int hdp, const act_t* src, size_t ld, int S, int hd) {
     const int c8n = hd >> 3;
     for (int idx = threadIdx.x; idx < S * c8n; idx += blockDim.x) {
         const int r = idx / c8n, c = idx % c8n;
         float f[8];
-        unpack8(*reinterpret_cast<const uint4*>(src + (size_t)r * ld + c * 8), f);
+        act_ld8(src + (size_t)r * ld + c * 8, f);
         float* d = dst + r * hdp + c * 8;
         *reinterpret_cast<float4*>(d) = make_float4(f[0], f[1], f[2], f[3]);
         *reinterpret_cast<float4*>(d + 4) = make_float4(f[4], f[5], f[6], f[7]);
@@ -498,8 +506,8 @@ __device__ __forceinline__ void load_head_rows(float* dst, int hdp, const op16_t
 }
 
 template <bool CAUSAL>
-__global__ __launch_bounds__(256) void k_attn_fwd(const op16_t* __restrict__ qkv, int S, int H, int hd, float scale,
-                                                  op16_t* __restrict__ out, float* __restrict__ lse) {
+__global__ __launch_bounds__(256) void k_attn_fwd(const act_t* __restrict__ qkv, int S, int H, int hd, float scale,
+                                                  act_t* __restrict__ out, float* __restrict__ lse) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int D = H * hd, hdp = hd + 4, Sp = S + 1;
     float* Qs = sm;
@@ -507,7 +515,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const op16_t* __restrict__ qkv
     float* Vs = Ks + S * hdp;
     float* Ps = Vs + S * hdp;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
-    const op16_t* base = qkv + (size_t)b * S * 3 * D + h * hd;
+    const act_t* base = qkv + (size_t)b * S * 3 * D + h * hd;
     load_head_rows(Qs, hdp, base, 3 * D, S, hd);
     load_head_rows(Ks, hdp, base + D, 3 * D, S, hd);
     load_head_rows(Vs, hdp, base + 2 * D, 3 * D, S, hd);
@@ -557,7 +565,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const op16_t* __restrict__ qkv
         }
         s = wave_sum(s);
         const float inv = 1.f / s;
-        for (int j = lane; j < S; j += 64) Ps[i * Sp + j] = op2f(f2op(Ps[i * Sp + j] * inv));   // P enters the PV product in bf16 (as in the MFMA kernel)
+        for (int j = lane; j < S; j += 64) Ps[i * Sp + j] = act_round(Ps[i * Sp + j] * inv);   // P enters the PV product in the operand type (as in the MFMA kernel); fp32 in the bf16x3 build
         if (lane == 0 && lse) lse[((size_t)b * H + h) * S + i] = m + __logf(s);
     }
     __syncthreads();
@@ -572,10 +580,11 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const op16_t* __restrict__ qkv
             const float4 v = *reinterpret_cast<const float4*>(Vs + j * hdp + d0);
             o.x += p * v.x; o.y += p * v.y; o.z += p * v.z; o.w += p * v.w;
         }
-        *reinterpret_cast<uint2*>(out + ((size_t)b * S + i) * D + h * hd + d0) = make_uint2(pack2op(o.x, o.y), pack2op(o.z, o.w));
+        act_st4(out + ((size_t)b * S + i) * D + h * hd + d0, o.x, o.y, o.z, o.w);
     }
 }
 
+#if CC_OP != 2      // the MFMA attention kernels work on 16-bit operands; the bf16x3 build runs the fp32 VALU kernels above / below
 // ------------------------------------------------------------------------------------------------------------
 // MFMA attention forward (head dim 64 / 96 / 128): one wave per (sample, head, 32-query block), flash-style loop
 // over 32-key blocks with v_mfma_f32_32x32x16_bf16.
@@ -1240,27 +1249,29 @@ static int attn_bwd_mfma_launch(const op16_t* qkv, const op16_t* dout, const op1
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
 
+#endif   // CC_OP != 2
+
 static size_t attn_fwd_lds(int S, int hd) { return ((size_t)3 * S * (hd + 4) + (size_t)S * (S + 1)) * 4; }
 static size_t attn_bwd_lds(int S, int hd) { return ((size_t)4 * S * (hd + 4) + (size_t)2 * S * (S + 1)) * 4; }
 
 // Attention probabilities of an un-masked self-attention layer, recomputed from the stored qkv rows: what the reference's
 // MultiHeadAttention.forward returns as its second value (attention.py:32-42, layout (b, n, m, h)).  One wave per (b, h, query);
 // an inspection / visualisation output, not on the training path.
-__global__ __launch_bounds__(256) void k_attn_probs(const op16_t* __restrict__ qkv, int B, int S, int H, int hd, float scale,
+__global__ __launch_bounds__(256) void k_attn_probs(const act_t* __restrict__ qkv, int B, int S, int H, int hd, float scale,
                                                     float* __restrict__ out) {
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (wave >= B * H * S) return;
     const int n = wave % S, h = (wave / S) % H, b = wave / (S * H);
     const int D = H * hd;
-    const op16_t* q = qkv + ((size_t)b * S + n) * 3 * D + h * hd;
+    const act_t* q = qkv + ((size_t)b * S + n) * 3 * D + h * hd;
     float mx = -INFINITY;
     for (int m0 = 0; m0 < S; m0 += 64) {
         const int m = m0 + lane;
         float sc = -INFINITY;
         if (m < S) {
-            const op16_t* k = qkv + ((size_t)b * S + m) * 3 * D + D + h * hd;
+            const act_t* k = qkv + ((size_t)b * S + m) * 3 * D + D + h * hd;
             float acc = 0.f;
-            for (int d = 0; d < hd; d++) acc += op2f(q[d]) * op2f(k[d]);
+            for (int d = 0; d < hd; d++) acc += act2f(q[d]) * act2f(k[d]);
             sc = acc * scale;
             out[(((size_t)b * S + n) * S + m) * H + h] = sc;
         }
@@ -1274,21 +1285,23 @@ __global__ __launch_bounds__(256) void k_attn_probs(const op16_t* __restrict__ q
         *o = __expf(*o - mx) / sum;
     }
 }
-int attn_probs(const op16_t* qkv, int B, int S, int H, int hd, float* out, hipStream_t st) {
+int attn_probs(const act_t* qkv, int B, int S, int H, int hd, float* out, hipStream_t st) {
     const int waves = B * H * S;
     if (waves <= 0) return CC_OK;
     hipLaunchKernelGGL(k_attn_probs, dim3((waves + 3) / 4), dim3(256), 0, st, qkv, B, S, H, hd, 1.0f / sqrtf((float)hd), out);
     return CC_OK;
 }
 
-int attn_fwd(const op16_t* qkv, int B, int S, int H, int hd, bool causal, op16_t* out, float* lse, hipStream_t st, Drop drop) {
+int attn_fwd(const act_t* qkv, int B, int S, int H, int hd, bool causal, act_t* out, float* lse, hipStream_t st, Drop drop) {
     if ((hd & 7) || S <= 0) return CC_ERR_SHAPE;
+#if CC_OP != 2
     static const bool no_mfma = getenv("CC_ATTN_VALU") != nullptr;   // A/B switch for profiling
     if (!no_mfma || drop.thresh) {
         if (hd == 64) return attn_fwd_mfma_launch<64>(qkv, B, S, H, causal, out, lse, st, drop);
         if (hd == 96) return attn_fwd_mfma_launch<96>(qkv, B, S, H, causal, out, lse, st, drop);
         if (hd == 128) return attn_fwd_mfma_launch<128>(qkv, B, S, H, causal, out, lse, st, drop);
     }
+#endif
     if (drop.thresh) return CC_ERR_SHAPE;          // the VALU fallback kernels have no dropout
     const size_t sh = attn_fwd_lds(S, hd);
     if (sh > 160 * 1024) return CC_ERR_SHAPE;
@@ -1306,9 +1319,9 @@ int attn_fwd(const op16_t* qkv, int B, int S, int H, int hd, bool causal, op16_t
 // Backward: recompute P from the saved lse; dP = dO V^T; delta_i = sum_j P_ij dP_ij (== dO_i . O_i);
 // dS = P (dP - delta) * scale; dQ = dS K; dK = dS^T Q; dV = P^T dO.  Writes dqkv (bf16) in the qkv layout.
 template <bool CAUSAL>
-__global__ __launch_bounds__(256) void k_attn_bwd(const op16_t* __restrict__ qkv, const op16_t* __restrict__ dout,
+__global__ __launch_bounds__(256) void k_attn_bwd(const act_t* __restrict__ qkv, const act_t* __restrict__ dout,
                                                   const float* __restrict__ lse, int S, int H, int hd, float scale,
-                                                  op16_t* __restrict__ dqkv) {
+                                                  act_t* __restrict__ dqkv) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int D = H * hd, hdp = hd + 4, Sp = S + 1;
     float* Qs = sm;
@@ -1318,7 +1331,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd(const op16_t* __restrict__ qkv
     float* Ps = Os + S * hdp;
     float* Ds = Ps + S * Sp;   // dP then dS
     const int b = blockIdx.x / H, h = blockIdx.x % H;
-    const op16_t* base = qkv + (size_t)b * S * 3 * D + h * hd;
+    const act_t* base = qkv + (size_t)b * S * 3 * D + h * hd;
     load_head_rows(Qs, hdp, base, 3 * D, S, hd);
     load_head_rows(Ks, hdp, base + D, 3 * D, S, hd);
     load_head_rows(Vs, hdp, base + 2 * D, 3 * D, S, hd);
@@ -1385,21 +1398,25 @@ __global__ __launch_bounds__(256) void k_attn_bwd(const op16_t* __restrict__ qkv
             dk.x += w * q.x; dk.y += w * q.y; dk.z += w * q.z; dk.w += w * q.w;
             dv.x += p * o.x; dv.y += p * o.y; dv.z += p * o.z; dv.w += p * o.w;
         }
-        op16_t* o = dqkv + ((size_t)b * S + r) * 3 * D + h * hd + d0;
-        *reinterpret_cast<uint2*>(o) = make_uint2(pack2op(dq.x, dq.y), pack2op(dq.z, dq.w));
-        *reinterpret_cast<uint2*>(o + D) = make_uint2(pack2op(dk.x, dk.y), pack2op(dk.z, dk.w));
-        *reinterpret_cast<uint2*>(o + 2 * D) = make_uint2(pack2op(dv.x, dv.y), pack2op(dv.z, dv.w));
+        act_t* o = dqkv + ((size_t)b * S + r) * 3 * D + h * hd + d0;
+        act_st4(o, dq.x, dq.y, dq.z, dq.w);
+        act_st4(o + D, dk.x, dk.y, dk.z, dk.w);
+        act_st4(o + 2 * D, dv.x, dv.y, dv.z, dv.w);
     }
 }
-int attn_bwd(const op16_t* qkv, const op16_t* dout, const op16_t* o, const float* lse, float* delta, int B, int S, int H, int hd, bool causal,
-             op16_t* dqkv, hipStream_t st, Drop drop) {
+int attn_bwd(const act_t* qkv, const act_t* dout, const act_t* o, const float* lse, float* delta, int B, int S, int H, int hd, bool causal,
+             act_t* dqkv, hipStream_t st, Drop drop) {
     if ((hd & 7) || S <= 0) return CC_ERR_SHAPE;
+#if CC_OP != 2
     static const bool no_mfma = getenv("CC_ATTN_VALU") != nullptr;
     if ((!no_mfma || drop.thresh) && o && delta) {
         if (hd == 64) return attn_bwd_mfma_launch<64>(qkv, dout, o, lse, delta, B, S, H, causal, dqkv, st, drop);
         if (hd == 96) return attn_bwd_mfma_launch<96>(qkv, dout, o, lse, delta, B, S, H, causal, dqkv, st, drop);
         if (hd == 128) return attn_bwd_mfma_launch<128>(qkv, dout, o, lse, delta, B, S, H, causal, dqkv, st, drop);
     }
+#else
+    (void)o; (void)delta;
+#endif
     if (drop.thresh) return CC_ERR_SHAPE;          // the VALU fallback kernel has no dropout
     const size_t sh = attn_bwd_lds(S, hd);
     if (sh > 160 * 1024) return CC_ERR_SHAPE;
@@ -1432,10 +1449,10 @@ __global__ void k_dropout_f32(float* __restrict__ x, size_t n4, Drop d) {
         reinterpret_cast<float4*>(x)[i] = v;
     }
 }
-__global__ void k_dropout_bf16(op16_t* __restrict__ x, size_t n8, Drop d) {
+__global__ void k_dropout_bf16(act_t* __restrict__ x, size_t n8, Drop d) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
         float f[8];
-        unpack8(reinterpret_cast<const uint4*>(x)[i], f);
+        act_ld8(x + i * 8, f);
         const unsigned e = (unsigned)(i * 8);
 #pragma unroll
         for (int k = 0; k < 8; k += 2) {
@@ -1443,7 +1460,7 @@ __global__ void k_dropout_bf16(op16_t* __restrict__ x, size_t n8, Drop d) {
             drop_mul_pair(d, e + k, m0, m1);
             f[k] *= m0; f[k + 1] *= m1;
         }
-        reinterpret_cast<uint4*>(x)[i] = pack8(f);
+        act_st8(x + i * 8, f);
     }
 }
 __global__ void k_dropout_mask(unsigned char* __restrict__ out, size_t n, Drop d) {
@@ -1456,7 +1473,7 @@ int dropout_f32(float* x, size_t n, Drop d, hipStream_t st) {
     hipLaunchKernelGGL(k_dropout_f32, dim3((int)std::min<size_t>((n / 4 + 255) / 256, 4096)), dim3(256), 0, st, x, n / 4, d);
     return CC_OK;
 }
-int dropout_bf16(op16_t* x, size_t n, Drop d, hipStream_t st) {
+int dropout_bf16(act_t* x, size_t n, Drop d, hipStream_t st) {
     if (!d.thresh || !n) return CC_OK;
     if (n & 7) return CC_ERR_SHAPE;
     hipLaunchKernelGGL(k_dropout_bf16, dim3((int)std::min<size_t>((n / 8 + 255) / 256, 4096)), dim3(256), 0, st, x, n / 8, d);
@@ -1516,16 +1533,16 @@ __global__ void k_embed_bwd(const float* __restrict__ dx0, const long long* __re
     }
 }
 // dst[r][c] = op16(src[r][c]) for c < V, 0 for V <= c < ldd (gradient of caller-visible fp32 logits -> the GEMM operand layout)
-__global__ __launch_bounds__(256) void k_f32_to_op16_pad(const float* __restrict__ src, long long lds, int V, op16_t* __restrict__ dst, int ldd,
+__global__ __launch_bounds__(256) void k_f32_to_op16_pad(const float* __restrict__ src, long long lds, int V, act_t* __restrict__ dst, int ldd,
                                                          int M) {
     const size_t total = (size_t)M * ldd;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % ldd);
         const size_t r = i / ldd;
-        dst[i] = c < V ? f2op(src[r * lds + c]) : (op16_t)0;
+        dst[i] = c < V ? f2act(src[r * lds + c]) : (act_t)0;
     }
 }
-int f32_to_op16_pad(const float* src, long long lds, int V, op16_t* dst, int ldd, int M, hipStream_t st) {
+int f32_to_op16_pad(const float* src, long long lds, int V, act_t* dst, int ldd, int M, hipStream_t st) {
     const size_t total = (size_t)M * ldd;
     if (!total) return CC_OK;
     hipLaunchKernelGGL(k_f32_to_op16_pad, dim3((int)std::min<size_t>((total + 255) / 256, 8192)), dim3(256), 0, st, src, lds, V, dst, ldd, M);
@@ -1612,7 +1629,7 @@ int ce_rows(const float* pmax, const float* psum, int npart, const int* target, 
     return CC_OK;
 }
 
-__global__ __launch_bounds__(256) void k_ce_dlogits(op16_t* __restrict__ logits, int ld, int V, const int* __restrict__ target,
+__global__ __launch_bounds__(256) void k_ce_dlogits(act_t* __restrict__ logits, int ld, int V, const int* __restrict__ target,
                                                     const float* __restrict__ lse, const float* __restrict__ denom,
                                                     const float* __restrict__ loss_scale, int M) {
     const int col = (blockIdx.x * 256 + threadIdx.x) * 8;
@@ -1622,18 +1639,18 @@ __global__ __launch_bounds__(256) void k_ce_dlogits(op16_t* __restrict__ logits,
         const int t = target[row];
         const float l = lse[row];
         const float w = (t != 0) ? inv : 0.f;
-        op16_t* p = logits + (size_t)row * ld + col;
+        act_t* p = logits + (size_t)row * ld + col;
         float f[8];
-        unpack8(*reinterpret_cast<const uint4*>(p), f);
+        act_ld8(p, f);
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             const int c = col + e;
             f[e] = (c < V) ? (__expf(f[e] - l) - (c == t ? 1.f : 0.f)) * w : 0.f;
         }
-        *reinterpret_cast<uint4*>(p) = pack8(f);
+        act_st8(p, f);
     }
 }
-int ce_dlogits(op16_t* logits, int ld, int V, const int* target, const float* lse, const float* denom, const float* loss_scale, int M,
+int ce_dlogits(act_t* logits, int ld, int V, const int* target, const float* lse, const float* denom, const float* loss_scale, int M,
                hipStream_t st) {
     if (ld & 7) return CC_ERR_SHAPE;
     if (M <= 0) return CC_OK;
@@ -1738,5 +1755,120 @@ int loss_scale_update(float* state, float* found_inf, float growth, float backof
     hipLaunchKernelGGL(k_loss_scale_update, dim3(1), dim3(64), 0, st, state, found_inf, growth, backoff, interval);
     return CC_OK;
 }
+
+#if CC_OP == 2
+// ------------------------------------------------------------------------------------------------------------
+// bf16x3 operand pairs (common.hip.h): x -> hi = bf16(x), lo = bf16(x - hi) (x - hi is exact in fp32), laid out along K so that the
+// unchanged NT kernels, run over K' = 3K, compute hi*hi + hi*lo + lo*hi:  A operand [hi | hi | lo],  B operand [hi | lo | hi].
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void x3_pair8(const float (&f)[8], uint4& hi, uint4& lo) {
+    hi = pack8(f);
+    float h[8], d[8];
+    unpack8(hi, h);
+#pragma unroll
+    for (int e = 0; e < 8; e++) d[e] = f[e] - h[e];
+    lo = pack8(d);
+}
+__device__ __forceinline__ void x3_store(op16_t* row3, int K, int c, int form, const uint4& hi, const uint4& lo) {
+    *reinterpret_cast<uint4*>(row3 + c) = hi;
+    *reinterpret_cast<uint4*>(row3 + K + c) = form ? lo : hi;
+    *reinterpret_cast<uint4*>(row3 + 2 * K + c) = form ? hi : lo;
+}
+__global__ __launch_bounds__(256) void k_x3_split_rows(const float* __restrict__ src, size_t lds, op16_t* __restrict__ dst, int M, int K, int form) {
+    const int k8 = K >> 3;
+    const size_t total = (size_t)M * k8;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / k8;
+        const int c = (int)(i - r * k8) * 8;
+        const float* sp = src + r * lds + c;
+        const float4 a = *reinterpret_cast<const float4*>(sp), b = *reinterpret_cast<const float4*>(sp + 4);
+        const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        uint4 hi, lo;
+        x3_pair8(f, hi, lo);
+        x3_store(dst + r * 3 * (size_t)K, K, c, form, hi, lo);
+    }
+}
+int x3_split_rows(const float* src, size_t lds, op16_t* dst, int M, int K, int form, hipStream_t st) {
+    if ((K & 7) || (lds & 3) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return CC_ERR_SHAPE;
+    const size_t total = (size_t)M * (K >> 3);
+    if (!total) return CC_OK;
+    hipLaunchKernelGGL(k_x3_split_rows, dim3((int)std::min<size_t>((total + 255) / 256, 8192)), dim3(256), 0, st, src, lds, dst, M, K, form);
+    return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+}
+// weights: 64 x 64 source tiles; tr = 1 goes through LDS so that both the fp32 reads and the 16-bit writes are row-contiguous
+__global__ __launch_bounds__(256) void k_x3_split_multi(X3SplitBatch b) {
+    const X3SplitBatch::Item& m = b.it[blockIdx.z];
+    if ((int)blockIdx.x * 64 >= m.C || (int)blockIdx.y * 64 >= m.R) return;
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, R = m.R, C = m.C;
+    const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;      // 8 chunks of 8 columns x 32 rows, two passes
+    if (!m.tr) {
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int r = r0 + rl + 32 * p, c = c0 + cg * 8;
+            if (r < R && c < C) {
+                const float* sp = m.src + (size_t)r * C + c;
+                const float4 a = *reinterpret_cast<const float4*>(sp), bb = *reinterpret_cast<const float4*>(sp + 4);
+                const float f[8] = {a.x, a.y, a.z, a.w, bb.x, bb.y, bb.z, bb.w};
+                uint4 hi, lo;
+                x3_pair8(f, hi, lo);
+                x3_store(m.dst + (size_t)r * 3 * C, C, c, m.form, hi, lo);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const int r = r0 + rl + 32 * p, c = c0 + cg * 8;
+        float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (r < R && c < C) {
+            const float* sp = m.src + (size_t)r * C + c;
+            const float4 a = *reinterpret_cast<const float4*>(sp), bb = *reinterpret_cast<const float4*>(sp + 4);
+            f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = bb.x; f[5] = bb.y; f[6] = bb.z; f[7] = bb.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) tile[rl + 32 * p][cg * 8 + k] = f[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const int c = c0 + rl + 32 * p, r = r0 + cg * 8;       // output row = source column c, 8 consecutive source rows
+        if (c < C && r < R) {
+            float f[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) f[k] = tile[cg * 8 + k][rl + 32 * p];
+            uint4 hi, lo;
+            x3_pair8(f, hi, lo);
+            x3_store(m.dst + (size_t)c * 3 * R, R, r, m.form, hi, lo);
+        }
+    }
+}
+int x3_split_multi(const X3SplitBatch& b, hipStream_t st) {
+    if (b.n <= 0) return CC_OK;
+    int mr = 0, mc = 0;
+    for (int i = 0; i < b.n; i++) {
+        if ((b.it[i].R & 7) || (b.it[i].C & 7)) return CC_ERR_SHAPE;
+        mr = std::max(mr, b.it[i].R);
+        mc = std::max(mc, b.it[i].C);
+    }
+    hipLaunchKernelGGL(k_x3_split_multi, dim3((mc + 63) / 64, (mr + 63) / 64, b.n), dim3(256), 0, st, b);
+    return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+}
+
+namespace {
+struct X3Scratch { char* base = nullptr; size_t bytes = 0, used = 0; };
+thread_local X3Scratch g_x3;
+}  // namespace
+void x3_set_scratch(void* base, size_t bytes) { g_x3.base = static_cast<char*>(base); g_x3.bytes = bytes; g_x3.used = 0; }
+const op16_t* x3_operand(const float* src, size_t ld, int rows, int width, int form, bool first, hipStream_t st, int* rc) {
+    if (first) g_x3.used = 0;
+    const size_t need = (((size_t)rows * 3 * width * sizeof(op16_t)) + 255) & ~size_t(255);
+    if (!g_x3.base || g_x3.used + need > g_x3.bytes) { *rc = CC_ERR_STATE; return nullptr; }
+    op16_t* dst = reinterpret_cast<op16_t*>(g_x3.base + g_x3.used);
+    g_x3.used += need;
+    *rc = x3_split_rows(src, ld, dst, rows, width, form, st);
+    return *rc == CC_OK ? dst : nullptr;
+}
+#endif   // CC_OP == 2
 
 }  // namespace CC_NS

@@ -16,7 +16,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from clipcap_amd import _lib
-from clipcap_amd._lib import OP_BF16, OP_FP16, Gpt2Cfg, Gpt2Shape, MapperCfg, check, op_dtype_of
+from clipcap_amd._lib import OP_BF16, OP_FP16, OP_X3, Gpt2Cfg, Gpt2Shape, MapperCfg, check, op_dtype_of
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -49,9 +49,8 @@ class _Arena:
         self.op_dtype = op_dtype
         self.w32 = torch.zeros(n, dtype=torch.float32, device=self.device)
         # [0,n): 16-bit cast of the master (bf16 or fp16, cfg.op_dtype); [n,2n): transposed copies of the GEMM weights
-        # (include/clipcap_hip.h Conventions)
-        self.w16 = torch.zeros(2 * n, dtype=torch.float16 if op_dtype == OP_FP16 else torch.bfloat16, device=self.device) \
-            if self.device.type == "cuda" else None
+        # (include/clipcap_hip.h Conventions).  bf16x3: 6n elements — [hi | lo | hi] row images of every GEMM weight and of its transpose
+        self.w16 = self._alloc_w16() if self.device.type == "cuda" else None
         self.g32: Optional[torch.Tensor] = None
         self.m: Optional[torch.Tensor] = None
         self.v: Optional[torch.Tensor] = None
@@ -60,6 +59,15 @@ class _Arena:
         # (ArenaModule._rebind) carry their own version counters, so load_state_dict / torch optimizers writing through them
         # would otherwise leave the bf16 operand copy stale.  The dirty stamp is the sum over w32 and every watched alias.
         self.watch: List[torch.Tensor] = []
+
+    def _alloc_w16(self) -> torch.Tensor:
+        return torch.zeros((6 if self.op_dtype == OP_X3 else 2) * self.n, dtype=torch.float16 if self.op_dtype == OP_FP16 else torch.bfloat16,
+                           device=self.device)
+
+    def mark_dirty(self) -> None:
+        """The fp32 master was written behind torch's back (a raw-pointer writer: an RCCL broadcast into the arena, a C-ABI caller):
+        the operand copy is rebuilt before its next use."""
+        self._w16_version = -1
 
     def _stamp(self) -> int:
         s = self.w32._version
@@ -77,11 +85,11 @@ class _Arena:
         self._w16_version = self._stamp()
 
     def set_op_dtype(self, op_dtype: int) -> None:
-        """Switch the 16-bit operand copy between bf16 and fp16 (re-cast lazily from the fp32 master)."""
+        """Switch the operand copy between bf16, fp16 and the split-bf16 images (rebuilt lazily from the fp32 master)."""
         if op_dtype != self.op_dtype:
             self.op_dtype = op_dtype
             if self.w16 is not None:
-                self.w16 = torch.zeros(2 * self.n, dtype=torch.float16 if op_dtype == OP_FP16 else torch.bfloat16, device=self.device)
+                self.w16 = self._alloc_w16()
             self._w16_version = -1
 
     def moved_to(self, device, sync_fn) -> "_Arena":
@@ -110,7 +118,7 @@ class _Arena:
         # The step also stores the 16-bit cast of every updated parameter (cc_adamw_step_cast), so the operand arena only needs its
         # transposed half rebuilt.  One corner keeps the full refresh: a step that may be SKIPPED on the device (fp16 overflow) leaves
         # the cast untouched, which is only right if the cast was current before the step.
-        if os.environ.get("CC_ADAMW_TWO_PASS"):          # A/B switch: the separate-cast form
+        if os.environ.get("CC_ADAMW_TWO_PASS") or self.op_dtype == OP_X3:   # A/B switch: the separate-cast form; bf16x3: operand images are per matrix
             check(_lib.lib().cc_adamw_step(_p(self.w32), _p(self.grads()), _p(self.m), _p(self.v), self.n, lr, betas[0], betas[1], eps,
                                            weight_decay, step, grad_scale, _p(scaler.scale) if scaler is not None else None,
                                            _p(scaler.found_inf) if scaler is not None else None, _stream(self.device)), "cc_adamw_step")
@@ -210,7 +218,8 @@ class MapperEngine:
         return self
 
     def set_precision(self, precision) -> None:
-        """16 -> fp16 operands (the reference's --fp-precision 16), 32 / 64 / 'bf16' -> bf16 operands.  fp32 master unchanged."""
+        """16 -> fp16 operands (the reference's --fp-precision 16), 32 / 64 -> split-bf16 operands (the reference's default precision),
+        'bf16' -> bf16 operands (_lib.op_dtype_of).  fp32 master unchanged."""
         self.op_dtype = op_dtype_of(precision)
         self.cfg.op_dtype = self.op_dtype
         self.arena.set_op_dtype(self.op_dtype)
@@ -522,7 +531,9 @@ class DecodeSession:
         self.pos = 0
         d = gpt2.dims
         dev = gpt2.arena.device
-        self.kv = torch.empty(d["NL"] * 2 * rows * self.ctx_max * d["D"], dtype=gpt2.arena.w16.dtype, device=dev)
+        # 16-bit operand type; fp32 in the bf16x3 mode (include/clipcap_hip.h OPERAND TYPE)
+        self.kv = torch.empty(d["NL"] * 2 * rows * self.ctx_max * d["D"], dtype=torch.float32 if gpt2.op_dtype == OP_X3 else gpt2.arena.w16.dtype,
+                              device=dev)
         self.row_map = torch.arange(rows, dtype=torch.int32, device=dev).view(rows, 1).repeat(1, self.ctx_max).contiguous()
         self._ws: Dict[int, torch.Tensor] = {}
         self._logits: Optional[torch.Tensor] = None

@@ -3,13 +3,20 @@
 ``--enable-deepspeed`` / ``--deepspeed-strategy`` select nothing here (multi-GPU is always one process per GPU + RCCL)."""
 from argparse import ArgumentParser
 
+
+def _precision(text: str):
+    """the reference's integer values (clipcap/train/args.py:30-34) plus 'bf16', the throughput mode of this build"""
+    return "bf16" if text.strip().lower() == "bf16" else int(text)
+
 _GROUPS = {
     "training": [
         ("--batch-size", int, 64, "Samples per batch (per process)."),
         ("--epochs", int, 5, "Passes over the training data."),
         ("--optimizer-lr", float, 2e-5, "AdamW learning rate."),
         ("--scheduler-warmup-steps", int, 5000, "Linear warm-up length in optimizer steps."),
-        ("--fp-precision", int, 32, "Floating point precision (16/32/64): 16 = fp16 MFMA operands + dynamic loss scaling, 32/64 = bf16 operands; fp32 accumulate and master weights."),
+        ("--fp-precision", _precision, 32, "Floating point precision (16/32/64, as the reference; or bf16): 32 / 64 = split-bf16 MFMA operands (3 terms per "
+         "product, fp32 activations: the reference's fp32 default to 1e-3 on the logits, ~1/3 of the GEMM rate), 16 = fp16 operands + dynamic "
+         "loss scaling, bf16 = bf16 operands (fastest).  fp32 accumulation and master weights in all of them."),
         ("--checkpoint-save-frequency", int, 1, "Write a checkpoint every n epochs."),
         ("--checkpoint-filename-prefix", str, 1, "Checkpoint file name prefix."),
         ("--device", str, "0", "GPU index, comma list, or -1 for all (one process per GPU via torchrun)."),

@@ -54,7 +54,7 @@ def train(args: Namespace, tokenizer=None, language_model=None) -> int:
         for mod in (model.transformer_mapper, model.language_model):
             a = mod.engine.arena
             torch.distributed.broadcast(a.w32, src=0)
-            a.w32.add_(0)                 # the collective wrote through a raw pointer: bump the version so bf16 copies refresh
+            a.mark_dirty()                # the collective wrote through a raw pointer: the operand copy is rebuilt before its next use
             if a.m is not None:
                 torch.distributed.broadcast(a.m, src=0)
                 torch.distributed.broadcast(a.v, src=0)

@@ -21,6 +21,14 @@
  *     torch.bfloat16 / torch.float16.  fp16 training runs its backward pass under a loss scale (cc_lmhead_ce_bwd,
  *     cc_grad_nonfinite, cc_loss_scale_update, cc_adamw_step) exactly as torch.cuda.amp.GradScaler does for the
  *     reference's Lightning fp16 path.
+ *     CC_OP_BF16X3 is the reference's DEFAULT precision (`--fp-precision 32`, clipcap/train/args.py:30-34, train.py:82) on a chip
+ *     without fp32 matrix cores: every GEMM operand x is split into bf16 hi = bf16(x), lo = bf16(x - hi) and each product runs as
+ *     three bf16 MFMA terms hi*hi + hi*lo + lo*hi with fp32 accumulation (about 16 mantissa bits per operand, a third of the bf16
+ *     rate); activations between kernels are fp32 and attention runs in fp32.  This is the mode in which logits match the fp32
+ *     reference to 1e-3 at full depth.  Its buffers differ in size only: the operand arena has 6*count 16-bit elements (the
+ *     [hi | lo | hi] image of every 2-D weight at 3x its offset, of its transpose at 3*(count + offset)), the KV cache holds fp32
+ *     (twice the bytes per element), workspaces are whatever cc_*_ws_bytes says.  cc_*_transpose_weights, cc_adamw_step_cast,
+ *     cc_cast_op16 and the bare GEMM hooks do not exist in this mode (CC_ERR_ARG): use cc_adamw_step + cc_*_sync_weights.
  *   - parameters live in flat arenas whose element offsets are defined by cc_*_param_offsets(); the fp32 arena is
  *     the master copy (nn.Parameter views alias it).  The 16-bit operand arena has 2*count elements: [0,count) is the
  *     cast of the master (same offsets, reference state-dict layouts: torch.nn.Linear weight [out,in]; HF Conv1D
@@ -49,6 +57,7 @@ int cc_abi_version(void);
 
 #define CC_OP_BF16 0
 #define CC_OP_FP16 1
+#define CC_OP_BF16X3 2   /* split operands: the reference's default --fp-precision 32 (see OPERAND TYPE above) */
 
 /* ------------------------------------------------------------------------------------------------------------
  * Mapper: clipcap/model/mapper.py:113-130 TransformerMapper (+ :133-160 windowed), layers :91-110, MLP :70-88,

@@ -12,7 +12,9 @@ reference's so a reference checkpoint can be fed to these func
 stored qkv / attention output / MLP hidden / logits-for-backward) is rounded to bf16 at the same place the
 kernels round it, with fp32 accumulation everywhere.  ``rb="fp16"`` does the same with IEEE half, the operand
 type of the kernels' fp16 build (the reference's ``--fp-precision 16``).  That is the like-for-like yardstick
-for the 1e-3 logits target (SURVEY.md §7 "Tolerance").
+for the 1e-3 logits target (SURVEY.md §7 "Tolerance").  ``rb="bf16x3"`` models the split-operand build (the reference's
+default ``--fp-precision 32``): a GEMM operand is worth bf16(x) + bf16(x - bf16(x)); the build keeps the activations between
+kernels in fp32 there, so the other rounding points are (nearly) exact — the difference from rb=False is ~1e-5.
 """
 from __future__ import annotations
 
@@ -30,6 +32,9 @@ def _r(t: Tensor, rb) -> Tensor:
     the kernels' --fp-precision 16 build).  Works for fp32 and fp64 tensors (the noise-floor runs evaluate the same points in fp64)."""
     if not rb:
         return t
+    if rb == "bf16x3":      # split operand of the kernels' bf16x3 build: hi = bf16(x), lo = bf16(x - hi); the operand is worth hi + lo
+        hi = t.to(torch.bfloat16).to(t.dtype)
+        return hi + (t - hi).to(torch.bfloat16).to(t.dtype)
     return t.to(torch.float16 if rb == "fp16" else torch.bfloat16).to(t.dtype)
 
 

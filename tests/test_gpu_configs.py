@@ -38,12 +38,12 @@ def _rel(a, b):
 
 def _full_model_case(name, tol, precision=None):
     """precision None = bf16 operands (oracle with bf16 rounding points), 16 = fp16 operands (oracle with fp16 rounding points; the
-    gradients in the arenas then carry the engine's loss scale)."""
+    gradients in the arenas then carry the engine's loss scale), 32 = split-bf16 operands (the reference's default precision)."""
     g = load_golden(name)
     sd, cfg, dims = seeded_full_model(g)
     me, ge, eng = _engines(sd, dims, precision)
-    rb = "fp16" if precision == 16 else True
-    pts = "fp16 points" if precision == 16 else "bf16 points"
+    rb = {16: "fp16", 32: "bf16x3"}.get(precision, True)
+    pts = {16: "fp16 points", 32: "split-bf16 operands"}.get(precision, "bf16 points")
     tokens, embeds = torch.from_numpy(g["in.tokens"]), torch.from_numpy(g["in.embeds"])
     L, V, cap, B = dims["L"], dims["V"], tokens.shape[1], tokens.shape[0]
     valid = torch.cat((torch.ones(B, L, dtype=torch.bool), tokens.ge(0)), dim=1)
@@ -155,13 +155,13 @@ def test_config4_full_size_step_properties():
 
 # ---------------------------------------------------------------- configs[4]: beam decode at GPT-2-medium size ---------------
 
-def _medium_lm(n_layer, wte_scale=2.0, seed=4401, npos=128):
+def _medium_lm(n_layer, wte_scale=2.0, seed=4401, npos=128, precision=None):
     from tests import seeded
     from clipcap_amd.model.gpt2 import GPT2LM
     D, n_head, V = 1024, 16, 50257
     gsd = seeded.state_dict(seeded.gpt2_shapes(D, n_layer, V, npos), seed)
     gsd["transformer.wte.weight"] = gsd["transformer.wte.weight"] * wte_scale
-    lm = GPT2LM(n_embd=D, n_layer=n_layer, n_head=n_head, vocab_size=V, n_positions=npos)
+    lm = GPT2LM(n_embd=D, n_layer=n_layer, n_head=n_head, vocab_size=V, n_positions=npos, precision=precision)
     lm.load_state_dict({k: torch.from_numpy(v) for k, v in gsd.items()}, strict=False)
     return lm.to("cuda"), gsd
 

@@ -1,0 +1,149 @@
+"""Split-bf16 operand mode (CC_OP_BF16X3): the reference's DEFAULT precision, ``--fp-precision 32`` (clipcap/train/args.py:30-34 ->
+``pl.Trainer(precision=...)``, train/train.py:82), on a chip without fp32 matrix cores: every GEMM product runs as three bf16 MFMA
+terms hi*hi + hi*lo + lo*hi with fp32 accumulation, activations between kernels and attention are fp32.
+
+north_star: "caption logits within 1e-3 of reference".  Asserted here, at FULL depth, against the reference's own fp32 outputs
+(tests/golden/config2_full: 8-layer mapper + 12-layer GPT-2-small; config4_full: E=1024 mapper + 24-layer GPT-2-medium, full
+finetune) — plus the gradients behind the mapper's ReLU (3.5-4.8 % off with bf16 operands), the beam search's batch-1 contract on
+all 64 prefixes, and the training loop in this mode.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import clipcap_oracle as O
+from tests.test_gpu_configs import _full_model_case, _medium_lm
+from tests.util import load_golden
+
+pytestmark = pytest.mark.gpu
+
+# measured (MI355X): logits 3e-5 .. 6e-5, prefix 2e-5 of its range, loss 1e-6, worst gradient tensor 1e-3 .. 3e-3
+X3_TOL = dict(prefix_rb=2e-4, prefix_32=2e-4, logits_rb=1e-3, logits_32=1e-3, loss_rb=5e-5, loss_32=5e-5, grad_rb=1e-2, grad_32=1e-2)
+
+
+def test_x3_config2_full_depth_logits_within_1e3_of_reference():
+    """configs[1] architecture, 8 + 12 layers, B=2, cap=40: |logits - reference fp32 logits| <= 1e-3 on every loss-relevant row (the
+    north-star bar, not a noise-floor argument), prefix, loss, and every mapper gradient tensor <= 1e-2 relative — including
+    mlp.fc1 / norm2, which sit behind the ReLU mask."""
+    r = _full_model_case("config2_full", X3_TOL, precision=32)
+    print(f"split-bf16 operands, config2 full depth: max |logits - reference fp32| = {r['e_32']:.3e} (bar 1e-3; bf16 operands 1.5e-2, "
+          f"fp16 operands 2.0e-3); worst gradient tensor vs reference {r['grad_32']:.3e}")
+    assert r["e_32"] <= 1e-3 and r["grad_32"] <= 1e-2
+
+
+def test_x3_config4_full_depth_medium_logits_within_1e3_of_reference():
+    """configs[3] architecture: E=1024 -> D=1024 mapper (hd 128) + 24-layer GPT-2-medium, FULL finetune (391 gradient tensors)."""
+    r = _full_model_case("config4_full", X3_TOL, precision=32)
+    print(f"split-bf16 operands, config4 full depth: max |logits - reference fp32| = {r['e_32']:.3e}; worst gradient tensor vs reference "
+          f"{r['grad_32']:.3e}")
+    assert r["e_32"] <= 1e-3 and r["grad_32"] <= 1e-2
+
+
+def test_x3_kv_cache_equals_reforward_24_layers():
+    """GPT-2-medium, 320 rows: KV-cached incremental logits == full re-forward, to fp32-level agreement in this mode."""
+    from clipcap_amd.engine import DecodeSession
+    lm, _ = _medium_lm(24, precision=32)
+    ge = lm.engine
+    torch.manual_seed(2)
+    x = torch.randn(320, 14, 1024, device="cuda") * 0.3
+    full = ge.logits(x[:8])
+    sess = DecodeSession(ge, 320, 32)
+    l = sess.forward(x[:, :10]).clone()
+    scale = max(1.0, full.abs().max().item())
+    worst = float((l[:8] - full[:, 9]).abs().max())
+    for t in range(10, 14):
+        l = sess.forward(x[:, t:t + 1])
+        worst = max(worst, float((l[:8] - full[:, t]).abs().max()))
+    print(f"split-bf16 decode: KV cache vs re-forward max |diff| {worst:.3e} (scale {scale:.1f})")
+    assert worst <= 2e-4 * scale
+
+
+def test_x3_batched_beam_equals_per_sample_all_64():
+    """The reference's batch-1 contract (inference/base.py:17) on ALL 64 prefixes of configs[4] (GPT-2-medium, 24 layers, beam 5): the
+    batched decode returns, for every sample, the caption that sample gets when decoded alone.  (bf16 operands: 61 / 64.)"""
+    from types import SimpleNamespace
+    from clipcap_amd.inference.base import generate_beam_tokens
+    lm, _ = _medium_lm(24, precision=32)
+    model = SimpleNamespace(language_model=lm)
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    pref = torch.randn(64, 10, 1024, generator=gen, device="cuda") * 0.5
+    toks, scores, lens = generate_beam_tokens(model, pref, 5, 12, 1.0, 50256)
+    same = 0
+    for i in range(64):
+        t1, s1, l1 = generate_beam_tokens(model, pref[i:i + 1], 5, 12, 1.0, 50256)
+        b, b1 = int(scores[i].argmax()), int(s1[0].argmax())
+        n = int(l1[0, b1])
+        if torch.equal(toks[i, b, :n], t1[0, b1, :n]) and int(lens[i, b]) == n:
+            same += 1
+            assert abs(float(scores[i, b]) - float(s1[0, b1])) <= 1e-3
+        else:      # a tolerated mismatch would have to be a genuine near-tie: show it
+            print(f"sample {i}: batched score {float(scores[i, b]):.6f} vs alone {float(s1[0, b1]):.6f}")
+    print(f"split-bf16 beam search: {same} / 64 batched captions identical to the per-sample decode")
+    assert same == 64
+
+
+def test_x3_beam_medium_tokens_vs_reference():
+    """beam-5 captions at GPT-2-medium width against the REFERENCE's own captions (tests/golden/beam_medium.npz): all four runs
+    token-exact (bf16 operands: >= 3 of 4)."""
+    from types import SimpleNamespace
+    from clipcap_amd.inference.base import generate_beam_tokens
+    g = load_golden("beam_medium")
+    D, NL, n_head, V, NPOS, seed = [int(v) for v in g["cfg"]]
+    lm, gsd = _medium_lm(NL, float(g["wte_scale"]), seed, NPOS, precision=32)
+    model = SimpleNamespace(language_model=lm)
+    for case in ("beam0a", "beam0b", "beam1a", "beam1b"):
+        eos, entry, beam = [int(v) for v in g[case + ".meta"]]
+        pref = torch.from_numpy(g[case + ".prefix"])
+        toks, scores, lens = generate_beam_tokens(model, pref.cuda(), beam, entry, 1.0, eos)
+        b = int(scores[0].argmax())
+        mine = toks[0, b, : int(lens[0, b])].cpu().numpy()
+        assert np.array_equal(mine, g[case + ".best"]), (case, mine, g[case + ".best"])
+
+
+def test_x3_training_loop_through_the_model_api():
+    """ClipCapModelPrefixOnly.set_precision(32) (what train() does for the reference's default --fp-precision): three optimizer steps
+    through the fused trainer path lower the loss, the operand images follow the master weights (the step after an update sees the new
+    weights), and the loss of step 0 equals the oracle's fp32 loss."""
+    from tests import seeded
+    from clipcap_amd.engine import ClipCapEngine, Gpt2Engine, MapperEngine
+    E, D, P, L, H, N, n_head, NL, V, NPOS, cap, B = 64, 128, 4, 4, 4, 2, 4, 2, 300, 32, 8, 4
+    gsd = seeded.state_dict(seeded.gpt2_shapes(D, NL, V, NPOS), 77)
+    msd = seeded.state_dict(seeded.mapper_shapes(E, D, P, L, N), 78)
+    sd = {"language_model." + k: torch.from_numpy(v) for k, v in gsd.items()}
+    sd.update({"transformer_mapper." + k: torch.from_numpy(v) for k, v in msd.items()})
+    me = MapperEngine(E, D, L, P, H, N, device="cuda", precision=32)
+    ge = Gpt2Engine(D, n_head, NL, V, NPOS, device="cuda", precision=32)
+    for pre, eng_ in (("transformer_mapper.", me), ("language_model.", ge)):
+        for k, v in eng_.views(eng_.arena.w32).items():
+            v.copy_(sd[pre + k])
+    eng = ClipCapEngine(me, ge, train_lm=True)
+    assert eng._scaler(torch.device("cuda", 0)) is None          # no loss scale in this mode
+    gen = torch.Generator().manual_seed(5)
+    tokens = torch.randint(1, V, (B, cap), generator=gen)
+    tokens[1, cap - 3:] = -1
+    embeds = torch.randn(B, E, generator=gen)
+    cfg = dict(projection_length=P, prefix_length=L, heads=H, layers=N, n_head=n_head, n_layer=NL)
+    with torch.no_grad():
+        ref = float(O.clipcap_loss(sd, tokens, embeds, cfg=cfg))
+    losses = []
+    for step in range(1, 4):
+        eng.zero_grad()
+        losses.append(float(eng.forward_backward(tokens.cuda(), embeds.cuda())))
+        eng.optimizer_step(1e-3, step)
+    print(f"split-bf16 training: losses {losses}; fp32 oracle loss at step 0 {ref:.6f}")
+    assert abs(losses[0] - ref) <= 2e-5
+    assert losses[2] < losses[1] < losses[0]
+
+
+def test_x3_sizes_and_refusals():
+    """Buffer sizes of the mode (include/clipcap_hip.h OPERAND TYPE) and the entry points that do not exist in it."""
+    import ctypes as C
+    from clipcap_amd import _lib
+    from clipcap_amd.engine import DecodeSession, Gpt2Engine
+    ge = Gpt2Engine(128, 4, 2, 300, 32, device="cuda", precision=32)
+    assert ge.arena.w16.numel() == 6 * ge.arena.n
+    sess = DecodeSession(ge, 3, 16)
+    assert sess.kv.dtype == torch.float32
+    l = _lib.lib()
+    assert l.cc_gpt2_transpose_weights(C.byref(ge.cfg), C.c_void_p(ge.arena.w16.data_ptr()), None) == -1
+    assert l.cc_cast_op16(2, C.c_void_p(ge.arena.w32.data_ptr()), C.c_void_p(ge.arena.w16.data_ptr()), 8, None) == -1
