@@ -311,7 +311,9 @@ def main():
     ap.add_argument("--config", default="2", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
     ap.add_argument("--site", default="lmhead_fwd", help="single GEMM call site timed for the roofline_lmhead object")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "16"], help="operand type: bf16 (default) or 16 = fp16 + loss scaling")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "16", "32"],
+                    help="operand mode: bf16 (default, BASELINE's configuration), 16 = fp16 + loss scaling, 32 = split-bf16 operands (the "
+                         "reference's fp32 default precision: 3 MFMA terms per product, the parity mode)")
     ap.add_argument("--comm", default="torch", choices=["torch", "cabi"],
                     help="N>1 collectives: torch.distributed (backend nccl = RCCL) or the library's own C-ABI RCCL communicator")
     ap.add_argument("--grad-wire", default="fp32", choices=["fp32", "bf16"],
@@ -323,10 +325,26 @@ def main():
     ap.add_argument("--no-dropout", action="store_true", help="configs 3/4: run the full finetune without GPT-2 dropout")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched bare (`python bench.py --gpus 8`): start the N ranks ourselves exactly as the driver's torchrun line does, and never
+        # print a 1-rank line for an N-GPU request
+        import socket
+        import subprocess
+        have = torch.cuda.device_count()
+        if have < args.gpus and "CC_BENCH_DEVICE" not in os.environ:
+            sys.exit(f"bench.py: --gpus {args.gpus} requested but {have} GPU(s) visible; refusing to report a smaller run")
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd, env=env).returncode)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     # test hooks (single-GPU boxes): CC_BENCH_DEVICE pins every rank to one device, CC_BENCH_BACKEND=gloo replaces RCCL, so the
     # whole multi-rank flow of this file can be exercised where only one GPU exists.  Never set by the driver.
     dev_index = int(os.environ.get("CC_BENCH_DEVICE", local))
@@ -355,9 +373,9 @@ def main():
     from clipcap_amd.train.ddp import GradReducer
     from clipcap_amd.model.optim import linear_warmup_decay
     me, ge, eng = init_engines(c, device)
-    if args.precision == "16":
-        me.set_precision(16)
-        ge.set_precision(16)
+    if args.precision != "bf16":
+        me.set_precision(int(args.precision))
+        ge.set_precision(int(args.precision))
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
     embeds = torch.randn(B, c["E"], generator=gen, device=device)
     tokens = torch.randint(1, c["V"], (B, cap), generator=gen, device=device)
@@ -467,7 +485,7 @@ def main():
     out = {
         "metric": "train samples/sec (512-d prefix, 40-tok caption)", "value": round(value, 2), "unit": "samples/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f16", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": {"bf16": "bf16", "16": "f16", "32": "bf16x3"}[args.precision], "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{int(args.config) - 1}]: {c['name']}", "per_gpu_batch": B, "global_batch": B * world,
                    "caption_tokens": cap, "encoder_dim": c["E"], "train_language_model": c["train_lm"],
                    "parallelism": f"dp{world}", "final_loss": round(float(loss.item()), 4)},
@@ -477,7 +495,7 @@ def main():
         "step_executed_frac_of_bf16_peak": round(exec_tflops / (PEAK_BF16_TFLOPS * world), 4),
     }
     if world > 1:
-        out["rccl_ranks"] = world if backend == "nccl" else 0
+        out["rccl_ranks"] = (comm.count() if comm is not None else torch.distributed.get_world_size()) if backend == "nccl" else 0
         out["collective_backend"] = "rccl (C ABI cc_allreduce_bucket)" if comm is not None else ("rccl" if backend == "nccl" else backend)
         out["allreduce_exposed_ms"] = round(exposed_ms, 3)
         out["gradient_payload_bytes"] = int(sum(a.n for a in arenas) * (2 if args.grad_wire == "bf16" else 4))
@@ -496,6 +514,26 @@ def main():
             db = decode_bench(argparse.Namespace(batch=0, steps=4, warmup=1), device)
             out["decode"] = {"metric": db["metric"], "tokens_per_s": db["value"], "beam_tokens_per_s": db["beam_tokens_per_s"],
                              "ms_per_batch": db["ms_per_step"], "config": db["config"]["workload"], "roofline": db["roofline"]}
+        if not args.no_sub_benches and args.precision == "bf16":
+            # the same step in the parity mode (--fp-precision 32, the reference's default: split-bf16 operands, logits within 1e-3 of
+            # the fp32 reference at full depth) next to the bf16 headline
+            torch.cuda.empty_cache()
+            me.set_precision(32)
+            ge.set_precision(32)
+            for i in range(nxt, nxt + 3):
+                one_step(i)
+            sync()
+            t0 = time.perf_counter()
+            k3 = 20
+            for i in range(nxt + 3, nxt + 3 + k3):
+                loss3 = one_step(i)
+            sync()
+            ms3 = (time.perf_counter() - t0) / k3 * 1e3
+            out["fp32_parity_mode"] = {"operands": "split bf16 (hi*hi + hi*lo + lo*hi), fp32 activations", "flag": "--fp-precision 32",
+                                       "ms_per_step": round(ms3, 3), "samples_per_s": round(B / ms3 * 1e3, 1), "steps": k3,
+                                       "slowdown_vs_bf16": round(ms3 / ms_per_step, 2), "final_loss": round(float(loss3.item()), 4)}
+            me.set_precision("bf16")
+            ge.set_precision("bf16")
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(c)
             if not args.no_sub_benches:

@@ -114,6 +114,7 @@ SIGNATURES = {
     "cc_comm_create": (_I, [C.POINTER(_P), _I, _I, _P]),
     "cc_allreduce_bucket": (_I, [_P, _P, _L, _I, _P]),
     "cc_comm_destroy": (_I, [_P]),
+    "cc_comm_count": (_I, [_P, C.POINTER(_I)]),
     "cc_prof_start": (_I, [_I, _I]),
     "cc_prof_stop": (_I, [C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(_I)]),
 }

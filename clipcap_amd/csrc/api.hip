@@ -856,13 +856,13 @@ int CC_API(cc_gpt2_bwd_range)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, cons
 // ---------------------------------------------------------------- optimizer / casts / test hooks -----------------
 int CC_API(cc_adamw_step)(float* p32, const float* g32, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int32_t step, float grad_scale, const float* loss_scale, const float* found_inf, void* stream) {
-    if (!p32 || !g32 || !m || !v || n < 0 || step < 1) return CC_ERR_ARG;
+    if (!p32 || !g32 || !m || !v || n < 0 || step < 0 || (step == 0 && !loss_scale)) return CC_ERR_ARG;
     return adamw(p32, g32, m, v, (size_t)n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, loss_scale, found_inf, S_(stream));
 }
 
 int CC_API(cc_adamw_step_cast)(float* p32, const float* g32, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                        float weight_decay, int32_t step, float grad_scale, const float* loss_scale, const float* found_inf, uint16_t* w16, void* stream) {
-    if (!p32 || !g32 || !m || !v || !w16 || n < 0 || step < 1) return CC_ERR_ARG;
+    if (!p32 || !g32 || !m || !v || !w16 || n < 0 || step < 0 || (step == 0 && !loss_scale)) return CC_ERR_ARG;
     if (kX3) return CC_ERR_ARG;      // bf16x3: the operand images are per-matrix row images, not a flat cast (use cc_adamw_step + cc_*_sync_weights)
     return adamw(p32, g32, m, v, (size_t)n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, loss_scale, found_inf, S_(stream), w16);
 }

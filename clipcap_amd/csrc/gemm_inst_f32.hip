@@ -84,6 +84,7 @@ static int wgrad_launch_group(WgradBatch& b, hipStream_t st) {
             if (cost < best_cost) { best_cost = cost; best_tile = tile; best_ks = ks; }
         }
     }
+    if (best_cost >= 1e30) return CC_ERR_STATE;      // no (tile, slices) fits the scratch: gemm_wgrad's admission check keeps this from happening
     const int bk = best_tile == 256 ? H_BK : G_BK, ksteps = K / bk;
     // slices are multiples of 64 deep for both kernels (k_chunk convention of GemmShape)
     const int kt64 = (K + G_BK - 1) / G_BK;
@@ -166,9 +167,18 @@ int gemm_wgrad(const act_t* Xa, int ldx, const act_t* Ya, int ldy, int Mw, int N
         if (rcf != CC_OK) return rcf;
     }
     // grouped path: park the problem; wgrad_flush launches the layer's gradients together (one tail, one launch floor)
+    // a deferred problem needs at least one slab behind the parked ones and the other deferred problems' slabs (wgrad_launch_group then
+    // finds a slice count that fits); a gradient whose single slab exceeds the scratch (GPT-2-xl width: c_fc 4 D^2 fp32 = 41 MB is fine,
+    // but 12 D^2 = 123 MB for the layer is not) makes the group flush early, one larger than the whole scratch is never deferred
+    const size_t slab_bytes = ((slab * sizeof(float)) + 255) & ~size_t(255);
     if (may_defer && batch && batch->defer && g_gemm_tile_mode != 0 && tt_ok && scratch && (K % G_BK) == 0 && K >= 1024 && (slab & 3) == 0 &&
-        (batch->nd == 0 || batch->d[0].K == K)) {
-        if (batch->nd == 4 || batch->n + batch->nd >= 8) { const int rcf = wgrad_flush(*batch, st); if (rcf != CC_OK) return rcf; }
+        slab_bytes <= WGRAD_SCRATCH_BYTES && (batch->nd == 0 || batch->d[0].K == K)) {
+        size_t pending = 0;
+        for (int i = 0; i < batch->nd; i++) pending += (((size_t)batch->d[i].Mw * batch->d[i].Nw * sizeof(float)) + 255) & ~size_t(255);
+        if (batch->nd == 4 || batch->n + batch->nd >= 8 || batch->used + pending + slab_bytes > WGRAD_SCRATCH_BYTES) {
+            const int rcf = wgrad_flush(*batch, st);
+            if (rcf != CC_OK) return rcf;
+        }
         batch->scratch = scratch;
         batch->d[batch->nd++] = WgradBatch::Deferred{X, Y, ldx, ldy, Mw, Nw, K, dW, ldw};
         return CC_OK;

@@ -505,9 +505,9 @@ __device__ __forceinline__ void load_head_rows(float* dst, int hdp, const act_t*
     }
 }
 
-template <bool CAUSAL>
+template <bool CAUSAL, bool DROP = false>
 __global__ __launch_bounds__(256) void k_attn_fwd(const act_t* __restrict__ qkv, int S, int H, int hd, float scale,
-                                                  act_t* __restrict__ out, float* __restrict__ lse) {
+                                                  act_t* __restrict__ out, float* __restrict__ lse, Drop drop = Drop()) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int D = H * hd, hdp = hd + 4, Sp = S + 1;
     float* Qs = sm;
@@ -576,7 +576,8 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const act_t* __restrict__ qkv,
         float4 o = make_float4(0, 0, 0, 0);
         const int jmax = CAUSAL ? i + 1 : S;
         for (int j = 0; j < jmax; j++) {
-            const float p = Ps[i * Sp + j];
+            float p = Ps[i * Sp + j];
+            if (DROP) p *= drop_mul(drop, ((unsigned)(b * H + h) * S + i) * S + j);      // attention-probability dropout: P V only, as in the MFMA kernel
             const float4 v = *reinterpret_cast<const float4*>(Vs + j * hdp + d0);
             o.x += p * v.x; o.y += p * v.y; o.z += p * v.z; o.w += p * v.w;
         }
@@ -1292,6 +1293,157 @@ int attn_probs(const act_t* qkv, int B, int S, int H, int hd, float* out, hipStr
     return CC_OK;
 }
 
+#if CC_OP == 2
+// ------------------------------------------------------------------------------------------------------------
+// bf16x3 build, sequences whose S x S tile does not fit the LDS kernels (the windowed mapper: S = 180): plain fp32 attention with one
+// wave per row, any S <= 2048, K / V / Q rows read through the caches.  Parity mode: simplicity over speed.
+//   forward   (wave per query i): scores over the keys -> LDS row, softmax, O_i = P_i V, log-sum-exp
+//   backward  dq  (wave per query i): P_i, dP_i = dO_i V^T, delta_i = dO_i . O_i (stored), dS_i -> LDS row, dQ_i = dS_i K
+//             dkv (wave per key j):   P_:j, dS_:j over the queries -> LDS, dK_j = dS_:j^T Q, dV_j = P_:j^T dO
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float row_dot(const float* a, const float* b, int hd) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int d = 0; d < hd; d += 8) {
+        const float4 x0 = *reinterpret_cast<const float4*>(a + d), y0 = *reinterpret_cast<const float4*>(b + d);
+        const float4 x1 = *reinterpret_cast<const float4*>(a + d + 4), y1 = *reinterpret_cast<const float4*>(b + d + 4);
+        s0 += x0.x * y0.x + x0.y * y0.y + x0.z * y0.z + x0.w * y0.w;
+        s1 += x1.x * y1.x + x1.y * y1.y + x1.z * y1.z + x1.w * y1.w;
+    }
+    return s0 + s1;
+}
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) void k_attn_fwd_rows(const float* __restrict__ qkv, int B, int S, int H, int hd, float scale, float* __restrict__ out,
+                                                       float* __restrict__ lse) {
+    extern __shared__ float rsm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= B * H * S) return;
+    const int i = item % S, h = (item / S) % H, b = item / (S * H);
+    const int D = H * hd;
+    const size_t rs = (size_t)3 * D;
+    const float* base = qkv + (size_t)b * S * rs + h * hd;
+    const float* q = base + (size_t)i * rs;
+    float* p = rsm + wave * S;
+    const int nk = CAUSAL ? i + 1 : S;
+    float m = -INFINITY;
+    for (int j = lane; j < nk; j += 64) {
+        const float sc = row_dot(q, base + D + (size_t)j * rs, hd) * scale;
+        p[j] = sc;
+        m = fmaxf(m, sc);
+    }
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int j = lane; j < nk; j += 64) {
+        const float e = __expf(p[j] - m);
+        p[j] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    for (int d = lane; d < hd; d += 64) {
+        float o = 0.f;
+        const float* v = base + 2 * D + d;
+        for (int j = 0; j < nk; j++) o += p[j] * v[(size_t)j * rs];
+        out[((size_t)b * S + i) * D + h * hd + d] = o * inv;
+    }
+    if (lane == 0 && lse) lse[((size_t)b * H + h) * S + i] = m + __logf(sum);
+}
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) void k_attn_bwd_rows_dq(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ o,
+                                                          const float* __restrict__ lse, float* __restrict__ delta, int B, int S, int H, int hd,
+                                                          float scale, float* __restrict__ dqkv) {
+    extern __shared__ float rsm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= B * H * S) return;
+    const int i = item % S, h = (item / S) % H, b = item / (S * H);
+    const int D = H * hd;
+    const size_t rs = (size_t)3 * D;
+    const float* base = qkv + (size_t)b * S * rs + h * hd;
+    const float* q = base + (size_t)i * rs;
+    const float* dor = dout + ((size_t)b * S + i) * D + h * hd;
+    const float* orow = o + ((size_t)b * S + i) * D + h * hd;
+    float* ds = rsm + wave * S;
+    float dl = 0.f;
+    for (int d = lane; d < hd; d += 64) dl += dor[d] * orow[d];
+    dl = wave_sum(dl);
+    const float l = lse[((size_t)b * H + h) * S + i];
+    if (lane == 0) delta[((size_t)b * H + h) * S + i] = dl;
+    const int nk = CAUSAL ? i + 1 : S;
+    for (int j = lane; j < nk; j += 64) {
+        const float pj = __expf(row_dot(q, base + D + (size_t)j * rs, hd) * scale - l);
+        const float dp = row_dot(dor, base + 2 * D + (size_t)j * rs, hd);
+        ds[j] = pj * (dp - dl) * scale;
+    }
+    for (int d = lane; d < hd; d += 64) {
+        float acc = 0.f;
+        const float* k = base + D + d;
+        for (int j = 0; j < nk; j++) acc += ds[j] * k[(size_t)j * rs];
+        dqkv[((size_t)b * S + i) * rs + h * hd + d] = acc;
+    }
+}
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) void k_attn_bwd_rows_dkv(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse,
+                                                           const float* __restrict__ delta, int B, int S, int H, int hd, float scale,
+                                                           float* __restrict__ dqkv) {
+    extern __shared__ float rsm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= B * H * S) return;
+    const int j = item % S, h = (item / S) % H, b = item / (S * H);
+    const int D = H * hd;
+    const size_t rs = (size_t)3 * D;
+    const float* base = qkv + (size_t)b * S * rs + h * hd;
+    const float* k = base + D + (size_t)j * rs;
+    const float* v = base + 2 * D + (size_t)j * rs;
+    const float* dbase = dout + (size_t)b * S * D + h * hd;
+    const float* lrow = lse + ((size_t)b * H + h) * S;
+    const float* drow = delta + ((size_t)b * H + h) * S;
+    float* pp = rsm + wave * 2 * S;
+    float* ds = pp + S;
+    const int i0 = CAUSAL ? j : 0;
+    for (int i = i0 + lane; i < S; i += 64) {
+        const float pij = __expf(row_dot(base + (size_t)i * rs, k, hd) * scale - lrow[i]);
+        const float dp = row_dot(dbase + (size_t)i * D, v, hd);
+        pp[i] = pij;
+        ds[i] = pij * (dp - drow[i]) * scale;
+    }
+    for (int d = lane; d < hd; d += 64) {
+        float dk = 0.f, dv = 0.f;
+        for (int i = i0; i < S; i++) {
+            dk += ds[i] * base[(size_t)i * rs + d];
+            dv += pp[i] * dbase[(size_t)i * D + d];
+        }
+        float* orow = dqkv + ((size_t)b * S + j) * rs + h * hd + d;
+        orow[D] = dk;
+        orow[2 * D] = dv;
+    }
+}
+static int attn_fwd_rows(const float* qkv, int B, int S, int H, int hd, bool causal, float* out, float* lse, float scale, hipStream_t st) {
+    if (S > 2048) return CC_ERR_SHAPE;
+    const int items = B * H * S;
+    const size_t sh = (size_t)4 * S * sizeof(float);
+    if (causal) hipLaunchKernelGGL(k_attn_fwd_rows<true>, dim3((items + 3) / 4), dim3(256), sh, st, qkv, B, S, H, hd, scale, out, lse);
+    else hipLaunchKernelGGL(k_attn_fwd_rows<false>, dim3((items + 3) / 4), dim3(256), sh, st, qkv, B, S, H, hd, scale, out, lse);
+    return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+}
+static int attn_bwd_rows(const float* qkv, const float* dout, const float* o, const float* lse, float* delta, int B, int S, int H, int hd,
+                         bool causal, float* dqkv, float scale, hipStream_t st) {
+    if (S > 2048) return CC_ERR_SHAPE;
+    const int items = B * H * S;
+    const dim3 gr((items + 3) / 4), bl(256);
+    const size_t sh1 = (size_t)4 * S * sizeof(float), sh2 = 2 * sh1;
+    if (causal) {
+        hipLaunchKernelGGL(k_attn_bwd_rows_dq<true>, gr, bl, sh1, st, qkv, dout, o, lse, delta, B, S, H, hd, scale, dqkv);
+        hipLaunchKernelGGL(k_attn_bwd_rows_dkv<true>, gr, bl, sh2, st, qkv, dout, lse, delta, B, S, H, hd, scale, dqkv);
+    } else {
+        hipLaunchKernelGGL(k_attn_bwd_rows_dq<false>, gr, bl, sh1, st, qkv, dout, o, lse, delta, B, S, H, hd, scale, dqkv);
+        hipLaunchKernelGGL(k_attn_bwd_rows_dkv<false>, gr, bl, sh2, st, qkv, dout, lse, delta, B, S, H, hd, scale, dqkv);
+    }
+    return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+}
+#endif   // CC_OP == 2
+
 int attn_fwd(const act_t* qkv, int B, int S, int H, int hd, bool causal, act_t* out, float* lse, hipStream_t st, Drop drop) {
     if ((hd & 7) || S <= 0) return CC_ERR_SHAPE;
 #if CC_OP != 2
@@ -1302,11 +1454,21 @@ int attn_fwd(const act_t* qkv, int B, int S, int H, int hd, bool causal, act_t* 
         if (hd == 128) return attn_fwd_mfma_launch<128>(qkv, B, S, H, causal, out, lse, st, drop);
     }
 #endif
-    if (drop.thresh) return CC_ERR_SHAPE;          // the VALU fallback kernels have no dropout
+    if (drop.thresh && (!kX3 || !causal)) return CC_ERR_SHAPE;          // dropout on the VALU kernels: the bf16x3 build's GPT-2 path only
     const size_t sh = attn_fwd_lds(S, hd);
-    if (sh > 160 * 1024) return CC_ERR_SHAPE;
     const float scale = 1.0f / sqrtf((float)hd);
-    if (causal) {
+    if (sh > 160 * 1024) {
+#if CC_OP == 2
+        if (drop.thresh) return CC_ERR_SHAPE;
+        return attn_fwd_rows(qkv, B, S, H, hd, causal, out, lse, scale, st);
+#else
+        return CC_ERR_SHAPE;
+#endif
+    }
+    if (drop.thresh) {
+        if (sh > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_attn_fwd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL((k_attn_fwd<true, true>), dim3(B * H), dim3(256), sh, st, qkv, S, H, hd, scale, out, lse, drop);
+    } else if (causal) {
         if (sh > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_attn_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         hipLaunchKernelGGL(k_attn_fwd<true>, dim3(B * H), dim3(256), sh, st, qkv, S, H, hd, scale, out, lse);
     } else {
@@ -1318,10 +1480,12 @@ int attn_fwd(const act_t* qkv, int B, int S, int H, int hd, bool causal, act_t* 
 
 // Backward: recompute P from the saved lse; dP = dO V^T; delta_i = sum_j P_ij dP_ij (== dO_i . O_i);
 // dS = P (dP - delta) * scale; dQ = dS K; dK = dS^T Q; dV = P^T dO.  Writes dqkv (bf16) in the qkv layout.
-template <bool CAUSAL>
+// With attention-probability dropout (DROP; mask M, keep scale 1/(1-p)): A_d = M A / (1-p) entered the forward's P V, so
+// dV = A_d^T dO, dA = M dA_d / (1-p) with dA_d = dO V^T, delta = rowsum(A dA), dS = A (dA - delta) scale.
+template <bool CAUSAL, bool DROP = false>
 __global__ __launch_bounds__(256) void k_attn_bwd(const act_t* __restrict__ qkv, const act_t* __restrict__ dout,
                                                   const float* __restrict__ lse, int S, int H, int hd, float scale,
-                                                  act_t* __restrict__ dqkv) {
+                                                  act_t* __restrict__ dqkv, Drop drop = Drop()) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int D = H * hd, hdp = hd + 4, Sp = S + 1;
     float* Qs = sm;
@@ -1367,7 +1531,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd(const act_t* __restrict__ qkv,
             if (i < S) {
                 const bool masked = CAUSAL && j > i;
                 Ps[i * Sp + j] = masked ? 0.f : __expf(s[ii] * scale - lrow[i]);
-                Ds[i * Sp + j] = masked ? 0.f : dp[ii];
+                Ds[i * Sp + j] = masked ? 0.f : (DROP ? dp[ii] * drop_mul(drop, ((unsigned)(b * H + h) * S + i) * S + j) : dp[ii]);
             }
         }
     }
@@ -1392,7 +1556,9 @@ __global__ __launch_bounds__(256) void k_attn_bwd(const act_t* __restrict__ qkv,
         }
         const int ilo = CAUSAL ? r : 0;       // dK_r, dV_r: queries i >= r
         for (int i = ilo; i < S; i++) {
-            const float w = Ds[i * Sp + r], p = Ps[i * Sp + r];
+            const float w = Ds[i * Sp + r];
+            float p = Ps[i * Sp + r];
+            if (DROP) p *= drop_mul(drop, ((unsigned)(b * H + h) * S + i) * S + r);
             const float4 q = *reinterpret_cast<const float4*>(Qs + i * hdp + d0);
             const float4 o = *reinterpret_cast<const float4*>(Os + i * hdp + d0);
             dk.x += w * q.x; dk.y += w * q.y; dk.z += w * q.z; dk.w += w * q.w;
@@ -1414,14 +1580,22 @@ int attn_bwd(const act_t* qkv, const act_t* dout, const act_t* o, const float* l
         if (hd == 96) return attn_bwd_mfma_launch<96>(qkv, dout, o, lse, delta, B, S, H, causal, dqkv, st, drop);
         if (hd == 128) return attn_bwd_mfma_launch<128>(qkv, dout, o, lse, delta, B, S, H, causal, dqkv, st, drop);
     }
-#else
-    (void)o; (void)delta;
 #endif
-    if (drop.thresh) return CC_ERR_SHAPE;          // the VALU fallback kernel has no dropout
+    if (drop.thresh && (!kX3 || !causal)) return CC_ERR_SHAPE;          // dropout on the VALU kernel: the bf16x3 build's GPT-2 path only
     const size_t sh = attn_bwd_lds(S, hd);
-    if (sh > 160 * 1024) return CC_ERR_SHAPE;
     const float scale = 1.0f / sqrtf((float)hd);
-    if (causal) {
+    if (sh > 160 * 1024) {
+#if CC_OP == 2
+        if (drop.thresh || !o || !delta) return CC_ERR_SHAPE;
+        return attn_bwd_rows(qkv, dout, o, lse, delta, B, S, H, hd, causal, dqkv, scale, st);
+#else
+        return CC_ERR_SHAPE;
+#endif
+    }
+    if (drop.thresh) {
+        if (sh > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_attn_bwd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL((k_attn_bwd<true, true>), dim3(B * H), dim3(256), sh, st, qkv, dout, lse, S, H, hd, scale, dqkv, drop);
+    } else if (causal) {
         if (sh > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_attn_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         hipLaunchKernelGGL(k_attn_bwd<true>, dim3(B * H), dim3(256), sh, st, qkv, dout, lse, S, H, hd, scale, dqkv);
     } else {
@@ -1682,9 +1856,14 @@ int ce_targets(const long long* tokens, int* target, int* row_map, int B, int ca
 __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                float* __restrict__ v, size_t n4, float lr, float b1, float b2, float eps, float wd, float bc1,
                                                float bc2_sqrt, float gscale, const float* __restrict__ loss_scale,
-                                               const float* __restrict__ found_inf, op16_t* __restrict__ w16) {
+                                               const float* __restrict__ found_inf, op16_t* __restrict__ w16, int dev_step) {
     if (found_inf && found_inf[0] != 0.f) return;
     if (loss_scale) gscale /= loss_scale[0];
+    if (dev_step) {      // step number = 1 + the loss scaler's count of APPLIED steps (loss_scale[2]): a skipped step does not advance Adam's bias correction
+        const float t = loss_scale[2] + 1.0f;
+        bc1 = 1.0f - powf(b1, t);
+        bc2_sqrt = sqrtf(1.0f - powf(b2, t));
+    }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 P = reinterpret_cast<float4*>(p)[i], G = reinterpret_cast<const float4*>(g)[i];
         float4 M = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i];
@@ -1709,11 +1888,12 @@ int adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, floa
           const float* loss_scale, const float* found_inf, hipStream_t st, op16_t* w16) {
     if (n & 3) return CC_ERR_SHAPE;
     if (!n) return CC_OK;
-    const float bc1 = 1.0f - powf(b1, (float)step);
-    const float bc2s = sqrtf(1.0f - powf(b2, (float)step));
+    if (step < 1 && !loss_scale) return CC_ERR_ARG;
+    const float bc1 = 1.0f - powf(b1, (float)std::max(step, 1));
+    const float bc2s = sqrtf(1.0f - powf(b2, (float)std::max(step, 1)));
     const size_t n4 = n >> 2;
     hipLaunchKernelGGL(k_adamw, dim3((int)std::min<size_t>((n4 + 255) / 256, 4096)), dim3(256), 0, st, p, g, m, v, n4, lr, b1, b2, eps, wd,
-                       bc1, bc2s, gscale, loss_scale, found_inf, w16);
+                       bc1, bc2s, gscale, loss_scale, found_inf, w16, step < 1 ? 1 : 0);
     return CC_OK;
 }
 
@@ -1748,6 +1928,7 @@ __global__ void k_loss_scale_update(float* state, float* found_inf, float growth
         } else {
             state[1] = good;
         }
+        state[2] += 1.f;      // optimizer steps actually applied (read by the next cc_adamw_step called with step = 0)
     }
     found_inf[0] = 0.f;
 }

@@ -75,6 +75,7 @@ struct Rccl {
     ncclResult_t (*init_rank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*all_reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*destroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*count)(const ncclComm_t, int*) = nullptr;
     bool ok = false;
     Rccl() {
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
@@ -85,6 +86,7 @@ struct Rccl {
         init_rank = reinterpret_cast<decltype(init_rank)>(dlsym(h, "ncclCommInitRank"));
         all_reduce = reinterpret_cast<decltype(all_reduce)>(dlsym(h, "ncclAllReduce"));
         destroy = reinterpret_cast<decltype(destroy)>(dlsym(h, "ncclCommDestroy"));
+        count = reinterpret_cast<decltype(count)>(dlsym(h, "ncclCommCount"));
         ok = get_uid && init_rank && all_reduce && destroy;
     }
 };
@@ -122,6 +124,15 @@ int cc_allreduce_bucket(void* comm, void* buf, int64_t count, int32_t dtype, voi
     const ncclDataType_t t = dtype == CC_RED_F32 ? ncclFloat32 : dtype == CC_RED_BF16 ? ncclBfloat16 : ncclFloat16;
     return rccl().all_reduce(buf, buf, (size_t)count, t, ncclSum, static_cast<ncclComm_t>(comm), static_cast<hipStream_t>(stream)) == ncclSuccess
                ? CC_OK : CC_ERR_LAUNCH;
+}
+
+int cc_comm_count(void* comm, int32_t* nranks) {
+    if (!comm || !nranks) return CC_ERR_ARG;
+    if (!rccl().ok || !rccl().count) return CC_ERR_STATE;
+    int n = 0;
+    if (rccl().count(static_cast<ncclComm_t>(comm), &n) != ncclSuccess) return CC_ERR_LAUNCH;
+    *nranks = n;
+    return CC_OK;
 }
 
 int cc_comm_destroy(void* comm) {

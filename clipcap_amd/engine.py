@@ -120,13 +120,14 @@ class _Arena:
         # the cast untouched, which is only right if the cast was current before the step.
         if os.environ.get("CC_ADAMW_TWO_PASS") or self.op_dtype == OP_X3:   # A/B switch: the separate-cast form; bf16x3: operand images are per matrix
             check(_lib.lib().cc_adamw_step(_p(self.w32), _p(self.grads()), _p(self.m), _p(self.v), self.n, lr, betas[0], betas[1], eps,
-                                           weight_decay, step, grad_scale, _p(scaler.scale) if scaler is not None else None,
+                                           weight_decay, 0 if scaler is not None else step, grad_scale, _p(scaler.scale) if scaler is not None else None,
                                            _p(scaler.found_inf) if scaler is not None else None, _stream(self.device)), "cc_adamw_step")
             self.refresh_bf16()
             return
         current = self._stamp() == self._w16_version
+        # with a loss scaler the Adam step number is the scaler's device-side count of applied steps (step = 0 asks the kernel for it)
         check(_lib.lib().cc_adamw_step_cast(self.op_dtype, _p(self.w32), _p(self.grads()), _p(self.m), _p(self.v), self.n, lr, betas[0],
-                                            betas[1], eps, weight_decay, step, grad_scale, _p(scaler.scale) if scaler is not None else None,
+                                            betas[1], eps, weight_decay, 0 if scaler is not None else step, grad_scale, _p(scaler.scale) if scaler is not None else None,
                                             _p(scaler.found_inf) if scaler is not None else None, _p(self.w16), _stream(self.device)),
               "cc_adamw_step_cast")
         if scaler is None or current:
@@ -139,12 +140,14 @@ class _Arena:
 class LossScaler:
     """Dynamic loss scale for fp16-operand training, torch.cuda.amp.GradScaler semantics (init 2^16, x2 every 2000 good steps, x0.5
     on overflow) — what Lightning wraps around the reference's model for ``--fp-precision 16`` — kept entirely on the device:
-    ``state`` = [scale, good-step counter], ``found_inf`` is raised by cc_grad_nonfinite and read by cc_adamw_step (which then skips
+    ``state`` = [scale, good-step counter, applied-step counter], ``found_inf`` is raised by cc_grad_nonfinite and read by cc_adamw_step (which then skips
     the step) and by cc_loss_scale_update.  No host synchronisation anywhere."""
 
     def __init__(self, device, init_scale: float = 65536.0, growth: float = 2.0, backoff: float = 0.5, interval: int = 2000):
         self.device = torch.device(device)
-        self.state = torch.tensor([init_scale, 0.0], dtype=torch.float32, device=self.device)
+        # [scale, good steps since the last change, optimizer steps actually APPLIED (skipped ones do not count: Adam's bias correction
+        # follows this counter, as torch.cuda.amp.GradScaler + torch.optim.AdamW do)]
+        self.state = torch.tensor([init_scale, 0.0, 0.0], dtype=torch.float32, device=self.device)
         self.found_inf = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.growth, self.backoff, self.interval = growth, backoff, interval
 
@@ -408,8 +411,23 @@ class Gpt2Engine:
         assert (B, T) == (shp.B, shp.T) and V == self.dims["V"]
         dx0 = torch.empty(B, T, self.dims["D"], dtype=torch.float32, device=a.device)
         ws = self.workspace(shp)
+        scale = keep = None
+        if self.op_dtype == OP_FP16:
+            # fp16 operands: d logits of a mean cross-entropy are p / N ~ 1e-9 .. 1e-5, below fp16's normal range (6e-5) — the whole
+            # backward runs under a power-of-two scale chosen on the device from max |d logits| (no host sync) and divided out of dx0
+            # and of the weight gradients afterwards, as the fused trainer does with its LossScaler
+            amax = dl.abs().amax().clamp_min(1e-30)
+            scale = torch.exp2(torch.floor(torch.log2(256.0 / amax)))
+            dl = dl * scale
+            if shp.mode == 2:
+                keep = a.grads().clone()
+                a.grads().zero_()
         check(_lib.lib().cc_gpt2_logits_bwd(C.byref(self.cfg), C.byref(shp), _p(a.w32), _p(a.w16), _p(ws), _p(dl), V, _p(dx0),
                                             _p(a.grads()) if shp.mode == 2 else None, _stream(a.device)), "cc_gpt2_logits_bwd")
+        if scale is not None:
+            dx0 = dx0 / scale
+            if keep is not None:
+                a.grads().div_(scale).add_(keep)
         return dx0
 
 
@@ -606,26 +624,24 @@ def embed_tokens(gpt2: "Gpt2Engine", tokens: torch.Tensor, out: torch.Tensor) ->
     return out
 
 
-_BEAM_BUFFERS: Dict[tuple, tuple] = {}
+def beam_buffers(device, samples: int, beam: int, V: int) -> tuple:
+    """(next_tokens int32 (samples*beam,), src_rows int32 (samples*beam,), scratch) of cc_beam_step.  Owned by ONE decode (a
+    generate_beam_tokens call allocates them once and reuses them from step to step: each step's outputs are consumed by
+    cc_beam_advance before the next update) — never shared between decodes, streams or threads."""
+    return (torch.empty(samples * beam, dtype=torch.int32, device=device), torch.empty(samples * beam, dtype=torch.int32, device=device),
+            torch.empty(_lib.lib().cc_beam_ws_bytes(samples, beam, V), dtype=torch.uint8, device=device))
 
 
 def beam_step(logits: torch.Tensor, samples: int, beam: int, temperature: float, first: bool, stop_token: int, scores: torch.Tensor,
-              seq_lengths: torch.Tensor, has_stopped: torch.Tensor):
+              seq_lengths: torch.Tensor, has_stopped: torch.Tensor, bufs: Optional[tuple] = None):
     """One device-side beam update for `samples` independent beam sets (reference inference/base.py:84-119).
     logits fp32 (samples*beam, V) (a view with row stride ldl is fine); state tensors are updated IN PLACE.
+    ``bufs``: the caller's beam_buffers(...) (fresh ones are allocated when omitted).
     Returns (next_tokens int32 (samples*beam,), src_rows int32 (samples*beam,) local row index inside each sample)."""
     dev = logits.device
     V = logits.shape[1]
     ldl = logits.stride(0)
-    key = (dev, samples, beam, V)
-    bufs = _BEAM_BUFFERS.get(key)
-    if bufs is None:       # outputs + scratch are reused from step to step (consumed by cc_beam_advance before the next update)
-        if len(_BEAM_BUFFERS) > 8:
-            _BEAM_BUFFERS.clear()
-        bufs = (torch.empty(samples * beam, dtype=torch.int32, device=dev), torch.empty(samples * beam, dtype=torch.int32, device=dev),
-                torch.empty(_lib.lib().cc_beam_ws_bytes(samples, beam, V), dtype=torch.uint8, device=dev))
-        _BEAM_BUFFERS[key] = bufs
-    nt, sr, ws = bufs
+    nt, sr, ws = bufs if bufs is not None else beam_buffers(dev, samples, beam, V)
     check(_lib.lib().cc_beam_step(samples, beam, V, _p(logits), ldl, float(temperature), int(first), int(stop_token), _p(scores), _p(seq_lengths),
                                  _p(has_stopped), _p(nt), _p(sr), _p(ws), _stream(dev)), "cc_beam_step")
     return nt, sr

@@ -12,7 +12,7 @@ from clipcap_amd.encoders.config import EncoderConfig
 @dataclass
 class TrainingConfig:
     optimizer_lr: float = 2e-5
-    use_deepspeed_optimisers: bool = True   # kept for yaml compatibility; the fused HIP AdamW is always used here
+    use_deepspeed_optimisers: bool = True   # the fused HIP AdamW is always used; True selects FusedAdam's weight decay (0.0), False torch AdamW's (0.01): model.py:72-77
     scheduler_warmup_steps: int = 123
     total_steps: int = 123
 

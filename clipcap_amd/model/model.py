@@ -112,12 +112,19 @@ class ClipCapModel(nn.Module):
         else:
             loss = eng.forward_backward(tokens, embeds, dropout=self._dropout())
         self._opt_step += 1
-        eng.optimizer_step(lr, self._opt_step)
+        eng.optimizer_step(lr, self._opt_step, weight_decay=self._weight_decay())
         return loss
+
+    def _weight_decay(self) -> float:
+        """model.py:72-77: ``--enable-deepspeed`` swaps torch.optim.AdamW (weight_decay 0.01) for DeepSpeed's
+        FusedAdam(adam_w_mode=True), whose default weight_decay is 0.0 — a run with that flag trains without decay; followed here."""
+        tc = self.config.training_config
+        return 0.0 if (tc is not None and tc.use_deepspeed_optimisers) else 0.01
 
     def set_precision(self, precision) -> "ClipCapModel":
         """What the reference hands to ``pl.Trainer(precision=args.fp_precision)`` (clipcap/train/train.py:82): 16 selects fp16 MFMA
-        operands + dynamic loss scaling for mapper and language model, 32 / 64 the default bf16 operands."""
+        operands + dynamic loss scaling for mapper and language model, 32 (the reference's default) / 64 split-bf16 operands (three
+        MFMA terms per product, logits within 1e-3 of the fp32 reference), "bf16" plain bf16 operands (_lib.op_dtype_of)."""
         self.transformer_mapper.set_precision(precision)
         self.language_model.set_precision(precision)
         self._engine = None
@@ -140,7 +147,7 @@ class ClipCapModel(nn.Module):
         tc = self.config.training_config
         assert tc is not None, "You must first use `set_training_config` before training."
         arenas = [self.transformer_mapper] + ([self.language_model] if self._train_lm else [])
-        optimizer = ArenaAdamW(arenas, lr=tc.optimizer_lr)
+        optimizer = ArenaAdamW(arenas, lr=tc.optimizer_lr, weight_decay=self._weight_decay())
         scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, linear_warmup_decay(tc.scheduler_warmup_steps, tc.total_steps))
         return {"optimizer": optimizer, "lr_scheduler": {"scheduler": scheduler, "interval": "step", "frequency": 1}}
 

@@ -1,6 +1,7 @@
 """``add_training_args`` — the reference's training / data / deepspeed / wandb flags with identical names, types and defaults
 (clipcap/train/args.py:3-113).  Flags that configured Lightning/DeepSpeed are accepted for command-line compatibility;
-``--enable-deepspeed`` / ``--deepspeed-strategy`` select nothing here (multi-GPU is always one process per GPU + RCCL)."""
+``--deepspeed-strategy`` selects nothing here (multi-GPU is always one process per GPU + RCCL); ``--enable-deepspeed`` keeps its one
+numerical effect, the optimizer's weight decay (0.0 under DeepSpeed's FusedAdam, 0.01 under torch.optim.AdamW)."""
 from argparse import ArgumentParser
 
 
@@ -29,7 +30,8 @@ _GROUPS = {
         ("--reader-parallel-pieces", int, 10, "Accepted for compatibility with the embedding-reader flags."),
     ],
     "deepspeed": [
-        ("--enable-deepspeed", bool, False, "Accepted for compatibility; no effect."),
+        ("--enable-deepspeed", bool, False, "No DeepSpeed here (one process per GPU + RCCL always); kept for its one numerical effect in the reference: "
+         "FusedAdam's default weight decay 0.0 instead of torch AdamW's 0.01 (clipcap/model/model.py:72-77)."),
         ("--deepspeed-strategy", str, None, "Accepted for compatibility; no effect."),
     ],
     "wandb": [

@@ -29,6 +29,9 @@ class CheckpointSaver:
             a = mod.engine.arena
             if a.m is not None:
                 opt[name] = {"m": a.m.cpu(), "v": a.v.cpu()}
+        sc = getattr(model.engine, "scaler", None)      # fp16 operands: [scale, good steps, applied steps] of the dynamic loss scale
+        if sc is not None:
+            extra = dict(extra, loss_scaler=sc.state.cpu())
         torch.save({"state_dict": state, "optimizer_state": opt, "optimizer_step": getattr(model, "_opt_step", 0), **extra}, path)
 
     def on_epoch_end(self, model, epoch: int, **extra) -> None:
@@ -50,4 +53,9 @@ def resume(model, ckpt_path: str) -> dict:
             a.m = st["m"].to(a.device)
             a.v = st["v"].to(a.device)
     model._opt_step = int(ck.get("optimizer_step", 0))
+    if "loss_scaler" in ck and model.language_model.engine.arena.device.type == "cuda":
+        sc = model.engine._scaler(model.language_model.engine.arena.device)
+        if sc is not None:      # resumed fp16 run: continue at the saved scale instead of restarting at 2^16 (and skipping steps again)
+            st = ck["loss_scaler"].to(sc.state.device, torch.float32)
+            sc.state[: st.numel()].copy_(st)
     return ck

@@ -69,6 +69,12 @@ class CAbiComm:
         self._lib.check(self._lib.lib().cc_allreduce_bucket(self._comm, self._C.c_void_p(t.data_ptr()), t.numel(), code,
                                                             self._C.c_void_p(st.cuda_stream)), "cc_allreduce_bucket")
 
+    def count(self) -> int:
+        """ncclCommCount: the ranks RCCL connected for this communicator."""
+        n = self._C.c_int32(0)
+        self._lib.check(self._lib.lib().cc_comm_count(self._comm, self._C.byref(n)), "cc_comm_count")
+        return int(n.value)
+
     def close(self) -> None:
         if self._comm:
             self._lib.lib().cc_comm_destroy(self._comm)

@@ -51,7 +51,8 @@ extern "C" {
 #define CC_ERR_LAUNCH (-3)
 #define CC_ERR_STATE (-4)
 
-/* bumped when an existing entry point changes; entry points ADDED since 2: cc_adamw_step_cast, cc_mapper_transpose_weights, cc_gpt2_transpose_weights */
+/* bumped when an existing entry point changes; entry points ADDED since 2: cc_adamw_step_cast, cc_mapper_transpose_weights, cc_gpt2_transpose_weights,
+ * cc_comm_count; operand mode ADDED: CC_OP_BF16X3 */
 #define CC_ABI_VERSION 2
 int cc_abi_version(void);
 
@@ -235,6 +236,9 @@ int cc_beam_advance(const cc_gpt2_cfg* cfg, int32_t R, int32_t beam, const float
  * model.py:79-83), flat over one arena.  The gradient used is g32 * grad_scale / (*loss_scale) (loss_scale: device float[1],
  * NULL = 1).  found_inf (device float[1], NULL = never): a non-zero value skips the update of every element — the step a
  * GradScaler drops when the scaled fp16 backward overflowed — and leaves m, v and the parameters untouched.
+ * step >= 1 is Adam's step number (bias correction).  step == 0 (needs loss_scale): the number is taken from the device,
+ * 1 + loss_scale[2], the loss scaler's count of steps actually applied (cc_loss_scale_update) — a skipped step must not advance
+ * the bias correction, and the host cannot know which steps were skipped without a synchronisation.
  * ------------------------------------------------------------------------------------------------------------ */
 int cc_adamw_step(float* p32, const float* g32, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int32_t step, float grad_scale, const float* loss_scale, const float* found_inf, void* stream);
@@ -249,8 +253,9 @@ int cc_cast_op16(int32_t op_dtype, const float* src, uint16_t* dst, int64_t n, v
  * model when --fp-precision 16, clipcap/train/train.py:77-85), entirely on the device:
  *   cc_grad_nonfinite: *found_inf = 1 if any of the n gradients is inf / nan (never clears it; call once per arena, after the
  *                      all-reduce in a multi-GPU step so that every rank takes the same decision);
- *   cc_loss_scale_update: state[0] = scale, state[1] = consecutive good steps.  found_inf != 0: scale *= backoff, counter = 0;
- *                      else counter += 1 and, at `interval`, scale *= growth and counter = 0.  Clears *found_inf. */
+ *   cc_loss_scale_update: state (device float[3]): [0] = scale, [1] = consecutive good steps, [2] = optimizer steps applied so far.
+ *                      found_inf != 0: scale *= backoff, counter = 0; else counter += 1 (at `interval`: scale *= growth, counter = 0)
+ *                      and state[2] += 1.  Clears *found_inf. */
 int cc_grad_nonfinite(const float* g32, int64_t n, float* found_inf, void* stream);
 int cc_loss_scale_update(float* state, float* found_inf, float growth, float backoff, int32_t interval, void* stream);
 
@@ -276,6 +281,8 @@ int cc_dropout_mask(uint64_t seed, int32_t site, int32_t layer, float p, int64_t
 int cc_comm_unique_id(uint8_t* uid_host);
 int cc_comm_create(void** comm, int32_t nranks, int32_t rank, const uint8_t* uid_host);
 int cc_allreduce_bucket(void* comm, void* buf, int64_t count, int32_t dtype, void* stream);
+/* ncclCommCount of the communicator: the number of ranks RCCL actually connected (what bench.py prints as rccl_ranks) */
+int cc_comm_count(void* comm, int32_t* nranks);
 int cc_comm_destroy(void* comm);
 
 /* ------------------------------------------------------------------------------------------------------------

@@ -290,3 +290,32 @@ def test_trim_padding_is_exact_on_the_oracle():
         outs.append((float(loss.detach()), torch.cat([sdr[k].grad.flatten() for k in names])))
     assert abs(outs[0][0] - outs[1][0]) <= 1e-6
     assert (outs[0][1] - outs[1][1]).abs().max().item() <= 1e-6
+
+
+def test_enable_deepspeed_selects_fusedadam_weight_decay():
+    """reference model.py:72-77: use_deepspeed_optimisers -> deepspeed FusedAdam(adam_w_mode=True) with ITS default weight decay
+    (0.0); otherwise torch.optim.AdamW (0.01).  The flag has no other effect here, but that one is followed."""
+    from clipcap_amd.encoders import EncoderConfig
+    from clipcap_amd.model import ClipCapModelPrefixOnly, Config, TrainingConfig
+    from clipcap_amd.model.gpt2 import GPT2LM
+    for ds, wd in ((True, 0.0), (False, 0.01)):
+        lm = GPT2LM(n_embd=64, n_layer=1, n_head=2, vocab_size=97, n_positions=16)
+        cfg = Config(language_model="unused", train_language_model=False, prefix_length=2, projection_length=2, transformer_layers=1,
+                     transformer_attention_heads=2, encoder_config=EncoderConfig(encoder_embedding_size=16),
+                     training_config=TrainingConfig(optimizer_lr=1e-3, use_deepspeed_optimisers=ds, scheduler_warmup_steps=1, total_steps=4))
+        m = ClipCapModelPrefixOnly(cfg, language_model=lm)
+        assert m._weight_decay() == wd
+        assert m.configure_optimizers()["optimizer"].param_groups[0]["weight_decay"] == wd
+
+
+def test_precision_flag_maps_to_operand_modes():
+    """--fp-precision as the reference defines it (train/args.py:30-34): 32 (default) / 64 -> split-bf16 operands, 16 -> fp16,
+    plus this build's 'bf16'."""
+    from clipcap_amd._lib import OP_BF16, OP_FP16, OP_X3, op_dtype_of
+    from clipcap_amd.train import add_training_args
+    assert [op_dtype_of(v) for v in (32, 64, 16, "bf16", None)] == [OP_X3, OP_X3, OP_FP16, OP_BF16, OP_BF16]
+    ap = add_training_args(argparse.ArgumentParser())
+    assert ap.parse_args([]).fp_precision == 32 and ap.parse_args(["--fp-precision", "bf16"]).fp_precision == "bf16"
+    assert ap.parse_args(["--fp-precision", "16"]).fp_precision == 16
+    with pytest.raises(ValueError):
+        op_dtype_of(8)

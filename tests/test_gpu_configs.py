@@ -320,3 +320,36 @@ def test_reference_cli_default_shapes_gpt2_xl_width():
     assert float((l - full[:, 9]).abs().max()) <= 8e-3 * scale
     for t in range(10, 13):
         assert float((sess.forward(x[:, t:t + 1]) - full[:, t]).abs().max()) <= 8e-3 * scale, t
+
+
+def test_full_finetune_gpt2_xl_width_grouped_weight_gradients_fit_their_scratch():
+    """GPT-2-xl width, FULL finetune: a layer's four deferred weight gradients need 12 D^2 fp32 = 123 MB of slabs at D = 1600 — more
+    than the 96 MiB weight-gradient scratch, so the group must flush early instead of writing past it.  K = B T = 1024
+    rows (the grouped path's minimum), 1 GPT-2 layer, small vocabulary; every GPT-2 and mapper gradient against the oracle."""
+    from tests import seeded
+    E, D, P, L, H, N, n_head, NL, V, NPOS, cap, B = 64, 1600, 10, 10, 8, 1, 25, 1, 1000, 64, 22, 32
+    gsd = seeded.state_dict(seeded.gpt2_shapes(D, NL, V, NPOS), 4701)
+    msd = seeded.state_dict(seeded.mapper_shapes(E, D, P, L, N), 4702)
+    sd = {"language_model." + k: torch.from_numpy(v) for k, v in gsd.items()}
+    sd.update({"transformer_mapper." + k: torch.from_numpy(v) for k, v in msd.items()})
+    cfg = dict(projection_length=P, prefix_length=L, heads=H, layers=N, n_head=n_head, n_layer=NL)
+    dims = dict(E=E, D=D, P=P, L=L, H=H, N=N, n_head=n_head, NL=NL, V=V, NPOS=NPOS, full=True)
+    me, ge, eng = _engines(sd, dims)
+    gen = torch.Generator().manual_seed(6)
+    tokens = torch.randint(1, V, (B, cap), generator=gen)
+    embeds = torch.randn(B, E, generator=gen)
+    eng.zero_grad()
+    loss = float(eng.forward_backward(tokens.cuda(), embeds.cuda()))
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.clipcap_loss(sdr, tokens, embeds, cfg=cfg, rb=True)
+    ref.backward()
+    assert abs(loss - float(ref)) <= 2e-3, (loss, float(ref))
+    gm, gg = me.views(me.arena.g32), ge.views(ge.arena.g32)
+    worst = ("", 0.0)
+    for k in sd:
+        mine = gm[k[len("transformer_mapper."):]] if k.startswith("transformer_mapper.") else gg[k[len("language_model."):]]
+        mine = mine.cpu()[:V] if k.endswith("wte.weight") else mine.cpu()
+        r = _rel(mine, sdr[k].grad)
+        worst = max(worst, (k, r), key=lambda t: t[1])
+        assert r <= 8e-2, (k, r)
+    print(f"gpt2-xl width full finetune: loss {loss:.5f} (oracle {float(ref):.5f}); worst relative gradient error {worst[1]:.3e} ({worst[0]})")

@@ -222,3 +222,68 @@ def test_fp16_beam_search_tokens_vs_oracle_and_reference():
         exact_ref += int(np.array_equal(best, g[f"beam{c}.best"]))
     print(f"fp16 beam search: {exact_ref}/{len(cases)} captions identical to the reference's fp32 run")
     assert exact_ref >= len(cases) - 1
+
+
+def test_fp16_language_model_logits_backward_runs_under_a_scale():
+    """``lm(inputs_embeds=x).logits`` under autograd with fp16 operands: d logits of a MEAN cross-entropy are p / N, far
+    below fp16's normal range — Gpt2Engine.logits_backward scales the pass by a power of two chosen on the device and divides it out.
+    Gradient wrt the inputs and wrt every GPT-2 parameter against fp32 torch autograd on the oracle; without the scale most of the
+    gradient flushes to zero (checked: the unscaled C-ABI call is far off)."""
+    from clipcap_amd.model.gpt2 import GPT2LM
+    g = load_golden("gpt2_tiny")
+    D, n_layer, n_head, V, npos = [int(v) for v in g["cfg"]]
+    lm = GPT2LM(n_embd=D, n_layer=n_layer, n_head=n_head, vocab_size=V, n_positions=npos, precision=16)
+    lm.load_state_dict(sd_of(g), strict=False)
+    lm = lm.to("cuda")
+    x0 = torch.from_numpy(g["in.x"])
+    B, T, _ = x0.shape
+    tgt = torch.randint(0, V, (B, T), generator=torch.Generator().manual_seed(3))
+    x = x0.cuda().requires_grad_(True)
+    logits = lm(inputs_embeds=x).logits
+    loss = torch.nn.functional.cross_entropy(logits.reshape(-1, V), tgt.flatten().cuda()) * 1e-3      # tiny d logits: ~1e-3 * p / (B T)
+    loss.backward()
+    sd = {"language_model." + k: v.clone().requires_grad_(True) for k, v in sd_of(g).items() if "lm_head" not in k}
+    xr = x0.clone().requires_grad_(True)
+    ref_logits = O.gpt2_logits(sd, xr, n_head, n_layer, pre="language_model.")
+    (torch.nn.functional.cross_entropy(ref_logits.reshape(-1, V), tgt.flatten()) * 1e-3).backward()
+    rel_x = float((x.grad.cpu() - xr.grad).norm() / xr.grad.norm())
+    worst = ("", 0.0)
+    for k, p in lm.named_parameters():
+        r = sd.get("language_model." + k)
+        if r is None or r.grad is None:
+            continue
+        rel = float((p.grad.cpu() - r.grad).norm() / r.grad.norm().clamp_min(1e-20))
+        worst = max(worst, (k, rel), key=lambda t: t[1])
+    print(f"fp16 .logits backward under a device-chosen scale: d inputs {rel_x:.3e}, worst parameter gradient {worst[1]:.3e} ({worst[0]})")
+    assert rel_x <= 2e-2 and worst[1] <= 3e-2, (rel_x, worst)
+
+
+def test_fp16_skipped_steps_do_not_advance_adams_step_and_the_scaler_is_checkpointed(tmp_path):
+    """GradScaler semantics: the loss scaler counts the optimizer steps actually applied on the device (state[2]) and Adam's
+    bias correction follows that count, so a run whose first steps overflow updates exactly like one that never overflowed; the
+    scaler state travels in the checkpoint and a resume continues at the saved scale."""
+    from clipcap_amd.train.callback import CheckpointSaver, resume
+    tokens = embeds = None
+    finals = []
+    for overflow_first in (False, True):
+        m, g = _tiny_model("prefix_only", 16)
+        m.train()
+        tokens, embeds = torch.from_numpy(g["in.tokens"]).cuda(), torch.from_numpy(g["in.embeds"]).cuda()
+        if overflow_first:
+            m.engine._scaler(torch.device("cuda", 0)).state[0] = 2.0 ** 41       # two skipped steps: 2^41 -> 2^40 -> 2^39 overflow
+            for _ in range(2):
+                m.fused_step((tokens.clone(), embeds), lr=1e-3)
+            assert float(m.engine.scaler.state[2]) == 0.0
+            m.engine.scaler.state[0] = 65536.0
+        for _ in range(2):
+            m.fused_step((tokens.clone(), embeds), lr=1e-3)
+        assert float(m.engine.scaler.state[2]) == 2.0
+        finals.append(m.transformer_mapper.engine.arena.w32.clone())
+    assert torch.allclose(finals[0], finals[1], rtol=0, atol=1e-7), float((finals[0] - finals[1]).abs().max())
+    # checkpoint round trip of [scale, good steps, applied steps]
+    m.engine.scaler.state[0] = 4096.0
+    saver = CheckpointSaver(str(tmp_path), "t")
+    saver.save_final_checkpoint(m)
+    m2, _ = _tiny_model("prefix_only", 16)
+    resume(m2.to("cuda"), str(tmp_path / "t_final.ckpt"))
+    assert m2.engine.scaler is not None and torch.equal(m2.engine.scaler.state.cpu(), m.engine.scaler.state.cpu())

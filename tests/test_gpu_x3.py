@@ -147,3 +147,72 @@ def test_x3_sizes_and_refusals():
     l = _lib.lib()
     assert l.cc_gpt2_transpose_weights(C.byref(ge.cfg), C.c_void_p(ge.arena.w16.data_ptr()), None) == -1
     assert l.cc_cast_op16(2, C.c_void_p(ge.arena.w32.data_ptr()), C.c_void_p(ge.arena.w16.data_ptr()), 8, None) == -1
+
+
+def test_x3_full_finetune_with_dropout_matches_oracle_with_the_same_masks():
+    """GPT-2 train-mode dropout in this mode (the fp32 attention kernels carry the attention-probability mask): loss and every
+    gradient against the oracle run with the kernels' own masks, to this mode's tolerances."""
+    from tests.test_gpu_dropout import _build, _mask
+    E, D, P, L, H, N, n_head, n_layer, V, npos = 16, 128, 2, 3, 2, 1, 2, 2, 157, 32
+    eng, sd, cfg = _build(E, D, P, L, H, N, n_head, n_layer, V, npos)
+    eng.mapper.set_precision(32)
+    eng.gpt2.set_precision(32)
+    torch.manual_seed(1)
+    B, cap = 3, 7
+    tokens, embeds = torch.randint(1, V, (B, cap)), torch.randn(B, E)
+    tokens[1, 5:] = -1
+    T = L + cap
+    p_e, p_a, p_r, seed = 0.1, 0.15, 0.2, 0x1234_5678_9abc
+    loss = eng.forward_backward(tokens.cuda(), embeds.cuda(), dropout=(p_e, p_a, p_r, seed))
+    drop = {"p_embd": p_e, "p_attn": p_a, "p_resid": p_r, "embd": _mask(seed, 0, 0, p_e, (B, T, D)),
+            "attn": [_mask(seed, 1, l, p_a, (B, n_head, T, T)) for l in range(n_layer)],
+            "resid_attn": [_mask(seed, 2, l, p_r, (B, T, D)) for l in range(n_layer)],
+            "resid_mlp": [_mask(seed, 3, l, p_r, (B, T, D)) for l in range(n_layer)]}
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.clipcap_loss(sdr, tokens, embeds, cfg=cfg, drop=drop)
+    ref.backward()
+    assert abs(float(loss) - float(ref.detach())) <= 2e-5, (float(loss), float(ref.detach()))
+    worst = ("", 0.0)
+    for pre, e in (("transformer_mapper.", eng.mapper), ("language_model.", eng.gpt2)):
+        for k, v in e.views(e.arena.g32).items():
+            r = sdr[pre + k].grad
+            if "lm_head" in k or r is None:
+                continue
+            if k.endswith("wte.weight"):
+                v = v[:V]
+            rel = ((v.cpu() - r).norm() / r.norm().clamp_min(1e-12)).item()
+            worst = max(worst, (pre + k, rel), key=lambda t: t[1])
+    print(f"split-bf16 operands, dropout: loss {float(loss):.6f} vs oracle {float(ref.detach()):.6f}; worst gradient {worst[1]:.3e} ({worst[0]})")
+    assert worst[1] <= 2e-3, worst
+
+
+def test_x3_windowed_mapper_at_real_sequence_length():
+    """TransformerMapperWindowed at the reference's default window (17 x 10 + 10 = 180 rows per sample) in this mode: the one-wave-per-row
+    fp32 attention kernels (the S x S tile does not fit the LDS kernels), forward and backward, against the fp32 oracle."""
+    from tests import seeded
+    from clipcap_amd.engine import MapperEngine
+    E, D, P, L, H, N, W, B = 512, 768, 10, 10, 8, 2, 17, 2
+    msd = seeded.state_dict(seeded.mapper_shapes(E, D, P, L, N, W=W, use_pos=True), 4501)
+    sd = {k: torch.from_numpy(v) for k, v in msd.items()}
+    sd["pos_embeddings"] = sd["pos_embeddings"] * 0.1
+    eng = MapperEngine(E, D, L, P, H, N, window=W, use_pos=True, device="cuda", precision=32)
+    for k, v in eng.views(eng.arena.w32).items():
+        v.copy_(sd[k])
+    x = torch.randn(B, W, E, generator=torch.Generator().manual_seed(3))
+    out = eng.forward(x.cuda(), save=True)
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.mapper_forward(sdr, x, projection_length=P, num_heads=H, num_layers=N, window=W)
+    scale = float(ref.detach().abs().max())
+    e_32 = float((out.cpu() - ref.detach()).abs().max())
+    ref.square().mean().backward()
+    eng.arena.grads().zero_()
+    eng.backward(2.0 * out / out.numel())
+    gv = eng.views(eng.arena.g32)
+    worst = ("", 0.0)
+    for k in sd:
+        r = float((gv[k].cpu() - sdr[k].grad).norm() / sdr[k].grad.norm().clamp_min(1e-20))
+        worst = max(worst, (k, r), key=lambda t: t[1])
+    print(f"split-bf16 windowed mapper S=180: |out|max {scale:.2f}; vs fp32 oracle {e_32:.3e}; worst gradient {worst[1]:.3e} ({worst[0]})")
+    assert e_32 <= 1e-4 * scale and worst[1] <= 5e-3
+    atts = eng.attention_probs(B)
+    assert atts[0].shape == (B, 180, 180, H) and float((atts[0].sum(dim=2) - 1).abs().max()) <= 1e-5

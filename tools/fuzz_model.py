@@ -88,7 +88,7 @@ def classify(eng, sd, cfg, tokens, embeds):
         ek, eo = rel(g, res["rb"][1][k]), rel(res["rb"][1][k], res["exact"][1][k])
         # The gradients behind the MLP's ReLU (fc1, norm2) see relu'(h) = [h > 0]: wherever |pre-activation| is below the forward
         # rounding noise the kernel's and the oracle's masks differ, and a flipped element is wrong by its full size — the error goes
-        # like sqrt(fraction flipped), 4-14 % at a dozen rows in bf16, in BOTH operand types' own units (tools/debug/dbg_mapper_top.py:
+        # like sqrt(fraction flipped), 4-14 % at a dozen rows in bf16, in BOTH operand types' own units:
         # 3.5-4.8 % on every layer's fc1 / norm2 in bf16 against ~1 % elsewhere, 0.8-2 % against 0.3 % in fp16).  Not a kernel property.
         lim = 0.25 if (".mlp.fc1." in k or ".norm2." in k) else 6e-2
         if ek > lim and ek > 3.0 * eo:
