@@ -242,6 +242,8 @@ struct Gpt2WS {
     int *target, *row_map;
     act_t* logits16;   // [B*cap, Vp]
     float *pmax, *psum, *tgt_logit, *lse_row, *row_loss;
+    float *cref, *lmfac;   // exponential form of the lm_head outputs (bf16 build): reference shift [Mc], row factors {r, w} [Mc][2]
+    act_t* hfs16;          // full finetune: r * hf rows, the weight-gradient operand of the exponential form
     // backward
     float* dx32;
     act_t *dx16, *dx16b, *dhf16, *du16, *dxn16, *datt16, *dqkv16;
@@ -289,6 +291,9 @@ void gpt2_carve(const cc_gpt2_cfg* c, int B, int T, int cap, int mode, void* ws,
         w.tgt_logit = cv.take<float>(Mc);
         w.lse_row = cv.take<float>(Mc);
         w.row_loss = cv.take<float>(Mc);
+        w.cref = cv.take<float>(Mc);
+        w.lmfac = cv.take<float>(2 * Mc);
+        w.hfs16 = full ? cv.take<act_t>(Mc * D) : nullptr;
         w.dx32 = cv.take<float>(M * D);
         w.dx16 = cv.take<act_t>(M * D);
         w.dx16b = full ? cv.take<act_t>(M * D) : w.dx16;    // full finetune: second copy so a layer's weight gradients can run grouped
@@ -302,6 +307,7 @@ void gpt2_carve(const cc_gpt2_cfg* c, int B, int T, int cap, int mode, void* ws,
     } else {
         w.wg_scratch = nullptr; w.adelta = nullptr;
         w.logits16 = nullptr; w.pmax = w.psum = w.tgt_logit = w.lse_row = w.row_loss = nullptr;
+        w.cref = w.lmfac = nullptr; w.hfs16 = nullptr;
         w.dx32 = nullptr; w.dx16 = w.dx16b = w.dhf16 = w.du16 = w.dxn16 = w.datt16 = w.dqkv16 = nullptr;
     }
     w.x3 = nullptr; w.x3_bytes = 0;
@@ -523,6 +529,12 @@ int CC_API(cc_mapper_bwd_range)(const cc_mapper_cfg* c, int32_t B, const float* 
 
 // ---------------------------------------------------------------- GPT-2 -----------------------------------------
 namespace {
+// Exponential form of the lm_head outputs (gemm.hip.h EpiLMHead): the bf16 build's training path stores exp(logit - target logit) and
+// never materialises the softmax gradient.  fp16 lacks the exponent range, the bf16x3 build keeps fp32 logits.  CC_LM_EXPFORM=0: A/B switch.
+static bool lm_exp_form() {
+    static const bool on = (CC_OP == 0) && []() { const char* e = getenv("CC_LM_EXPFORM"); return !e || atoi(e) != 0; }();
+    return on;
+}
 static bool shape_ok(const cc_gpt2_cfg* c, const cc_gpt2_shape* s) {
     return s && s->B > 0 && s->T > 0 && s->L >= 0 && s->L <= s->T && s->cap >= s->T - s->L && s->mode >= 0 && s->mode <= 2 && s->T <= c->NPOS &&
            s->p_embd >= 0.f && s->p_embd < 1.f && s->p_attn >= 0.f && s->p_attn < 1.f && s->p_resid >= 0.f && s->p_resid < 1.f;
@@ -722,8 +734,11 @@ int CC_API(cc_lmhead_ce_fwd)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const
     CC_TRY(ce_targets(reinterpret_cast<const long long*>(tokens), w.target, w.row_map, s->B, cap, s->L, s->T, st));
     // ln_f only on the rows the loss reads: L-1 .. T-2 of every sample (model.py:108)
     CC_TRY(ln_fwd(w.x[c->NL], D, w.row_map, w32 + o.lnf_w, w32 + o.lnf_b, w.hf16, nullptr, w.meanf, w.rstdf, Mc, D, st));
-    CC_TIMED(CC_SITE_LMHEAD_FWD, st, gemm_lmhead(w.hf16, D, W16(w16, o.wte), D, Mc, c->Vp, c->V, D, w.logits16, c->Vp, w.pmax, w.psum, npart, w.target, w.tgt_logit, st));
-    CC_TRY(ce_rows(w.pmax, w.psum, npart, w.target, w.tgt_logit, w.lse_row, w.row_loss, stats, Mc, st));
+    const bool ef = lm_exp_form();
+    if (ef) CC_TRY(lm_tgt_ref(w.hf16, W16(w16, o.wte), D, w.target, w.cref, Mc, st));
+    CC_TIMED(CC_SITE_LMHEAD_FWD, st, gemm_lmhead(w.hf16, D, W16(w16, o.wte), D, Mc, c->Vp, c->V, D, w.logits16, c->Vp, w.pmax, w.psum, npart, w.target, w.tgt_logit, st,
+                                                 ef ? w.cref : nullptr));
+    CC_TRY(ce_rows(w.pmax, w.psum, npart, w.target, ef ? w.cref : w.tgt_logit, w.lse_row, w.row_loss, stats, Mc, st));   // cref IS the target logit
     return CC_OK;
 }
 
@@ -739,16 +754,31 @@ int CC_API(cc_lmhead_ce_bwd)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const
     X3_SCRATCH(w);
     const int D = c->D, Mc = s->B * cap, M = s->B * s->T;
     const bool full = s->mode == 2;
-    CC_TRY(ce_dlogits(w.logits16, c->Vp, c->V, w.target, w.lse_row, denom, loss_scale, Mc, st));
+    // exponential form: logits16 holds E = exp(logit - cref); d logits = r E - w onehot is never written — the row factors go into the
+    // GEMMs' finishing passes (EpiLMHead comment).  Otherwise: the in-place softmax-gradient pass over the stored logits.
+    const bool ef = lm_exp_form();
+    const LmFix fix{w.lmfac, w.target, W16(w16, o.wte)};
+    if (ef) CC_TRY(lm_rowfac(w.cref, w.lse_row, w.target, denom, loss_scale, w.lmfac, Mc, st));
+    else CC_TRY(ce_dlogits(w.logits16, c->Vp, c->V, w.target, w.lse_row, denom, loss_scale, Mc, st));
     // d hf = dlogits · wte   ([Mc,Vp] x [Vp(k), D(n)])
     // K = Vp is deep and the output narrow: K slices over the idle CUs, slabs parked in du16 (free until the first layer's backward)
     const auto lm_dgrad = [&]() {
         const int rc = gemm_nt_deepk(w.logits16, c->Vp, W16(w16, o.total + o.wte), c->Vp, Mc, D, c->Vp, w.dhf16, D, reinterpret_cast<float*>(w.du16),
-                                     (size_t)M * 4 * D * sizeof(act_t), st);
-        return rc != CC_ERR_SHAPE ? rc : gemm_bf16out(0, 0, w.logits16, c->Vp, W16(w16, o.total + o.wte), c->Vp, Mc, D, c->Vp, w.dhf16, D, nullptr, 0, nullptr, st);
+                                     (size_t)M * 4 * D * sizeof(act_t), st, ef ? &fix : nullptr);
+        if (rc != CC_ERR_SHAPE) return rc;
+        const int rc2 = gemm_bf16out(0, 0, w.logits16, c->Vp, W16(w16, o.total + o.wte), c->Vp, Mc, D, c->Vp, w.dhf16, D, nullptr, 0, nullptr, st);
+        return (rc2 != CC_OK || !ef) ? rc2 : lm_dgrad_fix(w.dhf16, w.lmfac, w.target, fix.wte, D, Mc, st);
     };
     CC_TIMED(CC_SITE_LMHEAD_DGRAD, st, lm_dgrad());
-    if (full) CC_TRY(gemm_wgrad(w.logits16, c->Vp, w.hf16, D, c->Vp, D, Mc, g32 + o.wte, D, w.wg_scratch, st));  // tied lm_head: d wte += dlogits^T hf
+    if (full) {      // tied lm_head: d wte += dlogits^T hf  (= E^T (r hf) - onehot^T (w hf) in the exponential form)
+        if (ef) {
+            CC_TRY(lm_scale_rows(w.hf16, w.lmfac, w.hfs16, D, Mc, st));
+            CC_TRY(gemm_wgrad(w.logits16, c->Vp, w.hfs16, D, c->Vp, D, Mc, g32 + o.wte, D, w.wg_scratch, st));
+            CC_TRY(lm_wgrad_onehot(w.hf16, w.lmfac, w.target, g32 + o.wte, D, Mc, st));
+        } else {
+            CC_TRY(gemm_wgrad(w.logits16, c->Vp, w.hf16, D, c->Vp, D, Mc, g32 + o.wte, D, w.wg_scratch, st));
+        }
+    }
     if (hipMemsetAsync(w.dx32, 0, (size_t)M * D * sizeof(float), st) != hipSuccess) return CC_ERR_LAUNCH;
     if (hipMemsetAsync(w.dx16, 0, (size_t)M * D * sizeof(act_t), st) != hipSuccess) return CC_ERR_LAUNCH;
     CC_TRY(ln_bwd(w.dhf16, w.x[c->NL], D, w.row_map, w.meanf, w.rstdf, w32 + o.lnf_w, nullptr, w.dx32, w.dx16, full ? g32 + o.lnf_w : nullptr,

@@ -210,9 +210,9 @@ __device__ __forceinline__ void gemm_epilogue_regs(f32x4 (&acc)[NI][NJ], int lan
     }
     if constexpr (epi_row_strip<Epi>::value) {
         static_assert(!epi_row_strip<Epi>::value || NJ == 4, "row-strip epilogues need a 64-column wave strip");
-        int tg[NI];
+        typename Epi::RowAux tg[NI];
 #pragma unroll
-        for (int i = 0; i < NI; i++) tg[i] = epi.load_target(row0 + i * 16 + rl);
+        for (int i = 0; i < NI; i++) tg[i] = epi.load_row(row0 + i * 16 + rl);
 #pragma unroll
         for (int i = 0; i < NI; i++) {
             float va[8], vb[8];
@@ -1382,7 +1382,8 @@ struct EpiLMHead {
     }
     // 256-row kernels: the lane holds columns ca..ca+7 and cb..cb+7 of `row`; lanes l, l^16, l^32, l^48 together hold the row's
     // aligned 64-column block (all lanes of the wave must call this).
-    __device__ __forceinline__ int load_target(int row) const { return row < M ? target[row] : -1; }
+    typedef int RowAux;                                                               // per-row value fetched before the first store: the target id
+    __device__ __forceinline__ int load_row(int row) const { return row < M ? target[row] : -1; }
     __device__ __forceinline__ void strip(int row, int ca, int cb, float (&va)[8], float (&vb)[8], int t) const {
         constexpr float L2E = 1.4426950408889634f;
         float m, s = 0.f;
@@ -1427,7 +1428,71 @@ struct EpiLMHead {
         }
     }
 };
+// Exponential form of the lm_head outputs (bf16 build of the training path): what is stored is NOT the logit but
+// E = exp(logit - cref[row]), cref[row] = the row's own target logit computed ahead of the GEMM (k_lm_tgt_ref: the same bf16 products
+// in fp32, so it doubles as the loss's exact target logit), and the partials are pmax = cref[row], psum = sum of E over the block —
+// k_ce_rows then returns lse = cref + log(sum E) unchanged.  The softmax gradient (softmax - onehot) w is r[row] E - w onehot with
+// the per-row scalar r = exp(cref - lse) w: the lm_head input-gradient GEMM reads E as its A operand directly and applies r and the
+// one-hot row in its finishing pass (gemm_nt_deepk LmFix) — the 2 GB read-modify-write pass of k_ce_dlogits over the [B*cap, Vp]
+// matrix is gone, and the stored matrix is rounded to 16 bits once (E) instead of twice (logit, then gradient).  bf16 has fp32's
+// exponent range, so E is representable whenever logit - target logit < 88; the exponent is clamped at 80 (a row whose target token
+// has probability < e^-80 gets a distorted but finite gradient).  fp16 lacks that range: the fp16 build keeps the logit form.
+struct EpiLMHeadExp {
+    act_t* C;
+    float* pmax;
+    float* psum;           // [M][npart]
+    const float* cref;     // [M]
+    int ldc, M, V, npart;
+    __device__ __forceinline__ void operator()(int row, int col, float (&v)[8]) const {
+        constexpr float L2E = 1.4426950408889634f;
+        const bool ok = row < M && col < ldc;
+        const float ml = -(row < M ? cref[row] : 0.f) * L2E;
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            v[e] = (col + e < V) ? __builtin_amdgcn_exp2f(fminf(fmaf(v[e], L2E, ml), 80.f * L2E)) : 0.f;
+            s += v[e];
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        if (!ok) return;
+        if ((col & 63) == 0) {
+            const int blk = col >> 6;
+            pmax[(size_t)row * npart + blk] = col < V ? cref[row] : -INFINITY;
+            psum[(size_t)row * npart + blk] = s;
+        }
+        act_st8(C + (size_t)row * ldc + col, v);
+    }
+    typedef float RowAux;                                                             // the row's reference shift
+    __device__ __forceinline__ float load_row(int row) const { return row < M ? cref[row] : 0.f; }
+    __device__ __forceinline__ void strip(int row, int ca, int cb, float (&va)[8], float (&vb)[8], float c) const {
+        constexpr float L2E = 1.4426950408889634f;
+        const float ml = -c * L2E;
+        const bool inside = __builtin_amdgcn_readfirstlane(ca | 63) < V;              // whole 64-column block inside the vocabulary (wave-uniform)
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float ea = __builtin_amdgcn_exp2f(fminf(fmaf(va[e], L2E, ml), 80.f * L2E));
+            const float eb = __builtin_amdgcn_exp2f(fminf(fmaf(vb[e], L2E, ml), 80.f * L2E));
+            va[e] = (inside || ca + e < V) ? ea : 0.f;
+            vb[e] = (inside || cb + e < V) ? eb : 0.f;
+            s += va[e] + vb[e];
+        }
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (row >= M) return;
+        if ((ca & 63) == 0 && ca < ldc) {
+            const int blk = ca >> 6;
+            pmax[(size_t)row * npart + blk] = ca < V ? c : -INFINITY;
+            psum[(size_t)row * npart + blk] = s;
+        }
+        if (ca < ldc) act_st8(C + (size_t)row * ldc + ca, va);
+        if (cb < ldc) act_st8(C + (size_t)row * ldc + cb, vb);
+    }
+};
 template <> struct epi_row_strip<EpiLMHead> { static constexpr bool value = true; };
+template <> struct epi_row_strip<EpiLMHeadExp> { static constexpr bool value = true; };
 
 // ------------------------------------------------------------------------------------------------
 // Host launcher
@@ -1444,7 +1509,7 @@ inline int launch_gemm(int al, int bl, const op16_t* A, int lda, const op16_t* B
     if (bl == 0 && (K & 7)) return CC_ERR_SHAPE;
     if (al == 1 && (M & 7)) return CC_ERR_SHAPE;
     if (bl == 1 && (N & 7)) return CC_ERR_SHAPE;
-    if constexpr (!std::is_same<Epi, EpiLMHead>::value && !epi_strip_aux<Epi>::value) {
+    if constexpr (!epi_row_strip<Epi>::value && !epi_strip_aux<Epi>::value) {
         if (g_gemm_s64 > 0 && al == 0 && bl == 0 && (K % G_BK) == 0 && M <= 1024)     // tools/small_gemm_bench.py (CC_GEMM_S64 = 1 / 2)
             return launch_gemm_s64(A, lda, B, ldb, M, N, K, ksplit, g_gemm_s64, epi, nullptr, st);
     }
@@ -1477,7 +1542,7 @@ inline int launch_gemm(int al, int bl, const op16_t* A, int lda, const op16_t* B
         const double c128 = t128 <= 256 ? 16384.0 / 0.75 : (double)((t128 + 511) / 512) * 32768.0;
         const double c256 = (double)((t256 + 255) / 256) * 65536.0 / 1.2, c192 = (double)((t192 + 255) / 256) * 49152.0 / 1.15;
         const double c320 = (double)((t320 + 255) / 256) * 81920.0 / 1.3;
-        constexpr bool can192 = !std::is_same<Epi, EpiLMHead>::value;   // its partials assume 64-column wave strips
+        constexpr bool can192 = !epi_row_strip<Epi>::value;   // the lm_head partials assume 64-column wave strips
         // the activation-gradient epilogue (aux tile read + gelu' + store) is not hidden at one block per CU: 12800 x 3072 x 768 measured
         // 106.6 us on 320 x 256 vs 97.3 on 128 x 128 (two co-resident blocks), while the plain / gelu-forward epilogues gain (90 -> 78 us)
         constexpr bool can320 = !std::is_same<Epi, EpiDAct>::value;
@@ -1497,7 +1562,7 @@ inline int launch_gemm(int al, int bl, const op16_t* A, int lda, const op16_t* B
     }
         if (nj == 4 && ni == 8) CC_LAUNCH_STAG(4, 8)
         else if (nj == 4) CC_LAUNCH_STAG(4, 10)
-        else if constexpr (!std::is_same<Epi, EpiLMHead>::value) CC_LAUNCH_STAG(3, 8)
+        else if constexpr (!epi_row_strip<Epi>::value) CC_LAUNCH_STAG(3, 8)
 #undef CC_LAUNCH_STAG
     } else
 #ifdef CC_GEMM_ABLATION

@@ -25,8 +25,9 @@ int gemm_f32out(int al, int bl, const act_t* A, int lda, const op16_t* B, int ld
                 const float* bias, int mode, float alpha, int ksplit, hipStream_t st);
 int gemm_dact(int al, int bl, const act_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, act_t* C, int ldc,
               const act_t* aux, int act, hipStream_t st);
+// cref != nullptr: exponential form (C = exp(logit - cref[row]), see gemm.hip.h EpiLMHead)
 int gemm_lmhead(const act_t* A, int lda, const op16_t* B, int ldb, int M, int Vp, int V, int K, act_t* C, int ldc, float* pmax,
-                float* psum, int npart, const int* target, float* tgt_logit, hipStream_t st);
+                float* psum, int npart, const int* target, float* tgt_logit, hipStream_t st, const float* cref = nullptr);
 
 #if CC_OP == 2
 // bf16x3: scratch for the operand images of the GEMM being launched (stream order makes reuse by the next GEMM safe).  Thread-local:
@@ -89,8 +90,10 @@ int gemm_nt_skinny(const act_t* A, int lda, const op16_t* B, int ldb, int M, int
 // Narrow output, very deep K (the lm_head input gradient: [B*cap, Vp] x [Vp, D] -> 10240 x 768 over K = 50304): the 256 x 256 kernel on
 // 120 tiles leaves half the chip idle, so K is cut into as many slices as fill the CUs (fp32 slabs in `scratch`), and one elementwise
 // pass sums the slabs into the 16-bit output.  Returns CC_ERR_SHAPE when the shape does not call for it (caller then uses gemm_bf16out).
+// fix (optional): out[m][n] = fac[2m] * acc - fac[2m+1] * wte[target[m]][n] — the lm_head input gradient of the exponential form
+struct LmFix { const float* fac; const int* target; const op16_t* wte; };
 int gemm_nt_deepk(const act_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, act_t* out16, int ldo, float* scratch,
-                  size_t scratch_bytes, hipStream_t st);
+                  size_t scratch_bytes, hipStream_t st, const LmFix* fix = nullptr);
 int skinny_single_min_tiles();   // grids of at least this many 128 x 128 tiles skip split-K (CC_SKINNY_SINGLE; tuning knob)
 // whether gemm_nt_skinny will take the slab + row-finish path for this problem (the only path that supports SkinnyFuse)
 bool gemm_nt_skinny_can_fuse(int M, int N, int K, size_t scratch_bytes);

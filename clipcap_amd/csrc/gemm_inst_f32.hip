@@ -375,8 +375,29 @@ bool gemm_nt_skinny_can_fuse(int M, int N, int K, size_t scratch_bytes) {
     return M > 0 && N > 0 && (N & 7) == 0 && N <= 3072 && (K % G_BK) == 0 && scratch_bytes >= (size_t)M * N * sizeof(float);
 }
 
+// slab sum of the K-sliced lm_head input gradient in the exponential form: out = r * sum(slabs) - w * wte[target]
+__global__ __launch_bounds__(256) void k_deepk_finish_lm(const float* __restrict__ slabs, size_t slab_elems, int ks, int M, int N, LmFix f,
+                                                         act_t* __restrict__ out16, int ldo) {
+    const size_t n8 = (size_t)M * (N >> 3);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / (N >> 3)), col = (int)(i % (N >> 3)) * 8;
+        const size_t e = (size_t)row * N + col;
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, b[8];
+        for (int s = 0; s < ks; s++) {
+            const float4 a = *reinterpret_cast<const float4*>(slabs + s * slab_elems + e);
+            const float4 c = *reinterpret_cast<const float4*>(slabs + s * slab_elems + e + 4);
+            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += c.x; v[5] += c.y; v[6] += c.z; v[7] += c.w;
+        }
+        const float r = f.fac[2 * row], w = f.fac[2 * row + 1];
+        unpack8(*reinterpret_cast<const uint4*>(f.wte + (size_t)f.target[row] * N + col), b);
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = r * v[k] - w * b[k];
+        act_st8(out16 + (size_t)row * ldo + col, v);
+    }
+}
+
 int gemm_nt_deepk(const act_t* Aa, int lda, const op16_t* B, int ldb, int M, int N, int K, act_t* out16, int ldo, float* scratch,
-                  size_t scratch_bytes, hipStream_t st) {
+                  size_t scratch_bytes, hipStream_t st, const LmFix* fix) {
     static const int knob = []() { const char* e = getenv("CC_DEEPK"); return e ? atoi(e) : -1; }();   // 0 = off, n > 0 = force n slices
     if (knob == 0 || g_gemm_tile_mode == 0 || !scratch || (N & 7) || (ldo & 7) || (K % 64) || (lda & 7) || (ldb & 7)) return CC_ERR_SHAPE;
     const long tiles = (long)((M + H_BM - 1) / H_BM) * ((N + H_BN - 1) / H_BN);
@@ -399,8 +420,12 @@ int gemm_nt_deepk(const act_t* Aa, int lda, const op16_t* B, int ldb, int M, int
     if (rc != CC_OK) return rc;
     const int kt = K / G_BK, per = (kt + ks - 1) / ks, ks_eff = (kt + per - 1) / per;
     const size_t n8 = (size_t)M * (N >> 3);
-    hipLaunchKernelGGL(k_splitk_finish, dim3((int)std::min<size_t>((n8 + 255) / 256, 2048)), dim3(256), 0, st, scratch, slab, ks_eff, M, N, nullptr, 0,
-                       nullptr, nullptr, out16, ldo);
+    if (fix)
+        hipLaunchKernelGGL(k_deepk_finish_lm, dim3((int)std::min<size_t>((n8 + 255) / 256, 2048)), dim3(256), 0, st, scratch, slab, ks_eff, M, N, *fix,
+                           out16, ldo);
+    else
+        hipLaunchKernelGGL(k_splitk_finish, dim3((int)std::min<size_t>((n8 + 255) / 256, 2048)), dim3(256), 0, st, scratch, slab, ks_eff, M, N, nullptr, 0,
+                           nullptr, nullptr, out16, ldo);
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
 

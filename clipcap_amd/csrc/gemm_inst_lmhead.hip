@@ -2,11 +2,15 @@
 #include "gemm_api.h"
 namespace CC_NS {
 int gemm_lmhead(const act_t* A, int lda, const op16_t* B, int ldb, int M, int Vp, int V, int K, act_t* C, int ldc, float* pmax,
-                float* psum, int npart, const int* target, float* tgt_logit, hipStream_t st) {
+                float* psum, int npart, const int* target, float* tgt_logit, hipStream_t st, const float* cref) {
     cc_shared::ProfScope _all(cc_shared::SITE_ALL_GEMMS, st, 2.0 * M * V * (double)K);
     if ((ldc & 63) || ldc < Vp || npart * 64 < Vp) return CC_ERR_SHAPE;
     const op16_t* A16;
     CC_X3_NT(A, lda, ldb, M, K, A16, 0, 0, st);
+    if (cref) {      // exponential form: the caller takes the target logit from cref itself (tgt_logit unused)
+        EpiLMHeadExp e{C, pmax, psum, cref, ldc, M, V, npart};
+        return launch_gemm(0, 0, A16, lda, B, ldb, M, Vp, K, 1, e, st);
+    }
     EpiLMHead e{C, pmax, psum, target, tgt_logit, ldc, M, V, npart};
     return launch_gemm(0, 0, A16, lda, B, ldb, M, Vp, K, 1, e, st);
 }

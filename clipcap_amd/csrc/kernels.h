@@ -56,6 +56,16 @@ int ce_dlogits(act_t* logits, int ld, int V, const int* target, const float* lse
 int sample_rows(const float* logits, int R, int V, int ld, float temperature, int top_k, float top_p, int mode, const long long* hist,
                 int hist_len, int hist_ld, float rep_pen, const float* u, int* next_token, float* probs_out, hipStream_t st);
 int ce_targets(const long long* tokens, int* target, int* row_map, int B, int cap, int L, int T, hipStream_t st);
+// Exponential form of the lm_head outputs (gemm.hip.h EpiLMHead, bf16 build):
+//   lm_tgt_ref   cref[m] = hf[m] . wte[target[m]]  (16-bit operands, fp32 accumulate): the reference shift of row m
+//   lm_rowfac    fac[m] = {r, w}: w = (target[m] != 0) * loss_scale / max(denom, 1), r = exp(cref[m] - lse[m]) * w
+//   lm_dgrad_fix dhf[m][:] = r dhf[m][:] - w wte[target[m]][:]  (the path whose GEMM has no finishing pass of its own)
+//   lm_scale_rows out[m][:] = r hf[m][:] (weight-gradient operand);  lm_wgrad_onehot dwte[target[m]][:] -= w hf[m][:]
+int lm_tgt_ref(const act_t* hf, const op16_t* wte, int D, const int* target, float* cref, int M, hipStream_t st);
+int lm_rowfac(const float* cref, const float* lse, const int* target, const float* denom, const float* loss_scale, float* fac, int M, hipStream_t st);
+int lm_dgrad_fix(act_t* dhf, const float* fac, const int* target, const op16_t* wte, int D, int M, hipStream_t st);
+int lm_scale_rows(const act_t* hf, const float* fac, act_t* out, int D, int M, hipStream_t st);
+int lm_wgrad_onehot(const act_t* hf, const float* fac, const int* target, float* dwte, int D, int M, hipStream_t st);
 
 int adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd, int step, float gscale,
           const float* loss_scale, const float* found_inf, hipStream_t st, op16_t* w16 = nullptr);   // w16: also store the 16-bit copy of the updated parameters

@@ -1832,6 +1832,93 @@ int ce_dlogits(act_t* logits, int ld, int V, const int* target, const float* lse
     return CC_OK;
 }
 
+// ---- exponential form of the lm_head outputs (gemm.hip.h EpiLMHead): row helpers, one wave per row ----
+__global__ __launch_bounds__(256) void k_lm_tgt_ref(const act_t* __restrict__ hf, const op16_t* __restrict__ wte, int D, const int* __restrict__ target,
+                                                    float* __restrict__ cref, int M) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const act_t* h = hf + (size_t)row * D;
+    const op16_t* w = wte + (size_t)target[row] * D;
+    float acc = 0.f;
+    for (int d = lane * 8; d < D; d += 512) {
+        float a[8], b[8];
+        act_ld8(h + d, a);
+        unpack8(*reinterpret_cast<const uint4*>(w + d), b);
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc += a[e] * b[e];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) cref[row] = acc;
+}
+int lm_tgt_ref(const act_t* hf, const op16_t* wte, int D, const int* target, float* cref, int M, hipStream_t st) {
+    if (D & 7) return CC_ERR_SHAPE;
+    if (M <= 0) return CC_OK;
+    hipLaunchKernelGGL(k_lm_tgt_ref, dim3((M + 3) / 4), dim3(256), 0, st, hf, wte, D, target, cref, M);
+    return CC_OK;
+}
+__global__ void k_lm_rowfac(const float* __restrict__ cref, const float* __restrict__ lse, const int* __restrict__ target,
+                            const float* __restrict__ denom, const float* __restrict__ loss_scale, float* __restrict__ fac, int M) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const float inv = (loss_scale ? loss_scale[0] : 1.0f) / fmaxf(denom[0], 1.0f);
+    const float w = target[i] != 0 ? inv : 0.f;
+    fac[2 * i] = w != 0.f ? __expf(cref[i] - lse[i]) * w : 0.f;
+    fac[2 * i + 1] = w;
+}
+int lm_rowfac(const float* cref, const float* lse, const int* target, const float* denom, const float* loss_scale, float* fac, int M, hipStream_t st) {
+    if (M <= 0) return CC_OK;
+    hipLaunchKernelGGL(k_lm_rowfac, dim3((M + 255) / 256), dim3(256), 0, st, cref, lse, target, denom, loss_scale, fac, M);
+    return CC_OK;
+}
+// MODE 0: dhf = r dhf - w wte[t];  1: out = r hf;  2: dwte[t] -= w hf (fp32 atomics: several rows may share a target)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_lm_rows(act_t* __restrict__ io, const act_t* __restrict__ hf, const float* __restrict__ fac,
+                                                 const int* __restrict__ target, const op16_t* __restrict__ wte, float* __restrict__ dwte, int D, int M) {
+    const int d8n = D >> 3;
+    const size_t total = (size_t)M * d8n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / d8n), c = (int)(i % d8n) * 8;
+        const float r = fac[2 * row], w = fac[2 * row + 1];
+        float v[8];
+        if (MODE == 0) {
+            float b[8];
+            act_ld8(io + (size_t)row * D + c, v);
+            unpack8(*reinterpret_cast<const uint4*>(wte + (size_t)target[row] * D + c), b);
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = r * v[e] - w * b[e];
+            act_st8(io + (size_t)row * D + c, v);
+        } else if (MODE == 1) {
+            act_ld8(hf + (size_t)row * D + c, v);
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] *= r;
+            act_st8(io + (size_t)row * D + c, v);
+        } else {
+            if (w == 0.f) continue;
+            act_ld8(hf + (size_t)row * D + c, v);
+            float* dst = dwte + (size_t)target[row] * D + c;
+#pragma unroll
+            for (int e = 0; e < 8; e++) __hip_atomic_fetch_add(dst + e, -w * v[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+template <int MODE>
+static int lm_rows_launch(act_t* io, const act_t* hf, const float* fac, const int* target, const op16_t* wte, float* dwte, int D, int M, hipStream_t st) {
+    if (D & 7) return CC_ERR_SHAPE;
+    const size_t total = (size_t)M * (D >> 3);
+    if (!total) return CC_OK;
+    hipLaunchKernelGGL(k_lm_rows<MODE>, dim3((int)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, st, io, hf, fac, target, wte, dwte, D, M);
+    return CC_OK;
+}
+int lm_dgrad_fix(act_t* dhf, const float* fac, const int* target, const op16_t* wte, int D, int M, hipStream_t st) {
+    return lm_rows_launch<0>(dhf, nullptr, fac, target, wte, nullptr, D, M, st);
+}
+int lm_scale_rows(const act_t* hf, const float* fac, act_t* out, int D, int M, hipStream_t st) {
+    return lm_rows_launch<1>(out, hf, fac, nullptr, nullptr, nullptr, D, M, st);
+}
+int lm_wgrad_onehot(const act_t* hf, const float* fac, const int* target, float* dwte, int D, int M, hipStream_t st) {
+    return lm_rows_launch<2>(nullptr, hf, fac, target, nullptr, dwte, D, M, st);
+}
+
 // Targets of the caption rows: target[b*cap + c] = max(tokens[b,c], 0) (model.py:103-104); row_map[b*cap+c] = b*T + L-1+c.
 __global__ void k_ce_targets(const long long* __restrict__ tokens, int* __restrict__ target, int* __restrict__ row_map, int B, int cap,
                              int L, int T) {
