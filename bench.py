@@ -316,8 +316,10 @@ def main():
                          "reference's fp32 default precision: 3 MFMA terms per product, the parity mode)")
     ap.add_argument("--comm", default="torch", choices=["torch", "cabi"],
                     help="N>1 collectives: torch.distributed (backend nccl = RCCL) or the library's own C-ABI RCCL communicator")
-    ap.add_argument("--grad-wire", default="fp32", choices=["fp32", "bf16"],
-                    help="N>1: dtype of the gradient slices on the wire (bf16 halves the all-reduce bytes; fp32 arena stays the accumulator)")
+    ap.add_argument("--grad-wire", default="auto", choices=["auto", "fp32", "bf16"],
+                    help="N>1: dtype of the gradient slices on the wire (bf16 halves the all-reduce bytes; the fp32 arena stays the accumulator). "
+                         "auto = bf16 for frozen-LM runs (41.7 M mapper gradients that only the short mapper backward can hide; "
+                         "tests/test_ddp_gloo.py: 8e-3 on the gradients, loss trajectories equal to 2e-3 over 20 steps), fp32 for a full finetune")
     ap.add_argument("--no-roofline-pass", action="store_true",
                     help="skip the 25 extra event-bracketed steps (use under rocprofv3 --pmc, where every dispatch is serialised)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -368,6 +370,8 @@ def main():
     if args.batch:
         c["B"] = args.batch
     B, cap = c["B"], c["cap"]
+    if args.grad_wire == "auto":
+        args.grad_wire = "fp32" if c["train_lm"] else "bf16"
 
     from clipcap_amd import _lib
     from clipcap_amd.train.ddp import GradReducer

@@ -90,6 +90,9 @@ SIGNATURES = {
     "cc_gpt2_bwd": (_I, [_GC, _GS, _P, _P, _P, _P, _P, _P, _P]),
     "cc_decode_ws_bytes": (_L, [_GC, _I, _I]),
     "cc_decode_fwd": (_I, [_GC, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "cc_decode_part_floats": (_L, [_GC, _I]),
+    "cc_decode_fwd_p": (_I, [_GC, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P]),
+    "cc_beam_step_p": (_I, [_I, _I, _I, _P, _L, _P, _I, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "cc_decode_reorder": (_I, [_GC, _I, _I, _I, _I, _P, _P, _P, _P]),
     "cc_beam_step": (_I, [_I, _I, _I, _P, _L, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "cc_beam_ws_bytes": (_L, [_I, _I, _I]),

@@ -37,6 +37,45 @@ __global__ void k_add_wpe(const float* __restrict__ xin, const float* __restrict
     }
 }
 
+// x[r,:] = xin[r,:] + wpe[pos,:] and xn = LayerNorm(x) (layer 0's ln_1) in one launch: the single-position decode step (one wave per row)
+__global__ __launch_bounds__(256) void k_add_wpe_ln(const float* __restrict__ xin, const float* __restrict__ wpe, float* __restrict__ x,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta, act_t* __restrict__ xn,
+                                                    int R, int D, int pos) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    constexpr int MAXV = 8;                      // D <= 2048
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXV; it++) {
+        const int c = lane * 4 + it * 256;
+        if (c < D) {
+            const float4 a = *reinterpret_cast<const float4*>(xin + (size_t)row * D + c);
+            const float4 p = *reinterpret_cast<const float4*>(wpe + (size_t)pos * D + c);
+            v[it] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+            *reinterpret_cast<float4*>(x + (size_t)row * D + c) = v[it];
+            s += v[it].x + v[it].y + v[it].z + v[it].w;
+        }
+    }
+    const float mu = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXV; it++) {
+        const int c = lane * 4 + it * 256;
+        if (c < D) { const float a = v[it].x - mu, b = v[it].y - mu, c2 = v[it].z - mu, d = v[it].w - mu; q += a * a + b * b + c2 * c2 + d * d; }
+    }
+    const float rs = rsqrtf(wave_sum(q) / D + 1e-5f);
+#pragma unroll
+    for (int it = 0; it < MAXV; it++) {
+        const int c = lane * 4 + it * 256;
+        if (c < D) {
+            const float4 g = *reinterpret_cast<const float4*>(gamma + c), b = *reinterpret_cast<const float4*>(beta + c);
+            act_st4(xn + (size_t)row * D + c, (v[it].x - mu) * rs * g.x + b.x, (v[it].y - mu) * rs * g.y + b.y, (v[it].z - mu) * rs * g.z + b.z,
+                    (v[it].w - mu) * rs * g.w + b.w);
+        }
+    }
+}
+
 // attention of the Tn new queries of every row against the cache (ctx = pos0 + Tn, causal): one wave per (r,h,t).
 // scores: one key per lane (K row = hd contiguous bf16, 16-B loads).  PV: lane = (key group kg, 8-wide d chunk dc): every V load
 // is a 16-B vector, the key loop is 64/(hd/8) times shorter than one-d-per-lane, partial sums meet in wave-private LDS.
@@ -528,6 +567,233 @@ __global__ __launch_bounds__(64) void k_beam_final(int beam, int V, int first, i
     }
 }
 
+// ---- beam step in ONE kernel, fed by the lm_head epilogue's partials (gemm.hip.h EpiLogits) ----------------------------------
+// One block per sample.  The row statistics (max, sum of exp) come from the per-(row, 64-column block) partials — no pass over the
+// logits; every 64-column block is bounded by the key of its maximum, the TB-th largest bound is a lower bound of the sample's TB-th
+// best candidate, and only the blocks whose bound reaches it (a handful) are read from the logits matrix at all.  Same arithmetic
+// (softmax().log() as the reference writes it), same tie rule (lowest flat index) and same state update as the three-kernel path,
+// which stays as the fallback for temperature != 1, run-time beam widths and candidate-list overflow (e.g. all logits equal).
+template <int TB, int PER>      // PER: (row, block) partials per thread = ceil(TB * ceil(V / 64) / 256) at most (checked by the host)
+__global__ __launch_bounds__(256) void k_beam_fused(const float* __restrict__ logits, size_t ldl, int V, int npart, const float* __restrict__ pmax,
+                                                    const float* __restrict__ psum, int first, int stop_token, float* __restrict__ scores,
+                                                    float* __restrict__ seq_len, unsigned char* __restrict__ stopped, int* __restrict__ next_tok,
+                                                    int* __restrict__ src_row) {
+    constexpr int FCAP = 1024, SCAP = 512;
+    __shared__ float red[8];
+    __shared__ int redi[8];
+    __shared__ float rowred[4][TB];
+    __shared__ float s_m[TB], s_lsum[TB], s_sum[TB], s_sc[TB], s_len[TB];
+    __shared__ int s_st[TB];
+    __shared__ float fcv[FCAP];
+    __shared__ int fci[FCAP];
+    __shared__ int surv[SCAP];
+    __shared__ int fcount, scount;
+    __shared__ float sel_v[TB];
+    __shared__ int sel_i[TB];
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nrows = first ? 1 : TB;
+    const int nblk = (V + 63) >> 6;
+    // 1. every partial of the sample's rows is requested up front (entry i = tid + 256 e: row i / nblk, block i % nblk) — one round trip
+    //    instead of two dependent ones per row — and the row statistics m = max_j pmax, sum = sum_j psum exp(pmax - m) come from registers
+    const int total = nrows * nblk;
+    float pm[PER], ps[PER];
+#pragma unroll
+    for (int e = 0; e < PER; e++) {
+        const int i = tid + 256 * e;
+        const int b = min(i, total - 1) / nblk, j = min(i, total - 1) - b * nblk;
+        const size_t at = (size_t)(s * TB + b) * npart + j;
+        const float a = pmax[at], c = psum[at];
+        pm[e] = i < total ? a : -INFINITY;
+        ps[e] = i < total ? c : 0.f;
+    }
+    float lm[TB];
+#pragma unroll
+    for (int b = 0; b < TB; b++) lm[b] = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < PER; e++) {
+        const int b = min(tid + 256 * e, total - 1) / nblk;
+#pragma unroll
+        for (int q = 0; q < TB; q++) lm[q] = (q == b) ? fmaxf(lm[q], pm[e]) : lm[q];
+    }
+#pragma unroll
+    for (int b = 0; b < TB; b++) {
+        const float m = wave_max(lm[b]);
+        if (lane == 0) rowred[wv][b] = m;
+    }
+    __syncthreads();
+    float ls[TB];
+#pragma unroll
+    for (int b = 0; b < TB; b++) {
+        lm[b] = fmaxf(fmaxf(rowred[0][b], rowred[1][b]), fmaxf(rowred[2][b], rowred[3][b]));
+        ls[b] = 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < PER; e++) {
+        const int b = min(tid + 256 * e, total - 1) / nblk;
+        float mb = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < TB; q++) mb = (q == b) ? lm[q] : mb;
+        const float t = pm[e] != -INFINITY ? ps[e] * expf(pm[e] - mb) : 0.f;
+#pragma unroll
+        for (int q = 0; q < TB; q++) ls[q] += (q == b) ? t : 0.f;
+    }
+#pragma unroll
+    for (int b = 0; b < TB; b++) {
+        const float t = wave_sum(ls[b]);
+        if (lane == 0) rowred[wv][b] = t;
+    }
+    __syncthreads();
+    if (tid < nrows) {
+        const int b = tid;
+        const float t = (rowred[0][b] + rowred[1][b]) + (rowred[2][b] + rowred[3][b]);
+        const bool st = !first && stopped[s * TB + b];
+        float mb = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < TB; q++) mb = (q == b) ? lm[q] : mb;
+        s_m[b] = mb; s_sum[b] = t; s_lsum[b] = logf(t); s_st[b] = st;
+        s_sc[b] = first ? 0.f : scores[s * TB + b];
+        s_len[b] = first ? 1.f : (seq_len[s * TB + b] + (st ? 0.f : 1.f));
+    }
+    if (tid == 0) { fcount = 0; scount = 0; }
+    __syncthreads();
+    // cheap image of a candidate's value (monotone in the logit), and the exact value (base.py:96-101)
+    auto key_of = [&](int b, int v, float x) -> float {
+        if (s_st[b]) return v == 0 ? (first ? 0.f : (s_sc[b] + 0.f) / s_len[b]) : -INFINITY;
+        const float d = (x - s_m[b]) - s_lsum[b];
+        return first ? d : (s_sc[b] + d) * (1.0f / s_len[b]);
+    };
+    auto val_of = [&](int b, int v, float x) -> float {
+        if (s_st[b]) return v == 0 ? (first ? 0.f : (s_sc[b] + 0.f) / s_len[b]) : -INFINITY;
+        const float lp = logf(expf(x - s_m[b]) / s_sum[b]);
+        return first ? lp : (s_sc[b] + lp) / s_len[b];
+    };
+    // 2. bound of every (row, block): key of the block maximum (a stopped row: only token 0, i.e. block 0)
+    float bk[PER];
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < PER; e++) {
+        const int i = tid + 256 * e;
+        const int b = min(i, total - 1) / nblk, j = min(i, total - 1) - b * nblk;
+        const float k = s_st[b] ? (j == 0 ? key_of(b, 0, 0.f) : -INFINITY) : key_of(b, 1, pm[e]);
+        bk[e] = i < total ? k : -INFINITY;
+        tmax = fmaxf(tmax, bk[e]);
+    }
+    float thr = -INFINITY;
+    for (int k = 0; k < TB; k++) {
+        float bv = wave_max(tmax);
+        if (lane == 0) red[(k & 1) * 4 + wv] = bv;
+        __syncthreads();
+        thr = fmaxf(fmaxf(red[(k & 1) * 4], red[(k & 1) * 4 + 1]), fmaxf(red[(k & 1) * 4 + 2], red[(k & 1) * 4 + 3]));
+        if (tmax == thr) tmax = -INFINITY;            // equal maxima leave together: the bound only gets lower (still valid)
+    }
+    // 3. surviving blocks -> LDS list
+#pragma unroll
+    for (int e = 0; e < PER; e++) {
+        if (bk[e] > -INFINITY && bk[e] + 1e-3f >= thr) {
+            const int pos = atomicAdd(&scount, 1);
+            if (pos < SCAP) surv[pos] = tid + 256 * e;
+        }
+    }
+    __syncthreads();
+    const int ns = scount;
+    bool ok = ns <= SCAP;
+    if (ok) {       // 4. one wave per surviving block: its 64 logits, exact values of the candidates within 1e-3 of the bound
+        for (int q = wv; q < ns; q += 4) {
+            const int i = surv[q], b = i / nblk, j = i - b * nblk, v = j * 64 + lane;
+            if (v < V) {
+                const float x = s_st[b] ? 0.f : logits[(size_t)(s * TB + b) * ldl + v];
+                const float key = key_of(b, v, x);
+                if (key > -INFINITY && key + 1e-3f >= thr) {
+                    const int pos = atomicAdd(&fcount, 1);
+                    if (pos < FCAP) { fcv[pos] = val_of(b, v, x); fci[pos] = b * V + v; }
+                }
+            }
+        }
+        __syncthreads();
+        ok = fcount <= FCAP;
+    }
+    if (!ok) {
+        // block-uniform overflow path (degenerate inputs, e.g. all logits equal): TB rounds of a full scan, each picking the best candidate
+        // that comes strictly after the previous pick in the (value descending, flat index ascending) order.  Slow and exact.
+        float pv = INFINITY;
+        int pi = -1;
+        for (int k = 0; k < TB; k++) {
+            float bv = -INFINITY;
+            int bi = 0x7fffffff;
+            for (int b = 0; b < nrows; b++)
+                for (int v = tid; v < V; v += 256) {
+                    const float x = s_st[b] ? 0.f : logits[(size_t)(s * TB + b) * ldl + v];
+                    const float val = val_of(b, v, x);
+                    const int idx = b * V + v;
+                    if ((pi < 0 || cand_better(pv, pi, val, idx)) && cand_better(val, idx, bv, bi)) { bv = val; bi = idx; }
+                }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (cand_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+            }
+            if (lane == 0) { red[(k & 1) * 4 + wv] = bv; redi[(k & 1) * 4 + wv] = bi; }
+            __syncthreads();
+            bv = red[(k & 1) * 4]; bi = redi[(k & 1) * 4];
+#pragma unroll
+            for (int w = 1; w < 4; w++) {
+                const float ov = red[(k & 1) * 4 + w];
+                const int oi = redi[(k & 1) * 4 + w];
+                if (cand_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+            }
+            pv = bv; pi = bi;
+            if (tid == 0) { sel_v[k] = bi != 0x7fffffff ? bv : -INFINITY; sel_i[k] = bi; }
+        }
+        __syncthreads();
+    }
+    const int n = ok ? fcount : 0;
+    for (int k = 0; ok && k < TB; k++) {      // 5. TB rounds of block arg-max over the list (ties -> lowest flat index)
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int c = tid; c < n; c += 256)
+            if (fci[c] != 0x7fffffff && cand_better(fcv[c], fci[c], bv, bi)) { bv = fcv[c]; bi = fci[c]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (cand_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { red[(k & 1) * 4 + wv] = bv; redi[(k & 1) * 4 + wv] = bi; }
+        __syncthreads();
+        bv = red[(k & 1) * 4]; bi = redi[(k & 1) * 4];
+#pragma unroll
+        for (int w = 1; w < 4; w++) {
+            const float ov = red[(k & 1) * 4 + w];
+            const int oi = redi[(k & 1) * 4 + w];
+            if (cand_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+        }
+        for (int c = tid; c < n; c += 256)
+            if (fci[c] == bi) fci[c] = 0x7fffffff;
+        if (tid == 0) { sel_v[k] = bi != 0x7fffffff ? bv : -INFINITY; sel_i[k] = bi; }
+        __syncthreads();
+    }
+    if (tid < TB) {      // 6. gather / update state (base.py:86-119), as k_beam_final
+        const int idx = sel_i[tid];
+        const int b = idx / V, v = idx % V;
+        float nl, nsc;
+        int hs;
+        if (first) { nl = 1.f; nsc = sel_v[tid]; hs = 0; }
+        else {
+            nl = s_len[b];                          // = seq_len[b] + (stopped ? 0 : 1), read before any state was written
+            nsc = sel_v[tid] * nl;                  // scores = scores_sum_average * seq_lengths (base.py:114)
+            hs = s_st[b];
+        }
+        hs |= (v == stop_token) ? 1 : 0;
+        next_tok[s * TB + tid] = v;
+        src_row[s * TB + tid] = b;
+        scores[s * TB + tid] = nsc;
+        seq_len[s * TB + tid] = nl;
+        stopped[s * TB + tid] = (unsigned char)hs;
+    }
+}
+
 struct DecWS {
     float *x, *x1;
     act_t *xn, *qkv, *att, *hact, *hf;
@@ -582,8 +848,22 @@ int64_t CC_API(cc_decode_ws_bytes)(const cc_gpt2_cfg* cfg, int32_t R, int32_t Tn
     return (int64_t)w.bytes;
 }
 
+int64_t CC_API(cc_decode_part_floats)(const cc_gpt2_cfg* cfg, int32_t R) {
+    if (!cfg_ok(cfg) || R <= 0) return CC_ERR_SHAPE;
+    const int Ns = std::min(cfg->Vp, (cfg->V + 7) / 8 * 8);
+    return (int64_t)2 * R * ((Ns + 63) / 64);
+}
+
+int CC_API(cc_decode_fwd_p)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int32_t ctx_max, const float* w32, const uint16_t* w16,
+                    const float* x, uint16_t* kv, const int32_t* row_map, void* ws, float* logits, int64_t ldl, float* lpart, void* stream);
+
 int CC_API(cc_decode_fwd)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int32_t ctx_max, const float* w32, const uint16_t* w16,
                   const float* x, uint16_t* kv, const int32_t* row_map, void* ws, float* logits, int64_t ldl, void* stream) {
+    return CC_API(cc_decode_fwd_p)(c, R, Tn, pos0, ctx_max, w32, w16, x, kv, row_map, ws, logits, ldl, nullptr, stream);
+}
+
+int CC_API(cc_decode_fwd_p)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int32_t ctx_max, const float* w32, const uint16_t* w16,
+                    const float* x, uint16_t* kv, const int32_t* row_map, void* ws, float* logits, int64_t ldl, float* lpart, void* stream) {
     if (!cfg_ok(c) || R <= 0 || Tn <= 0 || pos0 < 0 || !w32 || !w16 || !x || !kv || !ws || !logits) return CC_ERR_ARG;
     const int Ns = std::min(c->Vp, (c->V + 7) / 8 * 8);
     if (pos0 + Tn > ctx_max || pos0 + Tn > c->NPOS || ldl < Ns || (ldl & 3) || ldl > 0x7fffffff) return CC_ERR_SHAPE;
@@ -600,7 +880,11 @@ int CC_API(cc_decode_fwd)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t p
     int64_t p = 0;
     const int64_t wte = p; p += (int64_t)c->Vp * D;
     const int64_t wpe = p; p += (int64_t)c->NPOS * D;
-    {
+    // single-position step: positional add + layer 0's ln_1 in one launch; the last layer's finishing pass applies ln_f (below)
+    const bool one = Tn == 1 && D <= 2048 && (D & 3) == 0;
+    if (one) {
+        hipLaunchKernelGGL(k_add_wpe_ln, dim3((R + 3) / 4), dim3(256), 0, st, x, w32 + wpe, w.x, w32 + p, w32 + p + D, w.xn, R, D, pos0);   // p = layer 0's ln_1.weight
+    } else {
         const size_t total = (size_t)M * (D >> 2);
         hipLaunchKernelGGL(k_add_wpe, dim3((int)std::min<size_t>((total + 255) / 256, 2048)), dim3(256), 0, st, x, w32 + wpe, w.x, R, Tn, D, pos0);
     }
@@ -608,7 +892,8 @@ int CC_API(cc_decode_fwd)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t p
     const int64_t total = (int64_t)c->Vp * D + (int64_t)c->NPOS * D + (int64_t)c->NL * (12 * (int64_t)D * D + 13 * (int64_t)D) + 2 * D;
     const uint16_t* w16t = w16 + (size_t)PL * total;   // transposed Conv1D weights (cc_gpt2_sync_weights): forward GEMMs are NT
     const float scale = 1.0f / sqrtf((float)hd);
-    bool xn_ready = false;
+    bool xn_ready = one;
+    bool hf_ready = false;
     for (int l = 0; l < c->NL; l++) {
         const int64_t l1w = p; p += D;
         const int64_t l1b = p; p += D;
@@ -649,17 +934,27 @@ int CC_API(cc_decode_fwd)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t p
         if (!f_d) CC_TRY(ln_fwd(w.x1, D, nullptr, w32 + l2w, w32 + l2b, w.xn, nullptr, nullptr, nullptr, M, D, st));
         CC_TRY(gemm_nt_skinny(w.xn, D, w16t + (size_t)PL * fw, D, M, 4 * D, D, w32 + fb, 2, nullptr, nullptr, w.hact, 4 * D, w.scratch, w.scratch_bytes, st));
         // mlp.c_proj + residual (+ fused ln_1 of the next layer: its parameters sit right behind this layer's in the arena)
-        const bool f_next = f_d && l + 1 < c->NL;
+        // (after the LAST layer p points at ln_f: with one new position per row the finishing pass normalises straight into hf)
+        const bool last = l + 1 == c->NL;
+        const bool f_next = f_d && (!last || one);
         SkinnyFuse f1;
-        f1.ln_gamma = w32 + p; f1.ln_beta = w32 + p + D; f1.ln_out16 = w.xn;       // p now points at layer l+1's ln_1.weight
+        f1.ln_gamma = w32 + p; f1.ln_beta = w32 + p + D; f1.ln_out16 = last ? w.hf : w.xn;       // p now points at layer l+1's ln_1.weight (or ln_f)
         CC_TRY(gemm_nt_skinny(w.hact, 4 * D, w16t + (size_t)PL * p2w, 4 * D, M, D, 4 * D, w32 + p2b, 0, w.x1, w.x, nullptr, D, w.scratch, w.scratch_bytes, st,
                               f_next ? &f1 : nullptr));
-        xn_ready = f_next;
+        xn_ready = f_next && !last;
+        hf_ready = f_next && last;
     }
     const int64_t lnf_w = p, lnf_b = p + D;
-    hipLaunchKernelGGL(k_last_rows, dim3((R + 255) / 256), dim3(256), 0, st, w.last, R, Tn);
-    CC_TRY(ln_fwd(w.x, D, w.last, w32 + lnf_w, w32 + lnf_b, w.hf, nullptr, w.meanf, w.rstdf, R, D, st));
-    CC_TRY(gemm_f32out(0, 0, w.hf, D, w16 + (size_t)PL * wte, D, R, Ns, D, logits, (int)ldl, nullptr, 0, 1.0f, 1, st));
+    if (!hf_ready) {
+        hipLaunchKernelGGL(k_last_rows, dim3((R + 255) / 256), dim3(256), 0, st, w.last, R, Tn);
+        CC_TRY(ln_fwd(w.x, D, w.last, w32 + lnf_w, w32 + lnf_b, w.hf, nullptr, w.meanf, w.rstdf, R, D, st));
+    }
+    if (lpart) {      // logits + per-(row, 64-column block) softmax partials for cc_beam_step_p
+        const int npart = (Ns + 63) / 64;
+        CC_TRY(gemm_logits_part(w.hf, D, w16 + (size_t)PL * wte, D, R, Ns, c->V, D, logits, (int)ldl, lpart, lpart + (size_t)R * npart, npart, st));
+    } else {
+        CC_TRY(gemm_f32out(0, 0, w.hf, D, w16 + (size_t)PL * wte, D, R, Ns, D, logits, (int)ldl, nullptr, 0, 1.0f, 1, st));
+    }
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
 
@@ -680,12 +975,40 @@ int64_t CC_API(cc_beam_ws_bytes)(int32_t S, int32_t beam, int32_t V) {
     return (int64_t)S * beam * 2 * sizeof(float) + (int64_t)S * BEAM_CHUNKS * beam * (sizeof(float) + sizeof(int)) + 512;
 }
 
+int CC_API(cc_beam_step_p)(int32_t S, int32_t beam, int32_t V, const float* logits, int64_t ldl, const float* lpart, int32_t npart, float temperature,
+                   int32_t first, int32_t stop_token, float* scores, float* seq_lengths, uint8_t* has_stopped, int32_t* next_tokens,
+                   int32_t* src_rows, void* ws, void* stream);
+
 int CC_API(cc_beam_step)(int32_t S, int32_t beam, int32_t V, const float* logits, int64_t ldl, float temperature, int32_t first, int32_t stop_token,
                  float* scores, float* seq_lengths, uint8_t* has_stopped, int32_t* next_tokens, int32_t* src_rows, void* ws, void* stream) {
+    return CC_API(cc_beam_step_p)(S, beam, V, logits, ldl, nullptr, 0, temperature, first, stop_token, scores, seq_lengths, has_stopped, next_tokens,
+                                  src_rows, ws, stream);
+}
+
+int CC_API(cc_beam_step_p)(int32_t S, int32_t beam, int32_t V, const float* logits, int64_t ldl, const float* lpart, int32_t npart, float temperature,
+                   int32_t first, int32_t stop_token, float* scores, float* seq_lengths, uint8_t* has_stopped, int32_t* next_tokens,
+                   int32_t* src_rows, void* ws, void* stream) {
     if (S <= 0 || beam <= 0 || beam > BEAM_MAX || V <= 0 || !logits || ldl < V || !scores || !seq_lengths || !has_stopped || !next_tokens ||
-        !src_rows || !ws)
+        !src_rows || !ws || (lpart && npart * 64 < V))
         return CC_ERR_ARG;
     hipStream_t st = S_(stream);
+    // partials from the lm_head epilogue (cc_decode_fwd_p), temperature 1: the whole update in one launch (k_beam_fused)
+    constexpr int FUSED_VMAX = 51200;      // the fused kernel's per-thread register image of the partials is sized for vocabularies up to this
+    if (lpart && (temperature <= 0.f || temperature == 1.0f) && (beam <= 5 || beam == 8) && V <= FUSED_VMAX) {
+        const float* pmax = lpart;
+        const float* psum = lpart + (size_t)S * beam * npart;
+#define BEAM_FUSED(TB) hipLaunchKernelGGL((k_beam_fused<TB, (TB * (FUSED_VMAX / 64) + 255) / 256>), dim3(S), dim3(256), 0, st, logits, (size_t)ldl, V, npart, pmax, psum, first, stop_token, scores, seq_lengths, has_stopped, next_tokens, src_rows)
+        switch (beam) {
+            case 1: BEAM_FUSED(1); break;
+            case 2: BEAM_FUSED(2); break;
+            case 3: BEAM_FUSED(3); break;
+            case 4: BEAM_FUSED(4); break;
+            case 5: BEAM_FUSED(5); break;
+            default: BEAM_FUSED(8); break;
+        }
+#undef BEAM_FUSED
+        return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+    }
     const float inv_temp = 1.0f / (temperature > 0.f ? temperature : 1.0f);   // base.py:83
     float* rs = static_cast<float*>(ws);
     float* pval = rs + (size_t)S * beam * 2;

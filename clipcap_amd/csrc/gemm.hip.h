@@ -1491,6 +1491,78 @@ struct EpiLMHeadExp {
         if (cb < ldc) act_st8(C + (size_t)row * ldc + cb, vb);
     }
 };
+// Decode lm_head: fp32 logits (what the beam / sampling kernels read) + the same per-(row, 64-column block) partials (max, sum of
+// exp(x - max)) from the accumulators, so the beam update needs no pass over the 64 MB logits matrix for its row statistics and can
+// bound every 64-column block by its maximum (decode.hip k_beam_fused).  Columns >= V are stored as computed (the caller's matrix may
+// be wider) but excluded from the partials.
+struct EpiLogits {
+    float* C;
+    float* pmax;
+    float* psum;           // [M][npart]
+    int ldc, M, Ns, V, npart;
+    __device__ __forceinline__ void operator()(int row, int col, float (&v)[8]) const {
+        const bool ok = row < M && col < Ns;
+        float m = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+            if (col + e < V) m = fmaxf(m, v[e]);
+        m = fmaxf(m, __shfl_xor(m, 1, 64));
+        m = fmaxf(m, __shfl_xor(m, 2, 64));
+        m = fmaxf(m, __shfl_xor(m, 4, 64));
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+            if (col + e < V) s += __expf(v[e] - m);
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        if (!ok) return;
+        if ((col & 63) == 0) {
+            const int blk = col >> 6;
+            pmax[(size_t)row * npart + blk] = m;
+            psum[(size_t)row * npart + blk] = (m == -INFINITY) ? 0.f : s;
+        }
+        float* p = C + (size_t)row * ldc + col;
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+    typedef int RowAux;
+    __device__ __forceinline__ int load_row(int) const { return 0; }
+    __device__ __forceinline__ void strip(int row, int ca, int cb, float (&va)[8], float (&vb)[8], int) const {
+        float m = -INFINITY, s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            if (ca + e < V) m = fmaxf(m, va[e]);
+            if (cb + e < V) m = fmaxf(m, vb[e]);
+        }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            if (ca + e < V) s += __expf(va[e] - m);
+            if (cb + e < V) s += __expf(vb[e] - m);
+        }
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (row >= M) return;
+        if ((ca & 63) == 0 && ca < Ns) {
+            const int blk = ca >> 6;
+            pmax[(size_t)row * npart + blk] = m;
+            psum[(size_t)row * npart + blk] = (m == -INFINITY) ? 0.f : s;
+        }
+        if (ca < Ns) {
+            float* p = C + (size_t)row * ldc + ca;
+            *reinterpret_cast<float4*>(p) = make_float4(va[0], va[1], va[2], va[3]);
+            *reinterpret_cast<float4*>(p + 4) = make_float4(va[4], va[5], va[6], va[7]);
+        }
+        if (cb < Ns) {
+            float* p = C + (size_t)row * ldc + cb;
+            *reinterpret_cast<float4*>(p) = make_float4(vb[0], vb[1], vb[2], vb[3]);
+            *reinterpret_cast<float4*>(p + 4) = make_float4(vb[4], vb[5], vb[6], vb[7]);
+        }
+    }
+};
+template <> struct epi_row_strip<EpiLogits> { static constexpr bool value = true; };
 template <> struct epi_row_strip<EpiLMHead> { static constexpr bool value = true; };
 template <> struct epi_row_strip<EpiLMHeadExp> { static constexpr bool value = true; };
 

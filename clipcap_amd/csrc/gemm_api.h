@@ -29,6 +29,11 @@ int gemm_dact(int al, int bl, const act_t* A, int lda, const op16_t* B, int ldb,
 int gemm_lmhead(const act_t* A, int lda, const op16_t* B, int ldb, int M, int Vp, int V, int K, act_t* C, int ldc, float* pmax,
                 float* psum, int npart, const int* target, float* tgt_logit, hipStream_t st, const float* cref = nullptr);
 
+// decode lm_head: fp32 logits [M][ldc] (Ns columns stored, Ns % 8 == 0) + per-(row, 64-column block) softmax partials over the V real
+// columns (pmax / psum [M][npart], npart >= ceil(Ns / 64)) — gemm.hip.h EpiLogits
+int gemm_logits_part(const act_t* A, int lda, const op16_t* B, int ldb, int M, int Ns, int V, int K, float* C, int ldc, float* pmax, float* psum,
+                     int npart, hipStream_t st);
+
 #if CC_OP == 2
 // bf16x3: scratch for the operand images of the GEMM being launched (stream order makes reuse by the next GEMM safe).  Thread-local:
 // the C ABI stays re-entrant across host threads / streams; every compute entry point sets it from its own workspace.

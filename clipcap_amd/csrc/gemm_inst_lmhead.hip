@@ -14,4 +14,13 @@ int gemm_lmhead(const act_t* A, int lda, const op16_t* B, int ldb, int M, int Vp
     EpiLMHead e{C, pmax, psum, target, tgt_logit, ldc, M, V, npart};
     return launch_gemm(0, 0, A16, lda, B, ldb, M, Vp, K, 1, e, st);
 }
+int gemm_logits_part(const act_t* A, int lda, const op16_t* B, int ldb, int M, int Ns, int V, int K, float* C, int ldc, float* pmax, float* psum,
+                     int npart, hipStream_t st) {
+    cc_shared::ProfScope _all(cc_shared::SITE_ALL_GEMMS, st, 2.0 * M * V * (double)K);
+    if ((ldc & 3) || (Ns & 7) || npart * 64 < Ns) return CC_ERR_SHAPE;
+    const op16_t* A16;
+    CC_X3_NT(A, lda, ldb, M, K, A16, 0, 0, st);
+    EpiLogits e{C, pmax, psum, ldc, M, Ns, V, npart};
+    return launch_gemm(0, 0, A16, lda, B, ldb, M, Ns, K, 1, e, st);
+}
 }  // namespace CC_NS

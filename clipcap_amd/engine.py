@@ -565,9 +565,10 @@ class DecodeSession:
             self._ws[tn] = ws
         return ws
 
-    def forward(self, x: torch.Tensor, rows: Optional[int] = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, rows: Optional[int] = None, partials: bool = False) -> torch.Tensor:
         """x fp32 (R', Tnew, D) input embeddings (no positional term), R' <= R active rows -> fp32 logits of the last new
-        position (R', V).  Valid until the next forward()."""
+        position (R', V).  Valid until the next forward().  ``partials``: also keep the lm_head epilogue's per-64-column softmax
+        partials of these logits in ``self.lpart`` = (tensor, npart) for beam_step (cc_decode_fwd_p / cc_beam_step_p)."""
         g = self.g
         x = x.to(device=g.arena.device, dtype=torch.float32).contiguous()
         Ra, tn, D = x.shape
@@ -581,8 +582,16 @@ class DecodeSession:
         logits = self._logits[:Ra]
         if Ra != self.R:   # fewer active rows (prefill with one row per sample): the cache row stride is still R rows
             raise RuntimeError("partial-row forward is expressed through a narrower session; use expand()")
-        check(_lib.lib().cc_decode_fwd(C.byref(g.cfg), Ra, tn, self.pos, self.ctx_max, _p(g.arena.w32), _p(g.arena.w16), _p(x), _p(self.kv),
-                                      _p(self.row_map), _p(self._workspace(tn)), _p(logits), Vp, _stream(g.arena.device)), "cc_decode_fwd")
+        self.lpart = None
+        if partials:
+            if getattr(self, "_lpart", None) is None:
+                n = _lib.lib().cc_decode_part_floats(C.byref(g.cfg), self.R)
+                check(n, "cc_decode_part_floats")
+                self._lpart = torch.empty(n, dtype=torch.float32, device=g.arena.device)
+            self.lpart = (self._lpart, self._lpart.numel() // (2 * self.R))
+        check(_lib.lib().cc_decode_fwd_p(C.byref(g.cfg), Ra, tn, self.pos, self.ctx_max, _p(g.arena.w32), _p(g.arena.w16), _p(x), _p(self.kv),
+                                        _p(self.row_map), _p(self._workspace(tn)), _p(logits), Vp, _p(self._lpart) if partials else None,
+                                        _stream(g.arena.device)), "cc_decode_fwd_p")
         self.pos += tn
         return logits[:, : g.dims["V"]]
 
@@ -633,17 +642,19 @@ def beam_buffers(device, samples: int, beam: int, V: int) -> tuple:
 
 
 def beam_step(logits: torch.Tensor, samples: int, beam: int, temperature: float, first: bool, stop_token: int, scores: torch.Tensor,
-              seq_lengths: torch.Tensor, has_stopped: torch.Tensor, bufs: Optional[tuple] = None):
+              seq_lengths: torch.Tensor, has_stopped: torch.Tensor, bufs: Optional[tuple] = None, lpart: Optional[tuple] = None):
     """One device-side beam update for `samples` independent beam sets (reference inference/base.py:84-119).
     logits fp32 (samples*beam, V) (a view with row stride ldl is fine); state tensors are updated IN PLACE.
-    ``bufs``: the caller's beam_buffers(...) (fresh ones are allocated when omitted).
+    ``bufs``: the caller's beam_buffers(...) (fresh ones are allocated when omitted).  ``lpart``: DecodeSession.lpart of the forward
+    that produced these logits (softmax partials from the lm_head epilogue): the update then runs as one launch (cc_beam_step_p).
     Returns (next_tokens int32 (samples*beam,), src_rows int32 (samples*beam,) local row index inside each sample)."""
     dev = logits.device
     V = logits.shape[1]
     ldl = logits.stride(0)
     nt, sr, ws = bufs if bufs is not None else beam_buffers(dev, samples, beam, V)
-    check(_lib.lib().cc_beam_step(samples, beam, V, _p(logits), ldl, float(temperature), int(first), int(stop_token), _p(scores), _p(seq_lengths),
-                                 _p(has_stopped), _p(nt), _p(sr), _p(ws), _stream(dev)), "cc_beam_step")
+    check(_lib.lib().cc_beam_step_p(samples, beam, V, _p(logits), ldl, _p(lpart[0]) if lpart is not None else None,
+                                   lpart[1] if lpart is not None else 0, float(temperature), int(first), int(stop_token), _p(scores),
+                                   _p(seq_lengths), _p(has_stopped), _p(nt), _p(sr), _p(ws), _stream(dev)), "cc_beam_step_p")
     return nt, sr
 
 

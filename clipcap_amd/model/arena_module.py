@@ -56,7 +56,9 @@ class ArenaModule(nn.Module):
 
     def set_precision(self, precision):
         """16 = fp16 GEMM / attention operands (the reference's ``--fp-precision 16``, clipcap/train/args.py:30-34; training then
-        runs under a dynamic loss scale); 32 / 64 / "bf16" = bf16 operands.  Master weights, accumulation and the optimizer stay fp32."""
+        runs under a dynamic loss scale); 32 (the reference's default) / 64 = split-bf16 operands (three MFMA terms per product, fp32
+        activations: logits within 1e-3 of the fp32 reference); "bf16" = bf16 operands.  Master weights, accumulation and the
+        optimizer stay fp32 (_lib.op_dtype_of)."""
         self.engine.set_precision(precision)
         return self
 

@@ -52,7 +52,7 @@ extern "C" {
 #define CC_ERR_STATE (-4)
 
 /* bumped when an existing entry point changes; entry points ADDED since 2: cc_adamw_step_cast, cc_mapper_transpose_weights, cc_gpt2_transpose_weights,
- * cc_comm_count; operand mode ADDED: CC_OP_BF16X3 */
+ * cc_comm_count, cc_decode_part_floats, cc_decode_fwd_p, cc_beam_step_p; operand mode ADDED: CC_OP_BF16X3 */
 #define CC_ABI_VERSION 2
 int cc_abi_version(void);
 
@@ -210,6 +210,15 @@ int64_t cc_decode_ws_bytes(const cc_gpt2_cfg* cfg, int32_t R, int32_t Tnew);
 int cc_decode_fwd(const cc_gpt2_cfg* cfg, int32_t R, int32_t Tnew, int32_t pos0, int32_t ctx_max, const float* w32,
                   const uint16_t* w16, const float* x, uint16_t* kv, const int32_t* row_map, void* ws, float* logits, int64_t ldl,
                   void* stream);
+/* cc_decode_fwd that also hands out, from the lm_head GEMM's epilogue, the softmax partials of every logits row: lpart (device, may be
+ * NULL = plain cc_decode_fwd) = pmax [R][npart] followed by psum [R][npart], npart = ceil(min(Vp, round_up(V, 8)) / 64); pmax = maximum of
+ * the row's logits in the 64-column block, psum = sum of exp(logit - pmax) over it (columns >= V excluded).  cc_decode_part_floats = the
+ * float count of lpart (2 * R * npart).  cc_beam_step_p uses them to run the whole beam update in one launch without a pass over the
+ * logits matrix. */
+int64_t cc_decode_part_floats(const cc_gpt2_cfg* cfg, int32_t R);
+int cc_decode_fwd_p(const cc_gpt2_cfg* cfg, int32_t R, int32_t Tnew, int32_t pos0, int32_t ctx_max, const float* w32,
+                    const uint16_t* w16, const float* x, uint16_t* kv, const int32_t* row_map, void* ws, float* logits, int64_t ldl,
+                    float* lpart, void* stream);
 /* reorder / expand cache rows after a beam step: kv_dst[:, :, r] = kv_src[:, :, src[r]] for positions < ctx and
  * r < R_dst (base.py:93,113: embeds.expand / embeds[next_tokens_source]); the two caches may have different row counts. */
 int cc_decode_reorder(const cc_gpt2_cfg* cfg, int32_t R_src, int32_t R_dst, int32_t ctx, int32_t ctx_max, const uint16_t* kv_src,
@@ -220,6 +229,12 @@ int cc_decode_reorder(const cc_gpt2_cfg* cfg, int32_t R_src, int32_t R_dst, int3
 int cc_beam_step(int32_t S, int32_t beam, int32_t V, const float* logits, int64_t ldl, float temperature, int32_t first,
                  int32_t stop_token, float* scores, float* seq_lengths, uint8_t* has_stopped, int32_t* next_tokens,
                  int32_t* src_rows, void* ws, void* stream);
+/* the same update given the logits' partials (lpart / npart as cc_decode_fwd_p writes them for the S * beam rows; NULL = cc_beam_step):
+ * row statistics from the partials, every 64-column block bounded by its maximum, only the handful of blocks that can hold a winner
+ * read — one launch.  Identical results (arithmetic, tie rule); temperature != 1 or widths other than 1..5, 8 take cc_beam_step's path. */
+int cc_beam_step_p(int32_t S, int32_t beam, int32_t V, const float* logits, int64_t ldl, const float* lpart, int32_t npart,
+                   float temperature, int32_t first, int32_t stop_token, float* scores, float* seq_lengths, uint8_t* has_stopped,
+                   int32_t* next_tokens, int32_t* src_rows, void* ws, void* stream);
 int64_t cc_beam_ws_bytes(int32_t S, int32_t beam, int32_t V);
 /* gathers wte rows for next tokens: out fp32 [R, D] (base.py:117) */
 int cc_embed_tokens(const cc_gpt2_cfg* cfg, int32_t R, const float* w32, const int32_t* tokens, float* out, void* stream);

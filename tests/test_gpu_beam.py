@@ -96,3 +96,56 @@ def test_beam_advance_matches_indexing():
     assert torch.equal(x.view(R, 64), wte[nxt.long()])
     assert torch.equal(sess.row_map[:, :6], before[g, :6])
     assert torch.equal(sess.row_map[:, 6:], torch.arange(R, dtype=torch.int32, device="cuda").view(R, 1).expand(R, 14))
+
+
+def _partials(lg, V):
+    """what the decode lm_head epilogue writes (gemm.hip.h EpiLogits): per (row, 64-column block) max and sum of exp(x - max)"""
+    R = lg.shape[0]
+    npart = (V + 63) // 64
+    pad = torch.full((R, npart * 64), float("-inf"), device=lg.device)
+    pad[:, :V] = lg[:, :V]
+    blk = pad.view(R, npart, 64)
+    pmax = blk.max(dim=2).values
+    psum = torch.exp(blk - pmax[:, :, None]).sum(dim=2)
+    return (torch.cat((pmax.reshape(-1), psum.reshape(-1))).contiguous(), npart)
+
+
+@pytest.mark.parametrize("beam,V,ld", [(5, 50257, 50304), (3, 50257, 50257), (8, 1001, 1001), (1, 50257, 50304), (4, 130, 136)])
+def test_beam_step_from_partials_matches_oracle(beam, V, ld):
+    """cc_beam_step_p: the one-launch update driven by the lm_head epilogue's partials (temperature 1) — same tokens, source rows,
+    scores, lengths and stop flags as the oracle, through stopped beams."""
+    torch.manual_seed(beam * 77 + V)
+    S, stop = 6, 17
+    R = S * beam
+    scores = torch.zeros(R, device="cuda")
+    seql = torch.ones(R, device="cuda")
+    stopped = torch.zeros(R, dtype=torch.uint8, device="cuda")
+    o_scores, o_seql, o_stopped = torch.zeros(R), torch.ones(R), torch.zeros(R, dtype=torch.bool)
+    for step in range(5):
+        buf = torch.randn(R, ld, device="cuda") * 3.0
+        if step >= 1:
+            buf[::3, stop] += 25.0
+        lg = buf[:, :V]
+        nt, sr = beam_step(lg, S, beam, 1.0, step == 0, stop, scores, seql, stopped, None, _partials(lg, V))
+        ont, osr = _oracle_step(lg.cpu().float(), step == 0, S, beam, 1.0, stop, o_scores, o_seql, o_stopped)
+        torch.cuda.synchronize()
+        assert torch.equal(nt.cpu().long(), ont), step
+        if step > 0:
+            assert torch.equal(sr.cpu().long(), osr), step
+        assert torch.allclose(scores.cpu(), o_scores, rtol=1e-5, atol=3e-5), step
+        assert torch.equal(seql.cpu(), o_seql) and torch.equal(stopped.cpu().bool(), o_stopped), step
+    assert o_stopped.any()
+
+
+def test_beam_step_from_partials_all_ties_takes_the_exact_overflow_path():
+    S, V, beam = 3, 50257, 5
+    R = S * beam
+    scores = torch.zeros(R, device="cuda")
+    seql = torch.ones(R, device="cuda")
+    stopped = torch.zeros(R, dtype=torch.uint8, device="cuda")
+    lg = torch.zeros(R, V, device="cuda")
+    part = _partials(lg, V)
+    nt, sr = beam_step(lg, S, beam, 1.0, True, 50256, scores, seql, stopped, None, part)
+    assert nt.view(S, beam).cpu().tolist() == [list(range(beam))] * S
+    nt, sr = beam_step(lg, S, beam, 1.0, False, 50256, scores, seql, stopped, None, part)
+    assert nt.view(S, beam).cpu().tolist() == [list(range(beam))] * S and sr.view(S, beam).cpu().tolist() == [[0] * beam] * S

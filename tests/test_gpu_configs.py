@@ -201,7 +201,7 @@ def test_config5_batched_beam_equals_per_sample_24_layers():
     assert toks.shape[:2] == (64, 5) and torch.isfinite(scores).all()
     # Beam search is chaotic under bf16 noise (a near-tie for the 5th beam at an early step changes which captions survive): over
     # all 64 samples 61 are identical (measured).  Identical captions must carry the same score.
-    same, checked = 0, (0, 5, 11, 23, 31, 40, 52, 63)
+    same, checked, misses = 0, (0, 5, 11, 23, 31, 40, 52, 63), []
     for i in checked:
         t1, s1, l1 = generate_beam_tokens(model, pref[i:i + 1], 5, 12, 1.0, 50256)
         b, b1 = int(scores[i].argmax()), int(s1[0].argmax())
@@ -209,7 +209,24 @@ def test_config5_batched_beam_equals_per_sample_24_layers():
         if torch.equal(toks[i, b, :n], t1[0, b1, :n]) and int(lens[i, b]) == n:
             same += 1
             assert abs(float(scores[i, b]) - float(s1[0, b1])) <= 2e-2
+        else:
+            misses.append((i, toks[i, b, : int(lens[i, b])].clone(), t1[0, b1, :n].clone()))
     assert same >= len(checked) - 1, same
+    # A tolerated mismatch must be a near-tie, not a defect: both captions are re-scored with the SPLIT-bf16 model (the reference's
+    # precision, logits 3e-5 from fp32; tests/test_gpu_x3.py shows 64 / 64 there) — their length-normalised log-probabilities differ
+    # by less than the bf16 logit noise accumulated over the caption.
+    if misses:
+        lm.set_precision(32)
+        wte = lm.get_input_embeddings().weight.detach()
+        for i, ca, cb in misses:
+            sc = []
+            for cap in (ca, cb):
+                x = torch.cat((pref[i:i + 1], wte[cap.long()][None]), dim=1)
+                lp = torch.log_softmax(lm.engine.logits(x)[0, 9:9 + cap.numel()], -1)
+                sc.append(float(lp.gather(1, cap.long()[:, None]).sum()) / cap.numel())
+            print(f"sample {i}: batched vs alone captions differ; split-bf16 scores {sc[0]:.5f} vs {sc[1]:.5f} (margin {abs(sc[0] - sc[1]):.2e})")
+            assert abs(sc[0] - sc[1]) <= 3e-2, (i, sc)
+        lm.set_precision("bf16")
 
 
 def test_beam_medium_width_tokens_vs_reference_and_oracle():
