@@ -126,6 +126,9 @@ __device__ __forceinline__ void l_store(const StageRegs& s, char* lds, int tid) 
 // per 16-row strip.
 // epilogue functors that reduce along a row (lm_head softmax partials) take the wave's whole 64-column strip: Epi::strip()
 template <class E> struct epi_row_strip { static constexpr bool value = false; };
+// functors whose additive input can initialise the accumulators (Epi::init_from_input() / init4(row, col, acc4)): see gemm_stag256_body
+template <class E, class = void> struct epi_acc_init { static constexpr bool value = false; };
+template <class E> struct epi_acc_init<E, decltype((void)&E::init4)> { static constexpr bool value = true; };
 template <class E, class = void> struct epi_strip_aux { static constexpr bool value = false; };
 template <class E> struct epi_strip_aux<E, decltype((void)sizeof(typename E::StripAux))> { static constexpr bool value = true; };
 
@@ -923,6 +926,20 @@ __device__ __forceinline__ void gemm_stag256_body(const op16_t* __restrict__ A, 
     for (int i = 0; i < NI; i++)
 #pragma unroll
         for (int j = 0; j < NJ; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Functors with an additive fp32 input (the residual stream) can start the accumulators FROM it: the 39 MB of residual reads of a
+    // 12800 x 768 launch then travel while the first operand tiles are in flight, instead of joining the store burst at the end of a
+    // single-round launch.  Issued before the first DMA so that every later counted vmcnt wait implies these loads have landed.
+    // (256 x 192 form only: the 256-wide forms have no registers to spare for the address arithmetic — 276 / 564 B of scratch measured)
+    constexpr bool kAccInit = epi_acc_init<Epi>::value && NJ == 3 && NI == 8;
+    if constexpr (kAccInit) {
+        if (zslice == 0 && epi.init_from_input()) {
+            const int q_ = lane >> 4, rl_ = lane & 15;
+#pragma unroll
+            for (int i = 0; i < NI; i++)
+#pragma unroll
+                for (int j = 0; j < NJ; j++) epi.init4(m0 + arow + i * 16 + rl_, n0 + bcol + j * 16 + q_ * 4, acc[i][j]);
+        }
+    }
     op16x8 af[NI], bfr[NJ];
     HTTFrag taf[TT ? NI : 1], tbf[TT ? NJ : 1];
     (void)taf; (void)tbf;
@@ -1000,7 +1017,13 @@ __device__ __forceinline__ void gemm_stag256_body(const op16_t* __restrict__ A, 
         H_MFMA(); H_SEGEND();
     }
     H_STAMP(0)
-    gemm_epilogue_regs<Epi, NI, NJ>(acc, lane, m0 + arow, n0 + bcol, epi);
+    if constexpr (epi_acc_init<Epi>::value && !kAccInit) {      // forms that did not start from the input: the epilogue adds it as before
+        Epi e2 = epi;
+        e2.acc_init = false;
+        gemm_epilogue_regs<Epi, NI, NJ>(acc, lane, m0 + arow, n0 + bcol, e2);
+    } else {
+        gemm_epilogue_regs<Epi, NI, NJ>(acc, lane, m0 + arow, n0 + bcol, epi);
+    }
     H_STAMP(7)                                         // epilogue
     H_STAMP_OUT
 }
@@ -1210,9 +1233,17 @@ struct EpiResid {
         *reinterpret_cast<float4*>(out + o) = make_float4(r0.x + y[0], r0.y + y[1], r0.z + y[2], r0.w + y[3]);
         *reinterpret_cast<float4*>(out + o + 4) = make_float4(r1.x + y[4], r1.y + y[5], r1.z + y[6], r1.w + y[7]);
     }
+    // 256-row kernels, no dropout: the accumulators START from the residual (gemm_stag256_body), pre4 then has nothing to add
+    bool acc_init = false;
+    __device__ __forceinline__ bool init_from_input() const { return acc_init; }
+    __device__ __forceinline__ void init4(int row, int col, f32x4& a) const {
+        if (row >= M || col >= Ns) return;
+        const float4 r = *reinterpret_cast<const float4*>(res + (size_t)row * ld + col);
+        a[0] = r.x; a[1] = r.y; a[2] = r.z; a[3] = r.w;
+    }
     static constexpr bool kPre = true;
     __device__ __forceinline__ void pre4(int row, int col, f32x4& a) const {        // acc += residual (with dropout: bias and mask too)
-        if (row >= M || col >= Ns) return;
+        if (acc_init || row >= M || col >= Ns) return;
         const size_t o = (size_t)row * ld + col;
         const float4 r = *reinterpret_cast<const float4*>(res + o);
         if (drop.thresh) {

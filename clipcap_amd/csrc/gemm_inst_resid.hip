@@ -8,6 +8,10 @@ int gemm_resid(int al, int bl, const act_t* A, int lda, const op16_t* B, int ldb
     const op16_t* A16;
     CC_X3_NT(A, lda, ldb, M, K, A16, al, bl, st);
     EpiResid e{out, res, bias, ld, M, N, drop};
+    // accumulators initialised from the residual (256-row kernels only read the flag): not with residual dropout, whose mask scales
+    // acc + bias but not the residual; CC_RESID_INIT=0 is the A/B switch
+    static const bool init_ok = []() { const char* v = getenv("CC_RESID_INIT"); return !v || atoi(v) != 0; }();
+    e.acc_init = init_ok && !drop.thresh;
     return launch_gemm(al, bl, A16, lda, B, ldb, M, N, K, 1, e, st);
 }
 }  // namespace CC_NS
