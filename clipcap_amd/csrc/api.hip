@@ -531,6 +531,11 @@ int CC_API(cc_mapper_bwd_range)(const cc_mapper_cfg* c, int32_t B, const float* 
 namespace {
 // Exponential form of the lm_head outputs (gemm.hip.h EpiLMHead): the bf16 build's training path stores exp(logit - target logit) and
 // never materialises the softmax gradient.  fp16 lacks the exponent range, the bf16x3 build keeps fp32 logits.  CC_LM_EXPFORM=0: A/B switch.
+// c_fc forward stores gelu_new'(u) where it used to store u (CC_GELU_GRAD_FWD=0: A/B switch; forward and backward read the same setting)
+static bool gelu_grad_fwd() {
+    static const bool on = []() { const char* e = getenv("CC_GELU_GRAD_FWD"); return !e || atoi(e) != 0; }();
+    return on;
+}
 static bool lm_exp_form() {
     static const bool on = (CC_OP == 0) && []() { const char* e = getenv("CC_LM_EXPFORM"); return !e || atoi(e) != 0; }();
     return on;
@@ -689,7 +694,8 @@ int CC_API(cc_gpt2_fwd)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const floa
         {
             static const int tile_fc = env_tile("CC_TILE_FC");
             TileScope ts(tile_fc);
-            CC_TIMED(CC_SITE_GPT2_FC_FWD, st, gemm_bf16out(0, 0, w.xn2[l], D, W16(w16t, y.fw), D, M, 4 * D, D, w.hact[l], 4 * D, w32 + y.fb, 2,
+            // act 3: the pre-activation slot receives gelu_new'(u) — one sigmoid serves both, and the backward's epilogue is a multiply
+            CC_TIMED(CC_SITE_GPT2_FC_FWD, st, gemm_bf16out(0, 0, w.xn2[l], D, W16(w16t, y.fw), D, M, 4 * D, D, w.hact[l], 4 * D, w32 + y.fb, (s->mode >= 1 && gelu_grad_fwd()) ? 3 : 2,
                                                             s->mode >= 1 ? w.u[l] : nullptr, st));
         }
         {
@@ -847,7 +853,7 @@ int CC_API(cc_gpt2_bwd_range)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, cons
         {
             static const int tile_dact = env_tile("CC_TILE_DACT");
             TileScope ts(tile_dact);
-            CC_TRY(gemm_dact(0, 0, w.dx16, D, W16(w16, y.p2w), D, M, D4, D, w.du16, D4, w.u[l], 2, st));
+            CC_TRY(gemm_dact(0, 0, w.dx16, D, W16(w16, y.p2w), D, M, D4, D, w.du16, D4, w.u[l], gelu_grad_fwd() ? 3 : 2, st));
         }
         // mlp.c_fc (Conv1D [D, 4D])
         if (full) {

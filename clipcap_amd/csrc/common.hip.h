@@ -146,6 +146,15 @@ __device__ __forceinline__ float gelu_sigmoid(float x, float x2) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * p));
 }
 __device__ __forceinline__ float gelu_new_f(float x) { return x * gelu_sigmoid(x, x * x); }
+// gelu_new and its derivative from ONE sigmoid evaluation (the forward epilogue that also stores the derivative for the backward pass)
+__device__ __forceinline__ void gelu_new_both(float x, float& g, float& dg) {
+    constexpr float K0 = 0.7978845608028654f, K1 = 0.044715f;
+    const float x2 = x * x;
+    const float s = gelu_sigmoid(x, x2);
+    const float q = __builtin_fmaf(x2, 6.0f * K0 * K1, 2.0f * K0);
+    g = x * s;
+    dg = __builtin_fmaf(x * q, __builtin_fmaf(-s, s, s), s);
+}
 __device__ __forceinline__ float gelu_new_grad(float x) {
     constexpr float K0 = 0.7978845608028654f, K1 = 0.044715f;
     const float x2 = x * x;

@@ -1163,7 +1163,7 @@ struct EpiBF16 {
     act_t* pre;         // nullable
     const float* bias;  // nullable
     int ldc, M, Ns;     // Ns: columns to store (multiple of 8)
-    int act;            // 0 none, 1 relu, 2 gelu_new
+    int act;            // 0 none, 1 relu, 2 gelu_new, 3 gelu_new with `pre` receiving gelu_new'(u) instead of u (the backward's multiplier)
     __device__ __forceinline__ void operator()(int row, int col, float (&v)[8]) const {
         if (row >= M || col >= Ns) return;
         if (bias) {
@@ -1171,13 +1171,20 @@ struct EpiBF16 {
             const float4 b1 = *reinterpret_cast<const float4*>(bias + col + 4);
             v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
         }
-        if (pre) act_st8(pre + (size_t)row * ldc + col, v);
-        if (act == 1) {
+        if (act == 3) {
+            float dg[8];
 #pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
-        } else if (act == 2) {
+            for (int e = 0; e < 8; e++) gelu_new_both(v[e], v[e], dg[e]);
+            if (pre) act_st8(pre + (size_t)row * ldc + col, dg);
+        } else {
+            if (pre) act_st8(pre + (size_t)row * ldc + col, v);
+            if (act == 1) {
 #pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = gelu_new_f(v[e]);
+                for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
+            } else if (act == 2) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] = gelu_new_f(v[e]);
+            }
         }
         act_st8(C + (size_t)row * ldc + col, v);
     }
@@ -1192,13 +1199,20 @@ struct EpiBF16 {
         if (row >= M || col >= Ns) return;
 #pragma unroll
         for (int e = 0; e < 8; e++) v[e] += b[e];
-        if (pre) act_st8(pre + (size_t)row * ldc + col, v);
-        if (act == 1) {
+        if (act == 3) {
+            float dg[8];
 #pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
-        } else if (act == 2) {
+            for (int e = 0; e < 8; e++) gelu_new_both(v[e], v[e], dg[e]);
+            if (pre) act_st8(pre + (size_t)row * ldc + col, dg);
+        } else {
+            if (pre) act_st8(pre + (size_t)row * ldc + col, v);
+            if (act == 1) {
 #pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = gelu_new_f(v[e]);
+                for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
+            } else if (act == 2) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] = gelu_new_f(v[e]);
+            }
         }
         act_st8(C + (size_t)row * ldc + col, v);
     }
@@ -1326,7 +1340,7 @@ struct EpiDAct {
     act_t* C;
     const act_t* aux;
     int ldc, M, Ns;
-    int act;  // 1 relu, 2 gelu_new
+    int act;  // 1 relu (aux = post-activation), 2 gelu_new (aux = pre-activation u), 3 multiply by aux (= gelu_new'(u) stored by the forward)
     __device__ __forceinline__ void operator()(int row, int col, float (&v)[8]) const {
         if (row >= M || col >= Ns) return;
         const size_t o = (size_t)row * ldc + col;
@@ -1335,6 +1349,9 @@ struct EpiDAct {
         if (act == 1) {
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] = a[e] > 0.f ? v[e] : 0.f;
+        } else if (act == 3) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] *= a[e];
         } else {
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] *= gelu_new_grad(a[e]);
@@ -1352,6 +1369,9 @@ struct EpiDAct {
         if (act == 1) {
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] = a[e] > 0.f ? v[e] : 0.f;
+        } else if (act == 3) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] *= a[e];
         } else {
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] *= gelu_new_grad(a[e]);
@@ -1364,7 +1384,7 @@ struct EpiDAct {
         float x[4];
         act_unpack4(act_ldraw4(aux + (size_t)row * ldc + col), x[0], x[1], x[2], x[3]);
 #pragma unroll
-        for (int e = 0; e < 4; e++) a[e] = act == 1 ? (x[e] > 0.f ? a[e] : 0.f) : a[e] * gelu_new_grad(x[e]);
+        for (int e = 0; e < 4; e++) a[e] = act == 1 ? (x[e] > 0.f ? a[e] : 0.f) : (act == 3 ? a[e] * x[e] : a[e] * gelu_new_grad(x[e]));
     }
     __device__ __forceinline__ void bias8(int, float (&b)[8]) const {
 #pragma unroll
@@ -1648,6 +1668,7 @@ inline int launch_gemm(int al, int bl, const op16_t* A, int lda, const op16_t* B
         constexpr bool can192 = !epi_row_strip<Epi>::value;   // the lm_head partials assume 64-column wave strips
         // the activation-gradient epilogue (aux tile read + gelu' + store) is not hidden at one block per CU: 12800 x 3072 x 768 measured
         // 106.6 us on 320 x 256 vs 97.3 on 128 x 128 (two co-resident blocks), while the plain / gelu-forward epilogues gain (90 -> 78 us)
+        // (also with the forward-stored derivative, act 3 — a single multiply —, the 128 x 128 kernel stays ahead: 12.31 vs 12.44 ms per step)
         constexpr bool can320 = !std::is_same<Epi, EpiDAct>::value;
         if (s256 == 5 || (can320 && s256 < 0 && c320 < 0.98 * c128 && c320 < c256 && (!can192 || c320 < c192))) { nj = 4; ni = 10; }
         else if (s256 == 4 || (s256 < 0 && c256 < 0.98 * c128 && (!can192 || c256 <= c192))) nj = 4;
