@@ -41,9 +41,9 @@ CONFIGS = {
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
 # Offline PMC measurements quoted in the JSON line (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 gfx950
 # correction; see the profile files).  They describe the build the profile was taken from; bench.py itself does not read counters.
-LMHEAD_TRAFFIC = {"bytes": (2 * 555411 + 1097446) * 1024, "source": "profiles/r02_k_pmc_fetch_write_train.md (offline PMC, this round's build)"}
-GEMM_TRAFFIC = {"bytes": int((2 * 9740151.8 + 7588918.7) * 1024), "source": "profiles/r02_k_pmc_fetch_write_train.md (offline PMC: sum over the gemm_* kernels of one step)"}
-DECODE_TRAFFIC = {"bytes": 3.31e9, "source": "profiles/r02_h_pmc_fetch_write_decode.md (offline PMC, this round's build)"}
+LMHEAD_TRAFFIC = {"bytes": 2263744409, "source": "profiles/r03_d_pmc_fetch_write_train.md (offline PMC, this round's build)"}
+GEMM_TRAFFIC = {"bytes": 27732100403, "source": "profiles/r03_d_pmc_fetch_write_train.md (offline PMC: sum over the gemm_* kernels of one step)"}
+DECODE_TRAFFIC = {"bytes": 3.11e+09, "source": "profiles/r03_e_pmc_fetch_write_decode.md (offline PMC, this round's build)"}
 
 
 def mapper_flops_fwd(c):   # 2*E*P*D + N*[S*2*D*(D+2D+D+rD+rD) + 4*S^2*D], r=2
@@ -473,7 +473,7 @@ def main():
         ach = site_flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         default_site = args.site == "lmhead_fwd" and args.config == "2" and not args.batch
         roof["roofline_lmhead" if args.site == "lmhead_fwd" else "roofline_site"] = {
-            "bound": "mfma", "kernel": ("gemm_nt_stag256_kernel<EpiLMHead,4,false,10> (320x256 tiles)" if args.site == "lmhead_fwd" else "NT GEMM") + f" @ {args.site}",
+            "bound": "mfma", "kernel": ("gemm_nt_stag256_kernel<EpiLMHeadExp,4,false,10> (320x256 tiles, exponential-form epilogue)" if args.site == "lmhead_fwd" else "NT GEMM") + f" @ {args.site}",
             "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
             "avg_launch_ms": round(avg_ms, 4), "launches": len(ms), "time_share_of_step": round(avg_ms * per_step / ms_per_step, 3),
             "traffic": LMHEAD_TRAFFIC["bytes"] if default_site else None, "traffic_source": LMHEAD_TRAFFIC["source"] if default_site else None,

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the per-round rocprofv3 evidence on a GPU box (run through gpurun from the repo root):
-#   tools/profile_round.sh r02     -> gpurun_out/<tag>_{train,mapper,decode}.md (kernel-trace stats) and <tag>_pmc_{fetch,write}.txt
+#   tools/profile_round.sh r03     -> gpurun_out/<tag>_{train,mapper,decode,x3_train}.md (kernel-trace stats), <tag>_pmc_{FETCH,WRITE}_SIZE.txt and <tag>_decode_pmc_*.txt
 # Counters are collected in their own passes (one TCC counter per pass; never combined with other trace domains).
 set -u
 TAG=${1:-rXX}
@@ -25,4 +25,13 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
     python $ROOT/tools/rocpd_pmc.py $(find $OUT/prof_pmc -name "*.db" | head -1) > $OUT/${TAG}_pmc_$ctr.txt
     rm -rf $OUT/prof_pmc
 done
+# decode: the same two counter passes on the beam-5 decode (per generated position = totals / (2 decodes x 67 positions))
+for ctr in FETCH_SIZE WRITE_SIZE; do
+    rm -rf $OUT/prof_pmc
+    rocprofv3 --kernel-trace --pmc $ctr --output-format rocpd -d $OUT/prof_pmc -- python $ROOT/bench.py --mode decode --steps 1 --warmup 1 > /dev/null 2>&1
+    python $ROOT/tools/rocpd_pmc.py $(find $OUT/prof_pmc -name "*.db" | head -1) > $OUT/${TAG}_decode_pmc_$ctr.txt
+    rm -rf $OUT/prof_pmc
+done
+# the training step in the split-bf16 (fp32 parity) mode
+run_trace x3_train python $ROOT/bench.py --precision 32 --steps 6 --warmup 2 --no-cpu-baseline --no-sub-benches --no-roofline-pass
 cd $ROOT
