@@ -216,3 +216,43 @@ def test_x3_windowed_mapper_at_real_sequence_length():
     assert e_32 <= 1e-4 * scale and worst[1] <= 5e-3
     atts = eng.attention_probs(B)
     assert atts[0].shape == (B, 180, 180, H) and float((atts[0].sum(dim=2) - 1).abs().max()) <= 1e-5
+
+
+def test_x3_module_autograd_paths_vs_reference_gradients():
+    """The reference-style autograd surface in this mode: ``lm(inputs_embeds=x).logits`` -> backward (cc_gpt2_logits_bwd) and
+    ``TransformerMapper(x)`` -> backward (cc_mapper_bwd) against the reference's own gradients (tests/golden/gpt2_tiny, mapper_tiny),
+    at fp32-level tolerances."""
+    from clipcap_amd.model.gpt2 import GPT2LM
+    from clipcap_amd.model.mapper import TransformerMapper
+    from tests.util import sd_of
+    g = load_golden("gpt2_tiny")
+    D, n_layer, n_head, V, npos = [int(v) for v in g["cfg"]]
+    lm = GPT2LM(n_embd=D, n_layer=n_layer, n_head=n_head, vocab_size=V, n_positions=npos, precision=32)
+    lm.load_state_dict(sd_of(g), strict=False)
+    lm = lm.to("cuda")
+    x = torch.from_numpy(g["in.x"]).cuda().requires_grad_(True)
+    logits = lm(inputs_embeds=x).logits
+    assert (logits.detach().cpu() - torch.from_numpy(g["logits"])).abs().max().item() <= 1e-4
+    logits.square().mean().backward()
+    ref = torch.from_numpy(g["grad.in.x"])
+    worst = float((x.grad.cpu() - ref).norm() / ref.norm())
+    for k, p in lm.named_parameters():
+        if "grad." + k in g and "lm_head" not in k:
+            r = torch.from_numpy(g["grad." + k])
+            worst = max(worst, float((p.grad.cpu() - r).norm() / r.norm().clamp_min(1e-12)))
+    gm = load_golden("mapper_tiny")
+    E, Dm, P, L, H, N, B = [int(v) for v in gm["dims"]]
+    m = TransformerMapper(E, Dm, L, P, H, N, precision=32)
+    m.load_state_dict(sd_of(gm))
+    m = m.to("cuda")
+    xin = torch.from_numpy(gm["in.x"]).cuda()
+    out = m(xin)
+    assert (out.detach().cpu() - torch.from_numpy(gm["out"])).abs().max().item() <= 1e-4
+    out.square().mean().backward()
+    wm = 0.0
+    for k, p in m.named_parameters():
+        if "grad." + k in gm:
+            r = torch.from_numpy(gm["grad." + k])
+            wm = max(wm, float((p.grad.cpu() - r).norm() / r.norm().clamp_min(1e-12)))
+    print(f"split-bf16 autograd paths: GPT-2 worst relative gradient error {worst:.2e}, mapper {wm:.2e}")
+    assert worst <= 2e-3 and wm <= 2e-3
