@@ -131,6 +131,18 @@ __device__ __forceinline__ void act_unpack4(const act_raw4& r, float& a, float& 
 __device__ __forceinline__ act_raw4 act_pack4(float a, float b, float c, float d) { return act_raw4{make_uint2(pack2op(a, b), pack2op(c, d))}; }
 __device__ __forceinline__ void act_straw4(act_t* p, const act_raw4& r) { *reinterpret_cast<uint2*>(p) = r.a; }
 #endif
+// non-temporal form for tensors that are written now and read much later (the forward's saved-for-backward copies): they should not
+// displace what the next kernels re-read from the 256 MB Infinity Cache
+__device__ __forceinline__ void act_st8_nt(act_t* p, const float (&f)[8]) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_hw;
+    const act_raw8 r = act_pack8(f);
+#if CC_OP == 2
+    __builtin_nontemporal_store(__builtin_bit_cast(u32x4_hw, r.a), reinterpret_cast<u32x4_hw*>(p));
+    __builtin_nontemporal_store(__builtin_bit_cast(u32x4_hw, r.b), reinterpret_cast<u32x4_hw*>(p + 4));
+#else
+    __builtin_nontemporal_store(__builtin_bit_cast(u32x4_hw, r.a), reinterpret_cast<u32x4_hw*>(p));
+#endif
+}
 __device__ __forceinline__ void act_ld8(const act_t* p, float (&f)[8]) { act_unpack8(act_ldraw8(p), f); }
 __device__ __forceinline__ void act_st8(act_t* p, const float (&f)[8]) { act_straw8(p, act_pack8(f)); }
 __device__ __forceinline__ void act_st4(act_t* p, float a, float b, float c, float d) { act_straw4(p, act_pack4(a, b, c, d)); }

@@ -1164,6 +1164,7 @@ struct EpiBF16 {
     const float* bias;  // nullable
     int ldc, M, Ns;     // Ns: columns to store (multiple of 8)
     int act;            // 0 none, 1 relu, 2 gelu_new, 3 gelu_new with `pre` receiving gelu_new'(u) instead of u (the backward's multiplier)
+    bool pre_nt = false; // act 3: `pre` is read only by the backward pass -> non-temporal stores
     __device__ __forceinline__ void operator()(int row, int col, float (&v)[8]) const {
         if (row >= M || col >= Ns) return;
         if (bias) {
@@ -1175,7 +1176,7 @@ struct EpiBF16 {
             float dg[8];
 #pragma unroll
             for (int e = 0; e < 8; e++) gelu_new_both(v[e], v[e], dg[e]);
-            if (pre) act_st8(pre + (size_t)row * ldc + col, dg);
+            if (pre) { if (pre_nt) act_st8_nt(pre + (size_t)row * ldc + col, dg); else act_st8(pre + (size_t)row * ldc + col, dg); }
         } else {
             if (pre) act_st8(pre + (size_t)row * ldc + col, v);
             if (act == 1) {
@@ -1203,7 +1204,7 @@ struct EpiBF16 {
             float dg[8];
 #pragma unroll
             for (int e = 0; e < 8; e++) gelu_new_both(v[e], v[e], dg[e]);
-            if (pre) act_st8(pre + (size_t)row * ldc + col, dg);
+            if (pre) { if (pre_nt) act_st8_nt(pre + (size_t)row * ldc + col, dg); else act_st8(pre + (size_t)row * ldc + col, dg); }
         } else {
             if (pre) act_st8(pre + (size_t)row * ldc + col, v);
             if (act == 1) {
