@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _build(E, D, P, L, H, N, n_head, n_layer, V, npos, seed=0, prec=None):
-    """prec None = bf16 operands, 16 = fp16 operands (the gradients in the arena then carry the engine's loss scale)."""
+    """prec None = bf16 operands, 16 = fp16 operands (the gradients in the arena then carry the engine's loss scale), 32 = split-bf16
+    operands (the reference's default precision: checked against the fp32 oracle at 50x tighter tolerances)."""
     from clipcap_amd.engine import ClipCapEngine, Gpt2Engine, MapperEngine
     torch.manual_seed(seed)
     me = MapperEngine(E, D, L, P, H, N, device="cuda", precision=prec)
@@ -42,17 +43,20 @@ def _check(eng, sd, cfg, tokens, embeds, tol=2e-3):
         assert torch.count_nonzero(eng.mapper.arena.g32) == 0
         return
     fp16 = eng.scaler is not None
-    ref = O.clipcap_loss(sdr, tokens, embeds, cfg=cfg, rb="fp16" if fp16 else True)
+    x3 = eng.mapper.op_dtype == 2
+    ref = O.clipcap_loss(sdr, tokens, embeds, cfg=cfg, rb=False if x3 else ("fp16" if fp16 else True))
     ref.backward()
+    if x3:
+        tol = min(tol, 5e-5)
     assert abs(float(loss) - float(ref)) <= tol, (float(loss), float(ref))
     unscale = 1.0 / float(eng.scaler.scale) if fp16 else 1.0
     gv = eng.mapper.views(eng.mapper.arena.g32)
     for k, v in gv.items():
         r = sdr["transformer_mapper." + k].grad
-        assert ((v.cpu() * unscale - r).norm() / r.norm().clamp_min(1e-12)).item() <= 6e-2, k
+        assert ((v.cpu() * unscale - r).norm() / r.norm().clamp_min(1e-12)).item() <= (2e-3 if x3 else 6e-2), k
 
 
-@pytest.mark.parametrize("prec", [None, 16])
+@pytest.mark.parametrize("prec", [None, 16, 32])
 @pytest.mark.parametrize("B,cap,P,L", [(1, 1, 1, 1), (1, 5, 2, 3), (3, 2, 4, 1), (2, 9, 1, 6)])
 def test_smallest_shapes(B, cap, P, L, prec):
     eng, sd, cfg = _build(16, 64, P, L, 4, 1, 4, 1, 97, 32, prec=prec)
@@ -60,7 +64,7 @@ def test_smallest_shapes(B, cap, P, L, prec):
     _check(eng, sd, cfg, torch.randint(1, 97, (B, cap)), torch.randn(B, 16))
 
 
-@pytest.mark.parametrize("prec", [None, 16])
+@pytest.mark.parametrize("prec", [None, 16, 32])
 def test_ragged_pads_zero_ids_and_fully_padded_rows(prec):
     eng, sd, cfg = _build(24, 64, 2, 3, 4, 2, 4, 2, 157, 40, prec=prec)
     torch.manual_seed(4)

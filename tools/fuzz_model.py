@@ -27,12 +27,12 @@ def one_step(rng):
     E_ = 8 * rng.randint(1, 12)
     V = rng.randint(50, 1500)
     B, cap = rng.randint(1, 7), rng.randint(1, 14)
-    prec = rng.choice([None, 16])
+    prec = rng.choice([None, 16, 32])
     mode = rng.choice([-1, -1, 0, 3, 4, 5])
     if "FUZZ_TILE" in os.environ:
         mode = int(os.environ["FUZZ_TILE"])
     if "FUZZ_PREC" in os.environ:
-        prec = None if os.environ["FUZZ_PREC"] == "bf16" else 16
+        prec = {"bf16": None, "16": 16, "32": 32}[os.environ["FUZZ_PREC"]]
     args = dict(E=E_, D=D, P=P, L=L, H=H, N=N, n_head=n_head, n_layer=n_layer, V=V, B=B, cap=cap, prec=prec, tile=mode)
     LAST.update(args=args)
     eng, sd, cfg = E._build(E_, D, P, L, H, N, n_head, n_layer, V, L + cap + 2, seed=rng.randint(0, 999), prec=prec)
@@ -74,7 +74,8 @@ def classify(eng, sd, cfg, tokens, embeds):
     unscale = 1.0 / float(eng.scaler.scale) if fp16 else 1.0
     got = {k: v.cpu().double() * unscale for k, v in eng.mapper.views(eng.mapper.arena.g32).items()}
     res = {}
-    for name, rb in (("rb", "fp16" if fp16 else True), ("exact", False)):
+    x3 = eng.mapper.op_dtype == 2
+    for name, rb in (("rb", "bf16x3" if x3 else ("fp16" if fp16 else True)), ("exact", False)):
         sdr = {k: v.double().clone().requires_grad_(k.startswith("transformer_mapper.")) for k, v in sd.items()}
         l = O.clipcap_loss(sdr, tokens, embeds.double(), cfg=cfg, rb=rb)
         l.backward()
@@ -143,7 +144,17 @@ def one_full(rng):
     sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     ref = O.clipcap_loss(sdr, tokens, embeds, cfg=cfg, rb=True, drop=drop)
     ref.backward()
-    assert abs(loss - float(ref.detach())) <= max(4e-3, 1e-3 * abs(float(ref.detach()))), (loss, float(ref.detach()))
+    if abs(loss - float(ref.detach())) > max(4e-3, 1e-3 * abs(float(ref.detach()))):
+        # a mean over a handful of targets: the same yardstick as for the gradients — the like-for-like oracle's own distance from exact arithmetic
+        with torch.no_grad():
+            le = float(O.clipcap_loss({kk: vv.double() for kk, vv in sd.items()}, tokens, embeds.double(), cfg=cfg, rb=False,
+                                      drop=None if drop is None else {dk: ([m.double() for m in dv] if isinstance(dv, list) else (dv.double() if torch.is_tensor(dv) else dv))
+                                                                      for dk, dv in drop.items()}))
+        if VERBOSE:
+            print(f"  loss: kernel {loss:.6f} oracle {float(ref.detach()):.6f} exact {le:.6f}")
+        assert abs(loss - float(ref.detach())) <= 3.0 * abs(float(ref.detach()) - le) + 1e-3, (loss, float(ref.detach()), le, args)
+        NOISE.append(f"loss {loss:.4f} vs {float(ref.detach()):.4f} (exact {le:.4f})")
+    exact = None
     for pre, e in (("transformer_mapper.", eng.mapper), ("language_model.", eng.gpt2)):
         for k, v in e.views(e.arena.g32).items():
             r = sdr[pre + k].grad
@@ -152,7 +163,21 @@ def one_full(rng):
             err = ((v.cpu() - r).norm() / r.norm().clamp_min(1e-12)).item()
             relu = (".mlp.fc1." in k or ".norm2." in k) and pre.startswith("transformer_mapper")      # ReLU-mask flips, see classify(); one flip weighs more the fewer rows there are
             lim = (0.4 if B * (P + L) <= 8 else 0.25) if relu else 8e-2
-            assert err <= lim, (pre + k, err)
+            if err > lim:
+                # outside the fixed tolerance: is the kernel further from the like-for-like oracle than that oracle is from exact (fp64,
+                # unrounded) arithmetic?  Gradients that are differences of nearly equal terms (attention queries / keys over two or
+                # three positions, LayerNorm weights at a handful of rows) move by tens of per cent under the 16-bit rounding points alone.
+                if exact is None:
+                    sde = {kk: vv.double().clone().requires_grad_(True) for kk, vv in sd.items()}
+                    O.clipcap_loss(sde, tokens, embeds.double(), cfg=cfg, rb=False,
+                                   drop=None if drop is None else {dk: ([m.double() for m in dv] if isinstance(dv, list) else (dv.double() if torch.is_tensor(dv) else dv))
+                                                                   for dk, dv in drop.items()}).backward()
+                    exact = {kk: vv.grad for kk, vv in sde.items() if vv.grad is not None}
+                eo = ((r.double() - exact[pre + k]).norm() / exact[pre + k].norm().clamp_min(1e-30)).item()
+                if VERBOSE:
+                    print(f"  {pre + k}: kernel-oracle {err:.2e}, oracle-exact {eo:.2e}")
+                assert err <= 3.0 * eo, (pre + k, err, eo)
+                NOISE.append(f"{k}: {err:.2e} vs oracle-exact {eo:.2e}")
     return args
 
 
