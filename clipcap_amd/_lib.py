@@ -92,6 +92,7 @@ SIGNATURES = {
     "cc_decode_fwd": (_I, [_GC, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     "cc_decode_part_floats": (_L, [_GC, _I]),
     "cc_decode_fwd_p": (_I, [_GC, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P]),
+    "cc_decode_fwd_g": (_I, [_GC, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _L, _P, _P]),
     "cc_beam_step_p": (_I, [_I, _I, _I, _P, _L, _P, _I, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "cc_decode_reorder": (_I, [_GC, _I, _I, _I, _I, _P, _P, _P, _P]),
     "cc_beam_step": (_I, [_I, _I, _I, _P, _L, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
@@ -122,6 +123,8 @@ SIGNATURES = {
     "cc_prof_stop": (_I, [C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(_I)]),
 }
 
+ABI_VERSION = 3       # CC_ABI_VERSION of include/clipcap_hip.h this binding was written against
+
 SITES = {"lmhead_fwd": 1, "lmhead_dgrad": 2, "gpt2_fc_fwd": 3, "gpt2_proj2_fwd": 4, "gpt2_fc_dgrad": 5, "mapper_fc1_fwd": 6,
          "mapper_qkv_fwd": 7, "mapper_wgrad_fc2": 8, "all_gemms": 100}
 
@@ -148,8 +151,8 @@ def lib() -> C.CDLL:
                 fn = getattr(l, name)
                 fn.restype = res
                 fn.argtypes = args
-            if l.cc_abi_version() != 2:
-                raise HipExtensionMissing("libclipcap_hip.so ABI version mismatch; rebuild")
+            if l.cc_abi_version() != ABI_VERSION:
+                raise HipExtensionMissing(f"libclipcap_hip.so ABI version {l.cc_abi_version()} != {ABI_VERSION} (include/clipcap_hip.h); rebuild")
             _lib = l
     return _lib
 

@@ -201,6 +201,219 @@ __global__ __launch_bounds__(256) void k_decode_attn(const act_t* __restrict__ q
     }
 }
 
+// Beam-group form of the single-position attention step (Tn == 1, head dim 64 = every GPT-2 size).  The G beams of a caption share
+// their prefix rows and most of their ancestors (tools/decode_union_stats.py: 56 distinct rows against 217 read per group on the
+// configs[4] decode), so
+//   k_group_union   (once per position, one wave per group) builds the UNION of the (cache row, position) pairs the group's ancestry
+//                   tables name: ent = {cache row * ctx_max + position, bit b set when beam b's table names that row}; the G new keys
+//                   (one per beam) are the last G entries;
+//   k_decode_attn_group (per layer, one 4-wave block per (group, head)) loads every distinct K / V row ONCE and scores it against all G
+//                   queries; a beam's softmax runs over the entries whose bit it owns (the others hold -inf), i.e. exactly the keys
+//                   k_decode_attn reads for it.  A wave owns 32 entries per pass (128 per block: one pass for the usual union): K as
+//                   (key group, 16-B chunk) lanes like k_decode_attn, V one element per lane (a wave instruction = one 128-B row) with
+//                   scalar entry loads, and ALL of a pass's K and V loads are in flight together — the chain is list -> rows -> done.
+// Any row_map is handled exactly (rows that share nothing give G entries per position); sharing only decides how many rows are read.
+// LDS per block: p[cap][8] | wmx[4][8] | wsum[8][8] | red2[8][G][64].
+template <int G>
+__global__ __launch_bounds__(64) void k_group_union(const int* __restrict__ row_map, int2* __restrict__ ent_g, int* __restrict__ cnt_g, int pos0,
+                                                    int ctx_max, int cap, int append) {
+    const int lane = threadIdx.x, s = blockIdx.x, r0 = s * G;
+    int2* ent = ent_g + (size_t)s * cap;
+    int nU = 0;
+    for (int j0 = 0; j0 < pos0; j0 += 64) {
+        const int j = j0 + lane;
+        const bool valid = j < pos0;
+        int m[G];
+#pragma unroll
+        for (int b = 0; b < G; b++) m[b] = valid ? (row_map ? row_map[(size_t)(r0 + b) * ctx_max + j] : r0 + b) : -1 - b;
+        unsigned lead = 0, mk[G];
+#pragma unroll
+        for (int b = 0; b < G; b++) {
+            unsigned k = 0;
+            bool l = valid;
+#pragma unroll
+            for (int b2 = 0; b2 < G; b2++)
+                if (m[b2] == m[b]) { k |= 1u << b2; if (b2 < b) l = false; }
+            mk[b] = k;
+            if (l) lead |= 1u << b;
+        }
+        const int cnt = __popc(lead);
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        int idx = nU + incl - cnt;
+#pragma unroll
+        for (int b = 0; b < G; b++)
+            if ((lead >> b) & 1) { ent[idx] = make_int2(m[b] * ctx_max + j, (int)mk[b]); idx++; }
+        nU += __shfl(incl, 63);
+    }
+    // the new position: one private key per beam; append: still in qkv (the attention kernel is the one that stores it), marked -1 - b
+    if (lane < G) ent[nU + lane] = make_int2(append ? -1 - lane : (r0 + lane) * ctx_max + pos0, 1 << lane);
+    nU += G;
+    // pad to whole passes of 128 with entries nobody owns (mask 0 -> score -inf -> weight 0) that name a readable row
+    const int dummy = append ? -1 : r0 * ctx_max + pos0;
+    for (int u = nU + lane; u < ((nU + 127) & ~127); u += 64) ent[u] = make_int2(dummy, 0);
+    if (lane == 0) cnt_g[s] = nU;
+}
+
+// two consecutive stored elements as one load (k_decode_attn_group's V lanes: 32 lanes x 2 elements = one 64-wide head row)
+#if CC_OP == 2
+typedef float act_v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void act_v2f(const act_v2& v, float& a, float& b) { a = v.x; b = v.y; }
+#else
+typedef unsigned act_v2;
+__device__ __forceinline__ void act_v2f(const act_v2& v, float& a, float& b) { unpack2(v, a, b); }
+#endif
+typedef const __attribute__((address_space(1))) act_v2* g_v2p;
+
+template <int G>
+__global__ __launch_bounds__(256, kX3 ? 3 : 4) void k_decode_attn_group(const act_t* __restrict__ qkv, act_t* __restrict__ kc, act_t* __restrict__ vc,
+                                                           const int2* __restrict__ ent_g, const int* __restrict__ cnt_g, act_t* __restrict__ out,
+                                                           int H, int pos0, int ctx_max, float scale, int cap, int append) {
+    constexpr int HD = 64, KPW = 32;                       // head dim; entries per wave and pass
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    float* p = gsm;                                        // p[u * 8 + b], u < cap (a multiple of 128)
+    float* wmx = p + (size_t)cap * 8;                      // [4][8]
+    float* wsm = wmx + 32;                                 // [8][8]  (wave, half)
+    float* red2 = wsm + 64;                                // [8][G][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s = blockIdx.x / H, h = blockIdx.x - s * H, r0 = s * G;
+    const int D = H * HD;
+    const int2* __restrict__ ent = ent_g + (size_t)s * cap;
+    const act_t* kb = kc + h * HD;
+    const act_t* vb = vc + h * HD;
+    const act_t* qrow = qkv + (size_t)r0 * 3 * D + h * HD;          // row r0 + b: + b * 3D;  K: + D, V: + 2D
+    const int skg = lane >> 3, sdc = lane & 7;
+    // pass 0 always exists: its entries, then all of its K and V rows, are requested before anything is waited for
+    int2 ek[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) ek[i] = ent[w * KPW + i * 8 + skg];
+    int2 ev = ent[w * KPW + (lane & 31)];
+    const int nU = cnt_g[s];
+    if (append && tid < G * 16) {
+        const int b = tid >> 4, wq = tid & 15, which = wq >> 3, c = wq & 7;
+        const act_raw8 v = act_ldraw8(qrow + (size_t)b * 3 * D + (which + 1) * D + c * 8);
+        act_straw8((which ? vc : kc) + ((size_t)(r0 + b) * ctx_max + pos0) * D + h * HD + c * 8, v);
+    }
+    float qf[G][8], mx[G];
+#pragma unroll
+    for (int b = 0; b < G; b++) { act_ld8(qrow + (size_t)b * 3 * D + sdc * 8, qf[b]); mx[b] = -INFINITY; }
+    const int npass = (nU + 4 * KPW - 1) / (4 * KPW);
+    // V lanes: (half = lane >> 5, element pair = lane & 31): one load instruction fetches the rows of two entries (2 x 128 B)
+    const int hf = lane >> 5, dp = lane & 31;
+#define CC_GRP_VLOAD()                                                                                                                        \
+    {                                                                                                                                         \
+        const act_t* vrow = ev.x < 0 ? qrow + (size_t)(-1 - ev.x) * 3 * D + 2 * D : vb + (size_t)ev.x * D;                                    \
+        const unsigned long long va = reinterpret_cast<unsigned long long>(vrow);                                                             \
+        const int valo = (int)(unsigned)va, vahi = (int)(unsigned)(va >> 32);                                                                 \
+        _Pragma("unroll") for (int k = 0; k < KPW / 2; k++) {                                                                                 \
+            const unsigned lo0 = __builtin_amdgcn_readlane(valo, 2 * k), hi0 = __builtin_amdgcn_readlane(vahi, 2 * k);                        \
+            const unsigned lo1 = __builtin_amdgcn_readlane(valo, 2 * k + 1), hi1 = __builtin_amdgcn_readlane(vahi, 2 * k + 1);                \
+            const unsigned long long a = ((unsigned long long)(hf ? hi1 : hi0) << 32) | (hf ? lo1 : lo0);                                     \
+            vreg[k] = reinterpret_cast<g_v2p>(a)[dp];                                                                                         \
+        }                                                                                                                                     \
+    }
+#define CC_GRP_PV()                                                                                                                           \
+    _Pragma("unroll") for (int k = 0; k < KPW / 2; k++) {                                                                                     \
+        float v0, v1;                                                                                                                         \
+        act_v2f(vreg[k], v0, v1);                                                                                                             \
+        const float* pu = p + (size_t)(ub + 2 * k + hf) * 8;                                                                                  \
+        const float4 pa = *reinterpret_cast<const float4*>(pu), pb = *reinterpret_cast<const float4*>(pu + 4);                                \
+        const float pj[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};                                                                 \
+        _Pragma("unroll") for (int b = 0; b < G; b++) { acc[b][0] += pj[b] * v0; acc[b][1] += pj[b] * v1; lsum[b] += pj[b]; }                 \
+    }
+    act_v2 vreg[KPW / 2];                                  // pass 0's V rows
+    for (int pass = 0; pass < npass; pass++) {
+        const int ub = pass * 4 * KPW + w * KPW;           // wave-uniform
+        if (pass > 0) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) ek[i] = ent[ub + i * 8 + skg];
+        }
+        act_raw8 kv[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const act_t* krow = ek[i].x < 0 ? qrow + (size_t)(-1 - ek[i].x) * 3 * D + D : kb + (size_t)ek[i].x * D;
+            kv[i] = act_ldraw8(krow + sdc * 8);
+        }
+        if (pass == 0) CC_GRP_VLOAD()
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float kf[8], sc[8];
+            act_unpack8(kv[i], kf);
+#pragma unroll
+            for (int b = 0; b < G; b++) {
+                float a = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; e++) a += qf[b][e] * kf[e];
+                sc[b] = a;
+            }
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+#pragma unroll
+                for (int b = 0; b < G; b++) sc[b] += __shfl_xor(sc[b], o);
+            }
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                sc[b] = (b < G && ((ek[i].y >> b) & 1)) ? sc[b] * scale : -INFINITY;
+                if (b < G) mx[b] = fmaxf(mx[b], sc[b]);
+            }
+            if (sdc == 0) {
+                float* pu = p + (size_t)(ub + i * 8 + skg) * 8;
+                *reinterpret_cast<float4*>(pu) = make_float4(sc[0], sc[1], sc[2], sc[3]);
+                *reinterpret_cast<float4*>(pu + 4) = make_float4(sc[4], sc[5], sc[6], sc[7]);
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < G; b++) mx[b] = wave_max(mx[b]);
+    if (lane == 0) {
+#pragma unroll
+        for (int b = 0; b < G; b++) wmx[w * 8 + b] = mx[b];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < G; b++) mx[b] = fmaxf(fmaxf(wmx[b], wmx[8 + b]), fmaxf(wmx[16 + b], wmx[24 + b]));     // finite: every beam owns its new key
+    // ---- exp of the wave's own entries (only this wave reads them again), then P V with two output elements per lane and half
+    float acc[G][2], lsum[G];
+#pragma unroll
+    for (int b = 0; b < G; b++) { acc[b][0] = acc[b][1] = 0.f; lsum[b] = 0.f; }
+    for (int pass = 0; pass < npass; pass++) {
+        const int ub = pass * 4 * KPW + w * KPW;
+#pragma unroll
+        for (int jj = 0; jj < KPW * 8 / 64; jj++) {
+            const int idx = jj * 64 + lane, b = idx & 7;
+            if (b < G) {
+                float m = mx[0];
+#pragma unroll
+                for (int b2 = 1; b2 < G; b2++) m = b == b2 ? mx[b2] : m;
+                p[(size_t)ub * 8 + idx] = __expf(p[(size_t)ub * 8 + idx] - m);
+            }
+        }
+        if (pass > 0) {
+            ev = ent[ub + (lane & 31)];
+            CC_GRP_VLOAD()
+        }
+        CC_GRP_PV()
+    }
+#undef CC_GRP_VLOAD
+#undef CC_GRP_PV
+#pragma unroll
+    for (int b = 0; b < G; b++) *reinterpret_cast<float2*>(red2 + ((w * 2 + hf) * G + b) * HD + 2 * dp) = make_float2(acc[b][0], acc[b][1]);
+    if (dp == 0) {
+#pragma unroll
+        for (int b = 0; b < G; b++) wsm[(w * 2 + hf) * 8 + b] = lsum[b];
+    }
+    __syncthreads();
+    for (int o = tid; o < G * HD; o += 256) {
+        const int b = o >> 6, d = o & 63;
+        float sum = 0.f, v = 0.f;
+#pragma unroll
+        for (int x = 0; x < 8; x++) { sum += wsm[x * 8 + b]; v += red2[(x * G + b) * HD + d]; }
+        out[(size_t)(r0 + b) * D + h * HD + d] = f2act(v / sum);
+    }
+}
+
 __global__ void k_kv_reorder(const act_t* __restrict__ src, act_t* __restrict__ dst, const int* __restrict__ map, int R_src, int R_dst,
                              int ctx, int ctx_max, int D, int NL2) {
     const int d8n = D * (int)sizeof(act_t) / 16;      // 16-B vectors per cache row
@@ -801,6 +1014,9 @@ struct DecWS {
     int* last;
     float* scratch;
     size_t scratch_bytes;
+    int2* grp_ent;         // beam-group attention: union list [R / group][group * (pos0 + 1)] + entry counts (k_group_union)
+    int* grp_cnt;
+    size_t grp_ents;
     char* x3;              // bf16x3 build: operand-image scratch (gemm_api.h)
     size_t x3_bytes;
     size_t bytes;
@@ -827,6 +1043,9 @@ void dec_carve(const cc_gpt2_cfg* c, int R, int Tn, void* ws, DecWS& w) {
     w.last = (int*)take((size_t)R * 4);
     w.scratch_bytes = (size_t)8 * M * 4 * D * 4;   // up to 8 K-slices of the widest (4D) output
     w.scratch = (float*)take(w.scratch_bytes);
+    w.grp_ents = Tn == 1 ? (size_t)R * c->NPOS + (size_t)R * 128 : 0;
+    w.grp_ent = (int2*)take(w.grp_ents * sizeof(int2));
+    w.grp_cnt = (int*)take((size_t)R * 4);
     w.x3_bytes = kX3 ? ((M * 3 * 4 * D * sizeof(op16_t) + 255) & ~size_t(255)) : 0;      // the deepest A image: mlp.c_proj, K = 4D
     w.x3 = kX3 ? take(w.x3_bytes) : nullptr;
     w.bytes = (off + 255) & ~size_t(255);
@@ -854,16 +1073,22 @@ int64_t CC_API(cc_decode_part_floats)(const cc_gpt2_cfg* cfg, int32_t R) {
     return (int64_t)2 * R * ((Ns + 63) / 64);
 }
 
-int CC_API(cc_decode_fwd_p)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int32_t ctx_max, const float* w32, const uint16_t* w16,
-                    const float* x, uint16_t* kv, const int32_t* row_map, void* ws, float* logits, int64_t ldl, float* lpart, void* stream);
+int CC_API(cc_decode_fwd_g)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int32_t ctx_max, const float* w32, const uint16_t* w16,
+                    const float* x, uint16_t* kv, const int32_t* row_map, int32_t group, void* ws, float* logits, int64_t ldl, float* lpart, void* stream);
 
 int CC_API(cc_decode_fwd)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int32_t ctx_max, const float* w32, const uint16_t* w16,
                   const float* x, uint16_t* kv, const int32_t* row_map, void* ws, float* logits, int64_t ldl, void* stream) {
-    return CC_API(cc_decode_fwd_p)(c, R, Tn, pos0, ctx_max, w32, w16, x, kv, row_map, ws, logits, ldl, nullptr, stream);
+    return CC_API(cc_decode_fwd_g)(c, R, Tn, pos0, ctx_max, w32, w16, x, kv, row_map, 1, ws, logits, ldl, nullptr, stream);
 }
 
 int CC_API(cc_decode_fwd_p)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int32_t ctx_max, const float* w32, const uint16_t* w16,
                     const float* x, uint16_t* kv, const int32_t* row_map, void* ws, float* logits, int64_t ldl, float* lpart, void* stream) {
+    return CC_API(cc_decode_fwd_g)(c, R, Tn, pos0, ctx_max, w32, w16, x, kv, row_map, 1, ws, logits, ldl, lpart, stream);
+}
+
+int CC_API(cc_decode_fwd_g)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int32_t ctx_max, const float* w32, const uint16_t* w16,
+                    const float* x, uint16_t* kv, const int32_t* row_map, int32_t group, void* ws, float* logits, int64_t ldl, float* lpart, void* stream) {
+    if (group < 1 || (R > 0 && R % group)) return CC_ERR_ARG;
     if (!cfg_ok(c) || R <= 0 || Tn <= 0 || pos0 < 0 || !w32 || !w16 || !x || !kv || !ws || !logits) return CC_ERR_ARG;
     const int Ns = std::min(c->Vp, (c->V + 7) / 8 * 8);
     if (pos0 + Tn > ctx_max || pos0 + Tn > c->NPOS || ldl < Ns || (ldl & 3) || ldl > 0x7fffffff) return CC_ERR_SHAPE;
@@ -892,6 +1117,12 @@ int CC_API(cc_decode_fwd_p)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t
     const int64_t total = (int64_t)c->Vp * D + (int64_t)c->NPOS * D + (int64_t)c->NL * (12 * (int64_t)D * D + 13 * (int64_t)D) + 2 * D;
     const uint16_t* w16t = w16 + (size_t)PL * total;   // transposed Conv1D weights (cc_gpt2_sync_weights): forward GEMMs are NT
     const float scale = 1.0f / sqrtf((float)hd);
+    // beam-group attention (k_decode_attn_group): single-position steps of `group` consecutive rows that share ancestry (a perf hint only)
+    const int grp_cap = (group * (pos0 + 1) + 127) & ~127;          // entries per group, whole passes of 128
+    const size_t grp_shm = ((size_t)grp_cap * 8 + 96 + (size_t)8 * group * 64) * sizeof(float);
+    static const int grp_knob = []() { const char* e = getenv("CC_DEC_GROUP"); return e ? atoi(e) : 1; }();     // 0: always the per-row kernel (A/B)
+    const bool grp_attn = grp_knob && Tn == 1 && group >= 2 && group <= 8 && hd == 64 && grp_shm <= 64 * 1024 &&
+                          (size_t)(R / group) * grp_cap <= w.grp_ents;
     bool xn_ready = one;
     bool hf_ready = false;
     for (int l = 0; l < c->NL; l++) {
@@ -918,7 +1149,17 @@ int CC_API(cc_decode_fwd_p)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t
         fq.kcache = kc; fq.vcache = vc; fq.Tn = Tn; fq.pos0 = pos0; fq.ctx_max = ctx_max;
         CC_TRY(gemm_nt_skinny(w.xn, D, w16t + (size_t)PL * aw, D, M, 3 * D, D, w32 + ab, 0, nullptr, nullptr, w.qkv, 3 * D, w.scratch, w.scratch_bytes, st,
                               f_qkv ? &fq : nullptr));
-        {
+        if (grp_attn) {
+            const int ng = R / group, app = f_qkv ? 0 : 1;
+#define CC_GRP(G_)                                                                                                                            \
+    case G_:                                                                                                                                  \
+        if (l == 0) hipLaunchKernelGGL((k_group_union<G_>), dim3(ng), dim3(64), 0, st, row_map, w.grp_ent, w.grp_cnt, pos0, ctx_max, grp_cap, app); \
+        hipLaunchKernelGGL((k_decode_attn_group<G_>), dim3(ng * H), dim3(256), grp_shm, st, w.qkv, kc, vc, w.grp_ent, w.grp_cnt, w.att, H, pos0,  \
+                           ctx_max, scale, grp_cap, app);                                                                                     \
+        break;
+            switch (group) { CC_GRP(2) CC_GRP(3) CC_GRP(4) CC_GRP(5) CC_GRP(6) CC_GRP(7) CC_GRP(8) default: return CC_ERR_ARG; }
+#undef CC_GRP
+        } else {
             const int nw = R * H * Tn;
             const size_t shm = (size_t)4 * (2 * ctx_max + 8 * hd) * sizeof(float);
             if (f_qkv)

@@ -565,10 +565,11 @@ class DecodeSession:
             self._ws[tn] = ws
         return ws
 
-    def forward(self, x: torch.Tensor, rows: Optional[int] = None, partials: bool = False) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, rows: Optional[int] = None, partials: bool = False, group: int = 1) -> torch.Tensor:
         """x fp32 (R', Tnew, D) input embeddings (no positional term), R' <= R active rows -> fp32 logits of the last new
         position (R', V).  Valid until the next forward().  ``partials``: also keep the lm_head epilogue's per-64-column softmax
-        partials of these logits in ``self.lpart`` = (tensor, npart) for beam_step (cc_decode_fwd_p / cc_beam_step_p)."""
+        partials of these logits in ``self.lpart`` = (tensor, npart) for beam_step (cc_decode_fwd_g / cc_beam_step_p).
+        ``group``: consecutive rows that share ancestry (beam search: the beam width) — a performance hint, results do not depend on it."""
         g = self.g
         x = x.to(device=g.arena.device, dtype=torch.float32).contiguous()
         Ra, tn, D = x.shape
@@ -589,9 +590,9 @@ class DecodeSession:
                 check(n, "cc_decode_part_floats")
                 self._lpart = torch.empty(n, dtype=torch.float32, device=g.arena.device)
             self.lpart = (self._lpart, self._lpart.numel() // (2 * self.R))
-        check(_lib.lib().cc_decode_fwd_p(C.byref(g.cfg), Ra, tn, self.pos, self.ctx_max, _p(g.arena.w32), _p(g.arena.w16), _p(x), _p(self.kv),
-                                        _p(self.row_map), _p(self._workspace(tn)), _p(logits), Vp, _p(self._lpart) if partials else None,
-                                        _stream(g.arena.device)), "cc_decode_fwd_p")
+        check(_lib.lib().cc_decode_fwd_g(C.byref(g.cfg), Ra, tn, self.pos, self.ctx_max, _p(g.arena.w32), _p(g.arena.w16), _p(x), _p(self.kv),
+                                        _p(self.row_map), int(group) if self.R % max(1, int(group)) == 0 else 1, _p(self._workspace(tn)), _p(logits), Vp,
+                                        _p(self._lpart) if partials else None, _stream(g.arena.device)), "cc_decode_fwd_g")
         self.pos += tn
         return logits[:, : g.dims["V"]]
 
@@ -623,6 +624,12 @@ class DecodeSession:
             if self.pos > 0 else src_rows.to(device=self.g.arena.device, dtype=torch.int32).contiguous()
         check(_lib.lib().cc_decode_reorder(C.byref(self.g.cfg), self.R, rows_out, self.pos, self.ctx_max, _p(self.kv), _p(out.kv), _p(src),
                                           _stream(self.g.arena.device)), "cc_decode_reorder")
+        if self.pos > 0:
+            # rows fanned out from one source hold identical prefix K / V: their ancestry tables all name the FIRST copy, so that the
+            # beam-group attention step (cc_decode_fwd_g) reads one copy per group instead of one per row
+            idx = torch.arange(rows_out, dtype=torch.int32, device=src.device)
+            first = torch.full((int(self.R),), rows_out, dtype=torch.int32, device=src.device).scatter_reduce(0, src.to(torch.int64), idx, "amin")
+            out.row_map[:, : self.pos] = first.index_select(0, src.to(torch.int64)).view(rows_out, 1)
         return out
 
 

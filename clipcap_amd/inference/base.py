@@ -63,7 +63,7 @@ def generate_beam_tokens(model, embeds: torch.Tensor, beam_size: int = 5, entry_
         # instead of four — cannot change the result.
         if step % 4 == 1 and bool(has_stopped.all()):
             break
-        logits = sess.forward(x, partials=True)                                 # x = wte[next_tokens] (base.py:117)
+        logits = sess.forward(x, partials=True, group=beam_size)                # x = wte[next_tokens] (base.py:117)
         next_tok, src = beam_step(logits, S, beam_size, temperature, False, stop_token, scores, seq_lengths, has_stopped, bufs, sess.lpart)
         sess.beam_advance(beam_size, next_tok, src, wte, step, tok[(step - 1) & 1], tok[step & 1], x)   # base.py:104-117
         n = step + 1

@@ -51,9 +51,12 @@ extern "C" {
 #define CC_ERR_LAUNCH (-3)
 #define CC_ERR_STATE (-4)
 
-/* bumped when an existing entry point changes; entry points ADDED since 2: cc_adamw_step_cast, cc_mapper_transpose_weights, cc_gpt2_transpose_weights,
- * cc_comm_count, cc_decode_part_floats, cc_decode_fwd_p, cc_beam_step_p; operand mode ADDED: CC_OP_BF16X3 */
-#define CC_ABI_VERSION 2
+/* bumped when an existing entry point changes.  3: cc_loss_scale_update's state is float[3] (applied-step counter in state[2]) and
+ * cc_adamw_step / cc_adamw_step_cast accept step == 0 (= take the step number from loss_scale[2]) — a version-2 caller passing float[2]
+ * would be written out of bounds, so clipcap_amd/_lib.py refuses a library whose version differs.  Entry points ADDED since 2:
+ * cc_adamw_step_cast, cc_mapper_transpose_weights, cc_gpt2_transpose_weights, cc_comm_count, cc_decode_part_floats, cc_decode_fwd_p,
+ * cc_beam_step_p; since 3: cc_decode_fwd_g; operand mode ADDED: CC_OP_BF16X3 */
+#define CC_ABI_VERSION 3
 int cc_abi_version(void);
 
 #define CC_OP_BF16 0
@@ -219,6 +222,13 @@ int64_t cc_decode_part_floats(const cc_gpt2_cfg* cfg, int32_t R);
 int cc_decode_fwd_p(const cc_gpt2_cfg* cfg, int32_t R, int32_t Tnew, int32_t pos0, int32_t ctx_max, const float* w32,
                     const uint16_t* w16, const float* x, uint16_t* kv, const int32_t* row_map, void* ws, float* logits, int64_t ldl,
                     float* lpart, void* stream);
+/* cc_decode_fwd_p for rows that come in groups of `group` consecutive rows sharing ancestry (beam search: group = beam width, the rows of
+ * one caption; R % group == 0, 1 <= group; 1 = cc_decode_fwd_p).  Results are those of cc_decode_fwd_p for ANY row_map; the hint lets the
+ * single-position attention step (Tnew == 1, group <= 8) read every distinct (cache row, position) of a group once for all its rows
+ * instead of once per row (inference/base.py:80-121 re-forwards every beam separately). */
+int cc_decode_fwd_g(const cc_gpt2_cfg* cfg, int32_t R, int32_t Tnew, int32_t pos0, int32_t ctx_max, const float* w32,
+                    const uint16_t* w16, const float* x, uint16_t* kv, const int32_t* row_map, int32_t group, void* ws, float* logits,
+                    int64_t ldl, float* lpart, void* stream);
 /* reorder / expand cache rows after a beam step: kv_dst[:, :, r] = kv_src[:, :, src[r]] for positions < ctx and
  * r < R_dst (base.py:93,113: embeds.expand / embeds[next_tokens_source]); the two caches may have different row counts. */
 int cc_decode_reorder(const cc_gpt2_cfg* cfg, int32_t R_src, int32_t R_dst, int32_t ctx, int32_t ctx_max, const uint16_t* kv_src,

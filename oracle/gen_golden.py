@@ -252,6 +252,42 @@ def _main_new(only):
             d[f"beam{i}b.best"] = np.array([int(s) for s in texts[0].split()] if texts[0] else [], dtype=np.int64)
             d[f"beam{i}b.meta"] = np.array([eos, 10, 5])
         np.savez_compressed(os.path.join(OUT, "beam_medium.npz"), **d)
+
+    # ---- (11) round 4 — BASELINE configs[2] architecture at full depth: the configs[1] mapper + 12-layer GPT-2-small, FULL finetune
+    #           (the LM's weight gradients at GPT-2-small shapes; config4_full covers them at GPT-2-medium shapes only) ----
+    if want("config3_full"):
+        _full_model_fixture("config3_full", E=512, D=768, P=10, L=10, H=8, N=8, NL=12, n_head=12, V=50257, NPOS=1024, seed=4501, full=True)
+
+    # ---- (12) round 4 — BASELINE configs[4] at GPT-2-medium DEPTH: the reference's generate_beam (inference/base.py:55-132) on the seeded
+    #           24-layer model, 2 prefixes, entry_length 12, each also with a stop token that freezes beams mid-way ----
+    if want("beam_deep"):
+        from clipcap.inference import base as ibase
+        D, NL, n_head, V, NPOS, seed, EL = 1024, 24, 16, 50257, 128, 4601, 12
+        gsd = seeded.state_dict(seeded.gpt2_shapes(D, NL, V, NPOS), seed)
+        gsd["transformer.wte.weight"] = gsd["transformer.wte.weight"] * 2.0
+        lm = GPT2LMHeadModel(GPT2Config(n_embd=D, n_layer=NL, n_head=n_head, vocab_size=V, n_positions=NPOS, resid_pdrop=0.0, embd_pdrop=0.0,
+                                        attn_pdrop=0.0)).eval()
+        lm.load_state_dict({k: torch.from_numpy(v) for k, v in gsd.items()}, strict=False)
+
+        class _M3:
+            language_model = lm
+
+        d = {"cfg": np.array([D, NL, n_head, V, NPOS, seed]), "wte_scale": np.array(2.0), "param_checksum": seeded.checksum(gsd)}
+        gen = torch.Generator().manual_seed(seed)
+        for i in range(2):
+            pref = torch.randn(1, 10, D, generator=gen) * 0.5
+            texts = ibase.generate_beam(_M3, FakeTokenizer(V - 1), pref, beam_size=5, entry_length=EL, temperature=1.0)
+            best = [int(s) for s in texts[0].split()]
+            d[f"beam{i}a.prefix"] = pref.numpy()
+            d[f"beam{i}a.best"] = np.array(best, dtype=np.int64)
+            d[f"beam{i}a.meta"] = np.array([V - 1, EL, 5])
+            eos = best[5]
+            texts = ibase.generate_beam(_M3, FakeTokenizer(eos), pref, beam_size=5, entry_length=EL, temperature=1.0)
+            d[f"beam{i}b.prefix"] = pref.numpy()
+            d[f"beam{i}b.best"] = np.array([int(s) for s in texts[0].split()] if texts[0] else [], dtype=np.int64)
+            d[f"beam{i}b.meta"] = np.array([eos, EL, 5])
+            print("beam_deep", i, best, d[f"beam{i}b.best"])
+        np.savez_compressed(os.path.join(OUT, "beam_deep.npz"), **d)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

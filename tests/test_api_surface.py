@@ -44,7 +44,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(l, name), f"{name} declared in clipcap_hip.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
-    assert l.cc_abi_version() == 2
+    assert l.cc_abi_version() == 3
     # both operand-type builds are linked in: every dispatched entry point exists as <name>_bf16 and <name>_f16
     for name in ("cc_mapper_fwd", "cc_gpt2_fwd", "cc_decode_fwd", "cc_lmhead_ce_fwd", "cc_attention_fwd"):
         assert hasattr(l, name + "_bf16") and hasattr(l, name + "_f16"), name
