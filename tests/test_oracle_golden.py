@@ -174,10 +174,10 @@ def test_mapper_shape_faithful_config2_one_layer():
         assert np.abs(smp - g[f"grad.{k}.sample"]).max() <= 2e-5 * max(1.0, np.abs(g[f"grad.{k}.sample"]).max()), k
 
 
-@pytest.mark.parametrize("name", ["config2_full", "config4_full"])
+@pytest.mark.parametrize("name", ["config2_full", "config3_full", "config4_full"])
 def test_full_depth_model_logits_loss_grads(name):
-    """BASELINE configs[1] / configs[3] architectures at full depth (8-layer mapper + 12-layer GPT-2-small; E=1024 mapper +
-    24-layer GPT-2-medium), B=2: the oracle against the reference's logits, prefix, loss and gradients."""
+    """BASELINE configs[1] / configs[2] / configs[3] architectures at full depth (8-layer mapper + 12-layer GPT-2-small, frozen and
+    full finetune; E=1024 mapper + 24-layer GPT-2-medium), B=2: the oracle against the reference's logits, prefix, loss and gradients."""
     from tests.util import sampled, seeded_full_model
     from tests.seeded import sample_idx
     g = load_golden(name)
@@ -248,6 +248,26 @@ def test_beam_search_medium_width():
     sd = {"language_model." + k: torch.from_numpy(v) for k, v in gsd.items()}
     torch.set_num_threads(max(1, min(8, torch.get_num_threads())))
     for case in ("beam0a", "beam0b", "beam1a", "beam1b"):
+        eos, entry, beam = [int(v) for v in g[case + ".meta"]]
+        toks, sc, lens, order = O.generate_beam_tokens(sd, torch.from_numpy(g[case + ".prefix"]), n_head=n_head, n_layer=NL, beam_size=beam,
+                                                       entry_length=entry, stop_token=eos)
+        best = toks[order[0]][: int(lens[order[0]])].numpy()
+        assert np.array_equal(best, g[case + ".best"]), (case, best, g[case + ".best"])
+
+
+def test_beam_search_medium_depth():
+    """BASELINE configs[4] at GPT-2-medium DEPTH (24 layers, D=1024, 16 heads, V=50257): the reference's beam-5 caption of prefix 0
+    (tests/golden/beam_deep.npz), without and with a stop token that freezes beams mid-way.  (Prefix 1 is covered by the GPU tests;
+    two 24-layer searches keep this suite at a few minutes.)"""
+    from tests import seeded
+    g = load_golden("beam_deep")
+    D, NL, n_head, V, NPOS, seed = [int(v) for v in g["cfg"]]
+    gsd = seeded.state_dict(seeded.gpt2_shapes(D, NL, V, NPOS), seed)
+    gsd["transformer.wte.weight"] = gsd["transformer.wte.weight"] * float(g["wte_scale"])
+    assert np.array_equal(seeded.checksum(gsd), g["param_checksum"])
+    sd = {"language_model." + k: torch.from_numpy(v) for k, v in gsd.items()}
+    torch.set_num_threads(max(1, min(8, torch.get_num_threads())))
+    for case in ("beam0a", "beam0b"):
         eos, entry, beam = [int(v) for v in g[case + ".meta"]]
         toks, sc, lens, order = O.generate_beam_tokens(sd, torch.from_numpy(g[case + ".prefix"]), n_head=n_head, n_layer=NL, beam_size=beam,
                                                        entry_length=entry, stop_token=eos)
