@@ -370,8 +370,8 @@ def main():
     if args.batch:
         c["B"] = args.batch
     B, cap = c["B"], c["cap"]
-    if args.grad_wire == "auto":
-        args.grad_wire = "fp32" if c["train_lm"] else "bf16"
+    if args.grad_wire == "auto":      # clipcap_amd.train.train.grad_wire_dtype: fp32 in the fp32-parity mode and for a full finetune
+        args.grad_wire = "fp32" if (c["train_lm"] or args.precision == "32") else "bf16"
 
     from clipcap_amd import _lib
     from clipcap_amd.train.ddp import GradReducer

@@ -58,4 +58,6 @@ def resume(model, ckpt_path: str) -> dict:
         if sc is not None:      # resumed fp16 run: continue at the saved scale instead of restarting at 2^16 (and skipping steps again)
             st = ck["loss_scaler"].to(sc.state.device, torch.float32)
             sc.state[: st.numel()].copy_(st)
+            if st.numel() < 3:      # checkpoint written before the applied-step counter existed: Adam's bias correction continues from the
+                sc.state[2] = float(model._opt_step)     # saved optimizer step instead of restarting at t = 1
     return ck

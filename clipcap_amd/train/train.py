@@ -17,7 +17,19 @@ from clipcap_amd.model.optim import linear_warmup_decay
 from clipcap_amd.train.args import add_training_args
 from clipcap_amd.train.callback import CheckpointSaver, resume
 from clipcap_amd.train.dataloader import DevicePrefetcher, get_dataloader
+from clipcap_amd._lib import OP_BF16, OP_FP16, OP_X3
 from clipcap_amd.train.ddp import GradReducer
+
+
+def grad_wire_dtype(op_dtype: int, train_lm: bool) -> torch.dtype:
+    """Element type of the gradient all-reduce.  The split-bf16 mode exists to reproduce the reference's fp32 arithmetic, so its gradients
+    travel in fp32 — N-rank gradients then equal 1-rank gradients to fp32 rounding, as in the reference's DDP (train.py:77-85).  In the
+    bf16 / fp16 throughput modes a frozen-LM run sends bf16 (only the mapper's 41.7 M gradients travel and only the short mapper backward
+    can hide them; the fp32 arena stays the accumulator; tests/test_ddp_gloo.py: gradients to 8e-3, 20-step loss trajectory to 2e-3); a
+    full finetune sends fp32."""
+    if op_dtype == OP_X3 or train_lm:
+        return torch.float32
+    return torch.bfloat16
 
 
 def train(args: Namespace, tokenizer=None, language_model=None) -> int:
@@ -63,9 +75,12 @@ def train(args: Namespace, tokenizer=None, language_model=None) -> int:
     if rank == 0:
         saver.save_config(config.to_dict())                                      # train.py:60-68
     arenas = [model.transformer_mapper.engine.arena] + ([model.language_model.engine.arena] if model._train_lm else [])
-    # frozen LM: only the mapper's 41.7 M gradients travel and only the short mapper backward can hide them -> bf16 on the wire (the fp32
-    # arena stays the accumulator; tests/test_ddp_gloo.py: gradients to 8e-3, 20-step loss trajectory to 2e-3); full finetune: fp32
-    wire = torch.float32 if model._train_lm else torch.bfloat16
+    wire = grad_wire_dtype(model.transformer_mapper.engine.op_dtype, model._train_lm)
+    if rank == 0:
+        mode = {OP_BF16: "bf16 operands (throughput mode; --fp-precision bf16)", OP_FP16: "fp16 operands + dynamic loss scale (--fp-precision 16)",
+                OP_X3: "split-bf16 operands = the reference's fp32 default (--fp-precision 32/64; ~3x the bf16 step time, logits within 1e-3)"}
+        print(f"clipcap_amd: operand mode: {mode[model.transformer_mapper.engine.op_dtype]}; gradient wire: {str(wire).replace('torch.', '')}"
+              + (f" over {world} ranks" if world > 1 else ""), flush=True)
     reducer = GradReducer([a.grads() for a in arenas], wire_dtype=wire) if world > 1 else None
     sched = linear_warmup_decay(args.scheduler_warmup_steps, args.total_steps)
     logger = None

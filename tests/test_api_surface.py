@@ -319,3 +319,12 @@ def test_precision_flag_maps_to_operand_modes():
     assert ap.parse_args(["--fp-precision", "16"]).fp_precision == 16
     with pytest.raises(ValueError):
         op_dtype_of(8)
+
+
+def test_gradient_wire_dtype_follows_the_operand_mode():
+    """the fp32-parity mode (split-bf16 operands, the CLI default) must not round its gradients to bf16 on the wire."""
+    from clipcap_amd._lib import OP_BF16, OP_FP16, OP_X3
+    from clipcap_amd.train.train import grad_wire_dtype
+    assert grad_wire_dtype(OP_X3, False) is torch.float32 and grad_wire_dtype(OP_X3, True) is torch.float32
+    assert grad_wire_dtype(OP_BF16, False) is torch.bfloat16 and grad_wire_dtype(OP_FP16, False) is torch.bfloat16
+    assert grad_wire_dtype(OP_BF16, True) is torch.float32 and grad_wire_dtype(OP_FP16, True) is torch.float32
