@@ -5,6 +5,7 @@
 #include "../../include/clipcap_hip.h"
 #include "gemm_api.h"
 #include "kernels.h"
+#include "decode_pk.h"
 
 using namespace CC_NS;
 
@@ -216,8 +217,10 @@ __global__ __launch_bounds__(256) void k_decode_attn(const act_t* __restrict__ q
 // LDS per block: p[cap][8] | wmx[4][8] | wsum[8][8] | red2[8][G][64].
 template <int G>
 __global__ __launch_bounds__(64) void k_group_union(const int* __restrict__ row_map, int2* __restrict__ ent_g, int* __restrict__ cnt_g, int pos0,
-                                                    int ctx_max, int cap, int append) {
+                                                    int ctx_max, int cap, int append, unsigned* __restrict__ zero, int nzero) {
     const int lane = threadIdx.x, s = blockIdx.x, r0 = s * G;
+    if (s == 0)                                            // the persistent layer launch that follows starts from cleared arrival counters
+        for (int i = lane; i < nzero; i += 64) zero[i] = 0u;
     int2* ent = ent_g + (size_t)s * cap;
     int nU = 0;
     for (int j0 = 0; j0 < pos0; j0 += 64) {
@@ -1014,6 +1017,8 @@ struct DecWS {
     int* last;
     float* scratch;
     size_t scratch_bytes;
+    unsigned long long* pk_prof;   // [256][21] profile of the persistent layer launch (CC_PK_PROF=1)
+    unsigned* pk_ctr;      // persistent layer launch (decode_pk.hip): arrival counters + error word
     int2* grp_ent;         // beam-group attention: union list [R / group][group * (pos0 + 1)] + entry counts (k_group_union)
     int* grp_cnt;
     size_t grp_ents;
@@ -1043,6 +1048,8 @@ void dec_carve(const cc_gpt2_cfg* c, int R, int Tn, void* ws, DecWS& w) {
     w.last = (int*)take((size_t)R * 4);
     w.scratch_bytes = (size_t)8 * M * 4 * D * 4;   // up to 8 K-slices of the widest (4D) output
     w.scratch = (float*)take(w.scratch_bytes);
+    w.pk_ctr = (unsigned*)take((size_t)PK_CTR_WORDS * 4);
+    w.pk_prof = (unsigned long long*)take((size_t)256 * 21 * 8);
     w.grp_ents = Tn == 1 ? (size_t)R * c->NPOS + (size_t)R * 128 : 0;
     w.grp_ent = (int2*)take(w.grp_ents * sizeof(int2));
     w.grp_cnt = (int*)take((size_t)R * 4);
@@ -1120,12 +1127,36 @@ int CC_API(cc_decode_fwd_g)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t
     // beam-group attention (k_decode_attn_group): single-position steps of `group` consecutive rows that share ancestry (a perf hint only)
     const int grp_cap = (group * (pos0 + 1) + 127) & ~127;          // entries per group, whole passes of 128
     const size_t grp_shm = ((size_t)grp_cap * 8 + 96 + (size_t)8 * group * 64) * sizeof(float);
-    static const int grp_knob = []() { const char* e = getenv("CC_DEC_GROUP"); return e ? atoi(e) : 1; }();     // 0: always the per-row kernel (A/B)
-    const bool grp_attn = grp_knob && Tn == 1 && group >= 2 && group <= 8 && hd == 64 && grp_shm <= 64 * 1024 &&
+    const bool grp_attn = (cc_shared::g_decode_mode & 1) && Tn == 1 && group >= 2 && group <= 8 && hd == 64 && grp_shm <= 64 * 1024 &&
                           (size_t)(R / group) * grp_cap <= w.grp_ents;
     bool xn_ready = one;
     bool hf_ready = false;
-    for (int l = 0; l < c->NL; l++) {
+    int l_first = 0;
+    if (grp_attn && one && !kX3 && (cc_shared::g_decode_mode & 2)) {
+        // the whole layer stack as ONE persistent launch (decode_pk.hip); CC_ERR_SHAPE = geometry not covered -> the per-op launches below
+        switch (group) {
+#define CC_GU(G_) case G_: hipLaunchKernelGGL((k_group_union<G_>), dim3(R / group), dim3(64), 0, st, row_map, w.grp_ent, w.grp_cnt, pos0, ctx_max, grp_cap, 1, w.pk_ctr, PK_CTR_WORDS); break;
+            CC_GU(2) CC_GU(3) CC_GU(4) CC_GU(5) CC_GU(6) CC_GU(7) CC_GU(8)
+#undef CC_GU
+            default: break;
+        }
+        PkLaunch L{};
+        L.w32 = w32; L.w16t = reinterpret_cast<const op16_t*>(w16t); L.D = D; L.H = H; L.NL = c->NL; L.M = M; L.group = group; L.pos0 = pos0; L.ctx_max = ctx_max;
+        L.layer0 = p; L.x = w.x; L.x1 = w.x1; L.xn = w.xn; L.qkv = w.qkv; L.att = w.att; L.hact = w.hact; L.hf = w.hf;
+        L.slab = w.scratch; L.slab_bytes = w.scratch_bytes; L.kv = reinterpret_cast<act_t*>(kv); L.cache_layer = cache_layer;
+        L.ent = w.grp_ent; L.cnt = w.grp_cnt; L.cap = grp_cap; L.ctr = w.pk_ctr;
+        static const bool pk_prof = getenv("CC_PK_PROF") != nullptr;
+        L.prof = pk_prof ? w.pk_prof : nullptr;
+        const int rc = decode_layers_persistent(L, st);
+        if (rc == CC_OK) {
+            l_first = c->NL;
+            p += (int64_t)c->NL * (12 * (int64_t)D * D + 13 * (int64_t)D);
+            hf_ready = true;
+        } else if (rc != CC_ERR_SHAPE) {
+            return rc;
+        }
+    }
+    for (int l = l_first; l < c->NL; l++) {
         const int64_t l1w = p; p += D;
         const int64_t l1b = p; p += D;
         const int64_t aw = p; p += (int64_t)D * 3 * D;
@@ -1153,7 +1184,8 @@ int CC_API(cc_decode_fwd_g)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t
             const int ng = R / group, app = f_qkv ? 0 : 1;
 #define CC_GRP(G_)                                                                                                                            \
     case G_:                                                                                                                                  \
-        if (l == 0) hipLaunchKernelGGL((k_group_union<G_>), dim3(ng), dim3(64), 0, st, row_map, w.grp_ent, w.grp_cnt, pos0, ctx_max, grp_cap, app); \
+        if (l == 0) hipLaunchKernelGGL((k_group_union<G_>), dim3(ng), dim3(64), 0, st, row_map, w.grp_ent, w.grp_cnt, pos0, ctx_max, grp_cap, app, \
+                                       (unsigned*)nullptr, 0);                                                                               \
         hipLaunchKernelGGL((k_decode_attn_group<G_>), dim3(ng * H), dim3(256), grp_shm, st, w.qkv, kc, vc, w.grp_ent, w.grp_cnt, w.att, H, pos0,  \
                            ctx_max, scale, grp_cap, app);                                                                                     \
         break;
@@ -1197,6 +1229,16 @@ int CC_API(cc_decode_fwd_g)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t
         CC_TRY(gemm_f32out(0, 0, w.hf, D, w16 + (size_t)PL * wte, D, R, Ns, D, logits, (int)ldl, nullptr, 0, 1.0f, 1, st));
     }
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+}
+
+int CC_API(cc_decode_ws_check)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, const void* ws, void* stream) {
+    if (!cfg_ok(c) || R <= 0 || Tn <= 0 || !ws) return CC_ERR_ARG;
+    DecWS w;
+    dec_carve(c, R, Tn, const_cast<void*>(ws), w);
+    unsigned e = 0;
+    if (hipStreamSynchronize(S_(stream)) != hipSuccess) return CC_ERR_LAUNCH;
+    if (hipMemcpy(&e, w.pk_ctr + 7 * PK_MAX_RT, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return CC_ERR_LAUNCH;
+    return e ? CC_ERR_STATE : CC_OK;
 }
 
 int CC_API(cc_decode_reorder)(const cc_gpt2_cfg* c, int32_t R_src, int32_t R_dst, int32_t ctx, int32_t ctx_max, const uint16_t* kv_src, uint16_t* kv_dst,

@@ -11,6 +11,13 @@ namespace cc_shared {
 int g_gemm_tile_mode = []() { const char* e = getenv("CC_GEMM_S256"); return e ? atoi(e) : -1; }();
 int g_gemm_s64 = []() { const char* e = getenv("CC_GEMM_S64"); return e ? atoi(e) : -1; }();
 int g_gemm_small_x2 = []() { const char* e = getenv("CC_GEMM_X2"); return e ? atoi(e) : 1; }();
+// bit 0: beam-group attention step (k_decode_attn_group), bit 1: the layer stack of a group step as one persistent launch (decode_pk.hip;
+// measured slower than the per-op launches on MI355X, DESIGN.md 4.5 — kept for A/B runs).  env CC_DEC_GROUP / CC_DEC_PK preset the bits.
+int g_decode_mode = []() {
+    const char* g = getenv("CC_DEC_GROUP");
+    const char* p = getenv("CC_DEC_PK");
+    return ((g ? atoi(g) : 1) ? 1 : 0) | ((p ? atoi(p) : 0) ? 2 : 0);
+}();
 Prof g_prof;
 }  // namespace cc_shared
 
@@ -23,6 +30,12 @@ int cc_abi_version(void) { return CC_ABI_VERSION; }
 int cc_gemm_tile_mode(int32_t mode) {
     const int old = g_gemm_tile_mode;
     g_gemm_tile_mode = mode;
+    return old;
+}
+
+int cc_decode_mode(int32_t mode) {
+    const int old = g_decode_mode;
+    if (mode >= 0) g_decode_mode = mode & 3;
     return old;
 }
 

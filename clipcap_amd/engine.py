@@ -561,7 +561,7 @@ class DecodeSession:
         if ws is None:
             nbytes = _lib.lib().cc_decode_ws_bytes(C.byref(self.g.cfg), self.R, tn)
             check(nbytes, "cc_decode_ws_bytes")
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.g.arena.device)
+            ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.g.arena.device)     # zeroed: cc_decode_ws_check's error word starts clear
             self._ws[tn] = ws
         return ws
 
@@ -595,6 +595,12 @@ class DecodeSession:
                                         _p(self._lpart) if partials else None, _stream(g.arena.device)), "cc_decode_fwd_g")
         self.pos += tn
         return logits[:, : g.dims["V"]]
+
+    def check(self, tn: int = 1) -> None:
+        """Synchronises and raises if the last single-position step on this session's workspace gave up on an in-launch hand-off
+        (cc_decode_ws_check; a debugging aid — a correct run never trips it)."""
+        if tn in self._ws:
+            check(_lib.lib().cc_decode_ws_check(C.byref(self.g.cfg), self.R, tn, _p(self._ws[tn]), _stream(self.g.arena.device)), "cc_decode_ws_check")
 
     def reorder(self, src_rows: torch.Tensor) -> "DecodeSession":
         """Logical row r continues the history of logical row src_rows[r] (same row count): permutes the ancestry table in place."""

@@ -11,7 +11,7 @@
  *     points keep no state and never allocate or synchronise; all work is enqueued on the caller's hipStream_t (passed
  *     as void*; NULL = default stream), so calls on different streams / from different host threads are independent.
  *     Per-step settings (GPT-2 dropout, loss scale) travel in the call's own arguments.  The only process-wide state is
- *     the three test / measurement hooks at the end of this file (cc_gemm_tile_mode, cc_gemm_skinny_mode, cc_prof_*),
+ *     the test / measurement hooks at the end of this file (cc_gemm_tile_mode, cc_gemm_skinny_mode, cc_decode_mode, cc_prof_*),
  *     which the product path never touches.
  *   - return value: 0 = ok, <0 = error (CC_ERR_*), never throws across the ABI.
  *   - OPERAND TYPE.  GEMM / attention operands and the stored 16-bit activations are bf16 (CC_OP_BF16, default) or IEEE
@@ -55,7 +55,7 @@ extern "C" {
  * cc_adamw_step / cc_adamw_step_cast accept step == 0 (= take the step number from loss_scale[2]) — a version-2 caller passing float[2]
  * would be written out of bounds, so clipcap_amd/_lib.py refuses a library whose version differs.  Entry points ADDED since 2:
  * cc_adamw_step_cast, cc_mapper_transpose_weights, cc_gpt2_transpose_weights, cc_comm_count, cc_decode_part_floats, cc_decode_fwd_p,
- * cc_beam_step_p; since 3: cc_decode_fwd_g; operand mode ADDED: CC_OP_BF16X3 */
+ * cc_beam_step_p; since 3: cc_decode_fwd_g, cc_decode_ws_check; operand mode ADDED: CC_OP_BF16X3 */
 #define CC_ABI_VERSION 3
 int cc_abi_version(void);
 
@@ -229,6 +229,11 @@ int cc_decode_fwd_p(const cc_gpt2_cfg* cfg, int32_t R, int32_t Tnew, int32_t pos
 int cc_decode_fwd_g(const cc_gpt2_cfg* cfg, int32_t R, int32_t Tnew, int32_t pos0, int32_t ctx_max, const float* w32,
                     const uint16_t* w16, const float* x, uint16_t* kv, const int32_t* row_map, int32_t group, void* ws, float* logits,
                     int64_t ldl, float* lpart, void* stream);
+/* Single-position group steps (cc_decode_fwd_g, Tnew == 1, bf16 / fp16 operands, head dim 64, R <= 512) run the whole layer stack as ONE
+ * persistent launch whose workgroups hand activations to each other through arrival counters in `ws`; every wait in it is bounded, and a
+ * wait that gives up raises an error word in `ws`.  cc_decode_ws_check synchronises `stream` and returns CC_ERR_STATE if the last step on
+ * this workspace gave up (its logits are then garbage), CC_OK otherwise.  A debugging / test aid: a correct run never trips it. */
+int cc_decode_ws_check(const cc_gpt2_cfg* cfg, int32_t R, int32_t Tnew, const void* ws, void* stream);
 /* reorder / expand cache rows after a beam step: kv_dst[:, :, r] = kv_src[:, :, src[r]] for positions < ctx and
  * r < R_dst (base.py:93,113: embeds.expand / embeds[next_tokens_source]); the two caches may have different row counts. */
 int cc_decode_reorder(const cc_gpt2_cfg* cfg, int32_t R_src, int32_t R_dst, int32_t ctx, int32_t ctx_max, const uint16_t* kv_src,
@@ -346,6 +351,11 @@ int cc_gemm_tile_mode(int32_t mode);
  * M <= 1024 through the 64 x 64 / 64 x 128 / 64 x 64 K-split-over-waves (3) form.  PROCESS-WIDE test knob; returns the previous mode.  For tests and
  * tools/small_gemm_bench.py. */
 int cc_gemm_skinny_mode(int32_t mode);
+/* How cc_decode_fwd_g runs a single-position group step.  bit 0 (default on): beam-group attention (every distinct KV row of a group read
+ * once); bit 1 (default off): the whole layer stack as ONE persistent launch with in-launch hand-offs (decode_pk.hip; bf16 / fp16 operands) —
+ * results equal the per-op launches to rounding, and on MI355X it measured SLOWER than them, so it is an A/B switch, not
+ * the product path.  mode < 0 only queries.  PROCESS-WIDE test knob; returns the previous mode (env CC_DEC_GROUP / CC_DEC_PK preset it). */
+int cc_decode_mode(int32_t mode);
 int cc_layernorm_fwd(int32_t op_dtype, const float* x, const float* gamma, const float* beta, uint16_t* y, float* mean, float* rstd, int32_t rows,
                      int32_t D, void* stream);
 int cc_attention_fwd(int32_t op_dtype, const uint16_t* qkv, int32_t B, int32_t S, int32_t H, int32_t hd, int32_t causal, uint16_t* out, float* lse,
