@@ -40,10 +40,38 @@ CONFIGS = {
 
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
 # Offline PMC measurements quoted in the JSON line (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 gfx950
-# correction; see the profile files).  They describe the build the profile was taken from; bench.py itself does not read counters.
-LMHEAD_TRAFFIC = {"bytes": 2263744409, "source": "profiles/r03_d_pmc_fetch_write_train.md (offline PMC, this round's build)"}
-GEMM_TRAFFIC = {"bytes": 27732100403, "source": "profiles/r03_d_pmc_fetch_write_train.md (offline PMC: sum over the gemm_* kernels of one step)"}
-DECODE_TRAFFIC = {"bytes": 3.11e+09, "source": "profiles/r03_e_pmc_fetch_write_decode.md (offline PMC, this round's build)"}
+# correction; tools/profile_round.sh writes them to profiles/pmc_constants.json together with a hash of the kernel sources they were
+# measured on).  bench.py does not read counters itself: when the sources have changed since the passes were taken, the numbers would
+# describe another build, and the fields are reported as null (with the reason) instead of silently going stale.
+ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources + the public header (what decides the machine code of libclipcap_hip.so)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "clipcap_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")) or f == "Makefile":
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "clipcap_hip.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_constant(name):
+    """{"bytes": int | None, "source": str, ...} for one offline counter measurement; bytes = None when absent or stale."""
+    path = os.path.join(ROOT, "profiles", "pmc_constants.json")
+    try:
+        with open(path) as f:
+            all_ = json.load(f)
+        e = dict(all_[name])
+    except (OSError, KeyError, ValueError):
+        return {"bytes": None, "source": None, "stale": "no offline PMC pass recorded (profiles/pmc_constants.json)"}
+    cur = kernel_source_hash()
+    if e.get("kernel_source_hash") != cur:
+        return {"bytes": None, "source": e.get("source"), "stale": f"kernel sources changed since the PMC pass (pass: {e.get('kernel_source_hash')}, now: {cur})"}
+    return e
 
 
 def mapper_flops_fwd(c):   # SURVEY.md §8d: 2*E*P*D + N*[S*2*D*(D+2D+D+rD+rD) + 4*S^2*D], r=2
@@ -61,6 +89,31 @@ def gpt2_flops_fwd(c):     # n_layer*[T*24*D^2 + 4*T^2*D] + 2*D*V*T
 def step_flops(c):         # frozen: 3*mapper + 2*LM ; full: 3*(mapper+LM)   (per sample)
     m, g = mapper_flops_fwd(c), gpt2_flops_fwd(c)
     return 3 * m + (3 if c["train_lm"] else 2) * g
+
+
+def gemm_family_algorithmic_bytes(c):
+    """HBM bytes one training step's GEMM launches need if every operand is read once and every output written once (the yardstick for
+    the counter-measured `traffic` of the GEMM family).  Accounting per launch: A + B operands (16-bit), the output (16-bit, or fp32 for
+    residual streams / weight gradients), and what the fused epilogue reads (fp32 residual, the stored gelu' tensor)."""
+    B, cap, D, NL, V = c["B"], c["cap"], c["D"], c["n_layer"], c["V"]
+    Vp = (V + 127) // 128 * 128
+    M, Mc = B * (c["L"] + cap), B * cap                        # GPT-2 rows, lm_head rows
+    h, f = 2, 4                                                # bytes: 16-bit operand, fp32
+
+    def lin(m, k, n, out_b, extra=0):                          # forward-shaped launch: A [m,k], W [n,k], out [m,n]
+        return m * k * h + n * k * h + m * n * out_b + extra
+
+    fwd = NL * (lin(M, D, 3 * D, h) + lin(M, D, D, f, M * D * f) + lin(M, D, 4 * D, h, M * 4 * D * h) + lin(M, 4 * D, D, f, M * D * f))
+    dgrad = NL * (lin(M, D, 4 * D, h, M * 4 * D * h) + lin(M, 4 * D, D, h) + lin(M, D, D, h) + lin(M, 3 * D, D, h))
+    wgrad = NL * sum(M * (k + n) * h + k * n * f for k, n in ((D, 3 * D), (D, D), (D, 4 * D), (4 * D, D))) if c["train_lm"] else 0
+    head = lin(Mc, D, Vp, h) + (Mc * Vp * h + Vp * D * h + Mc * D * h + 2 * Mc * D * f) + ((Mc * (Vp + D)) * h + Vp * D * f if c["train_lm"] else 0)
+    Mm, Dm, r = B * (c["P"] + c["L"]), D, 2
+    m_fwd = c["N"] * (lin(Mm, Dm, 3 * Dm, h) + lin(Mm, Dm, Dm, f, Mm * Dm * f) + lin(Mm, Dm, r * Dm, h) + lin(Mm, r * Dm, Dm, f, Mm * Dm * f))
+    m_dgrad = c["N"] * (lin(Mm, Dm, r * Dm, h, Mm * r * Dm * h) + lin(Mm, r * Dm, Dm, h) + lin(Mm, Dm, Dm, h) + lin(Mm, 3 * Dm, Dm, h))
+    m_wgrad = c["N"] * sum(Mm * (k + n) * h + k * n * f for k, n in ((Dm, 3 * Dm), (Dm, Dm), (Dm, r * Dm), (r * Dm, Dm)))
+    m_lin = 3 * (B * c["E"] * h + c["E"] * c["P"] * Dm * h + B * c["P"] * Dm * f)
+    return {"gpt2_forward": int(fwd), "gpt2_input_gradients": int(dgrad), "gpt2_weight_gradients": int(wgrad), "lm_head": int(head),
+            "mapper": int(m_fwd + m_dgrad + m_wgrad + m_lin), "total": int(fwd + dgrad + wgrad + head + m_fwd + m_dgrad + m_wgrad + m_lin)}
 
 
 def init_engines(c, device, seed=1234):
@@ -193,28 +246,70 @@ def decode_bench(args, device):
     dt = time.perf_counter() - t0
     steps_per_decode = toks.shape[2]
     wbytes = 2.0 * (lm.engine.arena.n - (lm.engine.dims["NPOS"] * 1024))     # bf16 weights read once per decode step
-    # + the KV cache rows every beam row attends to, 2 * n_layer * ctx * D * 2 B per row, averaged over the generated
-    # positions (upper bound: rows of one sample share ancestors, so part of it is the same memory)
+    # + the KV cache rows the step attends to.  Upper bound: every beam row reads its whole history (what a per-row
+    # attention kernel fetches): 2 * n_layer * ctx * D * 2 B per row.  MEASURED: the beam-group attention step reads every distinct
+    # (cache row, position) of a caption's beams once — counted from the ancestry tables of one extra, untimed decode.
     ctx_avg = L + (steps_per_decode - 1) / 2.0
-    kvbytes = 2.0 * 24 * ctx_avg * 1024 * 2 * S * beam
+    kvbytes_ub = 2.0 * 24 * ctx_avg * 1024 * 2 * S * beam
+    rows_distinct = decode_distinct_rows(model, prefix, beam, entry)
+    kvbytes = 2.0 * 24 * rows_distinct * 1024 * 2
+    tr = pmc_constant("decode_bytes_per_position") if S == 64 else {"bytes": None, "source": None, "stale": "offline pass is for 64 prefixes"}
+    per_pos_s = dt / args.steps / steps_per_decode
     return {"metric": "decode tok/s (beam=5, GPT-2-medium, KV cache)", "value": round(gen / dt, 1), "unit": "tokens/s", "n_gpus": 1,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE configs[4]: beam=5 decode, GPT-2-medium random init, 64 prefixes x 10 rows, 67 new tokens",
                        "prefixes": S, "beam": beam, "entry_length": entry, "generated_steps": steps_per_decode},
             "beam_tokens_per_s": round(gen * beam / dt, 1),
-            "roofline": {"bound": "hbm", "kernel": "whole decode step (weights once per generated position)",
-                         "achieved": round(wbytes * steps_per_decode * args.steps / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(wbytes * steps_per_decode * args.steps / dt / 8e12, 4),
-                         "algorithmic_bytes_per_position": int(wbytes),
-                         "kv_read_bytes_per_position_upper_bound": int(kvbytes),
-                         "achieved_incl_kv": round((wbytes + kvbytes) * steps_per_decode * args.steps / dt / 1e9, 1),
-                         # fabric bytes per generated position from separate PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, summed over
-                         # the step's kernels) — an OFFLINE measurement of an earlier build, quoted with its source, not of this run
-                         "traffic": DECODE_TRAFFIC["bytes"] if S == 64 else None,
-                         "traffic_source": DECODE_TRAFFIC["source"] if S == 64 else None,
-                         "traffic_over_algorithmic": round(DECODE_TRAFFIC["bytes"] / wbytes, 2) if S == 64 else None,
-                         "traffic_over_weights_plus_kv": round(DECODE_TRAFFIC["bytes"] / (wbytes + kvbytes), 2) if S == 64 else None}}
+            "roofline": {"bound": "hbm", "kernel": "whole decode step (weights once per generated position + the distinct KV rows of every beam group)",
+                         "achieved": round((wbytes + kvbytes) / per_pos_s / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round((wbytes + kvbytes) / per_pos_s / 8e12, 4),
+                         "frac_weights_only": round(wbytes / per_pos_s / 8e12, 4),
+                         "algorithmic_bytes_per_position": int(wbytes + kvbytes),
+                         "weight_bytes_per_position": int(wbytes),
+                         "kv_read_bytes_per_position": int(kvbytes),
+                         "kv_read_bytes_per_position_per_row_kernel": int(kvbytes_ub),
+                         "us_per_position": round(per_pos_s * 1e6, 1),
+                         # fabric bytes per generated position from separate PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, summed over the
+                         # step's kernels): an OFFLINE measurement, null unless it was taken on this build's kernel sources
+                         "traffic": tr["bytes"], "traffic_source": tr.get("source"), "traffic_stale": tr.get("stale"),
+                         "traffic_over_weights": round(tr["bytes"] / wbytes, 2) if tr["bytes"] else None,
+                         "traffic_over_weights_plus_kv": round(tr["bytes"] / (wbytes + kvbytes), 2) if tr["bytes"] else None}}
+
+
+@torch.no_grad()
+def decode_distinct_rows(model, prefix, beam, entry):
+    """Mean number of distinct (cache row, position) pairs — summed over the beam groups — that one generated position of the beam decode
+    attends to (what k_decode_attn_group reads per layer and K / V): one untimed decode with the ancestry tables inspected after every step."""
+    from clipcap_amd.engine import DecodeSession, beam_buffers, beam_step
+    lm = model.language_model
+    g = lm.engine
+    dev = prefix.device
+    S, L0, D = prefix.shape
+    R, V = S * beam, g.dims["V"]
+    wte = lm.get_input_embeddings().weight.detach()
+    scores = torch.zeros(R, device=dev)
+    seq_lengths = torch.ones(R, device=dev)
+    has_stopped = torch.zeros(R, dtype=torch.uint8, device=dev)
+    base = (torch.arange(S, device=dev, dtype=torch.int32) * beam).repeat_interleave(beam)
+    sess = DecodeSession(g, S, L0 + entry)
+    lg = torch.empty(R, V, device=dev)
+    lg[::beam] = sess.forward(prefix)
+    bufs = beam_buffers(dev, S, beam, V)
+    next_tok, src = beam_step(lg, S, beam, 1.0, True, 50256, scores, seq_lengths, has_stopped, bufs)
+    sess = sess.expand((base // beam).to(torch.int32), R)
+    tok = [torch.zeros(R, entry, dtype=torch.int32, device=dev) for _ in range(2)]
+    x = torch.empty(R, 1, D, device=dev)
+    sess.beam_advance(beam, next_tok, None, wte, 0, tok[1], tok[0], x)
+    total, n = 0.0, 0
+    for step in range(1, entry):
+        rm = sess.row_map[:, : sess.pos].view(S, beam, sess.pos).sort(dim=1).values
+        total += float((rm[:, 1:] != rm[:, :-1]).sum() + S * sess.pos + R)      # distinct old rows + the R new keys
+        n += 1
+        logits = sess.forward(x, partials=True, group=beam)
+        next_tok, src = beam_step(logits, S, beam, 1.0, False, 50256, scores, seq_lengths, has_stopped, bufs, sess.lpart)
+        sess.beam_advance(beam, next_tok, src, wte, step, tok[(step - 1) & 1], tok[step & 1], x)
+    return total / max(1, n)
 
 
 def sample_bench(args, device):
@@ -279,6 +374,45 @@ def mapper_bench(args, device):
                          "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": None}}
 
 
+def train_sub_bench(key, device, steps=12, warmup=3, repeats=3):
+    """One-GPU training step of another BASELINE configuration (configs[2]: full finetune of GPT-2-small, configs[3]: CLAP 1024-d ->
+    GPT-2-medium full finetune; GPT-2 train-mode dropout on, as the reference runs them) so that the driver's line times them too."""
+    from clipcap_amd.model.optim import linear_warmup_decay
+    c = dict(CONFIGS[key])
+    me, ge, eng = init_engines(c, device)
+    gen = torch.Generator(device=device).manual_seed(4321)
+    embeds = torch.randn(c["B"], c["E"], generator=gen, device=device)
+    tokens = torch.randint(1, c["V"], (c["B"], c["cap"]), generator=gen, device=device)
+    sched = linear_warmup_decay(2, 4 * (steps * repeats + warmup) + 64)
+
+    def one(i):
+        eng.zero_grad()
+        loss = eng.forward_backward(tokens, embeds, dropout=(0.1, 0.1, 0.1, 1000003 * (i + 1)) if c["train_lm"] else None)
+        eng.optimizer_step(2e-5 * sched(i), i + 1)
+        return loss
+
+    for i in range(warmup):
+        loss = one(i)
+    torch.cuda.synchronize()
+    each, i0 = [], warmup
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        for i in range(i0, i0 + steps):
+            loss = one(i)
+        torch.cuda.synchronize()
+        each.append((time.perf_counter() - t0) / steps * 1e3)
+        i0 += steps
+    ms = sorted(each)[len(each) // 2]
+    tf = step_flops(c) * c["B"] / (ms * 1e-3) / 1e12
+    out = {"workload": f"BASELINE configs[{int(key) - 1}]: {c['name']}", "per_gpu_batch": c["B"], "gpt2_dropout": 0.1 if c["train_lm"] else 0.0,
+           "ms_per_step": round(ms, 3), "ms_per_step_min": round(min(each), 3), "ms_per_step_max": round(max(each), 3), "regions": repeats,
+           "steps_per_region": steps, "samples_per_s": round(c["B"] / ms * 1e3, 1), "step_algorithmic_tflops": round(tf, 1),
+           "step_frac_of_bf16_peak": round(tf / PEAK_BF16_TFLOPS, 4), "final_loss": round(float(loss.item()), 4)}
+    del me, ge, eng
+    torch.cuda.empty_cache()
+    return out
+
+
 def executed_step_flops(c):
     """FLOPs the kernels actually run per sample: lm_head forward + dgrad (+wgrad) on the 40 caption rows the loss reads instead of
     all T = 50 (SURVEY.md 8d asks for the reduced figure to be stated next to the algorithmic one)."""
@@ -308,6 +442,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--regions", type=int, default=5,
+                    help="the timed region of exactly --steps steps is run this many times back to back (each bracketed by barrier + synchronize, "
+                         "max over ranks); ms_per_step / value are the MEDIAN region, min / max are reported beside it")
     ap.add_argument("--config", default="2", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
     ap.add_argument("--site", default="lmhead_fwd", help="single GEMM call site timed for the roofline_lmhead object")
@@ -318,13 +455,18 @@ def main():
                     help="N>1 collectives: torch.distributed (backend nccl = RCCL) or the library's own C-ABI RCCL communicator")
     ap.add_argument("--grad-wire", default="auto", choices=["auto", "fp32", "bf16"],
                     help="N>1: dtype of the gradient slices on the wire (bf16 halves the all-reduce bytes; the fp32 arena stays the accumulator). "
-                         "auto = bf16 for frozen-LM runs (41.7 M mapper gradients that only the short mapper backward can hide; "
-                         "tests/test_ddp_gloo.py: 8e-3 on the gradients, loss trajectories equal to 2e-3 over 20 steps), fp32 for a full finetune")
+                         "auto = bf16 for frozen-LM bf16 / fp16 runs (41.7 M mapper gradients that only the short mapper backward can hide; "
+                         "tests/test_ddp_gloo.py: 8e-3 on the gradients, loss trajectories equal to 2e-3 over 20 steps), fp32 for a full finetune "
+                         "and for the fp32-parity mode (--precision 32)")
     ap.add_argument("--no-roofline-pass", action="store_true",
                     help="skip the 25 extra event-bracketed steps (use under rocprofv3 --pmc, where every dispatch is serialised)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-sub-benches", action="store_true", help="skip the mapper / decode sub-objects of the default N=1 line")
+    ap.add_argument("--no-sub-benches", action="store_true", help="skip the mapper / decode / configs[2,3] sub-objects of the default N=1 line")
     ap.add_argument("--no-dropout", action="store_true", help="configs 3/4: run the full finetune without GPT-2 dropout")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: every rank walks THIS file's control flow (warm-up, timed regions, max-over-ranks, the no-all-reduce pass, the "
+                         "event-bracketed passes, process-group teardown, rank 0's sub-benches and CPU baseline) with a stub workload over gloo — "
+                         "what tests/test_ddp_gloo.py runs at 8 ranks to show that no rank is left waiting in a collective")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -333,7 +475,7 @@ def main():
         import socket
         import subprocess
         have = torch.cuda.device_count()
-        if have < args.gpus and "CC_BENCH_DEVICE" not in os.environ:
+        if have < args.gpus and "CC_BENCH_DEVICE" not in os.environ and not args.dry_run:
             sys.exit(f"bench.py: --gpus {args.gpus} requested but {have} GPU(s) visible; refusing to report a smaller run")
         with socket.socket() as sock:
             sock.bind(("127.0.0.1", 0))
@@ -347,16 +489,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    dry = args.dry_run
     # test hooks (single-GPU boxes): CC_BENCH_DEVICE pins every rank to one device, CC_BENCH_BACKEND=gloo replaces RCCL, so the
     # whole multi-rank flow of this file can be exercised where only one GPU exists.  Never set by the driver.
-    dev_index = int(os.environ.get("CC_BENCH_DEVICE", local))
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
+    if dry:
+        device = torch.device("cpu")
+    else:
+        dev_index = int(os.environ.get("CC_BENCH_DEVICE", local))
+        torch.cuda.set_device(dev_index)
+        device = torch.device("cuda", dev_index)
     backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = os.environ.get("CC_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+        backend = "gloo" if dry else os.environ.get("CC_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -373,60 +519,94 @@ def main():
     if args.grad_wire == "auto":      # clipcap_amd.train.train.grad_wire_dtype: fp32 in the fp32-parity mode and for a full finetune
         args.grad_wire = "fp32" if (c["train_lm"] or args.precision == "32") else "bf16"
 
-    from clipcap_amd import _lib
-    from clipcap_amd.train.ddp import GradReducer
-    from clipcap_amd.model.optim import linear_warmup_decay
-    me, ge, eng = init_engines(c, device)
-    if args.precision != "bf16":
-        me.set_precision(int(args.precision))
-        ge.set_precision(int(args.precision))
-    gen = torch.Generator(device=device).manual_seed(1234 + rank)
-    embeds = torch.randn(B, c["E"], generator=gen, device=device)
-    tokens = torch.randint(1, c["V"], (B, cap), generator=gen, device=device)
-    arenas = eng.arenas()
-    comm = None
-    if world > 1 and args.comm == "cabi":
-        from clipcap_amd.train.ddp import CAbiComm
-        comm = CAbiComm.from_process_group(device)
-    reducer = GradReducer([a.grads() for a in arenas], comm=comm,
-                          wire_dtype=torch.bfloat16 if args.grad_wire == "bf16" else torch.float32) if world > 1 else None
-    total_steps = args.steps + args.warmup
+    total_steps = args.steps * args.regions + args.warmup
     base_lr, warm = 2e-5, 2
-    sched = linear_warmup_decay(warm, 4 * total_steps + 64)
+    comm = None
+    if dry:
+        # stub workload: the same collectives in the same order as the real step (one gradient all-reduce per step when reducing), nothing else
+        arenas, lib, me, ge, eng = [], None, None, None, None
+        grad = torch.ones(1024)
 
-    def one_step(i, reduce=True):
-        eng.zero_grad()
-        # full finetune: GPT-2 train-mode dropout (p = 0.1 on embeddings, attention probabilities and both residual branches, the
-        # GPT2Config defaults the reference runs with), a new mask seed per step and rank
-        drop = (0.1, 0.1, 0.1, 1000003 * (i + 1) + rank) if (c["train_lm"] and not args.no_dropout) else None
-        if reducer and reduce:   # all-reduce of each layer slice starts as soon as its backward kernels are enqueued
-            reducer.begin()
-            loss = eng.forward_backward(tokens, embeds, reduce_stats=reducer.reduce_stats, on_grads_ready=reducer.on_grads_ready, dropout=drop)
-            reducer.finish()
-        else:
-            loss = eng.forward_backward(tokens, embeds, dropout=drop)
-        eng.optimizer_step(base_lr * sched(i), i + 1)
-        return loss
+        def one_step(i, reduce=True):
+            if world > 1 and reduce:
+                torch.distributed.all_reduce(grad)
+                grad.div_(world)
+            return torch.tensor(1.0)
 
-    def sync():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
+        def sync():
+            if world > 1:
+                torch.distributed.barrier()
+
+        def profile(n_steps, site, per_step, first_step):
+            for i in range(first_step, first_step + n_steps):
+                one_step(i)
+            sync()
+            return [1.0] * (per_step * n_steps), [1e9] * (per_step * n_steps)
+    else:
+        from clipcap_amd import _lib
+        from clipcap_amd.train.ddp import GradReducer
+        from clipcap_amd.model.optim import linear_warmup_decay
+        me, ge, eng = init_engines(c, device)
+        if args.precision != "bf16":
+            me.set_precision(int(args.precision))
+            ge.set_precision(int(args.precision))
+        gen = torch.Generator(device=device).manual_seed(1234 + rank)
+        embeds = torch.randn(B, c["E"], generator=gen, device=device)
+        tokens = torch.randint(1, c["V"], (B, cap), generator=gen, device=device)
+        arenas = eng.arenas()
+        if world > 1 and args.comm == "cabi":
+            from clipcap_amd.train.ddp import CAbiComm
+            comm = CAbiComm.from_process_group(device)
+        reducer = GradReducer([a.grads() for a in arenas], comm=comm,
+                              wire_dtype=torch.bfloat16 if args.grad_wire == "bf16" else torch.float32) if world > 1 else None
+        sched = linear_warmup_decay(warm, 4 * total_steps + 64)
+        lib = _lib.lib()
+
+        def one_step(i, reduce=True):
+            eng.zero_grad()
+            # full finetune: GPT-2 train-mode dropout (p = 0.1 on embeddings, attention probabilities and both residual branches, the
+            # GPT2Config defaults the reference runs with), a new mask seed per step and rank
+            drop = (0.1, 0.1, 0.1, 1000003 * (i + 1) + rank) if (c["train_lm"] and not args.no_dropout) else None
+            if reducer and reduce:   # all-reduce of each layer slice starts as soon as its backward kernels are enqueued
+                reducer.begin()
+                loss = eng.forward_backward(tokens, embeds, reduce_stats=reducer.reduce_stats, on_grads_ready=reducer.on_grads_ready, dropout=drop)
+                reducer.finish()
+            else:
+                loss = eng.forward_backward(tokens, embeds, dropout=drop)
+            eng.optimizer_step(base_lr * sched(i), i + 1)
+            return loss
+
+        def sync():
+            if world > 1:
+                torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+        def profile(n_steps, site, per_step, first_step):
+            return profile_sites(lib, one_step, sync, n_steps, site, per_step, first_step)
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return float(t.item())
 
     for i in range(args.warmup):
         loss = one_step(i)
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
-        loss = one_step(i)
-    sync()
-    dt = time.perf_counter() - t0
-    nxt = args.warmup + args.steps
+    nxt = args.warmup
+    region_s = []
+    for _ in range(max(1, args.regions)):
+        # one timed region: EXACTLY --steps steps between barrier + synchronize on both sides, max over ranks
+        sync()
+        t0 = time.perf_counter()
+        for i in range(nxt, nxt + args.steps):
+            loss = one_step(i)
+        sync()
+        region_s.append(max_over_ranks(time.perf_counter() - t0))
+        nxt += args.steps
+    dt = sorted(region_s)[len(region_s) // 2]
     exposed_ms = None
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
         # the same steps with the gradient all-reduce left out (timing only): the difference is the all-reduce time that backward
         # did not hide
         k2 = max(5, args.steps // 8)
@@ -435,12 +615,9 @@ def main():
         for i in range(nxt, nxt + k2):
             one_step(i, reduce=False)
         sync()
-        t2 = torch.tensor([(time.perf_counter() - t1) / k2], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t2, op=torch.distributed.ReduceOp.MAX)
-        exposed_ms = max(0.0, dt / args.steps - float(t2.item())) * 1e3
+        exposed_ms = max(0.0, dt / args.steps - max_over_ranks((time.perf_counter() - t1) / k2)) * 1e3
         nxt += k2
     ms_per_step = dt / args.steps * 1e3
-    lib = _lib.lib()
     T, D, Mc, M = c["L"] + cap, c["D"], B * cap, B * (c["L"] + cap)
     S = c["P"] + c["L"]
     roof = {}
@@ -450,21 +627,25 @@ def main():
         n_prof = 5
         default_cfg = args.config == "2" and not args.batch and args.precision == "bf16"
         per_step_cap = 64 + 24 * c["N"] + 16 * c["n_layer"]
-        ms, fl = profile_sites(lib, one_step, sync, n_prof, "all_gemms", per_step_cap, nxt)
+        ms, fl = profile(n_prof, "all_gemms", per_step_cap, nxt)
         nxt += n_prof
         gemm_ms, gemm_fl = sum(ms), sum(fl)
         fam = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        tr = pmc_constant("train_gemm_bytes_per_step") if default_cfg else {"bytes": None, "source": None, "stale": "offline pass is for the default configuration"}
+        alg = gemm_family_algorithmic_bytes(c)
         roof["roofline"] = {"bound": "mfma", "kernel": "bf16 MFMA GEMM family (gemm.hip.h: every NT / TT / lm_head launch of the step)",
                            "achieved": round(fam, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fam / PEAK_BF16_TFLOPS, 4),
                            "launches_per_step": len(ms) // n_prof, "avg_launch_ms": round(gemm_ms / max(1, len(ms)), 4),
                            "time_share_of_step": round(gemm_ms / n_prof / ms_per_step, 3),
                            "flops_per_step": gemm_fl / n_prof,
-                           "traffic": GEMM_TRAFFIC["bytes"] if default_cfg else None, "traffic_source": GEMM_TRAFFIC["source"] if default_cfg else None,
+                           "algorithmic_bytes": alg["total"], "algorithmic_bytes_by_part": {k: v for k, v in alg.items() if k != "total"},
+                           "traffic": tr["bytes"], "traffic_source": tr.get("source"), "traffic_stale": tr.get("stale"),
+                           "traffic_over_algorithmic": round(tr["bytes"] / alg["total"], 2) if tr["bytes"] else None,
                            "traffic_note": "HBM bytes of all GEMM launches of one step (per step, not per launch)"}
         # ---- second entry: the largest single launch (lm_head forward) at its own call site, 20 extra steps ----
         per_step = {"lmhead_fwd": 1, "lmhead_dgrad": 1, "gpt2_fc_fwd": c["n_layer"], "gpt2_proj2_fwd": c["n_layer"], "gpt2_fc_dgrad": c["n_layer"],
                     "mapper_fc1_fwd": c["N"], "mapper_qkv_fwd": c["N"], "mapper_wgrad_fc2": c["N"]}[args.site]
-        ms, _ = profile_sites(lib, one_step, sync, 20, args.site, per_step, nxt)
+        ms, _ = profile(20, args.site, per_step, nxt)
         nxt += 20
         avg_ms = sum(ms) / max(1, len(ms))
         site_flops = {"lmhead_fwd": 2.0 * Mc * c["V"] * D, "lmhead_dgrad": 2.0 * Mc * c["V"] * D, "gpt2_fc_fwd": 2.0 * M * D * 4 * D,
@@ -472,16 +653,22 @@ def main():
                       "mapper_qkv_fwd": 2.0 * B * S * D * 3 * D, "mapper_wgrad_fc2": 2.0 * B * S * D * 2 * D}[args.site]
         ach = site_flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         default_site = args.site == "lmhead_fwd" and args.config == "2" and not args.batch
+        trl = pmc_constant("lmhead_fwd_bytes_per_launch") if default_site else {"bytes": None, "source": None, "stale": "offline pass is for the default call site"}
         roof["roofline_lmhead" if args.site == "lmhead_fwd" else "roofline_site"] = {
             "bound": "mfma", "kernel": ("gemm_nt_stag256_kernel<EpiLMHeadExp,4,false,10> (320x256 tiles, exponential-form epilogue)" if args.site == "lmhead_fwd" else "NT GEMM") + f" @ {args.site}",
             "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
             "avg_launch_ms": round(avg_ms, 4), "launches": len(ms), "time_share_of_step": round(avg_ms * per_step / ms_per_step, 3),
-            "traffic": LMHEAD_TRAFFIC["bytes"] if default_site else None, "traffic_source": LMHEAD_TRAFFIC["source"] if default_site else None,
+            "traffic": trl["bytes"], "traffic_source": trl.get("source"), "traffic_stale": trl.get("stale"),
             "algorithmic_bytes": int(2 * (Mc * D + c["V"] * D + Mc * ((c["V"] + 127) // 128 * 128)) + 8 * Mc * ((c["V"] + 127) // 128 * 2))
             if args.site == "lmhead_fwd" else None}
+    # every collective of the run is behind us: all ranks leave the process group NOW, so that rank 0's single-rank extras (sub-benches,
+    # the CPU baseline: minutes) cannot leave the others waiting in a collective or a teardown barrier
+    rccl_ranks = None
+    if world > 1:
+        rccl_ranks = (comm.count() if comm is not None else torch.distributed.get_world_size()) if backend == "nccl" else 0
+        torch.distributed.destroy_process_group()
+        print(f"[bench rank {rank}] left the process group", file=sys.stderr, flush=True)
     if rank != 0:
-        if world > 1:
-            torch.distributed.destroy_process_group()
         return
     value = B * world * args.steps / dt
     step_tflops = step_flops(c) * B * world * args.steps / dt / 1e12
@@ -493,58 +680,81 @@ def main():
         "config": {"workload": f"BASELINE configs[{int(args.config) - 1}]: {c['name']}", "per_gpu_batch": B, "global_batch": B * world,
                    "caption_tokens": cap, "encoder_dim": c["E"], "train_language_model": c["train_lm"],
                    "parallelism": f"dp{world}", "final_loss": round(float(loss.item()), 4)},
+        "timed_regions": {"regions": len(region_s), "steps_per_region": args.steps, "statistic": "median region (ms_per_step, value)",
+                          "ms_per_step_each": [round(r / args.steps * 1e3, 3) for r in region_s],
+                          "ms_per_step_min": round(min(region_s) / args.steps * 1e3, 3), "ms_per_step_max": round(max(region_s) / args.steps * 1e3, 3)},
         "step_algorithmic_tflops": round(step_tflops, 1),
         "step_executed_tflops": round(exec_tflops, 1),
         "step_frac_of_bf16_peak": round(step_tflops / (PEAK_BF16_TFLOPS * world), 4),
         "step_executed_frac_of_bf16_peak": round(exec_tflops / (PEAK_BF16_TFLOPS * world), 4),
     }
+    if dry:
+        out["dry_run"] = True
+        out["data"] = "none (dry run: stub workload, control flow only)"
     if world > 1:
-        out["rccl_ranks"] = (comm.count() if comm is not None else torch.distributed.get_world_size()) if backend == "nccl" else 0
+        out["rccl_ranks"] = rccl_ranks
         out["collective_backend"] = "rccl (C ABI cc_allreduce_bucket)" if comm is not None else ("rccl" if backend == "nccl" else backend)
         out["allreduce_exposed_ms"] = round(exposed_ms, 3)
         out["gradient_payload_bytes"] = int(sum(a.n for a in arenas) * (2 if args.grad_wire == "bf16" else 4))
         out["gradient_wire_dtype"] = args.grad_wire
     out.update(roof)
-    if world == 1:
-        if not args.no_sub_benches:
-            # north_star sub-targets in the same line: mapping-transformer fwd+bwd alone (target >= 40 % of the bf16 peak at batch 256)
-            # and KV-cached beam decode (BASELINE configs[4])
-            sub = argparse.Namespace(config=args.config if args.config in ("2", "3", "4") else "2", batch=0, steps=100, warmup=5)
-            mb = mapper_bench(sub, device)
-            out["mapper"] = {"ms_fwd_bwd": mb["ms_per_step"], "samples_per_s": mb["value"], "tflops": mb["roofline"]["achieved"],
-                             "frac_of_bf16_peak": mb["roofline"]["frac"], "target_frac": 0.40, "batch": CONFIGS[sub.config]["B"]}
-            del mb
+    if dry:
+        # rank 0's single-rank extras, stubbed to a pause of the same order as the collectives' timeouts would need to survive
+        time.sleep(float(os.environ.get("CC_BENCH_DRY_EXTRAS_S", "2.0")))
+        out["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port", "sample": "dry run"}
+        print(json.dumps(out))
+        return
+    if world == 1 and not args.no_sub_benches:
+        # north_star sub-targets in the same line: mapping-transformer fwd+bwd alone (target >= 40 % of the bf16 peak at batch 256), the
+        # same at 4x / 16x the batch (is the limiter the problem size or the kernels?), and KV-cached beam decode (BASELINE configs[4])
+        key = args.config if args.config in ("2", "3", "4") else "2"
+        sub = argparse.Namespace(config=key, batch=0, steps=100, warmup=5)
+        mb = mapper_bench(sub, device)
+        out["mapper"] = {"ms_fwd_bwd": mb["ms_per_step"], "samples_per_s": mb["value"], "tflops": mb["roofline"]["achieved"],
+                         "frac_of_bf16_peak": mb["roofline"]["frac"], "target_frac": 0.40, "batch": CONFIGS[key]["B"], "batch_sweep": []}
+        for bsz, st_ in ((1024, 30), (4096, 10)):
+            mbs = mapper_bench(argparse.Namespace(config=key, batch=bsz, steps=st_, warmup=3), device)
+            out["mapper"]["batch_sweep"].append({"batch": bsz, "ms_fwd_bwd": mbs["ms_per_step"], "tflops": mbs["roofline"]["achieved"],
+                                                 "frac_of_bf16_peak": mbs["roofline"]["frac"]})
+            del mbs
             torch.cuda.empty_cache()
-            db = decode_bench(argparse.Namespace(batch=0, steps=4, warmup=1), device)
-            out["decode"] = {"metric": db["metric"], "tokens_per_s": db["value"], "beam_tokens_per_s": db["beam_tokens_per_s"],
-                             "ms_per_batch": db["ms_per_step"], "config": db["config"]["workload"], "roofline": db["roofline"]}
-        if not args.no_sub_benches and args.precision == "bf16":
-            # the same step in the parity mode (--fp-precision 32, the reference's default: split-bf16 operands, logits within 1e-3 of
-            # the fp32 reference at full depth) next to the bf16 headline
-            torch.cuda.empty_cache()
-            me.set_precision(32)
-            ge.set_precision(32)
-            for i in range(nxt, nxt + 3):
-                one_step(i)
-            sync()
-            t0 = time.perf_counter()
-            k3 = 20
-            for i in range(nxt + 3, nxt + 3 + k3):
-                loss3 = one_step(i)
-            sync()
-            ms3 = (time.perf_counter() - t0) / k3 * 1e3
-            out["fp32_parity_mode"] = {"operands": "split bf16 (hi*hi + hi*lo + lo*hi), fp32 activations", "flag": "--fp-precision 32",
-                                       "ms_per_step": round(ms3, 3), "samples_per_s": round(B / ms3 * 1e3, 1), "steps": k3,
-                                       "slowdown_vs_bf16": round(ms3 / ms_per_step, 2), "final_loss": round(float(loss3.item()), 4)}
-            me.set_precision("bf16")
-            ge.set_precision("bf16")
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(c)
-            if not args.no_sub_benches:
-                out["cpu_decode_baseline"] = cpu_decode_baseline()
+        del mb
+        torch.cuda.empty_cache()
+        db = decode_bench(argparse.Namespace(batch=0, steps=4, warmup=1), device)
+        out["decode"] = {"metric": db["metric"], "tokens_per_s": db["value"], "beam_tokens_per_s": db["beam_tokens_per_s"],
+                         "ms_per_batch": db["ms_per_step"], "config": db["config"]["workload"], "roofline": db["roofline"]}
+        del db
+        torch.cuda.empty_cache()
+        if args.config == "2" and not args.batch and args.precision == "bf16":
+            # the other single-GPU-sized BASELINE training configurations, timed by the same run
+            out["config3_full_finetune_small"] = train_sub_bench("3", device)
+            out["config4_clap_gpt2_medium"] = train_sub_bench("4", device)
+    if world == 1 and not args.no_sub_benches and args.precision == "bf16":
+        # the same step in the parity mode (--fp-precision 32, the reference's default: split-bf16 operands, logits within 1e-3 of
+        # the fp32 reference at full depth) next to the bf16 headline
+        torch.cuda.empty_cache()
+        me.set_precision(32)
+        ge.set_precision(32)
+        for i in range(nxt, nxt + 3):
+            one_step(i)
+        sync()
+        t0 = time.perf_counter()
+        k3 = 20
+        for i in range(nxt + 3, nxt + 3 + k3):
+            loss3 = one_step(i)
+        sync()
+        ms3 = (time.perf_counter() - t0) / k3 * 1e3
+        out["fp32_parity_mode"] = {"operands": "split bf16 (hi*hi + hi*lo + lo*hi), fp32 activations", "flag": "--fp-precision 32",
+                                   "ms_per_step": round(ms3, 3), "samples_per_s": round(B / ms3 * 1e3, 1), "steps": k3,
+                                   "slowdown_vs_bf16": round(ms3 / ms_per_step, 2), "final_loss": round(float(loss3.item()), 4)}
+        me.set_precision("bf16")
+        ge.set_precision("bf16")
+    if not args.no_cpu_baseline:
+        # rank 0, after the process group is gone (N > 1) — the other ranks have exited
+        out["cpu_baseline"] = cpu_baseline(c)
+        if world == 1 and not args.no_sub_benches:
+            out["cpu_decode_baseline"] = cpu_decode_baseline()
     print(json.dumps(out))
-    if world > 1:
-        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -103,6 +103,8 @@ SIGNATURES = {
     "cc_adamw_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P, _P, _P]),
     "cc_adamw_step_cast": (_I, [_I, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P, _P, _P, _P]),
     "cc_cast_op16": (_I, [_I, _P, _P, _L, _P]),
+    "cc_grad_wire_pack": (_I, [_P, _P, _L, _P]),
+    "cc_grad_wire_unpack": (_I, [_P, _P, _L, _P]),
     "cc_grad_nonfinite": (_I, [_P, _L, _P, _P]),
     "cc_loss_scale_update": (_I, [_P, _P, _F, _F, _I, _P]),
     "cc_dropout_mask": (_I, [C.c_uint64, _I, _I, _F, _L, _P, _P]),

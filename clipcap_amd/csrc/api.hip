@@ -908,6 +908,16 @@ int CC_API(cc_cast_op16)(const float* src, uint16_t* dst, int64_t n, void* strea
     return f32_to_bf16(src, dst, (size_t)n, S_(stream));
 }
 
+int CC_API(cc_grad_wire_pack)(const float* g32, uint16_t* wire, int64_t n, void* stream) {
+    if (!g32 || !wire || n < 0) return CC_ERR_ARG;
+    return wire_pack(g32, wire, (size_t)n, S_(stream));
+}
+
+int CC_API(cc_grad_wire_unpack)(const uint16_t* wire, float* g32, int64_t n, void* stream) {
+    if (!g32 || !wire || n < 0) return CC_ERR_ARG;
+    return wire_unpack(wire, g32, (size_t)n, S_(stream));
+}
+
 int CC_API(cc_grad_nonfinite)(const float* g32, int64_t n, float* found_inf, void* stream) {
     if (!g32 || !found_inf || n < 0) return CC_ERR_ARG;
     return grad_nonfinite(g32, (size_t)n, found_inf, S_(stream));

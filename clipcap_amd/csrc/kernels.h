@@ -8,7 +8,9 @@
 namespace CC_NS {
 
 int f32_to_bf16(const float* src, op16_t* dst, size_t n, hipStream_t st);      // 16-bit operand cast (weights)
-int f32_to_act(const float* src, act_t* dst, size_t n, hipStream_t st);         // fp32 -> stored-activation type (a copy in the bf16x3 build)
+int f32_to_act(const float* src, act_t* dst, size_t n, hipStream_t st);
+int wire_pack(const float* src, unsigned short* dst, size_t n, hipStream_t st);        // fp32 -> bf16 gradient wire slice (any n / alignment)
+int wire_unpack(const unsigned short* src, float* dst, size_t n, hipStream_t st);      // and back         // fp32 -> stored-activation type (a copy in the bf16x3 build)
 int slice_f32_to_bf16(const float* src, size_t src_stride, act_t* dst, size_t dst_stride, int len, int B, hipStream_t st);
 int broadcast_rows(float* dst, size_t dst_stride, const float* src, int len, int B, hipStream_t st);
 int add_rows(float* dst, size_t dst_stride, const float* add, int len, int B, hipStream_t st);

@@ -25,6 +25,45 @@ int f32_to_bf16(const float* src, op16_t* dst, size_t n, hipStream_t st) {
     return CC_OK;
 }
 
+// gradient wire format of the N-rank all-reduce (train/ddp.py, bf16 wire): fp32 arena slice <-> bf16 staging slice, any length / alignment
+// (a layer's slice starts wherever its first parameter does).  Always bf16 (round to nearest even), whatever the operand build.
+__device__ __forceinline__ unsigned short wire_bf16(float f) {
+    const unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);      // NaN stays NaN
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__global__ void k_wire_pack(const float* __restrict__ src, unsigned short* __restrict__ dst, size_t n) {
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
+        if (i + 4 <= n && ((reinterpret_cast<size_t>(src + i) & 15) == 0) && ((reinterpret_cast<size_t>(dst + i) & 7) == 0)) {
+            const float4 a = *reinterpret_cast<const float4*>(src + i);
+            *reinterpret_cast<uint2*>(dst + i) = make_uint2(wire_bf16(a.x) | ((unsigned)wire_bf16(a.y) << 16), wire_bf16(a.z) | ((unsigned)wire_bf16(a.w) << 16));
+        } else {
+            for (size_t j = i; j < n && j < i + 4; j++) dst[j] = wire_bf16(src[j]);
+        }
+    }
+}
+__global__ void k_wire_unpack(const unsigned short* __restrict__ src, float* __restrict__ dst, size_t n) {
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
+        if (i + 4 <= n && ((reinterpret_cast<size_t>(dst + i) & 15) == 0) && ((reinterpret_cast<size_t>(src + i) & 7) == 0)) {
+            const uint2 a = *reinterpret_cast<const uint2*>(src + i);
+            *reinterpret_cast<float4*>(dst + i) = make_float4(__uint_as_float(a.x << 16), __uint_as_float(a.x & 0xffff0000u), __uint_as_float(a.y << 16),
+                                                              __uint_as_float(a.y & 0xffff0000u));
+        } else {
+            for (size_t j = i; j < n && j < i + 4; j++) dst[j] = __uint_as_float((unsigned)src[j] << 16);
+        }
+    }
+}
+int wire_pack(const float* src, unsigned short* dst, size_t n, hipStream_t st) {
+    if (!n) return CC_OK;
+    hipLaunchKernelGGL(k_wire_pack, dim3((int)std::min<size_t>((n / 4 + 255) / 256 + 1, 2048)), dim3(256), 0, st, src, dst, n);
+    return CC_OK;
+}
+int wire_unpack(const unsigned short* src, float* dst, size_t n, hipStream_t st) {
+    if (!n) return CC_OK;
+    hipLaunchKernelGGL(k_wire_unpack, dim3((int)std::min<size_t>((n / 4 + 255) / 256 + 1, 2048)), dim3(256), 0, st, src, dst, n);
+    return CC_OK;
+}
+
 int f32_to_act(const float* src, act_t* dst, size_t n, hipStream_t st) {
     if constexpr (kX3) {
         if (!n) return CC_OK;

@@ -87,6 +87,23 @@ class CAbiComm:
             pass
 
 
+def _wire_cast(src: torch.Tensor, dst: torch.Tensor) -> None:
+    """fp32 <-> bf16 gradient slice on the current stream: the library's cc_grad_wire_pack / _unpack on the GPU (PyTorch is plumbing
+    there, not arithmetic); on CPU tensors (the gloo tests) torch's own cast — both round to nearest even, bit-identical."""
+    if src.numel() == 0:
+        return
+    if src.is_cuda:
+        from clipcap_amd import _lib
+        import ctypes as C
+        st = C.c_void_p(torch.cuda.current_stream(src.device).cuda_stream)
+        if src.dtype == torch.float32:
+            _lib.check(_lib.lib().cc_grad_wire_pack(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), src.numel(), st), "cc_grad_wire_pack")
+        else:
+            _lib.check(_lib.lib().cc_grad_wire_unpack(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), src.numel(), st), "cc_grad_wire_unpack")
+    else:
+        dst.copy_(src)
+
+
 class GradReducer:
     """Bucketed SUM all-reduce of flat gradient arenas plus the loss-statistics reduction.  Collectives go through torch.distributed
     (backend "nccl" = RCCL) or, with ``comm=CAbiComm(...)``, through the library's own C-ABI communicator."""
@@ -146,7 +163,7 @@ class GradReducer:
             return
         if self.stage is not None:
             st = self.stage[arena][lo:hi]
-            st.copy_(self.flats[arena][lo:hi])                                   # fp32 -> bf16 on the compute stream
+            _wire_cast(self.flats[arena][lo:hi], st)                             # fp32 -> bf16 on the compute stream (one library launch)
             if self.comm is not None:
                 side = self.comm.stream
                 side.wait_stream(torch.cuda.current_stream(self.comm.device))
@@ -175,7 +192,7 @@ class GradReducer:
         for arena, lo, hi, work in self._pending:                                # widen the reduced bf16 slices back into fp32
             if work is not None:
                 work.wait()
-            self.flats[arena][lo:hi].copy_(self.stage[arena][lo:hi])
+            _wire_cast(self.stage[arena][lo:hi], self.flats[arena][lo:hi])
         self._pending = []
         for f, c in zip(self.flats, self._covered):
             assert c == f.numel(), f"overlapped all-reduce covered {c} of {f.numel()} gradient elements"

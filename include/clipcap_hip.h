@@ -55,7 +55,7 @@ extern "C" {
  * cc_adamw_step / cc_adamw_step_cast accept step == 0 (= take the step number from loss_scale[2]) — a version-2 caller passing float[2]
  * would be written out of bounds, so clipcap_amd/_lib.py refuses a library whose version differs.  Entry points ADDED since 2:
  * cc_adamw_step_cast, cc_mapper_transpose_weights, cc_gpt2_transpose_weights, cc_comm_count, cc_decode_part_floats, cc_decode_fwd_p,
- * cc_beam_step_p; since 3: cc_decode_fwd_g, cc_decode_ws_check; operand mode ADDED: CC_OP_BF16X3 */
+ * cc_beam_step_p; since 3: cc_decode_fwd_g, cc_decode_ws_check, cc_decode_mode, cc_grad_wire_pack, cc_grad_wire_unpack; operand mode ADDED: CC_OP_BF16X3 */
 #define CC_ABI_VERSION 3
 int cc_abi_version(void);
 
@@ -279,6 +279,11 @@ int cc_adamw_step_cast(int32_t op_dtype, float* p32, const float* g32, float* m,
                        uint16_t* w16, void* stream);
 /* dst = cast of src to the 16-bit operand type op_dtype */
 int cc_cast_op16(int32_t op_dtype, const float* src, uint16_t* dst, int64_t n, void* stream);
+/* bf16 gradient wire of the N-rank all-reduce (train/train.py:77-85 runs DDP; clipcap_amd/train/ddp.py): wire[0:n] = bf16(g32[0:n]) (round to
+ * nearest even) before the collective, g32[0:n] = fp32(wire[0:n]) after it.  Any n and any element alignment (a layer's gradient slice
+ * starts wherever its first parameter does); always bf16, whatever the operand mode. */
+int cc_grad_wire_pack(const float* g32, uint16_t* wire, int64_t n, void* stream);
+int cc_grad_wire_unpack(const uint16_t* wire, float* g32, int64_t n, void* stream);
 /* Dynamic loss scaling for CC_OP_FP16 training (torch.cuda.amp.GradScaler semantics; what Lightning wraps around the reference's
  * model when --fp-precision 16, clipcap/train/train.py:77-85), entirely on the device:
  *   cc_grad_nonfinite: *found_inf = 1 if any of the n gradients is inf / nan (never clears it; call once per arena, after the

@@ -55,7 +55,7 @@ def _write_model(tmp_path, device="cpu"):
     os.makedirs(lm_dir)
     V = _byte_level_tokenizer_files(str(lm_dir))
     torch.manual_seed(5)
-    lm = GPT2LM(n_embd=64, n_layer=2, n_head=4, vocab_size=V, n_positions=64)
+    lm = GPT2LM(n_embd=64, n_layer=2, n_head=4, vocab_size=V, n_positions=128)
     lm.save_pretrained(str(lm_dir))
     cfg = Config(language_model=str(lm_dir), prefix_length=3, projection_length=2, transformer_layers=2, transformer_attention_heads=4,
                  encoder_config=EncoderConfig(encoder_model_name="clip", encoder_model_variant="ViT-L_14", encoder_embedding_size=24))

@@ -168,3 +168,31 @@ def test_twenty_step_loss_trajectory_bf16_wire_follows_fp32_wire(tmp_path):
     assert a[-5:].mean() < a[:5].mean() - 0.05                  # it trains
     assert np.abs(a - b).max() <= 2e-3 * np.abs(a).max(), np.abs(a - b).max()
     assert np.abs(a - b).max() <= 0.1 * np.abs(np.diff(a)).mean() + 1e-4 or np.abs(a - b).max() <= 1e-3
+
+
+def test_bench_eight_rank_dry_run_every_rank_leaves_before_rank_zero_extras():
+    """no 8-GPU node exists for this build, so the first 8-rank run of bench.py must not be the first time its control flow
+    executes.  `bench.py --gpus 8 --dry-run` walks the real flow of that file (warm-up, timed regions with max-over-ranks, the
+    no-all-reduce pass, both event-bracketed passes, teardown) over gloo with a stub step; rank 0 then spends seconds alone in its
+    single-rank extras.  Every rank must have left the process group BEFORE that, the run must end cleanly and print ONE 8-rank line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CC_BENCH_DRY_EXTRAS_S="3.0")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    t0 = __import__("time").time()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-run", "--steps", "3", "--warmup", "1", "--regions", "3"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    left = [ln for ln in out.stderr.splitlines() if "left the process group" in ln]
+    assert sorted(left) == sorted(f"[bench rank {r}] left the process group" for r in range(8)), left
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["dry_run"] is True and d["config"]["global_batch"] == 8 * 256 and d["config"]["parallelism"] == "dp8"
+    assert d["timed_regions"]["regions"] == 3 and len(d["timed_regions"]["ms_per_step_each"]) == 3
+    assert d["timed_regions"]["ms_per_step_min"] <= d["ms_per_step"] <= d["timed_regions"]["ms_per_step_max"]
+    assert "cpu_baseline" in d and "allreduce_exposed_ms" in d and d["collective_backend"] == "gloo"
+    print(f"8-rank dry run: {__import__('time').time() - t0:.1f} s")

@@ -166,3 +166,22 @@ def test_two_rank_rccl_step_equals_single_process(tmp_path):
     for i, a in enumerate(eng.arenas()):
         ref = a.g32.cpu().numpy()
         assert np.linalg.norm(res[f"g{i}"] - ref) / np.linalg.norm(ref) <= 2e-2
+
+
+def test_gradient_wire_kernels_equal_torch_casts_at_any_alignment():
+    """cc_grad_wire_pack / _unpack (the bf16 wire of GradReducer on the GPU): bit-identical to torch's fp32 -> bf16 -> fp32 casts for odd
+    lengths, slices that start at odd element offsets, denormals, infinities and NaN."""
+    from clipcap_amd.train.ddp import _wire_cast
+    torch.manual_seed(0)
+    base = torch.randn(100_003, device="cuda") * torch.logspace(-30, 30, 100_003, device="cuda")
+    base[17] = float("inf"); base[18] = float("-inf"); base[19] = float("nan"); base[20] = 1e-41; base[21] = 0.0
+    stage = torch.empty(100_003, dtype=torch.bfloat16, device="cuda")
+    back = torch.full((100_003,), 7.0, device="cuda")
+    for lo, hi in ((0, 100_003), (1, 9), (3, 100_000), (5, 6), (8, 4104), (2, 2)):
+        _wire_cast(base[lo:hi], stage[lo:hi])
+        want = base[lo:hi].to(torch.bfloat16)
+        assert torch.equal(stage[lo:hi].view(torch.int16), want.view(torch.int16)) or \
+            torch.equal(torch.nan_to_num(stage[lo:hi].float(), nan=123.0), torch.nan_to_num(want.float(), nan=123.0)), (lo, hi)
+        _wire_cast(stage[lo:hi], back[lo:hi])
+        assert torch.equal(torch.nan_to_num(back[lo:hi], nan=123.0), torch.nan_to_num(want.float(), nan=123.0)), (lo, hi)
+    assert float(back[100_002]) == float(base[100_002].to(torch.bfloat16).float())

@@ -8,7 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-TRAIN="python $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-sub-benches"
+TRAIN="python $ROOT/bench.py --steps 8 --warmup 2 --regions 1 --no-cpu-baseline --no-sub-benches"
 run_trace() {  # name, command...
     local name=$1; shift
     rm -rf $OUT/prof_$name
@@ -19,19 +19,23 @@ run_trace() {  # name, command...
 run_trace train $TRAIN
 run_trace mapper python $ROOT/bench.py --mode mapper --steps 10 --warmup 3
 run_trace decode python $ROOT/bench.py --mode decode --steps 1 --warmup 1
+# counter passes: one TCC counter per pass; the databases are kept until pmc_constants.py has read them
 for ctr in FETCH_SIZE WRITE_SIZE; do
-    rm -rf $OUT/prof_pmc
-    rocprofv3 --kernel-trace --pmc $ctr --output-format rocpd -d $OUT/prof_pmc -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-sub-benches --no-roofline-pass > /dev/null 2>&1
-    python $ROOT/tools/rocpd_pmc.py $(find $OUT/prof_pmc -name "*.db" | head -1) > $OUT/${TAG}_pmc_$ctr.txt
-    rm -rf $OUT/prof_pmc
+    rm -rf $OUT/prof_pmc_train_$ctr
+    rocprofv3 --kernel-trace --pmc $ctr --output-format rocpd -d $OUT/prof_pmc_train_$ctr -- python $ROOT/bench.py --steps 2 --warmup 1 --regions 1 --no-cpu-baseline --no-sub-benches --no-roofline-pass > /dev/null 2>&1
+    python $ROOT/tools/rocpd_pmc.py $(find $OUT/prof_pmc_train_$ctr -name "*.db" | head -1) > $OUT/${TAG}_pmc_$ctr.txt
 done
-# decode: the same two counter passes on the beam-5 decode (per generated position = totals / (2 decodes x 67 positions))
+# decode: the same two counter passes on the beam-5 decode (bench.py --mode decode --steps 1 --warmup 1 = 3 decodes: warm-up, timed, and the
+# untimed one that counts the distinct KV rows; per generated position = totals / (3 decodes x 67 positions))
 for ctr in FETCH_SIZE WRITE_SIZE; do
-    rm -rf $OUT/prof_pmc
-    rocprofv3 --kernel-trace --pmc $ctr --output-format rocpd -d $OUT/prof_pmc -- python $ROOT/bench.py --mode decode --steps 1 --warmup 1 > /dev/null 2>&1
-    python $ROOT/tools/rocpd_pmc.py $(find $OUT/prof_pmc -name "*.db" | head -1) > $OUT/${TAG}_decode_pmc_$ctr.txt
-    rm -rf $OUT/prof_pmc
+    rm -rf $OUT/prof_pmc_decode_$ctr
+    rocprofv3 --kernel-trace --pmc $ctr --output-format rocpd -d $OUT/prof_pmc_decode_$ctr -- python $ROOT/bench.py --mode decode --steps 1 --warmup 1 > /dev/null 2>&1
+    python $ROOT/tools/rocpd_pmc.py $(find $OUT/prof_pmc_decode_$ctr -name "*.db" | head -1) > $OUT/${TAG}_decode_pmc_$ctr.txt
 done
+python $ROOT/tools/pmc_constants.py $TAG $(find $OUT/prof_pmc_train_FETCH_SIZE -name "*.db" | head -1) $(find $OUT/prof_pmc_train_WRITE_SIZE -name "*.db" | head -1) 3 \
+    $(find $OUT/prof_pmc_decode_FETCH_SIZE -name "*.db" | head -1) $(find $OUT/prof_pmc_decode_WRITE_SIZE -name "*.db" | head -1) 3 67 > $OUT/${TAG}_pmc_constants.json
+cp $ROOT/profiles/pmc_constants.json $OUT/pmc_constants.json
+rm -rf $OUT/prof_pmc_train_* $OUT/prof_pmc_decode_*
 # the training step in the split-bf16 (fp32 parity) mode
 run_trace x3_train python $ROOT/bench.py --precision 32 --steps 6 --warmup 2 --no-cpu-baseline --no-sub-benches --no-roofline-pass
 cd $ROOT
