@@ -31,7 +31,8 @@ def op_dtype_of(precision) -> int:
 
     * 32 (the reference's default) / 64 / "32" / "bf16x3": split bf16 operands — every GEMM as three bf16 MFMA terms
       (hi*hi + hi*lo + lo*hi), fp32 activations and attention: logits within 1e-3 of the fp32 reference at full depth, about a third
-      of the GEMM rate.  MI355X has no fp32 / fp64 matrix path, so 64 runs the same mode.
+      of the GEMM rate.  (gfx950's fp32 MFMA, v_mfma_f32_32x32x2_f32, runs at 1/16 of the bf16 rate — three bf16 terms are ~5x
+      faster than it; 64 runs the same mode: ~16 mantissa bits per operand, fp32 accumulation.)
     * 16 / "fp16": IEEE fp16 operands + dynamic loss scaling (what Lightning gives the reference for --fp-precision 16).
     * "bf16" (or None, the engines' own default = BASELINE.json's bf16 configurations): bf16 operands, the throughput mode.
 

@@ -17,7 +17,7 @@
 #define CC_API(name) name##_f16
 #elif CC_OP == 2
 // CC_OP = 2, "bf16x3" (namespace cc_x3, <name>_x3): the reference's DEFAULT precision (`--fp-precision 32`, clipcap/train/args.py:30-34,
-// train.py:82).  gfx950 has no fp32 / xf32 MFMA, so every GEMM operand x is split into bf16 hi = bf16(x) and lo = bf16(x - hi) and a
+// train.py:82).  gfx950's fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at 1/16 of the bf16 rate and there is no xf32, so every GEMM operand x is split into bf16 hi = bf16(x) and lo = bf16(x - hi) and a
 // product runs as three bf16 MFMA terms hi*hi + hi*lo + lo*hi with fp32 accumulation (~16 mantissa bits per operand, 1/3 of the bf16
 // MFMA rate).  Realised without touching the GEMM main loops: the A operand is laid out [hi | hi | lo] and the B operand [hi | lo | hi]
 // along K, i.e. the same NT kernels run with K' = 3K (gemm_x3.hip.h).  Activations between kernels are stored as fp32 (act_t) and split

@@ -22,7 +22,7 @@
  *     cc_grad_nonfinite, cc_loss_scale_update, cc_adamw_step) exactly as torch.cuda.amp.GradScaler does for the
  *     reference's Lightning fp16 path.
  *     CC_OP_BF16X3 is the reference's DEFAULT precision (`--fp-precision 32`, clipcap/train/args.py:30-34, train.py:82) on a chip
- *     without fp32 matrix cores: every GEMM operand x is split into bf16 hi = bf16(x), lo = bf16(x - hi) and each product runs as
+ *     whose fp32 MFMA runs at 1/16 of its bf16 rate (three bf16 terms are ~5x faster than v_mfma_f32_32x32x2_f32): every GEMM operand x is split into bf16 hi = bf16(x), lo = bf16(x - hi) and each product runs as
  *     three bf16 MFMA terms hi*hi + hi*lo + lo*hi with fp32 accumulation (about 16 mantissa bits per operand, a third of the bf16
  *     rate); activations between kernels are fp32 and attention runs in fp32.  This is the mode in which logits match the fp32
  *     reference to 1e-3 at full depth.  Its buffers differ in size only: the operand arena has 6*count 16-bit elements (the
