@@ -1481,6 +1481,228 @@ static int attn_bwd_rows(const float* qkv, const float* dout, const float* o, co
     }
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// fp32 attention on the fp32 MATRIX pipe (round 4, an A/B option — see attn_f32mfma_ok for the measurement that keeps it off): the LDS-tile
+// kernels above with their three / five products moved from VALU dot
+// products to v_mfma_f32_32x32x2_f32 (gfx950's fp32 MFMA: 64 FLOP/clk/SIMD — 1/16 of the bf16 MFMA, twice the VALU FMA rate, and no
+// LDS operand read per FMA).  Same arithmetic (fp32 products, fp32 accumulation), same interface, same dropout rule; sequences up to 96
+// (32-row tiles: NT = ceil(S / 32) <= 3), head dims that are multiples of 32.  Fragments: a lane feeds A[row = lane % 32][k] and
+// B[k][col = lane % 32] with k chosen by its half (lane / 32); a 16-B LDS read per operand serves FOUR MFMAs (lanes < 32 hold
+// k = 8t .. 8t+3, lanes >= 32 hold 8t+4 .. 8t+7 — any pairing works as long as A and B use the same one).  Accumulator register r of a
+// lane is element (row 8 (r / 4) + 4 (lane / 32) + r % 4, col lane % 32).  Rows / columns beyond S are zero-filled in LDS.
+// ------------------------------------------------------------------------------------------------------------
+typedef float v16f __attribute__((ext_vector_type(16)));
+#define CC_MFMA_F32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0)
+
+__device__ __forceinline__ void load_head_rows_pad(float* dst, int hdp, const float* src, size_t ld, int S, int RP, int hd) {
+    const int c4n = hd >> 2;
+    for (int idx = threadIdx.x; idx < RP * c4n; idx += blockDim.x) {
+        const int r = idx / c4n, c = idx % c4n;
+        const float4 v = r < S ? *reinterpret_cast<const float4*>(src + (size_t)r * ld + c * 4) : make_float4(0, 0, 0, 0);
+        *reinterpret_cast<float4*>(dst + r * hdp + c * 4) = v;
+    }
+}
+// acc += X[rows r0 ..][d] . Y[rows c0 ..][d]^T over d < hd (both row-major with stride hdp): the scores / dP form
+__device__ __forceinline__ void mm_rows_rows(v16f& acc, const float* X, int r0, const float* Y, int c0, int hdp, int hd, int lane) {
+    const float* xa = X + (r0 + (lane & 31)) * hdp + 4 * (lane >> 5);
+    const float* yb = Y + (c0 + (lane & 31)) * hdp + 4 * (lane >> 5);
+    for (int d8 = 0; d8 < hd; d8 += 8) {
+        const float4 a = *reinterpret_cast<const float4*>(xa + d8), b = *reinterpret_cast<const float4*>(yb + d8);
+        acc = CC_MFMA_F32(a.x, b.x, acc);
+        acc = CC_MFMA_F32(a.y, b.y, acc);
+        acc = CC_MFMA_F32(a.z, b.z, acc);
+        acc = CC_MFMA_F32(a.w, b.w, acc);
+    }
+}
+
+template <bool CAUSAL, bool DROP>
+__global__ __launch_bounds__(256) void k_attn_fwd_f32mfma(const float* __restrict__ qkv, int S, int H, int hd, float scale, float* __restrict__ out,
+                                                          float* __restrict__ lse, Drop drop) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int D = H * hd, hdp = hd + 4, NT = (S + 31) >> 5, RP = NT * 32, Sp = RP + 4;
+    float* Qs = sm;
+    float* Ks = Qs + RP * hdp;
+    float* Vs = Ks + RP * hdp;
+    float* Ps = Vs + RP * hdp;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const float* base = qkv + (size_t)b * S * 3 * D + h * hd;
+    load_head_rows_pad(Qs, hdp, base, 3 * D, S, RP, hd);
+    load_head_rows_pad(Ks, hdp, base + D, 3 * D, S, RP, hd);
+    load_head_rows_pad(Vs, hdp, base + 2 * D, 3 * D, S, RP, hd);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
+    for (int t = wave; t < NT * NT; t += 4) {
+        const int ti = t / NT, tj = t - ti * NT;
+        v16f acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+        if (!(CAUSAL && tj > ti)) mm_rows_rows(acc, Qs, ti * 32, Ks, tj * 32, hdp, hd, lane);
+        const int j = tj * 32 + lr;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int i = ti * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+            Ps[i * Sp + j] = (j < S && !(CAUSAL && j > i)) ? acc[r] * scale : -INFINITY;
+        }
+    }
+    __syncthreads();
+    for (int i = wave; i < S; i += 4) {                    // softmax: one wave per row (padding columns hold -inf -> 0)
+        float m = -INFINITY;
+        for (int j = lane; j < RP; j += 64) m = fmaxf(m, Ps[i * Sp + j]);
+        m = wave_max(m);
+        float sum = 0.f;
+        for (int j = lane; j < RP; j += 64) {
+            const float e = __expf(Ps[i * Sp + j] - m);
+            Ps[i * Sp + j] = e;
+            sum += e;
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+        for (int j = lane; j < RP; j += 64) Ps[i * Sp + j] *= inv;
+        if (lane == 0 && lse) lse[((size_t)b * H + h) * S + i] = m + __logf(sum);
+    }
+    for (int i = S + wave; i < RP; i += 4)                 // padding rows: zero probabilities (never stored, but keep them finite)
+        for (int j = lane; j < RP; j += 64) Ps[i * Sp + j] = 0.f;
+    __syncthreads();
+    const int nd = hd >> 5;
+    for (int t = wave; t < NT * nd; t += 4) {              // O = P V, tile (ti, td)
+        const int ti = t / nd, td = t - ti * nd;
+        v16f acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+        const int jmax = CAUSAL ? (ti + 1) * 32 : RP;
+        const int i = ti * 32 + lr;
+        const float* pa = Ps + i * Sp + 4 * lh;
+        const float* vb = Vs + 4 * lh * hdp + td * 32 + lr;
+        for (int j8 = 0; j8 < jmax; j8 += 8) {
+            float4 a = *reinterpret_cast<const float4*>(pa + j8);
+            if (DROP) {                                    // attention-probability dropout: P V only
+                const unsigned e0 = ((unsigned)(b * H + h) * S + i) * S + j8 + 4 * lh;
+                a.x *= drop_mul(drop, e0); a.y *= drop_mul(drop, e0 + 1); a.z *= drop_mul(drop, e0 + 2); a.w *= drop_mul(drop, e0 + 3);
+            }
+            const float* v = vb + j8 * hdp;
+            acc = CC_MFMA_F32(a.x, v[0], acc);
+            acc = CC_MFMA_F32(a.y, v[hdp], acc);
+            acc = CC_MFMA_F32(a.z, v[2 * hdp], acc);
+            acc = CC_MFMA_F32(a.w, v[3 * hdp], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int io = ti * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+            if (io < S) out[((size_t)b * S + io) * D + h * hd + td * 32 + lr] = acc[r];
+        }
+    }
+}
+
+template <bool CAUSAL, bool DROP>
+__global__ __launch_bounds__(256) void k_attn_bwd_f32mfma(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse,
+                                                          int S, int H, int hd, float scale, float* __restrict__ dqkv, Drop drop) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int D = H * hd, hdp = hd + 4, NT = (S + 31) >> 5, RP = NT * 32, Sp = RP + 4;
+    float* Qs = sm;
+    float* Ks = Qs + RP * hdp;
+    float* Vs = Ks + RP * hdp;
+    float* Os = Vs + RP * hdp;   // dO
+    float* Ps = Os + RP * hdp;
+    float* Ds = Ps + RP * Sp;    // dP, then dS
+    float* Ls = Ds + RP * Sp;    // lse of the rows
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const float* base = qkv + (size_t)b * S * 3 * D + h * hd;
+    load_head_rows_pad(Qs, hdp, base, 3 * D, S, RP, hd);
+    load_head_rows_pad(Ks, hdp, base + D, 3 * D, S, RP, hd);
+    load_head_rows_pad(Vs, hdp, base + 2 * D, 3 * D, S, RP, hd);
+    load_head_rows_pad(Os, hdp, dout + (size_t)b * S * D + h * hd, D, S, RP, hd);
+    for (int i = threadIdx.x; i < RP; i += 256) Ls[i] = i < S ? lse[((size_t)b * H + h) * S + i] : 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
+    for (int t = wave; t < NT * NT; t += 4) {              // P = exp(Q K^T scale - lse), dP = dO V^T, tile (ti, tj)
+        const int ti = t / NT, tj = t - ti * NT;
+        v16f sa, da;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { sa[r] = 0.f; da[r] = 0.f; }
+        if (!(CAUSAL && tj > ti)) {
+            mm_rows_rows(sa, Qs, ti * 32, Ks, tj * 32, hdp, hd, lane);
+            mm_rows_rows(da, Os, ti * 32, Vs, tj * 32, hdp, hd, lane);
+        }
+        const int j = tj * 32 + lr;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int i = ti * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+            const bool live = i < S && j < S && !(CAUSAL && j > i);
+            Ps[i * Sp + j] = live ? __expf(sa[r] * scale - Ls[i]) : 0.f;
+            float dp = live ? da[r] : 0.f;
+            if (DROP && live) dp *= drop_mul(drop, ((unsigned)(b * H + h) * S + i) * S + j);
+            Ds[i * Sp + j] = dp;
+        }
+    }
+    __syncthreads();
+    for (int i = wave; i < S; i += 4) {                    // delta_i = sum_j P dP;  dS = P (dP - delta) scale
+        float dl = 0.f;
+        for (int j = lane; j < RP; j += 64) dl += Ps[i * Sp + j] * Ds[i * Sp + j];
+        dl = wave_sum(dl);
+        for (int j = lane; j < RP; j += 64) Ds[i * Sp + j] = Ps[i * Sp + j] * (Ds[i * Sp + j] - dl) * scale;
+    }
+    __syncthreads();
+    const int nd = hd >> 5, per = NT * nd;
+    for (int t = wave; t < 3 * per; t += 4) {              // dQ = dS K | dK = dS^T Q | dV = (P mask)^T dO, tile (tr, td)
+        const int which = t / per, u = t - which * per, tr = u / nd, td = u - tr * nd;
+        v16f acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+        if (which == 0) {
+            const int jmax = CAUSAL ? (tr + 1) * 32 : RP;
+            const float* pa = Ds + (tr * 32 + lr) * Sp + 4 * lh;
+            const float* kb = Ks + 4 * lh * hdp + td * 32 + lr;
+            for (int j8 = 0; j8 < jmax; j8 += 8) {
+                const float4 a = *reinterpret_cast<const float4*>(pa + j8);
+                const float* k = kb + j8 * hdp;
+                acc = CC_MFMA_F32(a.x, k[0], acc);
+                acc = CC_MFMA_F32(a.y, k[hdp], acc);
+                acc = CC_MFMA_F32(a.z, k[2 * hdp], acc);
+                acc = CC_MFMA_F32(a.w, k[3 * hdp], acc);
+            }
+        } else {
+            const int ilo = CAUSAL ? tr * 32 : 0;          // queries i >= key block
+            const float* W = which == 1 ? Ds : Ps;
+            const float* X = which == 1 ? Qs : Os;
+            const int j = tr * 32 + lr;
+            for (int i8 = ilo; i8 < RP; i8 += 8) {
+                const int i0 = i8 + 4 * lh;
+                float a0 = W[i0 * Sp + j], a1 = W[(i0 + 1) * Sp + j], a2 = W[(i0 + 2) * Sp + j], a3 = W[(i0 + 3) * Sp + j];
+                if (DROP && which == 2) {
+                    const unsigned e0 = ((unsigned)(b * H + h) * S + i0) * S + j;
+                    a0 *= drop_mul(drop, e0); a1 *= drop_mul(drop, e0 + S); a2 *= drop_mul(drop, e0 + 2 * S); a3 *= drop_mul(drop, e0 + 3 * S);
+                }
+                const float* x = X + i0 * hdp + td * 32 + lr;
+                acc = CC_MFMA_F32(a0, x[0], acc);
+                acc = CC_MFMA_F32(a1, x[hdp], acc);
+                acc = CC_MFMA_F32(a2, x[2 * hdp], acc);
+                acc = CC_MFMA_F32(a3, x[3 * hdp], acc);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int ro = tr * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+            if (ro < S) dqkv[((size_t)b * S + ro) * 3 * D + which * D + h * hd + td * 32 + lr] = acc[r];
+        }
+    }
+}
+static size_t attn_f32mfma_lds(int S, int hd, bool bwd) {
+    const size_t RP = (size_t)((S + 31) / 32) * 32, hdp = hd + 4, Sp = RP + 4;
+    return ((bwd ? 4 : 3) * RP * hdp + (bwd ? 2 : 1) * RP * Sp + (bwd ? RP : 0)) * sizeof(float);
+}
+static bool attn_f32mfma_ok(int S, int hd, bool bwd) {
+    // OFF by default: measured on MI355X (config-2 step, split-bf16 mode, two alternations) 40.4 ms with these kernels against 38.6 ms with the
+    // VALU LDS-tile kernels — the fp32 MFMA is only 2x the VALU FMA rate, and 32-row tiles pad S = 50 to 64 (1.64x the products) and skip
+    // causal work per tile (3 of 4 tiles) instead of per element (51 %).  CC_ATTN_F32MFMA=1 selects them (same results: tests pass either way).
+    static const bool on = getenv("CC_ATTN_F32MFMA") != nullptr;
+    return on && S <= 96 && (hd & 31) == 0 && attn_f32mfma_lds(S, hd, bwd) <= 160 * 1024;
+}
+#define CC_F32MFMA_LAUNCH(KERN, ...)                                                                                   \
+    {                                                                                                                  \
+        if (sh > 64 * 1024) (void)hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+        hipLaunchKernelGGL(KERN, dim3(B * H), dim3(256), sh, st, __VA_ARGS__);                                         \
+    }
 #endif   // CC_OP == 2
 
 int attn_fwd(const act_t* qkv, int B, int S, int H, int hd, bool causal, act_t* out, float* lse, hipStream_t st, Drop drop) {
@@ -1494,8 +1716,17 @@ int attn_fwd(const act_t* qkv, int B, int S, int H, int hd, bool causal, act_t* 
     }
 #endif
     if (drop.thresh && (!kX3 || !causal)) return CC_ERR_SHAPE;          // dropout on the VALU kernels: the bf16x3 build's GPT-2 path only
-    const size_t sh = attn_fwd_lds(S, hd);
     const float scale = 1.0f / sqrtf((float)hd);
+#if CC_OP == 2
+    if (attn_f32mfma_ok(S, hd, false)) {                                 // fp32 products on the fp32 MFMA
+        const size_t sh = attn_f32mfma_lds(S, hd, false);
+        if (drop.thresh) CC_F32MFMA_LAUNCH((k_attn_fwd_f32mfma<true, true>), qkv, S, H, hd, scale, out, lse, drop)
+        else if (causal) CC_F32MFMA_LAUNCH((k_attn_fwd_f32mfma<true, false>), qkv, S, H, hd, scale, out, lse, drop)
+        else CC_F32MFMA_LAUNCH((k_attn_fwd_f32mfma<false, false>), qkv, S, H, hd, scale, out, lse, drop)
+        return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+    }
+#endif
+    const size_t sh = attn_fwd_lds(S, hd);
     if (sh > 160 * 1024) {
 #if CC_OP == 2
         if (drop.thresh) return CC_ERR_SHAPE;
@@ -1621,8 +1852,17 @@ int attn_bwd(const act_t* qkv, const act_t* dout, const act_t* o, const float* l
     }
 #endif
     if (drop.thresh && (!kX3 || !causal)) return CC_ERR_SHAPE;          // dropout on the VALU kernel: the bf16x3 build's GPT-2 path only
-    const size_t sh = attn_bwd_lds(S, hd);
     const float scale = 1.0f / sqrtf((float)hd);
+#if CC_OP == 2
+    if (attn_f32mfma_ok(S, hd, true)) {
+        const size_t sh = attn_f32mfma_lds(S, hd, true);
+        if (drop.thresh) CC_F32MFMA_LAUNCH((k_attn_bwd_f32mfma<true, true>), qkv, dout, lse, S, H, hd, scale, dqkv, drop)
+        else if (causal) CC_F32MFMA_LAUNCH((k_attn_bwd_f32mfma<true, false>), qkv, dout, lse, S, H, hd, scale, dqkv, drop)
+        else CC_F32MFMA_LAUNCH((k_attn_bwd_f32mfma<false, false>), qkv, dout, lse, S, H, hd, scale, dqkv, drop)
+        return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+    }
+#endif
+    const size_t sh = attn_bwd_lds(S, hd);
     if (sh > 160 * 1024) {
 #if CC_OP == 2
         if (drop.thresh || !o || !delta) return CC_ERR_SHAPE;
