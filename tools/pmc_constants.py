@@ -52,11 +52,11 @@ def main():
     att_b = sum(dfk[k][1] for k in att) * 2 * kb / max(1, sum(dfk[k][0] for k in att))
     out = {
         "train_gemm_bytes_per_step": {"bytes": int(gem_f + gem_w), "fetch_bytes": int(gem_f), "write_bytes": int(gem_w), "kernel_source_hash": h,
-                                      "source": f"profiles/{tag}_pmc_fetch_write_train.md (offline PMC: sum over the gemm_* kernels of one step)"},
+                                      "source": f"profiles/{tag}_e_pmc_fetch_write_train.md (offline PMC: sum over the gemm_* kernels of one step)"},
         "lmhead_fwd_bytes_per_launch": {"bytes": int(lm_b) if lm_b else None, "kernel_source_hash": h,
-                                        "source": f"profiles/{tag}_pmc_fetch_write_train.md (offline PMC, lm_head forward launch)"},
+                                        "source": f"profiles/{tag}_e_pmc_fetch_write_train.md (offline PMC, lm_head forward launch)"},
         "decode_bytes_per_position": {"bytes": int(dec), "kernel_source_hash": h, "attention_fetch_bytes_per_launch": int(att_b),
-                                      "source": f"profiles/{tag}_pmc_fetch_write_decode.md (offline PMC: every kernel of {decodes} decodes / {decodes * positions} positions)"},
+                                      "source": f"profiles/{tag}_f_pmc_fetch_write_decode.md (offline PMC: every kernel of {decodes} decodes / {decodes * positions} positions)"},
     }
     with open(os.path.join(ROOT, "profiles", "pmc_constants.json"), "w") as fjson:
         json.dump(out, fjson, indent=1)
