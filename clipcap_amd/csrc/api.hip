@@ -275,7 +275,7 @@ void gpt2_carve(const cc_gpt2_cfg* c, int B, int T, int cap, int mode, void* ws,
         w.xn1[l] = f0 ? cv.take<act_t>(M * D) : w.xn1[0];
         w.xn2[l] = f0 ? cv.take<act_t>(M * D) : w.xn2[0];
         w.att[l] = k0 ? cv.take<act_t>(M * D) : w.att[0];    // attention output: needed by the backward's delta = rowsum(dO*O)
-        w.hact[l] = f0 ? cv.take<act_t>(M * 4 * D) : w.hact[0];
+        w.hact[l] = f0 ? cv.take<act_t>(M * 4 * D * ((kX3 && !full) ? 3 : 2) / 2) : w.hact[0];    // bf16x3, frozen LM: holds mlp.c_proj's operand IMAGE (6 B / element), written by c_fc's epilogue
     }
     const size_t Mh = std::max(M, Mc);
     w.hf16 = cv.take<act_t>(Mh * D);
@@ -298,7 +298,7 @@ void gpt2_carve(const cc_gpt2_cfg* c, int B, int T, int cap, int mode, void* ws,
         w.dx16 = cv.take<act_t>(M * D);
         w.dx16b = full ? cv.take<act_t>(M * D) : w.dx16;    // full finetune: second copy so a layer's weight gradients can run grouped
         w.dhf16 = cv.take<act_t>(Mc * D);
-        w.du16 = cv.take<act_t>(M * 4 * D);
+        w.du16 = cv.take<act_t>(M * 4 * D * ((kX3 && !full) ? 3 : 2) / 2);                       // likewise: c_fc's input-gradient operand image, written by the gelu' epilogue
         w.dxn16 = cv.take<act_t>(M * D);
         w.datt16 = cv.take<act_t>(M * D);
         w.dqkv16 = cv.take<act_t>(M * 3 * D);
@@ -536,6 +536,12 @@ static bool gelu_grad_fwd() {
     static const bool on = []() { const char* e = getenv("CC_GELU_GRAD_FWD"); return !e || atoi(e) != 0; }();
     return on;
 }
+// bf16x3, frozen LM: c_fc's forward epilogue and the gelu' input-gradient epilogue write the [hi | hi | lo] operand image of their consumer
+// GEMM directly instead of an fp32 activation that a split pass re-reads (CC_X3_IMG=0: A/B switch)
+static bool x3_img_on() {
+    static const bool on = []() { const char* e = getenv("CC_X3_IMG"); return !e || atoi(e) != 0; }();
+    return on;
+}
 static bool lm_exp_form() {
     static const bool on = (CC_OP == 0) && []() { const char* e = getenv("CC_LM_EXPFORM"); return !e || atoi(e) != 0; }();
     return on;
@@ -695,12 +701,18 @@ int CC_API(cc_gpt2_fwd)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const floa
             static const int tile_fc = env_tile("CC_TILE_FC");
             TileScope ts(tile_fc);
             // act 3: the pre-activation slot receives gelu_new'(u) — one sigmoid serves both, and the backward's epilogue is a multiply
+#if CC_OP == 2
+            if (s->mode <= 1 && x3_img_on()) x3_emit_image(w.hact[l], 4 * D);        // nobody but mlp.c_proj reads hact without a weight gradient: write its operand image directly
+#endif
             CC_TIMED(CC_SITE_GPT2_FC_FWD, st, gemm_bf16out(0, 0, w.xn2[l], D, W16(w16t, y.fw), D, M, 4 * D, D, w.hact[l], 4 * D, w32 + y.fb, (s->mode >= 1 && gelu_grad_fwd()) ? 3 : 2,
                                                             s->mode >= 1 ? w.u[l] : nullptr, st));
         }
         {
             static const int tile_proj2 = env_tile("CC_TILE_PROJ2");
             TileScope ts(tile_proj2);
+#if CC_OP == 2
+            if (s->mode <= 1 && x3_img_on()) x3_expect_image(w.hact[l]);
+#endif
             CC_TIMED(CC_SITE_GPT2_PROJ2_FWD, st, gemm_resid(0, 0, w.hact[l], 4 * D, W16(w16t, y.p2w), 4 * D, M, D, 4 * D, w.x[l + 1], w.x1[l], D, w32 + y.p2b, st,
                                                            make_drop(s->p_resid, s->drop_seed, DROP_RESID_MLP, l)));
         }
@@ -853,6 +865,9 @@ int CC_API(cc_gpt2_bwd_range)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, cons
         {
             static const int tile_dact = env_tile("CC_TILE_DACT");
             TileScope ts(tile_dact);
+#if CC_OP == 2
+            if (!full && x3_img_on()) x3_emit_image(w.du16, D4);                     // frozen LM: du is read by c_fc's input-gradient GEMM only
+#endif
             CC_TRY(gemm_dact(0, 0, w.dx16, D, W16(w16, y.p2w), D, M, D4, D, w.du16, D4, w.u[l], gelu_grad_fwd() ? 3 : 2, st));
         }
         // mlp.c_fc (Conv1D [D, 4D])
@@ -860,6 +875,9 @@ int CC_API(cc_gpt2_bwd_range)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, cons
             CC_TRY(gemm_wgrad(w.xn2[l], D, w.du16, D4, D, D4, M, g32 + y.fw, D4, w.wg_scratch, st, wbp));
             CC_TRY(colsum_bf16(w.du16, D4, M, D4, g32 + y.fb, st));
         }
+#if CC_OP == 2
+        if (!full && x3_img_on()) x3_expect_image(w.du16);
+#endif
         CC_TIMED(CC_SITE_GPT2_FC_DGRAD, st, gemm_bf16out(0, 0, w.du16, D4, W16(w16, y.fw), D4, M, D, D4, w.dxn16, D, nullptr, 0, nullptr, st));
         CC_TRY(ln_bwd(w.dxn16, w.x1[l], D, nullptr, w.mean2[l], w.rstd2[l], w32 + y.l2w, w.dx32, w.dx32, w.dx16b, full ? g32 + y.l2w : nullptr,
                       full ? g32 + y.l2b : nullptr, M, D, st, full ? g32 + y.pb : nullptr,

@@ -1158,6 +1158,28 @@ __device__ __forceinline__ void load_bias8(const float* bias, int col, int Ns, f
     }
 }
 
+// Output store of the 16-bit-activation epilogues.  bf16x3 build, img > 0: C is not an fp32 activation but the [hi | hi | lo] operand IMAGE
+// of the consumer GEMM (rows of 3 * img 16-bit elements, kernels.hip::k_x3_split_rows' layout and arithmetic) — the producer writes it
+// directly, 6 B per element, instead of 4 B here + a 4 B read and 6 B write in the split pass.  img == 0 (always, in the 16-bit builds): the
+// plain store.
+__device__ __forceinline__ void epi_store8(act_t* C, int ldc, int row, int col, const float (&v)[8], int img) {
+#if CC_OP == 2
+    if (img > 0) {
+        const uint4 hi = pack8(v);
+        float h[8], d[8];
+        unpack8(hi, h);
+#pragma unroll
+        for (int e = 0; e < 8; e++) d[e] = v[e] - h[e];
+        const uint4 lo = pack8(d);
+        op16_t* r3 = reinterpret_cast<op16_t*>(C) + (size_t)row * 3 * img + col;
+        *reinterpret_cast<uint4*>(r3) = hi;
+        *reinterpret_cast<uint4*>(r3 + img) = hi;
+        *reinterpret_cast<uint4*>(r3 + 2 * img) = lo;
+        return;
+    }
+#endif
+    act_st8(C + (size_t)row * ldc + col, v);
+}
 struct EpiBF16 {
     act_t* C;
     act_t* pre;         // nullable
@@ -1165,6 +1187,7 @@ struct EpiBF16 {
     int ldc, M, Ns;     // Ns: columns to store (multiple of 8)
     int act;            // 0 none, 1 relu, 2 gelu_new, 3 gelu_new with `pre` receiving gelu_new'(u) instead of u (the backward's multiplier)
     bool pre_nt = false; // act 3: `pre` is read only by the backward pass -> non-temporal stores
+    int img = 0;         // bf16x3: > 0 = write C as the consumer's operand image with this row width (epi_store8)
     __device__ __forceinline__ void operator()(int row, int col, float (&v)[8]) const {
         if (row >= M || col >= Ns) return;
         if (bias) {
@@ -1187,7 +1210,7 @@ struct EpiBF16 {
                 for (int e = 0; e < 8; e++) v[e] = gelu_new_f(v[e]);
             }
         }
-        act_st8(C + (size_t)row * ldc + col, v);
+        epi_store8(C, ldc, row, col, v, img);
     }
     // Split form for the 256-row kernels (see gemm_nt_stag256_kernel): every global LOAD of the epilogue happens before its first
     // STORE — with loads and stores both pending on the one vmcnt counter the compiler must wait vmcnt(0), i.e. drain the store
@@ -1215,7 +1238,7 @@ struct EpiBF16 {
                 for (int e = 0; e < 8; e++) v[e] = gelu_new_f(v[e]);
             }
         }
-        act_st8(C + (size_t)row * ldc + col, v);
+        epi_store8(C, ldc, row, col, v, img);
     }
 };
 
@@ -1342,6 +1365,7 @@ struct EpiDAct {
     const act_t* aux;
     int ldc, M, Ns;
     int act;  // 1 relu (aux = post-activation), 2 gelu_new (aux = pre-activation u), 3 multiply by aux (= gelu_new'(u) stored by the forward)
+    int img = 0;   // bf16x3: > 0 = write C as the consumer's operand image (epi_store8); aux keeps the plain [M][ldc] layout
     __device__ __forceinline__ void operator()(int row, int col, float (&v)[8]) const {
         if (row >= M || col >= Ns) return;
         const size_t o = (size_t)row * ldc + col;
@@ -1357,7 +1381,7 @@ struct EpiDAct {
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] *= gelu_new_grad(a[e]);
         }
-        act_st8(C + o, v);
+        epi_store8(C, ldc, row, col, v, img);
     }
     typedef act_raw8 StripAux;                                                        // 128 x 128 strip epilogue: aux fetched up front
     __device__ __forceinline__ act_raw8 load_aux(int row, int col) const {
@@ -1377,7 +1401,7 @@ struct EpiDAct {
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] *= gelu_new_grad(a[e]);
         }
-        act_st8(C + (size_t)row * ldc + col, v);
+        epi_store8(C, ldc, row, col, v, img);
     }
     static constexpr bool kPre = true;
     __device__ __forceinline__ void pre4(int row, int col, f32x4& a) const {        // acc *= act'(aux)
@@ -1393,7 +1417,7 @@ struct EpiDAct {
     }
     __device__ __forceinline__ void fin(int row, int col, float (&v)[8], const float (&)[8]) const {
         if (row >= M || col >= Ns) return;
-        act_st8(C + (size_t)row * ldc + col, v);
+        epi_store8(C, ldc, row, col, v, img);
     }
 };
 

@@ -41,12 +41,24 @@ void x3_set_scratch(void* base, size_t bytes);
 // split `rows` x `width` fp32 (row stride ld) into the scratch: form 0 = [hi | hi | lo] (A side), 1 = [hi | lo | hi] (B side).
 // first = true restarts the scratch (one GEMM's operands live there at a time).  Returns nullptr (rc set) when it does not fit.
 const op16_t* x3_operand(const float* src, size_t ld, int rows, int width, int form, bool first, hipStream_t st, int* rc);
+// Producer-written operand images (round 4): x3_expect_image(p) before a GEMM wrapper call says "the A pointer p of the next call already
+// IS its [hi | hi | lo] image" (written by the previous GEMM's epilogue, epi_store8) — the split pass is skipped; x3_emit_image(p, n) says
+// "write the output C == p of the next gemm_bf16out / gemm_dact call as the image of an n-wide A operand".  Thread-local one-shot hints
+// (consumed by the next matching call), like the scratch: the C ABI stays re-entrant.
+void x3_expect_image(const void* a);
+bool x3_take_expected(const void* a);
+void x3_emit_image(const void* c, int width);
+int x3_take_emit(const void* c);
 #define CC_X3_NT(A, lda, ldb, M, K, A16, al, bl, st)                                      \
     {                                                                                     \
         if ((al) || (bl)) return CC_ERR_ARG;                                              \
-        int rc_ = CC_OK;                                                                  \
-        A16 = x3_operand(A, (size_t)(lda), M, K, 0, true, st, &rc_);                      \
-        if (!A16) return rc_;                                                             \
+        if (x3_take_expected(A)) {                                                        \
+            A16 = reinterpret_cast<const op16_t*>(A);                                     \
+        } else {                                                                          \
+            int rc_ = CC_OK;                                                              \
+            A16 = x3_operand(A, (size_t)(lda), M, K, 0, true, st, &rc_);                  \
+            if (!A16) return rc_;                                                         \
+        }                                                                                 \
         lda = 3 * (K); ldb = 3 * (ldb); K = 3 * (K);                                      \
     }
 #else

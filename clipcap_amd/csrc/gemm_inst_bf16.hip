@@ -8,6 +8,9 @@ int gemm_bf16out(int al, int bl, const act_t* A, int lda, const op16_t* B, int l
     const op16_t* A16;
     CC_X3_NT(A, lda, ldb, M, K, A16, al, bl, st);
     EpiBF16 e{C, pre, bias, ldc, M, N, act};
+#if CC_OP == 2
+    e.img = x3_take_emit(C);
+#endif
     static const bool nt = []() { const char* v = getenv("CC_PRE_NT"); return v && atoi(v) != 0; }();      // experiment switch
     e.pre_nt = nt;
     return launch_gemm(al, bl, A16, lda, B, ldb, M, N, K, 1, e, st);

@@ -8,6 +8,9 @@ int gemm_dact(int al, int bl, const act_t* A, int lda, const op16_t* B, int ldb,
     const op16_t* A16;
     CC_X3_NT(A, lda, ldb, M, K, A16, al, bl, st);
     EpiDAct e{C, aux, ldc, M, N, act};
+#if CC_OP == 2
+    e.img = x3_take_emit(C);
+#endif
     return launch_gemm(al, bl, A16, lda, B, ldb, M, N, K, 1, e, st);
 }
 }  // namespace CC_NS

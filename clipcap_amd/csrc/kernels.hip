@@ -2410,6 +2410,24 @@ struct X3Scratch { char* base = nullptr; size_t bytes = 0, used = 0; };
 thread_local X3Scratch g_x3;
 }  // namespace
 void x3_set_scratch(void* base, size_t bytes) { g_x3.base = static_cast<char*>(base); g_x3.bytes = bytes; g_x3.used = 0; }
+namespace {
+thread_local const void* g_x3_expect = nullptr;
+thread_local const void* g_x3_emit = nullptr;
+thread_local int g_x3_emit_w = 0;
+}  // namespace
+void x3_expect_image(const void* a) { g_x3_expect = a; }
+bool x3_take_expected(const void* a) {
+    const bool hit = a && g_x3_expect == a;
+    g_x3_expect = nullptr;                       // one shot: a hint never outlives the call it was set for
+    return hit;
+}
+void x3_emit_image(const void* c, int width) { g_x3_emit = c; g_x3_emit_w = width; }
+int x3_take_emit(const void* c) {
+    const int w = (c && g_x3_emit == c) ? g_x3_emit_w : 0;
+    g_x3_emit = nullptr;
+    g_x3_emit_w = 0;
+    return w;
+}
 const op16_t* x3_operand(const float* src, size_t ld, int rows, int width, int form, bool first, hipStream_t st, int* rc) {
     if (first) g_x3.used = 0;
     const size_t need = (((size_t)rows * 3 * width * sizeof(op16_t)) + 255) & ~size_t(255);
