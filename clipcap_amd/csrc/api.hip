@@ -272,9 +272,9 @@ void gpt2_carve(const cc_gpt2_cfg* c, int B, int T, int cap, int mode, void* ws,
         w.rstd1[l] = k0 ? cv.take<float>(M) : w.rstd1[0];
         w.mean2[l] = k0 ? cv.take<float>(M) : w.mean2[0];
         w.rstd2[l] = k0 ? cv.take<float>(M) : w.rstd2[0];
-        w.xn1[l] = f0 ? cv.take<act_t>(M * D) : w.xn1[0];
-        w.xn2[l] = f0 ? cv.take<act_t>(M * D) : w.xn2[0];
-        w.att[l] = k0 ? cv.take<act_t>(M * D) : w.att[0];    // attention output: needed by the backward's delta = rowsum(dO*O)
+        w.xn1[l] = f0 ? cv.take<act_t>(M * D * ((kX3 && !full) ? 3 : 2) / 2) : w.xn1[0];       // bf16x3, frozen LM: LayerNorm writes c_attn's / c_fc's operand image
+        w.xn2[l] = f0 ? cv.take<act_t>(M * D * ((kX3 && !full) ? 3 : 2) / 2) : w.xn2[0];
+        w.att[l] = k0 ? cv.take<act_t>(M * D * ((kX3 && !full) ? 3 : 2) / 2) : w.att[0];    // attention output: needed by the backward's delta = rowsum(dO*O) (bf16x3, frozen LM: attn.c_proj's operand image)
         w.hact[l] = f0 ? cv.take<act_t>(M * 4 * D * ((kX3 && !full) ? 3 : 2) / 2) : w.hact[0];    // bf16x3, frozen LM: holds mlp.c_proj's operand IMAGE (6 B / element), written by c_fc's epilogue
     }
     const size_t Mh = std::max(M, Mc);
@@ -295,13 +295,13 @@ void gpt2_carve(const cc_gpt2_cfg* c, int B, int T, int cap, int mode, void* ws,
         w.lmfac = cv.take<float>(2 * Mc);
         w.hfs16 = full ? cv.take<act_t>(Mc * D) : nullptr;
         w.dx32 = cv.take<float>(M * D);
-        w.dx16 = cv.take<act_t>(M * D);
+        w.dx16 = cv.take<act_t>(M * D * ((kX3 && !full) ? 3 : 2) / 2);                            // bf16x3, frozen LM: operand images written by their producers (LayerNorm backward, attention backward)
         w.dx16b = full ? cv.take<act_t>(M * D) : w.dx16;    // full finetune: second copy so a layer's weight gradients can run grouped
         w.dhf16 = cv.take<act_t>(Mc * D);
         w.du16 = cv.take<act_t>(M * 4 * D * ((kX3 && !full) ? 3 : 2) / 2);                       // likewise: c_fc's input-gradient operand image, written by the gelu' epilogue
         w.dxn16 = cv.take<act_t>(M * D);
         w.datt16 = cv.take<act_t>(M * D);
-        w.dqkv16 = cv.take<act_t>(M * 3 * D);
+        w.dqkv16 = cv.take<act_t>(M * 3 * D * ((kX3 && !full) ? 3 : 2) / 2);
         w.wg_scratch = full ? cv.take<float>(WGRAD_SCRATCH_BYTES / sizeof(float)) : nullptr;
         w.adelta = cv.take<float>((size_t)B * c->H * T);
     } else {
@@ -542,6 +542,9 @@ static bool x3_img_on() {
     static const bool on = []() { const char* e = getenv("CC_X3_IMG"); return !e || atoi(e) != 0; }();
     return on;
 }
+#if CC_OP == 2
+static bool gpt2_bwd_images(const cc_gpt2_shape* s) { return s->mode == 1 && x3_img_on() && s->p_resid == 0.f && s->p_attn == 0.f && s->p_embd == 0.f; }
+#endif
 static bool lm_exp_form() {
     static const bool on = (CC_OP == 0) && []() { const char* e = getenv("CC_LM_EXPFORM"); return !e || atoi(e) != 0; }();
     return on;
@@ -686,23 +689,40 @@ int CC_API(cc_gpt2_fwd)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const floa
     for (int l = 0; l < c->NL; l++) {
         const auto& y = o.layer[l];
         // hf :262-310: x1 = x + c_proj(attn(c_attn(ln_1 x)))
+#if CC_OP == 2
+        const bool ximg = s->mode <= 1 && x3_img_on();          // no weight gradient reads the normalised rows: LayerNorm writes the GEMM operand image
+        if (ximg) x3_emit_image(w.xn1[l], D);
+#endif
         CC_TRY(ln_fwd(w.x[l], D, nullptr, w32 + y.l1w, w32 + y.l1b, w.xn1[l], nullptr, w.mean1[l], w.rstd1[l], M, D, st));
+#if CC_OP == 2
+        if (ximg) x3_expect_image(w.xn1[l]);
+#endif
         CC_TRY(gemm_bf16out(0, 0, w.xn1[l], D, W16(w16t, y.aw), D, M, 3 * D, D, w.qkv[l], 3 * D, w32 + y.ab, 0, nullptr, st));
+#if CC_OP == 2
+        const bool aimg = ximg && attn_fwd_can_image(s->T, hd);      // the fp32-VALU attention pair: the backward recomputes what it needs from qkv
+        if (aimg) x3_emit_image(w.att[l], D);
+#endif
         CC_TRY(attn_fwd(w.qkv[l], s->B, s->T, H, hd, true, w.att[l], w.lse[l], st, make_drop(s->p_attn, s->drop_seed, DROP_ATTN, l)));
         {
             static const int tile_proj = env_tile("CC_TILE_PROJ");
             TileScope ts(tile_proj);
+#if CC_OP == 2
+            if (aimg) x3_expect_image(w.att[l]);
+#endif
             CC_TRY(gemm_resid(0, 0, w.att[l], D, W16(w16t, y.pw), D, M, D, D, w.x1[l], w.x[l], D, w32 + y.pb, st,
                               make_drop(s->p_resid, s->drop_seed, DROP_RESID_ATTN, l)));
         }
         // x = x1 + c_proj(gelu_new(c_fc(ln_2 x1)))   (hf :229-243)
+#if CC_OP == 2
+        if (ximg) x3_emit_image(w.xn2[l], D);
+#endif
         CC_TRY(ln_fwd(w.x1[l], D, nullptr, w32 + y.l2w, w32 + y.l2b, w.xn2[l], nullptr, w.mean2[l], w.rstd2[l], M, D, st));
         {
             static const int tile_fc = env_tile("CC_TILE_FC");
             TileScope ts(tile_fc);
             // act 3: the pre-activation slot receives gelu_new'(u) — one sigmoid serves both, and the backward's epilogue is a multiply
 #if CC_OP == 2
-            if (s->mode <= 1 && x3_img_on()) x3_emit_image(w.hact[l], 4 * D);        // nobody but mlp.c_proj reads hact without a weight gradient: write its operand image directly
+            if (ximg) { x3_emit_image(w.hact[l], 4 * D); x3_expect_image(w.xn2[l]); }   // nobody but mlp.c_proj reads hact without a weight gradient: write its operand image directly
 #endif
             CC_TIMED(CC_SITE_GPT2_FC_FWD, st, gemm_bf16out(0, 0, w.xn2[l], D, W16(w16t, y.fw), D, M, 4 * D, D, w.hact[l], 4 * D, w32 + y.fb, (s->mode >= 1 && gelu_grad_fwd()) ? 3 : 2,
                                                             s->mode >= 1 ? w.u[l] : nullptr, st));
@@ -777,14 +797,29 @@ int CC_API(cc_lmhead_ce_bwd)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const
     const bool ef = lm_exp_form();
     const LmFix fix{w.lmfac, w.target, W16(w16, o.wte)};
     if (ef) CC_TRY(lm_rowfac(w.cref, w.lse_row, w.target, denom, loss_scale, w.lmfac, Mc, st));
-    else CC_TRY(ce_dlogits(w.logits16, c->Vp, c->V, w.target, w.lse_row, denom, loss_scale, Mc, st));
+    const act_t* dlog = w.logits16;            // the A operand of the input-gradient GEMM
+#if CC_OP == 2
+    // frozen LM: nothing but that GEMM reads d logits -> the softmax-gradient pass writes its [hi | hi | lo] operand image straight into the
+    // call's operand scratch (sized for exactly this image, gpt2_carve) instead of fp32 values a split pass would re-read
+    op16_t* dimg = (!ef && !full && x3_img_on()) ? x3_scratch_block(x3_img(Mc, c->Vp)) : nullptr;
+    if (dimg) dlog = reinterpret_cast<const act_t*>(dimg);
+    if (!ef) CC_TRY(ce_dlogits(w.logits16, c->Vp, c->V, w.target, w.lse_row, denom, loss_scale, Mc, st, dimg));
+#else
+    if (!ef) CC_TRY(ce_dlogits(w.logits16, c->Vp, c->V, w.target, w.lse_row, denom, loss_scale, Mc, st));
+#endif
     // d hf = dlogits · wte   ([Mc,Vp] x [Vp(k), D(n)])
     // K = Vp is deep and the output narrow: K slices over the idle CUs, slabs parked in du16 (free until the first layer's backward)
     const auto lm_dgrad = [&]() {
-        const int rc = gemm_nt_deepk(w.logits16, c->Vp, W16(w16, o.total + o.wte), c->Vp, Mc, D, c->Vp, w.dhf16, D, reinterpret_cast<float*>(w.du16),
+#if CC_OP == 2
+        if (dimg) x3_expect_image(dlog);
+#endif
+        const int rc = gemm_nt_deepk(dlog, c->Vp, W16(w16, o.total + o.wte), c->Vp, Mc, D, c->Vp, w.dhf16, D, reinterpret_cast<float*>(w.du16),
                                      (size_t)M * 4 * D * sizeof(act_t), st, ef ? &fix : nullptr);
         if (rc != CC_ERR_SHAPE) return rc;
-        const int rc2 = gemm_bf16out(0, 0, w.logits16, c->Vp, W16(w16, o.total + o.wte), c->Vp, Mc, D, c->Vp, w.dhf16, D, nullptr, 0, nullptr, st);
+#if CC_OP == 2
+        if (dimg) x3_expect_image(dlog);
+#endif
+        const int rc2 = gemm_bf16out(0, 0, dlog, c->Vp, W16(w16, o.total + o.wte), c->Vp, Mc, D, c->Vp, w.dhf16, D, nullptr, 0, nullptr, st);
         return (rc2 != CC_OK || !ef) ? rc2 : lm_dgrad_fix(w.dhf16, w.lmfac, w.target, fix.wte, D, Mc, st);
     };
     CC_TIMED(CC_SITE_LMHEAD_DGRAD, st, lm_dgrad());
@@ -798,7 +833,11 @@ int CC_API(cc_lmhead_ce_bwd)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const
         }
     }
     if (hipMemsetAsync(w.dx32, 0, (size_t)M * D * sizeof(float), st) != hipSuccess) return CC_ERR_LAUNCH;
-    if (hipMemsetAsync(w.dx16, 0, (size_t)M * D * sizeof(act_t), st) != hipSuccess) return CC_ERR_LAUNCH;
+    size_t dx16_bytes = (size_t)M * D * sizeof(act_t);
+#if CC_OP == 2
+    if (gpt2_bwd_images(s)) { dx16_bytes = (size_t)M * D * 3 * sizeof(op16_t); x3_emit_image(w.dx16, D); }     // the top layer's backward reads it as an operand image
+#endif
+    if (hipMemsetAsync(w.dx16, 0, dx16_bytes, st) != hipSuccess) return CC_ERR_LAUNCH;
     CC_TRY(ln_bwd(w.dhf16, w.x[c->NL], D, w.row_map, w.meanf, w.rstdf, w32 + o.lnf_w, nullptr, w.dx32, w.dx16, full ? g32 + o.lnf_w : nullptr,
                   full ? g32 + o.lnf_b : nullptr, Mc, D, st));
     return CC_OK;
@@ -821,6 +860,9 @@ int CC_API(cc_gpt2_logits_bwd)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, con
     CC_TRY(gemm_bf16out(0, 0, w.logits16, c->Vp, W16(w16, o.total + o.wte), c->Vp, M, D, c->Vp, w.dhf16, D, nullptr, 0, nullptr, st));
     if (full) CC_TRY(gemm_wgrad(w.logits16, c->Vp, w.hf16, D, c->Vp, D, M, g32 + o.wte, D, w.wg_scratch, st));
     if (hipMemsetAsync(w.dx32, 0, (size_t)M * D * sizeof(float), st) != hipSuccess) return CC_ERR_LAUNCH;
+#if CC_OP == 2
+    if (gpt2_bwd_images(s)) x3_emit_image(w.dx16, D);
+#endif
     CC_TRY(ln_bwd(w.dhf16, w.x[c->NL], D, nullptr, w.meanf, w.rstdf, w32 + o.lnf_w, nullptr, w.dx32, w.dx16, full ? g32 + o.lnf_w : nullptr,
                   full ? g32 + o.lnf_b : nullptr, M, D, st));
     CC_TRY(CC_API(cc_gpt2_bwd_range)(c, s, w32, w16, ws, nullptr, nullptr, g32, c->NL, 0, stream));
@@ -853,6 +895,10 @@ int CC_API(cc_gpt2_bwd_range)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, cons
     // The 16-bit copy of the residual gradient that feeds a c_proj's backward GEMMs is the dropout-masked one, and the c_proj's bias
     // gradient is its column sum.  Both are produced by the LayerNorm backward that writes the copy (ln_bwd dmask / dcol) — except for
     // the top layer, whose copy comes from ln_f's row-mapped backward and is masked / summed by separate launches.
+#if CC_OP == 2
+    // frozen LM, no dropout: the 16-bit gradient copies are read by input-gradient GEMMs only -> their producers write operand images
+    const bool bimg = gpt2_bwd_images(s);
+#endif
     for (int l = l_hi - 1; l >= l_lo; l--) {
         const auto& y = o.layer[l];
         const bool top = l == c->NL - 1;
@@ -868,6 +914,9 @@ int CC_API(cc_gpt2_bwd_range)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, cons
 #if CC_OP == 2
             if (!full && x3_img_on()) x3_emit_image(w.du16, D4);                     // frozen LM: du is read by c_fc's input-gradient GEMM only
 #endif
+#if CC_OP == 2
+            if (bimg) x3_expect_image(w.dx16);                        // written as an image by the LayerNorm backward above it (or the lm_head's)
+#endif
             CC_TRY(gemm_dact(0, 0, w.dx16, D, W16(w16, y.p2w), D, M, D4, D, w.du16, D4, w.u[l], gelu_grad_fwd() ? 3 : 2, st));
         }
         // mlp.c_fc (Conv1D [D, 4D])
@@ -879,12 +928,22 @@ int CC_API(cc_gpt2_bwd_range)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, cons
         if (!full && x3_img_on()) x3_expect_image(w.du16);
 #endif
         CC_TIMED(CC_SITE_GPT2_FC_DGRAD, st, gemm_bf16out(0, 0, w.du16, D4, W16(w16, y.fw), D4, M, D, D4, w.dxn16, D, nullptr, 0, nullptr, st));
+#if CC_OP == 2
+        if (bimg) x3_emit_image(w.dx16b, D);
+#endif
         CC_TRY(ln_bwd(w.dxn16, w.x1[l], D, nullptr, w.mean2[l], w.rstd2[l], w32 + y.l2w, w.dx32, w.dx32, w.dx16b, full ? g32 + y.l2w : nullptr,
                       full ? g32 + y.l2b : nullptr, M, D, st, full ? g32 + y.pb : nullptr,
                       make_drop(s->p_resid, s->drop_seed, DROP_RESID_ATTN, l)));
         // attn.c_proj (Conv1D [D, D])
         if (full) CC_TRY(gemm_wgrad(w.att[l], D, w.dx16b, D, D, D, M, g32 + y.pw, D, w.wg_scratch, st, wbp));
+#if CC_OP == 2
+        if (bimg) x3_expect_image(w.dx16b);
+#endif
         CC_TRY(gemm_bf16out(0, 0, w.dx16b, D, W16(w16, y.pw), D, M, D, D, w.datt16, D, nullptr, 0, nullptr, st));
+#if CC_OP == 2
+        const bool qimg = bimg && attn_bwd_can_image(s->T, hd);
+        if (qimg) x3_emit_image(w.dqkv16, D3);
+#endif
         CC_TRY(attn_bwd(w.qkv[l], w.datt16, w.att[l], w.lse[l], w.adelta, s->B, s->T, H, hd, true, w.dqkv16, st,
                         make_drop(s->p_attn, s->drop_seed, DROP_ATTN, l)));
         // attn.c_attn (Conv1D [D, 3D])
@@ -892,9 +951,15 @@ int CC_API(cc_gpt2_bwd_range)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, cons
             CC_TRY(gemm_wgrad(w.xn1[l], D, w.dqkv16, D3, D, D3, M, g32 + y.aw, D3, w.wg_scratch, st, wbp));
             CC_TRY(colsum_bf16(w.dqkv16, D3, M, D3, g32 + y.ab, st));
         }
+#if CC_OP == 2
+        if (qimg) x3_expect_image(w.dqkv16);
+#endif
         CC_TRY(gemm_bf16out(0, 0, w.dqkv16, D3, W16(w16, y.aw), D3, M, D, D3, w.dxn16, D, nullptr, 0, nullptr, st));
         // deferred weight gradients: dx16 (masked layer-input gradient), du16, dx16b, dqkv16 are all still intact here
         if (full) CC_TRY(wgrad_flush(wb, st));
+#if CC_OP == 2
+        if (bimg) x3_emit_image(w.dx16, D);
+#endif
         CC_TRY(ln_bwd(w.dxn16, w.x[l], D, nullptr, w.mean1[l], w.rstd1[l], w32 + y.l1w, w.dx32, w.dx32, w.dx16, full ? g32 + y.l1w : nullptr,
                       full ? g32 + y.l1b : nullptr, M, D, st, (full && l > 0) ? g32 + o.layer[l - 1].p2b : nullptr,
                       l > 0 ? make_drop(s->p_resid, s->drop_seed, DROP_RESID_MLP, l - 1) : Drop()));

@@ -45,6 +45,7 @@ const op16_t* x3_operand(const float* src, size_t ld, int rows, int width, int f
 // IS its [hi | hi | lo] image" (written by the previous GEMM's epilogue, epi_store8) — the split pass is skipped; x3_emit_image(p, n) says
 // "write the output C == p of the next gemm_bf16out / gemm_dact call as the image of an n-wide A operand".  Thread-local one-shot hints
 // (consumed by the next matching call), like the scratch: the C ABI stays re-entrant.
+op16_t* x3_scratch_block(size_t bytes);
 void x3_expect_image(const void* a);
 bool x3_take_expected(const void* a);
 void x3_emit_image(const void* c, int width);

@@ -41,6 +41,8 @@ int attn_fwd(const act_t* qkv, int B, int S, int H, int hd, bool causal, act_t* 
 int attn_bwd(const act_t* qkv, const act_t* dout, const act_t* o, const float* lse, float* delta, int B, int S, int H, int hd, bool causal,
              act_t* dqkv, hipStream_t st, Drop drop = Drop());
 // in-place dropout of an fp32 / bf16 buffer of n elements (n % 4 == 0 / n % 8 == 0): x[i] *= keep(i) / (1 - p)
+bool attn_fwd_can_image(int S, int hd);      // bf16x3: attn_fwd will honour x3_emit_image(out) (and the backward will not need the fp32 output)
+bool attn_bwd_can_image(int S, int hd);      // bf16x3: attn_bwd will honour x3_emit_image(dqkv) for this shape
 int dropout_f32(float* x, size_t n, Drop drop, hipStream_t st);
 int dropout_bf16(act_t* x, size_t n, Drop drop, hipStream_t st);
 int dropout_mask_u8(unsigned char* out, size_t n, Drop drop, hipStream_t st);   // test hook: out[i] = keep(i)
@@ -53,7 +55,7 @@ int embed_bwd(const float* dx0, const long long* tokens, int cap, float* dwte, f
 int ce_rows(const float* pmax, const float* psum, int npart, const int* target, const float* tgt_logit, float* lse, float* row_loss,
             float* stats, int M, hipStream_t st);
 int ce_dlogits(act_t* logits, int ld, int V, const int* target, const float* lse, const float* denom, const float* loss_scale, int M,
-               hipStream_t st);
+               hipStream_t st, op16_t* img = nullptr);   // img (bf16x3): write the gradient as the dgrad GEMM's operand image there instead of in place
 // sample.hip: one sampling step per row (temperature, repetition penalty, top-k, top-p, inverse-CDF draw at u[row])
 int sample_rows(const float* logits, int R, int V, int ld, float temperature, int top_k, float top_p, int mode, const long long* hist,
                 int hist_len, int hist_ld, float rep_pen, const float* u, int* next_token, float* probs_out, hipStream_t st);

@@ -257,7 +257,9 @@ template <int NV>   // float4 per lane actually used: D <= 256 NV (a run-time bo
 __global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ x, int ldx, const int* __restrict__ row_map,
                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                 act_t* __restrict__ y, float* __restrict__ y32, float* __restrict__ mean,
-                                                float* __restrict__ rstd, int rows, int D, float eps) {
+                                                float* __restrict__ rstd, int rows, int D, float eps, int img) {
+    // img (bf16x3 build only): y receives the [hi | hi | lo] operand image of the consumer GEMM (rows of 3 D 16-bit elements) instead of
+    // the fp32 activation — gemm.hip.h::epi_store8's layout and arithmetic, four elements at a time
     constexpr int R = NV <= 4 ? 2 : 1;       // rows per wave, loaded together: one row per wave is a chain of exposed round trips
     const int lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
@@ -311,6 +313,19 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ x, int
             if (c < D) {
                 const float o0 = (v[r][it].x - mu[r]) * rs[r] * g[it].x + bt[it].x, o1 = (v[r][it].y - mu[r]) * rs[r] * g[it].y + bt[it].y;
                 const float o2 = (v[r][it].z - mu[r]) * rs[r] * g[it].z + bt[it].z, o3 = (v[r][it].w - mu[r]) * rs[r] * g[it].w + bt[it].w;
+#if CC_OP == 2
+                if (y && img) {
+                    const unsigned h01 = pack2op(o0, o1), h23 = pack2op(o2, o3);
+                    float a0, a1, a2, a3;
+                    unpack2(h01, a0, a1);
+                    unpack2(h23, a2, a3);
+                    const uint2 hi = make_uint2(h01, h23), lo = make_uint2(pack2op(o0 - a0, o1 - a1), pack2op(o2 - a2, o3 - a3));
+                    op16_t* r3 = reinterpret_cast<op16_t*>(y) + (size_t)row * 3 * D + c;
+                    *reinterpret_cast<uint2*>(r3) = hi;
+                    *reinterpret_cast<uint2*>(r3 + D) = hi;
+                    *reinterpret_cast<uint2*>(r3 + 2 * D) = lo;
+                } else
+#endif
                 if (y) act_st4(y + (size_t)row * D + c, o0, o1, o2, o3);
                 if (y32) *reinterpret_cast<float4*>(y32 + (size_t)row * D + c) = make_float4(o0, o1, o2, o3);
             }
@@ -323,7 +338,11 @@ int ln_fwd(const float* x, int ldx, const int* row_map, const float* gamma, cons
     if (rows <= 0) return CC_OK;
     const int rpb = D <= 1024 ? 8 : 4;      // rows per block: 4 waves x (2 rows for NV <= 4, else 1)
     const dim3 gr((rows + rpb - 1) / rpb);
-#define LN_FWD(NV) hipLaunchKernelGGL(k_ln_fwd<NV>, gr, dim3(256), 0, st, x, ldx, row_map, gamma, beta, y, y32, mean, rstd, rows, D, 1e-5f)
+    int img = 0;
+#if CC_OP == 2
+    img = x3_take_emit(y) ? 1 : 0;            // the caller asked for y as its consumer GEMM's operand image (gemm_api.h x3_emit_image)
+#endif
+#define LN_FWD(NV) hipLaunchKernelGGL(k_ln_fwd<NV>, gr, dim3(256), 0, st, x, ldx, row_map, gamma, beta, y, y32, mean, rstd, rows, D, 1e-5f, img)
     if (D <= 256) LN_FWD(1); else if (D <= 512) LN_FWD(2); else if (D <= 768) LN_FWD(3); else if (D <= 1024) LN_FWD(4); else LN_FWD(LN_MAXV);
 #undef LN_FWD
     return CC_OK;
@@ -340,7 +359,8 @@ __global__ __launch_bounds__(NW * 64) void k_ln_bwd(const act_t* __restrict__ dy
                                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                 const float* __restrict__ dres, float* __restrict__ dx32,
                                                 act_t* __restrict__ dx16, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                float* __restrict__ dcol, int rows, int D, Drop dmask) {
+                                                float* __restrict__ dcol, int rows, int D, Drop dmask, int img) {
+    // img (bf16x3 build, ldx == D): dx16 receives the [hi | hi | lo] operand image of the input-gradient GEMM that reads it
     extern __shared__ __attribute__((aligned(16))) float ln_red[];  // [2][NW][D] when dgamma
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float4 pg[DG ? NV : 1], pb[DG ? NV : 1], pc[DG ? NV : 1];
@@ -417,6 +437,19 @@ __global__ __launch_bounds__(NW * 64) void k_ln_bwd(const act_t* __restrict__ dy
                         o.x *= m0; o.y *= m1; o.z *= m2; o.w *= m3;
                     }
                     const act_raw4 pk = act_pack4(o.x, o.y, o.z, o.w);
+#if CC_OP == 2
+                    if (img) {
+                        const unsigned h01 = pack2op(o.x, o.y), h23 = pack2op(o.z, o.w);
+                        float a0, a1, a2, a3;
+                        unpack2(h01, a0, a1);
+                        unpack2(h23, a2, a3);
+                        const uint2 hi = make_uint2(h01, h23), lo = make_uint2(pack2op(o.x - a0, o.y - a1), pack2op(o.z - a2, o.w - a3));
+                        op16_t* r3 = reinterpret_cast<op16_t*>(dx16) + 3 * (size_t)xr + c;
+                        *reinterpret_cast<uint2*>(r3) = hi;
+                        *reinterpret_cast<uint2*>(r3 + D) = hi;
+                        *reinterpret_cast<uint2*>(r3 + 2 * D) = lo;
+                    } else
+#endif
                     act_straw4(dx16 + xr + c, pk);
                     if constexpr (DG) {
                         if (dcol) {
@@ -478,7 +511,11 @@ int ln_bwd(const act_t* dy, const float* x, int ldx, const int* row_map, const f
     static const int dg_grid = []() { const char* e = getenv("CC_LNBWD_GRID"); return e ? atoi(e) : 256; }();   // tuning knob
     const int grid = std::min((rows + nw - 1) / nw, dgamma ? dg_grid : 8192);
     const size_t sh = dgamma ? (size_t)2 * nw * D * sizeof(float) : 0;
-#define LN_BWD(NV, DG, NW) hipLaunchKernelGGL((k_ln_bwd<NV, DG, NW>), dim3(grid), dim3(NW * 64), sh, st, dy, x, ldx, row_map, mean, rstd, gamma, dres, dx32, dx16, dgamma, dbeta, dcol, rows, D, dmask)
+    int img = 0;
+#if CC_OP == 2
+    img = (x3_take_emit(dx16) && ldx == D && !dcol && !dmask.thresh) ? 1 : 0;
+#endif
+#define LN_BWD(NV, DG, NW) hipLaunchKernelGGL((k_ln_bwd<NV, DG, NW>), dim3(grid), dim3(NW * 64), sh, st, dy, x, ldx, row_map, mean, rstd, gamma, dres, dx32, dx16, dgamma, dbeta, dcol, rows, D, dmask, img)
 #define LN_BWD_D(DG, NW) { if (D <= 256) LN_BWD(1, DG, NW); else if (D <= 512) LN_BWD(2, DG, NW); else if (D <= 768) LN_BWD(3, DG, NW); else if (D <= 1024) LN_BWD(4, DG, NW); else LN_BWD(LN_MAXV, DG, NW); }
     if (dgamma && nw == 8) LN_BWD_D(true, 8) else if (dgamma) LN_BWD_D(true, 4) else LN_BWD_D(false, 4)
 #undef LN_BWD_D
@@ -546,7 +583,8 @@ __device__ __forceinline__ void load_head_rows(float* dst, int hdp, const act_t*
 
 template <bool CAUSAL, bool DROP = false>
 __global__ __launch_bounds__(256) void k_attn_fwd(const act_t* __restrict__ qkv, int S, int H, int hd, float scale,
-                                                  act_t* __restrict__ out, float* __restrict__ lse, Drop drop = Drop()) {
+                                                  act_t* __restrict__ out, float* __restrict__ lse, Drop drop = Drop(), int img = 0) {
+    // img (bf16x3 build): out receives the [hi | hi | lo] operand image (rows of 3 D 16-bit elements) of attn.c_proj's GEMM
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int D = H * hd, hdp = hd + 4, Sp = S + 1;
     float* Qs = sm;
@@ -620,6 +658,20 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const act_t* __restrict__ qkv,
             const float4 v = *reinterpret_cast<const float4*>(Vs + j * hdp + d0);
             o.x += p * v.x; o.y += p * v.y; o.z += p * v.z; o.w += p * v.w;
         }
+#if CC_OP == 2
+        if (img) {
+            const unsigned h01 = pack2op(o.x, o.y), h23 = pack2op(o.z, o.w);
+            float a0, a1, a2, a3;
+            unpack2(h01, a0, a1);
+            unpack2(h23, a2, a3);
+            const uint2 hi = make_uint2(h01, h23), lo = make_uint2(pack2op(o.x - a0, o.y - a1), pack2op(o.z - a2, o.w - a3));
+            op16_t* r3 = reinterpret_cast<op16_t*>(out) + ((size_t)b * S + i) * 3 * D + h * hd + d0;
+            *reinterpret_cast<uint2*>(r3) = hi;
+            *reinterpret_cast<uint2*>(r3 + D) = hi;
+            *reinterpret_cast<uint2*>(r3 + 2 * D) = lo;
+            continue;
+        }
+#endif
         act_st4(out + ((size_t)b * S + i) * D + h * hd + d0, o.x, o.y, o.z, o.w);
     }
 }
@@ -1735,15 +1787,19 @@ int attn_fwd(const act_t* qkv, int B, int S, int H, int hd, bool causal, act_t* 
         return CC_ERR_SHAPE;
 #endif
     }
+    int img = 0;
+#if CC_OP == 2
+    img = x3_take_emit(out) ? 1 : 0;        // requested by the caller after attn_fwd_can_image()
+#endif
     if (drop.thresh) {
         if (sh > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_attn_fwd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        hipLaunchKernelGGL((k_attn_fwd<true, true>), dim3(B * H), dim3(256), sh, st, qkv, S, H, hd, scale, out, lse, drop);
+        hipLaunchKernelGGL((k_attn_fwd<true, true>), dim3(B * H), dim3(256), sh, st, qkv, S, H, hd, scale, out, lse, drop, img);
     } else if (causal) {
         if (sh > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_attn_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        hipLaunchKernelGGL(k_attn_fwd<true>, dim3(B * H), dim3(256), sh, st, qkv, S, H, hd, scale, out, lse);
+        hipLaunchKernelGGL(k_attn_fwd<true>, dim3(B * H), dim3(256), sh, st, qkv, S, H, hd, scale, out, lse, Drop(), img);
     } else {
         if (sh > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_attn_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        hipLaunchKernelGGL(k_attn_fwd<false>, dim3(B * H), dim3(256), sh, st, qkv, S, H, hd, scale, out, lse);
+        hipLaunchKernelGGL(k_attn_fwd<false>, dim3(B * H), dim3(256), sh, st, qkv, S, H, hd, scale, out, lse, Drop(), img);
     }
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
@@ -1755,7 +1811,8 @@ int attn_fwd(const act_t* qkv, int B, int S, int H, int hd, bool causal, act_t* 
 template <bool CAUSAL, bool DROP = false>
 __global__ __launch_bounds__(256) void k_attn_bwd(const act_t* __restrict__ qkv, const act_t* __restrict__ dout,
                                                   const float* __restrict__ lse, int S, int H, int hd, float scale,
-                                                  act_t* __restrict__ dqkv, Drop drop = Drop()) {
+                                                  act_t* __restrict__ dqkv, Drop drop = Drop(), int img = 0) {
+    // img (bf16x3 build): dqkv receives the [hi | hi | lo] operand image (rows of 3 * 3D 16-bit elements) of c_attn's input-gradient GEMM
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int D = H * hd, hdp = hd + 4, Sp = S + 1;
     float* Qs = sm;
@@ -1834,11 +1891,49 @@ __global__ __launch_bounds__(256) void k_attn_bwd(const act_t* __restrict__ qkv,
             dk.x += w * q.x; dk.y += w * q.y; dk.z += w * q.z; dk.w += w * q.w;
             dv.x += p * o.x; dv.y += p * o.y; dv.z += p * o.z; dv.w += p * o.w;
         }
+#if CC_OP == 2
+        if (img) {
+            op16_t* r3 = reinterpret_cast<op16_t*>(dqkv) + ((size_t)b * S + r) * 9 * D + h * hd + d0;
+            const float4 gq[3] = {dq, dk, dv};
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                const unsigned h01 = pack2op(gq[t].x, gq[t].y), h23 = pack2op(gq[t].z, gq[t].w);
+                float a0, a1, a2, a3;
+                unpack2(h01, a0, a1);
+                unpack2(h23, a2, a3);
+                const uint2 hi = make_uint2(h01, h23), lo = make_uint2(pack2op(gq[t].x - a0, gq[t].y - a1), pack2op(gq[t].z - a2, gq[t].w - a3));
+                *reinterpret_cast<uint2*>(r3 + t * D) = hi;
+                *reinterpret_cast<uint2*>(r3 + 3 * D + t * D) = hi;
+                *reinterpret_cast<uint2*>(r3 + 6 * D + t * D) = lo;
+            }
+            continue;
+        }
+#endif
         act_t* o = dqkv + ((size_t)b * S + r) * 3 * D + h * hd + d0;
         act_st4(o, dq.x, dq.y, dq.z, dq.w);
         act_st4(o + D, dk.x, dk.y, dk.z, dk.w);
         act_st4(o + 2 * D, dv.x, dv.y, dv.z, dv.w);
     }
+}
+// bf16x3: whether attn_fwd will honour an x3_emit_image(out) request — the LDS-tile VALU kernels must serve BOTH directions for this shape
+// (the backward of the other attention forms reads the fp32 output again)
+bool attn_fwd_can_image(int S, int hd) {
+#if CC_OP == 2
+    return (hd & 7) == 0 && S > 0 && !attn_f32mfma_ok(S, hd, false) && attn_fwd_lds(S, hd) <= 160 * 1024 && !attn_f32mfma_ok(S, hd, true) &&
+           attn_bwd_lds(S, hd) <= 160 * 1024;
+#else
+    (void)S; (void)hd;
+    return false;
+#endif
+}
+// bf16x3: whether attn_bwd will honour an x3_emit_image(dqkv) request for this shape (only the LDS-tile VALU kernel writes images)
+bool attn_bwd_can_image(int S, int hd) {
+#if CC_OP == 2
+    return (hd & 7) == 0 && S > 0 && !attn_f32mfma_ok(S, hd, true) && attn_bwd_lds(S, hd) <= 160 * 1024;
+#else
+    (void)S; (void)hd;
+    return false;
+#endif
 }
 int attn_bwd(const act_t* qkv, const act_t* dout, const act_t* o, const float* lse, float* delta, int B, int S, int H, int hd, bool causal,
              act_t* dqkv, hipStream_t st, Drop drop) {
@@ -1871,15 +1966,19 @@ int attn_bwd(const act_t* qkv, const act_t* dout, const act_t* o, const float* l
         return CC_ERR_SHAPE;
 #endif
     }
+    int img = 0;
+#if CC_OP == 2
+    img = x3_take_emit(dqkv) ? 1 : 0;       // requested by the caller after attn_bwd_can_image()
+#endif
     if (drop.thresh) {
         if (sh > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_attn_bwd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        hipLaunchKernelGGL((k_attn_bwd<true, true>), dim3(B * H), dim3(256), sh, st, qkv, dout, lse, S, H, hd, scale, dqkv, drop);
+        hipLaunchKernelGGL((k_attn_bwd<true, true>), dim3(B * H), dim3(256), sh, st, qkv, dout, lse, S, H, hd, scale, dqkv, drop, img);
     } else if (causal) {
         if (sh > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_attn_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        hipLaunchKernelGGL(k_attn_bwd<true>, dim3(B * H), dim3(256), sh, st, qkv, dout, lse, S, H, hd, scale, dqkv);
+        hipLaunchKernelGGL(k_attn_bwd<true>, dim3(B * H), dim3(256), sh, st, qkv, dout, lse, S, H, hd, scale, dqkv, Drop(), img);
     } else {
         if (sh > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_attn_bwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        hipLaunchKernelGGL(k_attn_bwd<false>, dim3(B * H), dim3(256), sh, st, qkv, dout, lse, S, H, hd, scale, dqkv);
+        hipLaunchKernelGGL(k_attn_bwd<false>, dim3(B * H), dim3(256), sh, st, qkv, dout, lse, S, H, hd, scale, dqkv, Drop(), img);
     }
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
@@ -2082,9 +2181,11 @@ int ce_rows(const float* pmax, const float* psum, int npart, const int* target, 
     return CC_OK;
 }
 
+// img (bf16x3 build): the gradient is written as the [hi | hi | lo] operand image of the lm_head's input-gradient GEMM (rows of 3 ld
+// 16-bit elements) into img instead of in place over the fp32 logits
 __global__ __launch_bounds__(256) void k_ce_dlogits(act_t* __restrict__ logits, int ld, int V, const int* __restrict__ target,
                                                     const float* __restrict__ lse, const float* __restrict__ denom,
-                                                    const float* __restrict__ loss_scale, int M) {
+                                                    const float* __restrict__ loss_scale, int M, op16_t* __restrict__ img) {
     const int col = (blockIdx.x * 256 + threadIdx.x) * 8;
     if (col >= ld) return;
     const float inv = (loss_scale ? loss_scale[0] : 1.0f) / fmaxf(denom[0], 1.0f);
@@ -2100,14 +2201,29 @@ __global__ __launch_bounds__(256) void k_ce_dlogits(act_t* __restrict__ logits, 
             const int c = col + e;
             f[e] = (c < V) ? (__expf(f[e] - l) - (c == t ? 1.f : 0.f)) * w : 0.f;
         }
+#if CC_OP == 2
+        if (img) {
+            const uint4 hi = pack8(f);
+            float h[8], d[8];
+            unpack8(hi, h);
+#pragma unroll
+            for (int e = 0; e < 8; e++) d[e] = f[e] - h[e];
+            const uint4 lo = pack8(d);
+            op16_t* r3 = img + (size_t)row * 3 * ld + col;
+            *reinterpret_cast<uint4*>(r3) = hi;
+            *reinterpret_cast<uint4*>(r3 + ld) = hi;
+            *reinterpret_cast<uint4*>(r3 + 2 * ld) = lo;
+            continue;
+        }
+#endif
         act_st8(p, f);
     }
 }
 int ce_dlogits(act_t* logits, int ld, int V, const int* target, const float* lse, const float* denom, const float* loss_scale, int M,
-               hipStream_t st) {
+               hipStream_t st, op16_t* img) {
     if (ld & 7) return CC_ERR_SHAPE;
     if (M <= 0) return CC_OK;
-    hipLaunchKernelGGL(k_ce_dlogits, dim3((ld / 8 + 255) / 256, std::min(M, 32768)), dim3(256), 0, st, logits, ld, V, target, lse, denom, loss_scale, M);
+    hipLaunchKernelGGL(k_ce_dlogits, dim3((ld / 8 + 255) / 256, std::min(M, 32768)), dim3(256), 0, st, logits, ld, V, target, lse, denom, loss_scale, M, img);
     return CC_OK;
 }
 
@@ -2415,6 +2531,8 @@ thread_local const void* g_x3_expect = nullptr;
 thread_local const void* g_x3_emit = nullptr;
 thread_local int g_x3_emit_w = 0;
 }  // namespace
+// the call's operand-image scratch as one block (a producer kernel writes the NEXT GEMM's A image there itself); nullptr when it does not fit
+op16_t* x3_scratch_block(size_t bytes) { return (g_x3.base && bytes <= g_x3.bytes) ? reinterpret_cast<op16_t*>(g_x3.base) : nullptr; }
 void x3_expect_image(const void* a) { g_x3_expect = a; }
 bool x3_take_expected(const void* a) {
     const bool hit = a && g_x3_expect == a;
