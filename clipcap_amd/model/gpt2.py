@@ -64,8 +64,15 @@ class _Embedding(nn.Module):
         return self._owner._arena_params["transformer.wte.weight"]
 
     def forward(self, ids: torch.Tensor) -> torch.Tensor:
-        w = self.weight if (torch.is_grad_enabled() and self.weight.requires_grad) else self.weight.detach()
-        return torch.nn.functional.embedding(ids.to(w.device), w)
+        need_grad = torch.is_grad_enabled() and self.weight.requires_grad
+        w = self.weight if need_grad else self.weight.detach()
+        if w.is_cuda and not need_grad and ids.numel() > 0:
+            # inference / frozen-LM paths: the library's gather (cc_embed_tokens, reference inference/base.py:117,184) — exact, like F.embedding
+            from clipcap_amd.engine import embed_tokens
+            out = torch.empty(*ids.shape, w.shape[1], dtype=torch.float32, device=w.device)
+            embed_tokens(self._owner.engine, ids.to(device=w.device, dtype=torch.int32).contiguous().view(-1), out.view(-1, w.shape[1]))
+            return out
+        return torch.nn.functional.embedding(ids.to(w.device), w)       # autograd path (a full finetune through Module.forward) and CPU
 
 
 class _TiedHead(nn.Module):
