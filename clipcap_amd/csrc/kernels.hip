@@ -513,7 +513,10 @@ int ln_bwd(const act_t* dy, const float* x, int ldx, const int* row_map, const f
     const size_t sh = dgamma ? (size_t)2 * nw * D * sizeof(float) : 0;
     int img = 0;
 #if CC_OP == 2
-    img = (x3_take_emit(dx16) && ldx == D && !dcol && !dmask.thresh) ? 1 : 0;
+    if (x3_take_emit(dx16)) {                 // the caller's next GEMM will read dx16 as an operand image: either honour it or fail loudly
+        if (ldx != D || dcol || dmask.thresh) return CC_ERR_STATE;
+        img = 1;
+    }
 #endif
 #define LN_BWD(NV, DG, NW) hipLaunchKernelGGL((k_ln_bwd<NV, DG, NW>), dim3(grid), dim3(NW * 64), sh, st, dy, x, ldx, row_map, mean, rstd, gamma, dres, dx32, dx16, dgamma, dbeta, dcol, rows, D, dmask, img)
 #define LN_BWD_D(DG, NW) { if (D <= 256) LN_BWD(1, DG, NW); else if (D <= 512) LN_BWD(2, DG, NW); else if (D <= 768) LN_BWD(3, DG, NW); else if (D <= 1024) LN_BWD(4, DG, NW); else LN_BWD(LN_MAXV, DG, NW); }
@@ -1759,6 +1762,13 @@ static bool attn_f32mfma_ok(int S, int hd, bool bwd) {
 
 int attn_fwd(const act_t* qkv, int B, int S, int H, int hd, bool causal, act_t* out, float* lse, hipStream_t st, Drop drop) {
     if ((hd & 7) || S <= 0) return CC_ERR_SHAPE;
+    int img = 0;
+#if CC_OP == 2
+    if (x3_take_emit(out)) {                // the caller's next GEMM will read `out` as an operand image (asked after attn_fwd_can_image)
+        if (!attn_fwd_can_image(S, hd)) return CC_ERR_STATE;
+        img = 1;
+    }
+#endif
 #if CC_OP != 2
     static const bool no_mfma = getenv("CC_ATTN_VALU") != nullptr;   // A/B switch for profiling
     if (!no_mfma || drop.thresh) {
@@ -1787,10 +1797,6 @@ int attn_fwd(const act_t* qkv, int B, int S, int H, int hd, bool causal, act_t* 
         return CC_ERR_SHAPE;
 #endif
     }
-    int img = 0;
-#if CC_OP == 2
-    img = x3_take_emit(out) ? 1 : 0;        // requested by the caller after attn_fwd_can_image()
-#endif
     if (drop.thresh) {
         if (sh > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_attn_fwd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         hipLaunchKernelGGL((k_attn_fwd<true, true>), dim3(B * H), dim3(256), sh, st, qkv, S, H, hd, scale, out, lse, drop, img);
@@ -1938,6 +1944,13 @@ bool attn_bwd_can_image(int S, int hd) {
 int attn_bwd(const act_t* qkv, const act_t* dout, const act_t* o, const float* lse, float* delta, int B, int S, int H, int hd, bool causal,
              act_t* dqkv, hipStream_t st, Drop drop) {
     if ((hd & 7) || S <= 0) return CC_ERR_SHAPE;
+    int img = 0;
+#if CC_OP == 2
+    if (x3_take_emit(dqkv)) {
+        if (!attn_bwd_can_image(S, hd)) return CC_ERR_STATE;
+        img = 1;
+    }
+#endif
 #if CC_OP != 2
     static const bool no_mfma = getenv("CC_ATTN_VALU") != nullptr;
     if ((!no_mfma || drop.thresh) && o && delta) {
@@ -1966,10 +1979,6 @@ int attn_bwd(const act_t* qkv, const act_t* dout, const act_t* o, const float* l
         return CC_ERR_SHAPE;
 #endif
     }
-    int img = 0;
-#if CC_OP == 2
-    img = x3_take_emit(dqkv) ? 1 : 0;       // requested by the caller after attn_bwd_can_image()
-#endif
     if (drop.thresh) {
         if (sh > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_attn_bwd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         hipLaunchKernelGGL((k_attn_bwd<true, true>), dim3(B * H), dim3(256), sh, st, qkv, dout, lse, S, H, hd, scale, dqkv, drop, img);
