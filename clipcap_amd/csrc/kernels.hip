@@ -1347,7 +1347,11 @@ static int attn_bwd_mfma_launch(const op16_t* qkv, const op16_t* dout, const op1
 #endif   // CC_OP != 2
 
 static size_t attn_fwd_lds(int S, int hd) { return ((size_t)3 * S * (hd + 4) + (size_t)S * (S + 1)) * 4; }
-static size_t attn_bwd_lds(int S, int hd) { return ((size_t)4 * S * (hd + 4) + (size_t)2 * S * (S + 1)) * 4; }
+static size_t attn_bwd_lds(int S, int hd) {
+    if (S < 32) return ((size_t)4 * S * (hd + 4) + (size_t)2 * S * (S + 1)) * 4;      // k_attn_bwd_small
+    const size_t S4 = (S + 3) & ~3;
+    return ((size_t)4 * S4 * (hd + 4) + (size_t)2 * S4 * (S4 + 4)) * 4;
+}
 
 // Attention probabilities of an un-masked self-attention layer, recomputed from the stored qkv rows: what the reference's
 // MultiHeadAttention.forward returns as its second value (attention.py:32-42, layout (b, n, m, h)).  One wave per (b, h, query);
@@ -1818,6 +1822,159 @@ template <bool CAUSAL, bool DROP = false>
 __global__ __launch_bounds__(256) void k_attn_bwd(const act_t* __restrict__ qkv, const act_t* __restrict__ dout,
                                                   const float* __restrict__ lse, int S, int H, int hd, float scale,
                                                   act_t* __restrict__ dqkv, Drop drop = Drop(), int img = 0) {
+    // img (bf16x3 build): dqkv receives the [hi | hi | lo] operand image (rows of 3 * 3D 16-bit elements) of c_attn's input-gradient GEMM.
+    // Round 4: 4 x 4 register blocks.  The first form (a thread = 4 queries x 1 key, then 1 row x 4 columns) read 5-6 B of LDS per FMA and
+    // was bound by the LDS port (2.9 MB per block at S = 50, hd = 64); blocks of 4 queries x 4 keys and 4 rows x 4 columns read 2 B per
+    // FMA.  Rows / columns beyond S are zero in LDS, so the inner loops carry no bounds or mask tests.
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int D = H * hd, hdp = hd + 4, S4 = (S + 3) & ~3, Sp = S4 + 4, NB = S4 >> 2;
+    float* Qs = sm;
+    float* Ks = Qs + S4 * hdp;
+    float* Vs = Ks + S4 * hdp;
+    float* Os = Vs + S4 * hdp;  // dO
+    float* Ps = Os + S4 * hdp;
+    float* Ds = Ps + S4 * Sp;   // dP then dS
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const act_t* base = qkv + (size_t)b * S * 3 * D + h * hd;
+    load_head_rows(Qs, hdp, base, 3 * D, S, hd);
+    load_head_rows(Ks, hdp, base + D, 3 * D, S, hd);
+    load_head_rows(Vs, hdp, base + 2 * D, 3 * D, S, hd);
+    load_head_rows(Os, hdp, dout + (size_t)b * S * D + h * hd, D, S, hd);
+    for (int idx = threadIdx.x; idx < (S4 - S) * hdp; idx += 256) {          // zero rows S .. S4-1 of the four operand tiles
+        const int o = S * hdp + idx;
+        Qs[o] = 0.f; Ks[o] = 0.f; Vs[o] = 0.f; Os[o] = 0.f;
+    }
+    __syncthreads();
+    const float* lrow = lse + ((size_t)b * H + h) * S;
+    // ---- P = exp(Q K^T scale - lse), dP = dO V^T: thread = (4 queries, 4 keys)
+    for (int idx = threadIdx.x; idx < NB * NB; idx += 256) {
+        const int qb = idx / NB, kb = idx - qb * NB, i0 = qb * 4, j0 = kb * 4;
+        float sa[4][4], da[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) { sa[i][j] = 0.f; da[i][j] = 0.f; }
+        if (!(CAUSAL && kb > qb)) {
+            for (int d = 0; d < hd; d += 4) {
+                float4 q[4], o[4], k[4], v[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    q[i] = *reinterpret_cast<const float4*>(Qs + (i0 + i) * hdp + d);
+                    o[i] = *reinterpret_cast<const float4*>(Os + (i0 + i) * hdp + d);
+                    k[i] = *reinterpret_cast<const float4*>(Ks + (j0 + i) * hdp + d);
+                    v[i] = *reinterpret_cast<const float4*>(Vs + (j0 + i) * hdp + d);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        sa[i][j] += q[i].x * k[j].x + q[i].y * k[j].y + q[i].z * k[j].z + q[i].w * k[j].w;
+                        da[i][j] += o[i].x * v[j].x + o[i].y * v[j].y + o[i].z * v[j].z + o[i].w * v[j].w;
+                    }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int qi = i0 + i;
+            const float l = qi < S ? lrow[qi] : 0.f;
+            float pr[4], dp[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int kj = j0 + j;
+                const bool live = qi < S && kj < S && !(CAUSAL && kj > qi);
+                pr[j] = live ? __expf(sa[i][j] * scale - l) : 0.f;
+                dp[j] = live ? (DROP ? da[i][j] * drop_mul(drop, ((unsigned)(b * H + h) * S + qi) * S + kj) : da[i][j]) : 0.f;
+            }
+            *reinterpret_cast<float4*>(Ps + qi * Sp + j0) = make_float4(pr[0], pr[1], pr[2], pr[3]);
+            *reinterpret_cast<float4*>(Ds + qi * Sp + j0) = make_float4(dp[0], dp[1], dp[2], dp[3]);
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = wave; i < S; i += 4) {                    // delta_i = sum_j P dP;  dS = P (dP - delta) scale
+        float dl = 0.f;
+        for (int j = lane; j < S4; j += 64) dl += Ps[i * Sp + j] * Ds[i * Sp + j];
+        dl = wave_sum(dl);
+        for (int j = lane; j < S4; j += 64) Ds[i * Sp + j] = Ps[i * Sp + j] * (Ds[i * Sp + j] - dl) * scale;
+    }
+    __syncthreads();
+    // ---- dQ = dS K, dK = dS^T Q, dV = (P mask)^T dO: thread = (4 rows, 4 columns) of all three (dQ's work grows with the row block,
+    //      dK / dV's shrinks: balanced under the causal mask)
+    const int d4n = hd >> 2;
+    for (int idx = threadIdx.x; idx < NB * d4n; idx += 256) {
+        const int rb = idx / d4n, d0 = (idx - rb * d4n) * 4, r0 = rb * 4;
+        float4 dq[4], dk[4], dv[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { dq[i] = make_float4(0, 0, 0, 0); dk[i] = dq[i]; dv[i] = dq[i]; }
+        const int jhi = CAUSAL ? r0 + 4 : S4;              // dQ rows r0..r0+3: keys j <= r (dS is zero above the diagonal and beyond S)
+        for (int j = 0; j < jhi; j += 4) {
+            float4 w[4], k[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                w[i] = *reinterpret_cast<const float4*>(Ds + (r0 + i) * Sp + j);
+                k[i] = *reinterpret_cast<const float4*>(Ks + (j + i) * hdp + d0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                dq[i].x += w[i].x * k[0].x + w[i].y * k[1].x + w[i].z * k[2].x + w[i].w * k[3].x;
+                dq[i].y += w[i].x * k[0].y + w[i].y * k[1].y + w[i].z * k[2].y + w[i].w * k[3].y;
+                dq[i].z += w[i].x * k[0].z + w[i].y * k[1].z + w[i].z * k[2].z + w[i].w * k[3].z;
+                dq[i].w += w[i].x * k[0].w + w[i].y * k[1].w + w[i].z * k[2].w + w[i].w * k[3].w;
+            }
+        }
+        const int ilo = CAUSAL ? r0 : 0;                   // dK / dV rows (keys) r0..r0+3: queries i >= r
+        for (int i = ilo; i < S4; i++) {
+            const float4 w = *reinterpret_cast<const float4*>(Ds + i * Sp + r0);
+            float4 pm = *reinterpret_cast<const float4*>(Ps + i * Sp + r0);
+            if (DROP) {
+                const unsigned e0 = ((unsigned)(b * H + h) * S + i) * S + r0;
+                pm.x *= drop_mul(drop, e0); pm.y *= drop_mul(drop, e0 + 1); pm.z *= drop_mul(drop, e0 + 2); pm.w *= drop_mul(drop, e0 + 3);
+            }
+            const float4 q = *reinterpret_cast<const float4*>(Qs + i * hdp + d0), o = *reinterpret_cast<const float4*>(Os + i * hdp + d0);
+            dk[0].x += w.x * q.x; dk[0].y += w.x * q.y; dk[0].z += w.x * q.z; dk[0].w += w.x * q.w;
+            dk[1].x += w.y * q.x; dk[1].y += w.y * q.y; dk[1].z += w.y * q.z; dk[1].w += w.y * q.w;
+            dk[2].x += w.z * q.x; dk[2].y += w.z * q.y; dk[2].z += w.z * q.z; dk[2].w += w.z * q.w;
+            dk[3].x += w.w * q.x; dk[3].y += w.w * q.y; dk[3].z += w.w * q.z; dk[3].w += w.w * q.w;
+            dv[0].x += pm.x * o.x; dv[0].y += pm.x * o.y; dv[0].z += pm.x * o.z; dv[0].w += pm.x * o.w;
+            dv[1].x += pm.y * o.x; dv[1].y += pm.y * o.y; dv[1].z += pm.y * o.z; dv[1].w += pm.y * o.w;
+            dv[2].x += pm.z * o.x; dv[2].y += pm.z * o.y; dv[2].z += pm.z * o.z; dv[2].w += pm.z * o.w;
+            dv[3].x += pm.w * o.x; dv[3].y += pm.w * o.y; dv[3].z += pm.w * o.z; dv[3].w += pm.w * o.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r = r0 + i;
+            if (r >= S) break;
+#if CC_OP == 2
+            if (img) {
+                op16_t* r3 = reinterpret_cast<op16_t*>(dqkv) + ((size_t)b * S + r) * 9 * D + h * hd + d0;
+                const float4 gq[3] = {dq[i], dk[i], dv[i]};
+#pragma unroll
+                for (int t = 0; t < 3; t++) {
+                    const unsigned h01 = pack2op(gq[t].x, gq[t].y), h23 = pack2op(gq[t].z, gq[t].w);
+                    float a0, a1, a2, a3;
+                    unpack2(h01, a0, a1);
+                    unpack2(h23, a2, a3);
+                    const uint2 hi = make_uint2(h01, h23), lo = make_uint2(pack2op(gq[t].x - a0, gq[t].y - a1), pack2op(gq[t].z - a2, gq[t].w - a3));
+                    *reinterpret_cast<uint2*>(r3 + t * D) = hi;
+                    *reinterpret_cast<uint2*>(r3 + 3 * D + t * D) = hi;
+                    *reinterpret_cast<uint2*>(r3 + 6 * D + t * D) = lo;
+                }
+                continue;
+            }
+#endif
+            act_t* o = dqkv + ((size_t)b * S + r) * 3 * D + h * hd + d0;
+            act_st4(o, dq[i].x, dq[i].y, dq[i].z, dq[i].w);
+            act_st4(o + D, dk[i].x, dk[i].y, dk[i].z, dk[i].w);
+            act_st4(o + 2 * D, dv[i].x, dv[i].y, dv[i].z, dv[i].w);
+        }
+    }
+}
+// Short sequences (S < 32: the mapper's 20 rows): the first form — a thread = 4 queries x 1 key, then 1 row x 4 columns.  The 4 x 4 blocks
+// above leave 25 of 256 threads busy there (measured 47 -> 55 us per mapper layer).
+template <bool CAUSAL, bool DROP = false>
+__global__ __launch_bounds__(256) void k_attn_bwd_small(const act_t* __restrict__ qkv, const act_t* __restrict__ dout,
+                                                  const float* __restrict__ lse, int S, int H, int hd, float scale,
+                                                  act_t* __restrict__ dqkv, Drop drop = Drop(), int img = 0) {
     // img (bf16x3 build): dqkv receives the [hi | hi | lo] operand image (rows of 3 * 3D 16-bit elements) of c_attn's input-gradient GEMM
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int D = H * hd, hdp = hd + 4, Sp = S + 1;
@@ -1979,7 +2136,16 @@ int attn_bwd(const act_t* qkv, const act_t* dout, const act_t* o, const float* l
         return CC_ERR_SHAPE;
 #endif
     }
-    if (drop.thresh) {
+    if (S < 32) {
+        if (sh > 64 * 1024) {
+            (void)hipFuncSetAttribute((const void*)k_attn_bwd_small<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+            (void)hipFuncSetAttribute((const void*)k_attn_bwd_small<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+            (void)hipFuncSetAttribute((const void*)k_attn_bwd_small<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        }
+        if (drop.thresh) hipLaunchKernelGGL((k_attn_bwd_small<true, true>), dim3(B * H), dim3(256), sh, st, qkv, dout, lse, S, H, hd, scale, dqkv, drop, img);
+        else if (causal) hipLaunchKernelGGL(k_attn_bwd_small<true>, dim3(B * H), dim3(256), sh, st, qkv, dout, lse, S, H, hd, scale, dqkv, Drop(), img);
+        else hipLaunchKernelGGL(k_attn_bwd_small<false>, dim3(B * H), dim3(256), sh, st, qkv, dout, lse, S, H, hd, scale, dqkv, Drop(), img);
+    } else if (drop.thresh) {
         if (sh > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_attn_bwd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         hipLaunchKernelGGL((k_attn_bwd<true, true>), dim3(B * H), dim3(256), sh, st, qkv, dout, lse, S, H, hd, scale, dqkv, drop, img);
     } else if (causal) {
