@@ -110,6 +110,7 @@ SIGNATURES = {
     "cc_loss_scale_update": (_I, [_P, _P, _F, _F, _I, _P]),
     "cc_dropout_mask": (_I, [C.c_uint64, _I, _I, _F, _L, _P, _P]),
     "cc_sample_step": (_I, [_P, _I, _I, _I, _F, _I, _F, _I, _P, _I, _I, _F, _P, _P, _P, _P]),
+    "cc_sample_step_lp": (_I, [_P, _I, _I, _I, _F, _I, _F, _I, _P, _I, _I, _F, _I, _F, _P, _P, _P, _P]),
     "cc_wgrad_scratch_bytes": (_L, []),
     "cc_gemm_wgrad": (_I, [_I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _P]),
     "cc_gemm_tile_mode": (_I, [_I]),
@@ -122,6 +123,7 @@ SIGNATURES = {
     "cc_comm_unique_id": (_I, [_P]),
     "cc_comm_create": (_I, [C.POINTER(_P), _I, _I, _P]),
     "cc_allreduce_bucket": (_I, [_P, _P, _L, _I, _P]),
+    "cc_broadcast_bucket": (_I, [_P, _P, _L, _I, _I, _P]),
     "cc_comm_destroy": (_I, [_P]),
     "cc_comm_count": (_I, [_P, C.POINTER(_I)]),
     "cc_prof_start": (_I, [_I, _I]),

@@ -1025,6 +1025,14 @@ int CC_API(cc_sample_step)(const float* logits, int32_t R, int32_t V, int32_t ld
                        repetition_penalty, u, next_token, probs_out, S_(stream));
 }
 
+int CC_API(cc_sample_step_lp)(const float* logits, int32_t R, int32_t V, int32_t ld, float temperature, int32_t top_k, float top_p, int32_t mode,
+                      const int64_t* history, int32_t hist_len, int32_t hist_ld, float repetition_penalty, int32_t stop_token,
+                      float length_penalty, const float* u, int32_t* next_token, float* probs_out, void* stream) {
+    if (!logits || !u || !next_token || R < 0) return CC_ERR_ARG;
+    return sample_rows(logits, R, V, ld, temperature, top_k, top_p, mode, reinterpret_cast<const long long*>(history), hist_len, hist_ld,
+                       repetition_penalty, u, next_token, probs_out, S_(stream), stop_token, length_penalty);
+}
+
 int64_t CC_API(cc_wgrad_scratch_bytes)(void) { return (int64_t)WGRAD_SCRATCH_BYTES; }
 
 int CC_API(cc_gemm_wgrad)(const uint16_t* X, int32_t ldx, const uint16_t* Y, int32_t ldy, int32_t Mw, int32_t Nw, int32_t K, float* dW, int32_t ldw,

@@ -58,7 +58,8 @@ int ce_dlogits(act_t* logits, int ld, int V, const int* target, const float* lse
                hipStream_t st, op16_t* img = nullptr);   // img (bf16x3): write the gradient as the dgrad GEMM's operand image there instead of in place
 // sample.hip: one sampling step per row (temperature, repetition penalty, top-k, top-p, inverse-CDF draw at u[row])
 int sample_rows(const float* logits, int R, int V, int ld, float temperature, int top_k, float top_p, int mode, const long long* hist,
-                int hist_len, int hist_ld, float rep_pen, const float* u, int* next_token, float* probs_out, hipStream_t st);
+                int hist_len, int hist_ld, float rep_pen, const float* u, int* next_token, float* probs_out, hipStream_t st, int stop_tok = -1,
+                float len_pen = 1.0f);   // stop_tok >= 0: sentence-length penalty (history tokens whose filtered value == stop id are scaled by len_pen)
 int ce_targets(const long long* tokens, int* target, int* row_map, int B, int cap, int L, int T, hipStream_t st);
 // Exponential form of the lm_head outputs (gemm.hip.h EpiLMHead, bf16 build):
 //   lm_tgt_ref   cref[m] = hf[m] . wte[target[m]]  (16-bit operands, fp32 accumulate): the reference shift of row m

@@ -190,7 +190,8 @@ __device__ unsigned sm_select(const SmRow& r, int V, unsigned long long target, 
 //         largest (all ties), then the minimal sorted prefix with cumulative mass > top_p relative to the top-k set.
 __global__ __launch_bounds__(SM_T) void k_sample_rows(const float* __restrict__ logits, int ld, int V, float inv_temp, int top_k, float top_p,
                                                       int mode, const long long* __restrict__ hist, int hist_len, int hist_ld, float rep_pen,
-                                                      const float* __restrict__ u, int* __restrict__ next_token, float* __restrict__ probs_out) {
+                                                      const float* __restrict__ u, int* __restrict__ next_token, float* __restrict__ probs_out,
+                                                      int stop_tok, float len_pen) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm_raw[];
     unsigned long long* hist_w = reinterpret_cast<unsigned long long*>(sm_raw);                 // [SM_NB]
     unsigned long long* red = hist_w + SM_NB;                                                   // [SM_T/64 + 2]
@@ -206,7 +207,12 @@ __global__ __launch_bounds__(SM_T) void k_sample_rows(const float* __restrict__ 
     r.rep_pen = rep_pen;
     r.inv_temp = inv_temp;
     r.use_rep = hist != nullptr && hist_len > 0 && rep_pen != 1.0f;
-    if (r.use_rep) {
+    // Sentence-length penalty of generate_no_beam (no_beam.py:55-60 -> utils.py:40-51): AFTER filtering, a history token whose value
+    // EQUALS float(stop token id) is multiplied by len_pen (the reference compares the gathered logit VALUES with the id, and this does
+    // the same).  stop_tok < 0 = off.
+    const bool slp = stop_tok >= 0 && hist != nullptr && hist_len > 0;
+    const float stopf = (float)stop_tok;
+    if (r.use_rep || slp) {
         for (int i = threadIdx.x; i < (V + 31) / 32; i += SM_T) bitmap[i] = 0;
         __syncthreads();
         for (int i = threadIdx.x; i < hist_len; i += SM_T) {
@@ -324,10 +330,26 @@ __global__ __launch_bounds__(SM_T) void k_sample_rows(const float* __restrict__ 
         if (!p_on) return true;
         return k > Tp || (k == Tp && p_keep > 0 && (unsigned)i <= p_last);
     };
+    // final values: the kept set with the sentence-length penalty applied; their maximum replaces m in the softmax weights (the
+    // penalised value may exceed the row maximum, or the row maximum may be the value that shrinks)
+    auto fin = [=](int i, float v) { return (slp && v == stopf && ((bitmap[i >> 5] >> (i & 31)) & 1u)) ? v * len_pen : v; };
+    float m2 = m;
+    if (slp) {
+        float mm = -INFINITY;
+        sm_for_strided(r, V, [&](int i, float v) { if (kept(i, sm_key(v))) mm = fmaxf(mm, fin(i, v)); });
+        for (int o = 32; o > 0; o >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o, 64));
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) fred[threadIdx.x >> 6] = mm;
+        __syncthreads();
+        mm = fred[0];
+        for (int i = 1; i < SM_T / 64; i++) mm = fmaxf(mm, fred[i]);
+        m2 = mm;
+    }
+    auto wfin = [=](int i, float v) { return (unsigned long long)(unsigned)(__expf(fin(i, v) - m2) * 4294967040.0f); };
     // kept mass per wave range (index order across waves), total, and the draw: inverse CDF in index order at u
     unsigned long long mine = 0;
     sm_for_wave_range(r, w_lo, w_hi, lane, [&](int i, float v, bool valid) {
-        if (valid && kept(i, sm_key(v))) mine += wfix(v);
+        if (valid && kept(i, sm_key(v))) mine += wfin(i, v);
         return true;
     });
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
@@ -345,7 +367,7 @@ __global__ __launch_bounds__(SM_T) void k_sample_rows(const float* __restrict__ 
     if (mine > 0 && pick >= base && pick < base + mine) {                // the drawn token lies in this wave's range
         unsigned long long run = base;
         sm_for_wave_range(r, w_lo, w_hi, lane, [&](int i, float v, bool valid) {
-            const unsigned long long w = (valid && kept(i, sm_key(v))) ? wfix(v) : 0;
+            const unsigned long long w = (valid && kept(i, sm_key(v))) ? wfin(i, v) : 0;
             unsigned long long inc = w;                                  // inclusive prefix over the 64 lanes
             for (int o = 1; o < 64; o <<= 1) {
                 const unsigned long long n = __shfl_up(inc, o, 64);
@@ -360,7 +382,7 @@ __global__ __launch_bounds__(SM_T) void k_sample_rows(const float* __restrict__ 
     __syncthreads();
     if (probs_out) {
         const float inv_total = total > 0 ? 1.0f / (float)total : 0.f;
-        sm_for_strided(r, V, [&](int i, float v) { probs_out[(size_t)row * V + i] = kept(i, sm_key(v)) ? (float)wfix(v) * inv_total : 0.f; });
+        sm_for_strided(r, V, [&](int i, float v) { probs_out[(size_t)row * V + i] = kept(i, sm_key(v)) ? (float)wfin(i, v) * inv_total : 0.f; });
     }
     if (threadIdx.x == 0) {
         unsigned t = bcast[2];
@@ -374,7 +396,8 @@ size_t sample_lds_bytes(int V) {
 }
 
 int sample_rows(const float* logits, int R, int V, int ld, float temperature, int top_k, float top_p, int mode, const long long* hist,
-                int hist_len, int hist_ld, float rep_pen, const float* u, int* next_token, float* probs_out, hipStream_t st) {
+                int hist_len, int hist_ld, float rep_pen, const float* u, int* next_token, float* probs_out, hipStream_t st, int stop_tok,
+                float len_pen) {
     if (R <= 0) return CC_OK;
     if (V <= 0 || ld < V || (mode != 0 && mode != 1)) return CC_ERR_ARG;
     const size_t sh = sample_lds_bytes(V);
@@ -383,7 +406,7 @@ int sample_rows(const float* logits, int R, int V, int ld, float temperature, in
     if (!attr) { (void)hipFuncSetAttribute((const void*)k_sample_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
     const float inv_temp = temperature > 0.f ? 1.0f / temperature : 1.0f;          // base.py:163
     hipLaunchKernelGGL(k_sample_rows, dim3(R), dim3(SM_T), sh, st, logits, ld, V, inv_temp, top_k, top_p, mode, hist, hist_len, hist_ld,
-                       rep_pen, u, next_token, probs_out);
+                       rep_pen, u, next_token, probs_out, stop_tok, len_pen);
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
 

@@ -55,6 +55,8 @@ class _Arena:
         self.m: Optional[torch.Tensor] = None
         self.v: Optional[torch.Tensor] = None
         self._w16_version = -1
+        # optimizer-state sharding (train/ddp.py ZeroShard): (rank, [(lo, hi)] per rank, gather(t, ranges)).  m / v then cover the own range only
+        self.zero = None
         # tensors aliasing w32 whose in-place writes do NOT bump w32._version: nn.Parameters re-pointed with ``p.data = view``
         # (ArenaModule._rebind) carry their own version counters, so load_state_dict / torch optimizers writing through them
         # would otherwise leave the bf16 operand copy stale.  The dirty stamp is the sum over w32 and every watched alias.
@@ -103,6 +105,34 @@ class _Arena:
                 setattr(new, name, t.to(new.device))
         return new
 
+    def shard_optimizer_state(self, rank: int, world: int, gather) -> None:
+        """ZeRO stage 1 (the reference's --deepspeed-strategy, clipcap/train/args.py:87-92, which Lightning hands to DeepSpeed): this rank
+        keeps the AdamW moments of elements [lo, hi) of the arena only and steps only those; ``gather(w32, ranges)`` then broadcasts every
+        owner's updated slice (ddp.ZeroShard).  Gradients stay all-reduced over the whole arena, so the update of an element is the one
+        the unsharded step computes, bit for bit.  Full moments already present (a resumed run) are cut down to the own range."""
+        per = (((self.n + world - 1) // world) + 7) // 8 * 8
+        ranges = [(min(self.n, r * per), min(self.n, (r + 1) * per)) for r in range(world)]
+        lo, hi = ranges[rank]
+        for name in ("m", "v"):
+            t = getattr(self, name)
+            if t is not None and t.numel() == self.n:
+                setattr(self, name, t[lo:hi].clone())
+        self.zero = (rank, ranges, gather)
+
+    def full_moments(self):
+        """(m, v) over the whole arena — with sharded optimizer state a COLLECTIVE (every rank calls it): the owners' slices gathered."""
+        if self.zero is None or self.m is None:
+            return self.m, self.v
+        rank, ranges, gather = self.zero
+        lo, hi = ranges[rank]
+        out = []
+        for t in (self.m, self.v):
+            full = torch.zeros(self.n, dtype=torch.float32, device=self.device)
+            full[lo:hi].copy_(t)
+            gather(full, ranges)
+            out.append(full)
+        return out[0], out[1]
+
     def grads(self) -> torch.Tensor:
         if self.g32 is None:
             self.g32 = torch.zeros(self.n, dtype=torch.float32, device=self.device)
@@ -112,6 +142,21 @@ class _Arena:
                    scaler: Optional["LossScaler"] = None):
         """torch.optim.AdamW math (reference model.py:73-77) over the whole arena, refreshing the 16-bit operand copy.
         ``scaler`` (fp16 operands): the gradients carry its loss scale, and a step whose backward overflowed is skipped on the device."""
+        if self.zero is not None:                       # sharded optimizer state: own slice, then the owners' slices travel
+            rank, ranges, gather = self.zero
+            lo, hi = ranges[rank]
+            if self.m is None:
+                self.m = torch.zeros(hi - lo, dtype=torch.float32, device=self.device)
+                self.v = torch.zeros(hi - lo, dtype=torch.float32, device=self.device)
+            assert self.m.numel() == hi - lo
+            if hi > lo:
+                check(_lib.lib().cc_adamw_step(_p(self.w32[lo:hi]), _p(self.grads()[lo:hi]), _p(self.m), _p(self.v), hi - lo, lr, betas[0], betas[1],
+                                               eps, weight_decay, 0 if scaler is not None else step, grad_scale,
+                                               _p(scaler.scale) if scaler is not None else None,
+                                               _p(scaler.found_inf) if scaler is not None else None, _stream(self.device)), "cc_adamw_step")
+            gather(self.w32, ranges)
+            self.refresh_bf16()
+            return
         if self.m is None:
             self.m = torch.zeros_like(self.w32)
             self.v = torch.zeros_like(self.w32)
@@ -672,10 +717,13 @@ def beam_step(logits: torch.Tensor, samples: int, beam: int, temperature: float,
 
 
 def sample_step(logits: torch.Tensor, u: torch.Tensor, temperature: float = 1.0, top_k: int = 0, top_p: float = 0.0, mode: int = 0,
-                history: torch.Tensor = None, hist_len: int = 0, repetition_penalty: float = 1.0, return_probs: bool = False):
+                history: torch.Tensor = None, hist_len: int = 0, repetition_penalty: float = 1.0, return_probs: bool = False,
+                length_penalty_stop: int = -1, length_penalty: float = 1.0):
     """One device-side sampling step for every row of fp32 ``logits`` (R, V) (reference inference/base.py:159-184 for mode 0 =
     generate_nucleus_sampling, :245-262 + utils.py:5-37 for mode 1 = top_k_top_p_filtering + softmax).  ``u`` (R,) uniforms in
-    [0, 1) drive the inverse-CDF draw; ``history`` int64 (R, >= hist_len) feeds the repetition penalty.
+    [0, 1) drive the inverse-CDF draw; ``history`` int64 (R, >= hist_len) feeds the repetition penalty and, with
+    ``length_penalty_stop`` >= 0, the sentence-length penalty of no_beam.py:55-60 (history tokens whose filtered value equals
+    float(stop id) are multiplied by ``length_penalty``, utils.py:40-51).
     Returns next_tokens int32 (R,) [, probs fp32 (R, V) — the pre-sampling distribution]."""
     dev = logits.device
     R, V = logits.shape
@@ -683,8 +731,9 @@ def sample_step(logits: torch.Tensor, u: torch.Tensor, temperature: float = 1.0,
     probs = torch.empty(R, V, dtype=torch.float32, device=dev) if return_probs else None
     if history is not None:
         assert history.dtype == torch.int64 and history.shape[0] == R and history.stride(1) == 1
-    check(_lib.lib().cc_sample_step(_p(logits), R, V, logits.stride(0), float(temperature), int(top_k or 0), float(top_p or 0.0), int(mode),
-                                   _p(history) if history is not None else None, int(hist_len), history.stride(0) if history is not None else 0,
-                                   float(repetition_penalty), _p(u), _p(nt), _p(probs) if probs is not None else None, _stream(dev)),
-          "cc_sample_step")
+    check(_lib.lib().cc_sample_step_lp(_p(logits), R, V, logits.stride(0), float(temperature), int(top_k or 0), float(top_p or 0.0), int(mode),
+                                      _p(history) if history is not None else None, int(hist_len),
+                                      history.stride(0) if history is not None else 0, float(repetition_penalty), int(length_penalty_stop),
+                                      float(length_penalty), _p(u), _p(nt), _p(probs) if probs is not None else None, _stream(dev)),
+          "cc_sample_step_lp")
     return (nt, probs) if return_probs else nt

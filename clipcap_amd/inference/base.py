@@ -92,12 +92,16 @@ def generate_beam(model, tokenizer: Callable, embeds: torch.Tensor, number_to_ge
 @torch.no_grad()
 def sample_tokens(model, embeds: torch.Tensor, entry_length: int = 67, stop_token: int = 50256, *, mode: int = 0, top_p: float = 0.8,
                   top_k: Optional[int] = None, temperature: float = 1.0, repetition_penalty: float = 1.0,
-                  generator: Optional[torch.Generator] = None, head_tokens: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                  generator: Optional[torch.Generator] = None, head_tokens: Optional[torch.Tensor] = None,
+                  desired_sentence_length: Optional[int] = None, sentence_length_factor: float = 1.0) -> Tuple[torch.Tensor, torch.Tensor]:
     """KV-cached sampling for a batch of prefixes, every step on the device (cc_decode_fwd + cc_sample_step, no host sync except
     an all-rows-stopped poll every 4th step).  embeds fp32 (R, L, D).  mode 0 = the nucleus rule of generate_nucleus_sampling
     (base.py:165-181), mode 1 = top_k_top_p_filtering + softmax (base.py:245-262).
     ``head_tokens`` int64 (R, H0) or (1, H0): tokens that precede the generated ones in the repetition-penalty history (the
     reference penalises ``tokens`` = text_prefix_tokens ++ generated, no_beam.py:32,45-48).
+    ``desired_sentence_length`` not None: the sentence-length penalty of no_beam.py:55-60 — with a non-empty history, history tokens
+    whose filtered logit equals float(stop_token) are scaled by (len(history) / desired_sentence_length) * sentence_length_factor
+    (utils.py:40-51) before the softmax, inside cc_sample_step_lp.
     Returns (tokens int64 (R, n), stop_pos int64 (R,)): stop_pos[r] = index of the first stop token of row r (n if none)."""
     lm = model.language_model
     g = lm.engine
@@ -117,7 +121,9 @@ def sample_tokens(model, embeds: torch.Tensor, entry_length: int = 67, stop_toke
         logits = sess.forward(x)                                                     # (R, V) fp32
         u = torch.rand(R, device=dev, generator=generator)
         nxt = sample_step(logits, u, temperature=temperature, top_k=top_k or 0, top_p=top_p, mode=mode, history=hist, hist_len=H0 + step,
-                          repetition_penalty=repetition_penalty)                     # int32 (R,)
+                          repetition_penalty=repetition_penalty,
+                          length_penalty_stop=stop_token if desired_sentence_length is not None else -1,
+                          length_penalty=((H0 + step) / desired_sentence_length) * sentence_length_factor if desired_sentence_length else 1.0)  # int32 (R,)
         toks[:, step] = nxt
         n = step + 1
         # every row has produced its stop token: polled every 4th step (one host sync instead of four; the extra tokens are cut below)
@@ -155,9 +161,9 @@ def generate_no_beam(model, tokenizer: Callable, embeds: torch.Tensor, text_pref
                      sweep: bool = True, generator: Optional[torch.Generator] = None) -> List[str]:
     """base.py:204-279: the reference's debugging sweep over top_p x temperature (sweep=True reproduces it; sweep=False samples
     once with the given top_p / temperature).  Like the reference, ``repetition_penalty`` is accepted but not applied (its call is
-    commented out, base.py:236-239), and the sentence-length penalty (base.py:248-254) is omitted: it multiplies logits whose
-    VALUE equals the stop token id (utils.py:45 compares values, not ids), which never happens for real logits.  The text of a
-    row excludes its stop token (the reference breaks before appending, base.py:261-262)."""
+    commented out, base.py:236-239).  The sentence-length penalty (base.py:248-254) is applied as the reference applies it: after the
+    filter, history tokens whose VALUE equals the stop token id (utils.py:45 compares values, not ids) are scaled — on the device,
+    inside the sampling step.  The text of a row excludes its stop token (the reference breaks before appending, base.py:261-262)."""
     stop = _stop_id(tokenizer)
     embeds = _with_text_prefix(model, embeds, text_prefix_tokens)
     grid = [(p, t) for p in (0.5, 0.55, 0.6, 0.65, 0.7, 0.75, 0.8, 0.85, 0.9, 0.95, 1.0) for t in (0.9, 0.95, 1.0)] if sweep \
@@ -165,7 +171,9 @@ def generate_no_beam(model, tokenizer: Callable, embeds: torch.Tensor, text_pref
     head = [] if text_prefix_tokens is None else [int(v) for v in text_prefix_tokens.flatten()]
     gens = []
     for p, t in grid:
-        toks, stop_pos = sample_tokens(model, embeds, entry_length, stop, mode=1, top_p=p, top_k=int(top_k), temperature=t, generator=generator)
+        toks, stop_pos = sample_tokens(model, embeds, entry_length, stop, mode=1, top_p=p, top_k=int(top_k), temperature=t, generator=generator,
+                                       head_tokens=text_prefix_tokens, desired_sentence_length=desired_sentence_length,
+                                       sentence_length_factor=sentence_length_factor)
         toks, stop_pos = toks.cpu(), stop_pos.cpu()
         gens.extend(tokenizer.decode(head + toks[r, :int(stop_pos[r])].tolist()) for r in range(toks.shape[0]))
     return gens

@@ -6,11 +6,12 @@ It is NOT the function of the same name in inference/base.py (:204-279, a top_p 
   * applies the repetition penalty (default 1.2) to every token already in ``tokens`` = text_prefix_tokens ++ generated
     (no_beam.py:45-48; utils.py:33-37), BEFORE temperature and top-k / top-p filtering (:50-52);
   * returns text_prefix_tokens ++ generated without the stop token (it breaks before appending, :67-75).
-The sentence-length penalty (no_beam.py:55-60) multiplies logits whose VALUE equals the stop-token id (utils.py:45 compares
-gathered logit values with the id), which cannot happen for real-valued logits other than by coincidence; it is not applied.
+  * applies the sentence-length penalty (no_beam.py:55-60) the way the reference does: after the filter, history tokens whose logit
+    VALUE equals the stop-token id (utils.py:45 compares gathered logit values with the id) are multiplied by
+    len(tokens) / desired_sentence_length * sentence_length_factor.
 
 Device path: one KV-cached batched decode (cc_decode_fwd) with all ``number_to_generate`` repetitions as rows, the whole
-per-step rule (penalty with a history bitmap, temperature, filter, softmax, draw) in cc_sample_step.
+per-step rule (penalties with a history bitmap, temperature, filter, softmax, draw) in cc_sample_step_lp.
 """
 from __future__ import annotations
 
@@ -29,7 +30,8 @@ def generate_no_beam(model, tokenizer: Callable, embeds: torch.Tensor, number_to
     embeds = _with_text_prefix(model, embeds, text_prefix_tokens)                     # no_beam.py:28-30
     rows = _rows_for(embeds, number_to_generate)
     toks, stop_pos = sample_tokens(model, rows, entry_length, stop, mode=1, top_p=top_p, top_k=int(top_k), temperature=temperature,
-                                   repetition_penalty=repetition_penalty, generator=generator, head_tokens=text_prefix_tokens)
+                                   repetition_penalty=repetition_penalty, generator=generator, head_tokens=text_prefix_tokens,
+                                   desired_sentence_length=desired_sentence_length, sentence_length_factor=sentence_length_factor)
     head = [] if text_prefix_tokens is None else [int(v) for v in text_prefix_tokens.flatten()]
     toks, stop_pos = toks.cpu(), stop_pos.cpu()
     return [tokenizer.decode(head + toks[r, :int(stop_pos[r])].tolist()) for r in range(toks.shape[0])]

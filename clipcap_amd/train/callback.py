@@ -22,13 +22,24 @@ class CheckpointSaver:
         with open(self.output_path / f"{self.filename_prefix}_config.yaml", "w+") as f:
             yaml.dump(config, f, default_flow_style=False)
 
-    def _write(self, model, path: Path, extra: dict) -> None:
-        state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    @staticmethod
+    def optimizer_state(model) -> dict:
+        """AdamW moments per arena over the WHOLE arena.  With sharded optimizer state (ddp.ZeroShard) this is a collective: every rank
+        calls it, rank 0 writes the result."""
         opt = {}
         for name, mod in (("mapper", model.transformer_mapper), ("lm", model.language_model)):
             a = mod.engine.arena
             if a.m is not None:
-                opt[name] = {"m": a.m.cpu(), "v": a.v.cpu()}
+                m, v = a.full_moments()
+                opt[name] = {"m": m.cpu(), "v": v.cpu()}
+        return opt
+
+    def _write(self, model, path: Path, extra: dict) -> None:
+        state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        extra = dict(extra)
+        opt = extra.pop("optimizer_state", None)
+        if opt is None:
+            opt = self.optimizer_state(model)
         sc = getattr(model.engine, "scaler", None)      # fp16 operands: [scale, good steps, applied steps] of the dynamic loss scale
         if sc is not None:
             extra = dict(extra, loss_scaler=sc.state.cpu())
@@ -52,6 +63,9 @@ def resume(model, ckpt_path: str) -> dict:
             a = mod.engine.arena
             a.m = st["m"].to(a.device)
             a.v = st["v"].to(a.device)
+            if a.zero is not None:                      # sharding already configured: keep the own range only
+                lo, hi = a.zero[1][a.zero[0]]
+                a.m, a.v = a.m[lo:hi].clone(), a.v[lo:hi].clone()
     model._opt_step = int(ck.get("optimizer_step", 0))
     if "loss_scaler" in ck and model.language_model.engine.arena.device.type == "cuda":
         sc = model.engine._scaler(model.language_model.engine.arena.device)

@@ -87,6 +87,46 @@ class CAbiComm:
             pass
 
 
+class ZeroShard:
+    """Optimizer-state sharding (ZeRO stage 1; what ``--deepspeed-strategy`` asks DeepSpeed for in the reference, clipcap/train/args.py:87-92
+    -> train.py:77-85): rank r owns the AdamW moments of one contiguous slice of every parameter arena, steps that slice, and the
+    slices are exchanged by one broadcast per owner (slices may differ in length, which an all-gather would not allow in place).
+    ``gather`` is the callable ``_Arena.shard_optimizer_state`` takes; it runs on the current stream (the next forward needs the result)."""
+
+    def __init__(self, rank: int, world: int, group=None, comm: Optional["CAbiComm"] = None):
+        self.rank, self.world, self.group, self.comm = rank, world, group, comm
+
+    def gather(self, t: torch.Tensor, ranges) -> None:
+        if self.comm is not None:
+            C, lib = self.comm._C, self.comm._lib
+            st = C.c_void_p(torch.cuda.current_stream(self.comm.device).cuda_stream)
+            for r, (lo, hi) in enumerate(ranges):
+                if hi > lo:
+                    lib.check(lib.lib().cc_broadcast_bucket(self.comm._comm, C.c_void_p(t[lo:hi].data_ptr()), hi - lo, 0, r, st), "cc_broadcast_bucket")
+            return
+        works = [dist.broadcast(t[lo:hi], src=dist.get_global_rank(self.group, r) if self.group is not None else r, group=self.group, async_op=True)
+                 for r, (lo, hi) in enumerate(ranges) if hi > lo]
+        for w in works:
+            w.wait()
+
+    def apply(self, arenas) -> None:
+        for a in arenas:
+            a.shard_optimizer_state(self.rank, self.world, self.gather)
+
+
+def zero_stage(strategy: Optional[str]) -> int:
+    """``--deepspeed-strategy`` (Lightning's names: deepspeed_stage_1 / _2 / _2_offload / _3 / _3_offload, or a bare digit) -> 0 (replicated
+    optimizer state) or 1 (sharded).  Stages 2 and 3 also shard gradients / parameters in DeepSpeed; the flat arenas here stay replicated
+    (they are what the kernels read), so every stage >= 1 shards the optimizer state — the largest of the three for AdamW."""
+    if not strategy:
+        return 0
+    s = str(strategy).lower()
+    for d in "321":
+        if d in s:
+            return 1
+    return 0
+
+
 def _wire_cast(src: torch.Tensor, dst: torch.Tensor) -> None:
     """fp32 <-> bf16 gradient slice on the current stream: the library's cc_grad_wire_pack / _unpack on the GPU (PyTorch is plumbing
     there, not arithmetic); on CPU tensors (the gloo tests) torch's own cast — both round to nearest even, bit-identical."""

@@ -18,7 +18,7 @@ from clipcap_amd.train.args import add_training_args
 from clipcap_amd.train.callback import CheckpointSaver, resume
 from clipcap_amd.train.dataloader import DevicePrefetcher, get_dataloader
 from clipcap_amd._lib import OP_BF16, OP_FP16, OP_X3
-from clipcap_amd.train.ddp import GradReducer
+from clipcap_amd.train.ddp import GradReducer, ZeroShard, zero_stage
 
 
 def grad_wire_dtype(op_dtype: int, train_lm: bool) -> torch.dtype:
@@ -82,6 +82,13 @@ def train(args: Namespace, tokenizer=None, language_model=None) -> int:
         print(f"clipcap_amd: operand mode: {mode[model.transformer_mapper.engine.op_dtype]}; gradient wire: {str(wire).replace('torch.', '')}"
               + (f" over {world} ranks" if world > 1 else ""), flush=True)
     reducer = GradReducer([a.grads() for a in arenas], wire_dtype=wire) if world > 1 else None
+    sharded = world > 1 and zero_stage(getattr(args, "deepspeed_strategy", None)) > 0
+    if sharded:
+        # --deepspeed-strategy (args.py:87-92): AdamW moments sharded over the ranks (ZeRO stage 1); after the resume broadcast above, so
+        # that full moments of a resumed run are cut down to each rank's own range
+        ZeroShard(rank, world).apply(arenas)
+        if rank == 0:
+            print(f"clipcap_amd: optimizer state sharded over {world} ranks (--deepspeed-strategy {args.deepspeed_strategy})", flush=True)
     sched = linear_warmup_decay(args.scheduler_warmup_steps, args.total_steps)
     logger = None
     if args.enable_wandb and rank == 0:
@@ -99,10 +106,13 @@ def train(args: Namespace, tokenizer=None, language_model=None) -> int:
                 print(f"epoch {epoch} step {step}/{args.total_steps} loss {val:.4f}", flush=True)
                 if logger is not None:
                     logger.log({"loss": val}, step=step)
+        # with sharded optimizer state, collecting the moments is a collective: every rank takes part, rank 0 writes
+        opt = CheckpointSaver.optimizer_state(model) if sharded and epoch % saver.save_every_n_epochs == 0 else None
         if rank == 0:
-            saver.on_epoch_end(model, epoch, step=step)
+            saver.on_epoch_end(model, epoch, step=step, **({"optimizer_state": opt} if opt is not None else {}))
+    opt = CheckpointSaver.optimizer_state(model) if sharded else None
     if rank == 0:
-        saver.save_final_checkpoint(model, step=step)
+        saver.save_final_checkpoint(model, step=step, **({"optimizer_state": opt} if opt is not None else {}))
     return 0
 
 

@@ -55,7 +55,8 @@ extern "C" {
  * cc_adamw_step / cc_adamw_step_cast accept step == 0 (= take the step number from loss_scale[2]) — a version-2 caller passing float[2]
  * would be written out of bounds, so clipcap_amd/_lib.py refuses a library whose version differs.  Entry points ADDED since 2:
  * cc_adamw_step_cast, cc_mapper_transpose_weights, cc_gpt2_transpose_weights, cc_comm_count, cc_decode_part_floats, cc_decode_fwd_p,
- * cc_beam_step_p; since 3: cc_decode_fwd_g, cc_decode_ws_check, cc_decode_mode, cc_grad_wire_pack, cc_grad_wire_unpack; operand mode ADDED: CC_OP_BF16X3 */
+ * cc_beam_step_p; since 3: cc_decode_fwd_g, cc_decode_ws_check, cc_decode_mode, cc_grad_wire_pack, cc_grad_wire_unpack,
+ * cc_sample_step_lp, cc_broadcast_bucket; operand mode ADDED: CC_OP_BF16X3 */
 #define CC_ABI_VERSION 3
 int cc_abi_version(void);
 
@@ -316,6 +317,10 @@ int cc_dropout_mask(uint64_t seed, int32_t site, int32_t layer, float p, int64_t
 int cc_comm_unique_id(uint8_t* uid_host);
 int cc_comm_create(void** comm, int32_t nranks, int32_t rank, const uint8_t* uid_host);
 int cc_allreduce_bucket(void* comm, void* buf, int64_t count, int32_t dtype, void* stream);
+/* In-place ncclBroadcast of buf[0, count) from rank `root`: with optimizer-state sharding (--deepspeed-strategy stage 1 / 2 of
+ * clipcap/train/args.py:87-92) every rank runs cc_adamw_step on its own slice of the parameter arena and the owners' slices are
+ * broadcast back, one call per owner. */
+int cc_broadcast_bucket(void* comm, void* buf, int64_t count, int32_t dtype, int32_t root, void* stream);
 /* ncclCommCount of the communicator: the number of ranks RCCL actually connected (what bench.py prints as rccl_ranks) */
 int cc_comm_count(void* comm, int32_t* nranks);
 int cc_comm_destroy(void* comm);
@@ -335,6 +340,13 @@ int cc_comm_destroy(void* comm);
 int cc_sample_step(const float* logits, int32_t R, int32_t V, int32_t ld, float temperature, int32_t top_k, float top_p, int32_t mode,
                    const int64_t* history, int32_t hist_len, int32_t hist_ld, float repetition_penalty, const float* u, int32_t* next_token,
                    float* probs_out, void* stream);
+/* The same step with generate_no_beam's sentence-length penalty (clipcap/inference/no_beam.py:55-60 -> utils.py:40-51): AFTER the
+ * filter and before the softmax, a history token whose value EQUALS float(stop_token) is multiplied by length_penalty
+ * (= current_length / desired_sentence_length * sentence_length_factor; the reference compares the gathered logit VALUES with the
+ * token id, and so does this).  stop_token < 0 or an empty history: exactly cc_sample_step. */
+int cc_sample_step_lp(const float* logits, int32_t R, int32_t V, int32_t ld, float temperature, int32_t top_k, float top_p, int32_t mode,
+                      const int64_t* history, int32_t hist_len, int32_t hist_ld, float repetition_penalty, int32_t stop_token,
+                      float length_penalty, const float* u, int32_t* next_token, float* probs_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Unit-test hooks (first argument op_dtype = CC_OP_BF16 / CC_OP_FP16: the type of the 16-bit tensors).

@@ -288,6 +288,42 @@ def _main_new(only):
             d[f"beam{i}b.meta"] = np.array([eos, EL, 5])
             print("beam_deep", i, best, d[f"beam{i}b.best"])
         np.savez_compressed(os.path.join(OUT, "beam_deep.npz"), **d)
+
+    # ---- (13) round 4 — the sentence-length penalty of no_beam.py:55-60 on rows where it FIRES: utils.py:40-51 multiplies the logits of
+    #           history tokens whose VALUE equals the stop-token id, so the rows below carry history tokens whose filtered logit is exactly
+    #           float(stop).  The per-step rule is the reference's own call sequence (no_beam.py:45-63) on 1-D logits. ----
+    if want("length_penalty"):
+        from clipcap.inference import utils as iu
+        import torch.nn.functional as F
+        d = {}
+        gen = torch.Generator().manual_seed(4701)
+        cases = [  # V, stop, temperature, repetition penalty, top_p, top_k, desired length, factor, history length
+            (97, 13, 1.0, 1.0, 0.9, 0, 50, 1.0, 6), (1000, 13, 0.5, 1.0, 0.95, 0, 10, 3.0, 9), (1000, 7, 1.0, 1.25, 1.0, 40, 4, 1.0, 12),
+            (50257, 13, 1.0, 1.0, 0.9, 0, 50, 1.0, 30), (50257, 13, 1.0, 1.0, 0.8, 0, 5, 2.0, 20), (211, 5, 2.0, 1.0, 0.0, 8, 50, 0.0, 3)]
+        for ci, (V, stop, temp, rep, top_p, top_k, want_len, factor, hl) in enumerate(cases):
+            lg = torch.randn(V, generator=gen) * 3.0
+            hist = torch.randint(0, V, (hl,), generator=gen)
+            hist[1] = hist[0]                                        # a repeated history token
+            # two history tokens and one non-history token whose value after repetition penalty and temperature is exactly float(stop)
+            nonh = int([t for t in range(V) if t not in set(hist.tolist())][3])
+            for t in (int(hist[0]), int(hist[2]), nonh):
+                lg[t] = float(stop) * temp * (rep if t != nonh else 1.0)
+            x = lg.clone()
+            if rep != 1.0:
+                x = iu.repetition_penalty_apply(x, hist, rep)
+            x = x / (temp if temp > 0 else 1.0)
+            x = iu.top_k_top_p_filtering(x, top_p=top_p, top_k=top_k)
+            fired = int((x[hist] == stop).sum())
+            x = iu.sentence_length_penalty_apply(x, hist, stop, hist.numel(), want_len, factor)
+            pr = F.softmax(x, dim=-1)
+            d[f"c{ci}.logits"] = lg.numpy()
+            d[f"c{ci}.hist"] = hist.numpy()
+            d[f"c{ci}.kw"] = np.array([stop, temp, rep, top_p, top_k, want_len, factor, fired], dtype=np.float64)
+            nzi = torch.nonzero(pr > 0).flatten()
+            d[f"c{ci}.idx"] = nzi.numpy()
+            d[f"c{ci}.probs"] = pr[nzi].numpy()
+            print("length_penalty", ci, "history entries at the stop value:", fired, "kept:", nzi.numel())
+        np.savez_compressed(os.path.join(OUT, "length_penalty.npz"), **d)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

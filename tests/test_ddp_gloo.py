@@ -196,3 +196,57 @@ def test_bench_eight_rank_dry_run_every_rank_leaves_before_rank_zero_extras():
     assert d["timed_regions"]["ms_per_step_min"] <= d["ms_per_step"] <= d["timed_regions"]["ms_per_step_max"]
     assert "cpu_baseline" in d and "allreduce_exposed_ms" in d and d["collective_backend"] == "gloo"
     print(f"8-rank dry run: {__import__('time').time() - t0:.1f} s")
+
+
+def _adamw_ref(w, g, m, v, lr, t, b1=0.9, b2=0.999, eps=1e-8, wd=0.01):
+    """torch.optim.AdamW's update, in place, on flat tensors (what cc_adamw_step computes on the device)."""
+    w.mul_(1 - lr * wd)
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    w.addcdiv_(m / (1 - b1 ** t), (v / (1 - b2 ** t)).sqrt_().add_(eps), value=-lr)
+
+
+def _zero_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from clipcap_amd.engine import _Arena
+    from clipcap_amd.train.ddp import ZeroShard
+    n = 1003                                              # not a multiple of the world size or of the 8-element slice granule
+    gen = torch.Generator().manual_seed(11)
+    a = _Arena(n, "cpu")
+    a.w32.copy_(torch.randn(n, generator=gen))
+    if rank == 0:                                        # a resumed run: full moments present before sharding is configured
+        a.m, a.v = torch.zeros(n), torch.zeros(n)
+    ZeroShard(rank, world).apply([a])
+    r, ranges, gather = a.zero
+    lo, hi = ranges[rank]
+    assert ranges[0][0] == 0 and ranges[-1][1] == n and all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+    assert all(lo_ % 8 == 0 for lo_, _ in ranges)
+    if a.m is None:
+        a.m, a.v = torch.zeros(hi - lo), torch.zeros(hi - lo)
+    assert a.m.numel() == hi - lo
+    for t in range(1, 4):
+        g = torch.randn(n, generator=gen)                # the all-reduced gradient: the same on every rank
+        _adamw_ref(a.w32[lo:hi], g[lo:hi], a.m, a.v, 1e-2, t)
+        gather(a.w32, ranges)
+    m, v = a.full_moments()                              # collective
+    if rank == 0:
+        np.savez(out, w=a.w32.numpy(), m=m.numpy(), v=v.numpy())
+    dist.destroy_process_group()
+
+
+def test_sharded_optimizer_state_three_ranks(tmp_path):
+    """ddp.ZeroShard + _Arena.shard_optimizer_state / full_moments on 3 gloo ranks (uneven slices): stepping the own slice and broadcasting
+    the owners' slices reproduces the replicated update exactly; the gathered moments are the replicated moments."""
+    from clipcap_amd.train.ddp import zero_stage
+    out = str(tmp_path / "zero.npz")
+    mp.spawn(_zero_worker, args=(3, _free_port(), out), nprocs=3, join=True)
+    res = np.load(out)
+    n = 1003
+    gen = torch.Generator().manual_seed(11)
+    w, m, v = torch.randn(n, generator=gen), torch.zeros(n), torch.zeros(n)
+    for t in range(1, 4):
+        _adamw_ref(w, torch.randn(n, generator=gen), m, v, 1e-2, t)
+    assert np.array_equal(res["w"], w.numpy()) and np.array_equal(res["m"], m.numpy()) and np.array_equal(res["v"], v.numpy())
+    assert [zero_stage(s) for s in (None, "", "deepspeed_stage_1", "deepspeed_stage_2_offload", "deepspeed_stage_3", "2", "ddp")] == [0, 0, 1, 1, 1, 1, 0]

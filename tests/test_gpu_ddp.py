@@ -96,6 +96,22 @@ def test_c_abi_rccl_communicator_single_rank_and_overlapped_reducer():
         assert float(loss0) == float(loss1)
         for a, r in zip(eng.arenas(), ref):
             assert torch.allclose(a.g32, r, rtol=1e-4, atol=1e-7)
+        # sharded optimizer state over the same communicator (cc_broadcast_bucket = ncclBroadcast): with one rank the own slice is the
+        # whole arena and the step must equal the replicated step
+        from clipcap_amd.train.ddp import ZeroShard
+        w_before = [a.w32.clone() for a in eng.arenas()]
+        eng.optimizer_step(1e-3, 1, weight_decay=0.01)
+        w_rep = [a.w32.clone() for a in eng.arenas()]
+        for a, w in zip(eng.arenas(), w_before):
+            a.w32.copy_(w)
+            a.m = a.v = None
+        ZeroShard(0, 1, comm=comm).apply(eng.arenas())
+        eng.optimizer_step(1e-3, 1, weight_decay=0.01)
+        torch.cuda.synchronize()
+        for a, w in zip(eng.arenas(), w_rep):
+            assert torch.equal(a.w32, w)
+            m, v = a.full_moments()
+            assert m.numel() == a.n and float(m.abs().max()) > 0
     finally:
         comm.close()
 
@@ -185,3 +201,50 @@ def test_gradient_wire_kernels_equal_torch_casts_at_any_alignment():
         _wire_cast(stage[lo:hi], back[lo:hi])
         assert torch.equal(torch.nan_to_num(back[lo:hi], nan=123.0), torch.nan_to_num(want.float(), nan=123.0)), (lo, hi)
     assert float(back[100_002]) == float(base[100_002].to(torch.bfloat16).float())
+
+
+def _zero_worker(rank, world, port, sharded, out, mode):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from clipcap_amd.train.ddp import GradReducer, ZeroShard, shard_batch
+    eng, tokens, embeds = _build(mode)
+    arenas = eng.arenas()
+    red = GradReducer([a.grads() for a in arenas])
+    if sharded:
+        ZeroShard(rank, world).apply(arenas)
+    tk, em = shard_batch(tokens, embeds, rank, world)
+    for step in range(1, 4):
+        eng.zero_grad()
+        red.begin()
+        eng.forward_backward(tk.cuda(), em.cuda(), reduce_stats=red.reduce_stats, on_grads_ready=red.on_grads_ready)
+        red.finish()
+        eng.optimizer_step(1e-3, step, weight_decay=0.01)
+    if sharded:
+        lo, hi = arenas[0].zero[1][rank]
+        assert arenas[0].m.numel() == hi - lo < arenas[0].n            # this rank holds its own slice of the moments only
+    moments = [a.full_moments() for a in arenas]                      # collective when sharded
+    logits = eng.gpt2.logits(torch.randn(2, 5, eng.gpt2.dims["D"], generator=torch.Generator().manual_seed(1)).cuda())   # the operand copies were refreshed
+    torch.cuda.synchronize()
+    if rank == 0:
+        np.savez(out, logits=logits.cpu().numpy(), **{f"w{i}": a.w32.cpu().numpy() for i, a in enumerate(arenas)},
+                 **{f"m{i}": m.cpu().numpy() for i, (m, _) in enumerate(moments)}, **{f"v{i}": v.cpu().numpy() for i, (_, v) in enumerate(moments)})
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["prefix_only", "full"])
+def test_sharded_optimizer_state_steps_equal_replicated_steps(tmp_path, mode):
+    """--deepspeed-strategy stage >= 1 (ddp.ZeroShard): each of 2 ranks keeps and steps half of the AdamW moments; after 3 steps the
+    parameters, the gathered moments and the logits through the refreshed operand copies equal the replicated-state run.  Two runs of
+    the same step differ in the last bits (LayerNorm parameter gradients and the token-embedding gradient are summed with fp32 atomics),
+    so the bar is 1e-6 of each tensor's scale; the exact equality of the sharded update is tests/test_ddp_gloo.py's (3 ranks, CPU)."""
+    outs = []
+    for sharded in (False, True):
+        out = str(tmp_path / f"zero{int(sharded)}.npz")
+        mp.spawn(_zero_worker, args=(2, _free_port(), sharded, out, mode), nprocs=2, join=True)
+        outs.append(np.load(out))
+    a, b = outs
+    for k in a.files:
+        tol = 1e-6 * max(1e-30, np.abs(a[k]).max()) if k[0] in "mv" else 1e-6 * max(1.0, np.abs(a[k]).max()) + (2e-2 if k == "logits" else 0.0)
+        assert np.abs(a[k] - b[k]).max() <= tol, (k, np.abs(a[k] - b[k]).max(), tol)
+    assert np.abs(a["m0"]).max() > 0

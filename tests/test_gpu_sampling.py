@@ -183,7 +183,7 @@ def test_generate_variants_step_distributions_vs_reference(case, monkeypatch):
     for i, (lg, hist) in enumerate(logit_rec):
         if case.startswith("no_beam"):
             want = oracle.no_beam_step_distribution(lg, hist if hist is not None and hist.numel() else None, top_p=top_p, top_k=int(top_k),
-                                                    temperature=temp, repetition_penalty=pen)
+                                                    temperature=temp, repetition_penalty=pen, stop_token=int(stop))
         else:
             want = oracle.nucleus_final_p((lg / temp).unsqueeze(0), top_p=top_p, top_k=(int(top_k) or None))[0]
         same_set = bool(((got[i] > 0) == (want.numpy() > 0)).all())
@@ -208,3 +208,43 @@ def test_selection_passes_bucket_an_element_identically(V, scale, top_p, top_k, 
     not at another, the element changed bucket between the histogram pass and the radix passes, no crossing was found and the row
     kept all V tokens instead of its 30 / 285-token nucleus."""
     test_nucleus_distribution_matches_reference_semantics(V, scale, top_p, top_k, temperature)
+
+
+def test_sentence_length_penalty_fires_like_the_reference():
+    """no_beam.py:55-60 / utils.py:40-51 on rows where the penalty FIRES (history tokens whose filtered logit equals float(stop id)):
+    tests/golden/length_penalty.npz holds the reference's own per-step distributions for such rows (oracle/gen_golden.py (13))."""
+    import numpy as np
+    from tests.util import load_golden
+    g = load_golden("length_penalty")
+    n = len([k for k in g if k.endswith(".logits")])
+    assert n >= 6
+    for ci in range(n):
+        stop, temp, rep, top_p, top_k, want_len, factor, fired = [float(v) for v in g[f"c{ci}.kw"]]
+        assert fired >= 2
+        lg = torch.from_numpy(g[f"c{ci}.logits"]).cuda().unsqueeze(0)
+        hist = torch.from_numpy(g[f"c{ci}.hist"]).cuda().unsqueeze(0)
+        hl = hist.shape[1]
+        u = torch.tensor([0.37], device="cuda")
+        ref = np.zeros(lg.shape[1], dtype=np.float32)
+        ref[g[f"c{ci}.idx"]] = g[f"c{ci}.probs"]
+        nt, probs = _eng().sample_step(lg, u, temperature=temp, top_k=int(top_k), top_p=top_p, mode=1, history=hist, hist_len=hl,
+                                       repetition_penalty=rep, return_probs=True, length_penalty_stop=int(stop),
+                                       length_penalty=(hl / want_len) * factor)
+        got = probs[0].cpu().numpy()
+        # the device sums probability mass in 2^-32 fixed point relative to the largest kept value: a kept token whose probability is
+        # below ~2.3e-10 (the rows whose penalised value towers over the rest: the reference's fp32 softmax leaves denormals there)
+        # carries weight 0.  The kept SET is compared where the reference's probability is representable.
+        big = ref > 1e-8
+        assert ((got > 0)[big]).all() and not (got[ref == 0] > 0).any(), ci
+        assert np.abs(got - ref).max() <= 2e-6, (ci, np.abs(got - ref).max())
+        assert got[int(nt[0])] > 0
+        # and it differs from the step without the penalty (unless the factor makes it the identity)
+        _, off = _eng().sample_step(lg, u, temperature=temp, top_k=int(top_k), top_p=top_p, mode=1, history=hist, hist_len=hl,
+                                    repetition_penalty=rep, return_probs=True)
+        if abs((hl / want_len) * factor - 1.0) > 1e-6:
+            assert np.abs(off[0].cpu().numpy() - got).max() > 1e-4, ci
+        # an empty history switches it off (the reference's `tokens is not None`)
+        _, p0 = _eng().sample_step(lg, u, temperature=temp, top_k=int(top_k), top_p=top_p, mode=1, return_probs=True, length_penalty_stop=int(stop),
+                                   length_penalty=3.0)
+        _, p1 = _eng().sample_step(lg, u, temperature=temp, top_k=int(top_k), top_p=top_p, mode=1, return_probs=True)
+        assert torch.equal(p0, p1)

@@ -237,6 +237,26 @@ def test_sampling_variants_step_distributions():
         assert np.array_equal(np.concatenate([head.numpy(), g[case + ".forced"]]), g[case + ".text"]), case
 
 
+def test_sentence_length_penalty_where_it_fires():
+    """no_beam.py:55-60 / utils.py:40-51: rows whose history tokens carry a filtered logit equal to float(stop id), so that the
+    reference's value comparison is true (tests/golden/length_penalty.npz, oracle/gen_golden.py (13))."""
+    g = load_golden("length_penalty")
+    n = len([k for k in g if k.endswith(".logits")])
+    assert n >= 6
+    for ci in range(n):
+        stop, temp, rep, top_p, top_k, want_len, factor, fired = [float(v) for v in g[f"c{ci}.kw"]]
+        lg, hist = torch.from_numpy(g[f"c{ci}.logits"]), torch.from_numpy(g[f"c{ci}.hist"])
+        got = O.no_beam_step_distribution(lg, hist, top_p=top_p, top_k=int(top_k), temperature=temp, repetition_penalty=rep, stop_token=int(stop),
+                                          desired_sentence_length=int(want_len), sentence_length_factor=factor).numpy()
+        ref = np.zeros_like(got)
+        ref[g[f"c{ci}.idx"]] = g[f"c{ci}.probs"]
+        assert np.array_equal(got > 0, ref > 0), ci
+        assert np.abs(got - ref).max() <= 1e-7, ci
+        off = O.no_beam_step_distribution(lg, hist, top_p=top_p, top_k=int(top_k), temperature=temp, repetition_penalty=rep).numpy()
+        if abs(hist.numel() / want_len * factor - 1.0) > 1e-6:
+            assert np.abs(off - got).max() > 1e-4, ci
+
+
 def test_beam_search_medium_width():
     """BASELINE configs[4] width (D=1024, 16 heads, V=50257; 4 layers): the reference's beam-5 captions, incl. runs that stop on EOS."""
     from tests import seeded
