@@ -679,7 +679,6 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const act_t* __restrict__ qkv,
     }
 }
 
-#if CC_OP != 2      // the MFMA attention kernels work on 16-bit operands; the bf16x3 build runs the fp32 VALU kernels above / below
 // ------------------------------------------------------------------------------------------------------------
 // MFMA attention forward (head dim 64 / 96 / 128): one wave per (sample, head, 32-query block), flash-style loop
 // over 32-key blocks with v_mfma_f32_32x32x16_bf16.
@@ -712,6 +711,175 @@ __device__ __forceinline__ op16x8 frag_tr(const op16_t* blk, int nb, int t, int 
     return __builtin_bit_cast(op16x8, v);
 }
 
+#if CC_OP == 2
+// ------------------------------------------------------------------------------------------------------------
+// The same forward for the split-bf16 build (round 4; fp32 activations in, fp32 or operand-image out): every product is the three bf16
+// MFMA terms hi*hi + hi*lo + lo*hi of the GEMMs — Q, K rows and the probabilities are split in registers, the V block sits
+// in LDS as a hi plane and a lo plane.  Softmax statistics, the running rescale and the output stay fp32.  Replaces the fp32 VALU
+// LDS-tile kernel (k_attn_fwd) for head dims 64 / 96 / 128 (CC_ATTN_X3MFMA=0 switches back); any S (the windowed mapper's 180 too).
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void x3_split8(const float (&f)[8], op16x8& hi, op16x8& lo) {
+    const uint4 h = pack8(f);
+    float hf[8], d[8];
+    unpack8(h, hf);
+#pragma unroll
+    for (int e = 0; e < 8; e++) d[e] = f[e] - hf[e];
+    hi = __builtin_bit_cast(op16x8, h);
+    lo = __builtin_bit_cast(op16x8, pack8(d));
+}
+template <int HD, bool CAUSAL, bool DROP = false>
+__global__ __launch_bounds__(256, 2) void k_attn_fwd_mfma3(const float* __restrict__ qkv, int B, int S, int H, float scale, float* __restrict__ out,
+                                                           float* __restrict__ lse_out, Drop drop, int img) {
+    constexpr int KK = HD / 16, NB = HD / 32, C8 = HD / 8, LD = AttLd<HD>::v;
+    __shared__ __attribute__((aligned(16))) op16_t vsm[4][2][32 * LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nqb = (S + 31) >> 5;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= B * H * nqb) return;  // wave-uniform; no block-level barrier is used below
+    const int qb = item % nqb, h = (item / nqb) % H, b = item / (nqb * H);
+    const int D = H * HD;
+    const size_t rs = (size_t)3 * D;
+    const float* base = qkv + (size_t)b * S * rs + h * HD;
+    const int half = lane >> 5, q = qb * 32 + (lane & 31);
+    op16_t* vh = vsm[wave][0];
+    op16_t* vl = vsm[wave][1];
+    auto ld8 = [](const float* p, bool ok, float (&f)[8]) {
+        const float4 a = ok ? *reinterpret_cast<const float4*>(p) : make_float4(0, 0, 0, 0);
+        const float4 c = ok ? *reinterpret_cast<const float4*>(p + 4) : make_float4(0, 0, 0, 0);
+        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = c.x; f[5] = c.y; f[6] = c.z; f[7] = c.w;
+    };
+    op16x8 qh[KK], ql[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; kk++) {
+        float f[8];
+        ld8(base + (size_t)min(q, S - 1) * rs + kk * 16 + half * 8, q < S, f);
+        x3_split8(f, qh[kk], ql[kk]);
+    }
+    f32x16 o[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[nb][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const int nkb = CAUSAL ? qb + 1 : nqb;
+    const int key_l = lane & 31;
+    for (int kb = 0; kb < nkb; kb++) {
+        // V block -> wave-private LDS planes [32 keys][LD] (hi, lo); the previous block's fragment reads were consumed by its MFMAs
+#pragma unroll
+        for (int c = 0; c < HD / 16; c++) {
+            const int idx = lane + 64 * c;
+            const int vk = idx / C8, vc = idx % C8;
+            float f[8];
+            ld8(base + 2 * D + (size_t)min(kb * 32 + vk, S - 1) * rs + vc * 8, kb * 32 + vk < S, f);
+            op16x8 a, c2;
+            x3_split8(f, a, c2);
+            *reinterpret_cast<op16x8*>(vh + vk * LD + vc * 8) = a;
+            *reinterpret_cast<op16x8*>(vl + vk * LD + vc * 8) = c2;
+        }
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; r++) s[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++) {
+            float f[8];
+            const int key = kb * 32 + key_l;
+            ld8(base + D + (size_t)min(key, S - 1) * rs + kk * 16 + half * 8, key < S, f);
+            op16x8 kh, kl;
+            x3_split8(f, kh, kl);
+            s = CC_MFMA_32x32x16(kl, qh[kk], s);          // small terms first
+            s = CC_MFMA_32x32x16(kh, ql[kk], s);
+            s = CC_MFMA_32x32x16(kh, qh[kk], s);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int kr = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const bool ok = kr < S && (!CAUSAL || kr <= q);
+            s[r] = ok ? s[r] * scale : -INFINITY;
+            mx = fmaxf(mx, s[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m, mx);
+        const float alpha = (m == -INFINITY) ? 0.f : __expf(m - m_new);
+        float p[16], ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            p[r] = (m_new == -INFINITY) ? 0.f : __expf(s[r] - m_new);
+            ps += p[r];
+        }
+        ps += __shfl_xor(ps, 32, 64);
+        l = l * alpha + ps;
+        m = m_new;
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) o[nb][r] *= alpha;
+        if (DROP) {     // attention-probability dropout: P V only, the row sum l stays (as in the 16-bit kernel)
+            const unsigned rowbase = ((unsigned)(b * H + h) * S + min(q, S - 1)) * S;
+#pragma unroll
+            for (int r = 0; r < 16; r++) p[r] *= drop_mul(drop, rowbase + min(kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, S - 1));
+        }
+        op16x8 ph[2], pl[2];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const float f[8] = {p[t * 8 + 0], p[t * 8 + 1], p[t * 8 + 2], p[t * 8 + 3], p[t * 8 + 4], p[t * 8 + 5], p[t * 8 + 6], p[t * 8 + 7]};
+            x3_split8(f, ph[t], pl[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) {
+                const op16x8 fh = frag_tr<HD>(vh, nb, t, lane), fl = frag_tr<HD>(vl, nb, t, lane);
+                o[nb] = CC_MFMA_32x32x16(fl, ph[t], o[nb]);
+                o[nb] = CC_MFMA_32x32x16(fh, pl[t], o[nb]);
+                o[nb] = CC_MFMA_32x32x16(fh, ph[t], o[nb]);
+            }
+    }
+    if (q < S) {
+        const float inv = l > 0.f ? 1.f / l : 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int d0 = nb * 32 + 8 * g + 4 * half;
+                const float o0 = o[nb][g * 4 + 0] * inv, o1 = o[nb][g * 4 + 1] * inv, o2 = o[nb][g * 4 + 2] * inv, o3 = o[nb][g * 4 + 3] * inv;
+                if (img) {                                  // [hi | hi | lo] operand image of attn.c_proj's GEMM (rows of 3 D 16-bit elements)
+                    const unsigned h01 = pack2op(o0, o1), h23 = pack2op(o2, o3);
+                    float a0, a1, a2, a3;
+                    unpack2(h01, a0, a1);
+                    unpack2(h23, a2, a3);
+                    const uint2 hi = make_uint2(h01, h23), lo = make_uint2(pack2op(o0 - a0, o1 - a1), pack2op(o2 - a2, o3 - a3));
+                    op16_t* r3 = reinterpret_cast<op16_t*>(out) + ((size_t)b * S + q) * 3 * D + h * HD + d0;
+                    *reinterpret_cast<uint2*>(r3) = hi;
+                    *reinterpret_cast<uint2*>(r3 + D) = hi;
+                    *reinterpret_cast<uint2*>(r3 + 2 * D) = lo;
+                } else {
+                    *reinterpret_cast<float4*>(out + ((size_t)b * S + q) * D + h * HD + d0) = make_float4(o0, o1, o2, o3);
+                }
+            }
+        if (half == 0 && lse_out) lse_out[((size_t)b * H + h) * S + q] = m + __logf(l);
+    }
+}
+template <int HD>
+static int attn_fwd_mfma3_launch(const float* qkv, int B, int S, int H, bool causal, float* out, float* lse, hipStream_t st, Drop drop, int img) {
+    const int items = B * H * ((S + 31) / 32);
+    const float scale = 1.0f / sqrtf((float)HD);
+    if (drop.thresh) {
+        if (!causal) return CC_ERR_SHAPE;
+        hipLaunchKernelGGL((k_attn_fwd_mfma3<HD, true, true>), dim3((items + 3) / 4), dim3(256), 0, st, qkv, B, S, H, scale, out, lse, drop, img);
+    } else if (causal)
+        hipLaunchKernelGGL((k_attn_fwd_mfma3<HD, true>), dim3((items + 3) / 4), dim3(256), 0, st, qkv, B, S, H, scale, out, lse, drop, img);
+    else
+        hipLaunchKernelGGL((k_attn_fwd_mfma3<HD, false>), dim3((items + 3) / 4), dim3(256), 0, st, qkv, B, S, H, scale, out, lse, drop, img);
+    return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+}
+static bool attn_x3mfma_on() {
+    static const bool on = !(getenv("CC_ATTN_X3MFMA") && atoi(getenv("CC_ATTN_X3MFMA")) == 0) && !getenv("CC_ATTN_F32MFMA");
+    return on;
+}
+#endif   // CC_OP == 2
+
+#if CC_OP != 2      // the 16-bit MFMA attention kernels; the bf16x3 build runs the three-term form above and the fp32 VALU backward below
 template <int HD, bool CAUSAL, bool DROP = false>
 __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void k_attn_fwd_mfma(const op16_t* __restrict__ qkv, int B, int S, int H, float scale,
                                                        op16_t* __restrict__ out, float* __restrict__ lse_out, Drop drop = Drop()) {
@@ -1784,6 +1952,11 @@ int attn_fwd(const act_t* qkv, int B, int S, int H, int hd, bool causal, act_t* 
     if (drop.thresh && (!kX3 || !causal)) return CC_ERR_SHAPE;          // dropout on the VALU kernels: the bf16x3 build's GPT-2 path only
     const float scale = 1.0f / sqrtf((float)hd);
 #if CC_OP == 2
+    if (attn_x3mfma_on() && (hd == 64 || hd == 96 || hd == 128)) {       // three bf16 MFMA terms per product
+        if (hd == 64) return attn_fwd_mfma3_launch<64>(qkv, B, S, H, causal, out, lse, st, drop, img);
+        if (hd == 96) return attn_fwd_mfma3_launch<96>(qkv, B, S, H, causal, out, lse, st, drop, img);
+        return attn_fwd_mfma3_launch<128>(qkv, B, S, H, causal, out, lse, st, drop, img);
+    }
     if (attn_f32mfma_ok(S, hd, false)) {                                 // fp32 products on the fp32 MFMA
         const size_t sh = attn_f32mfma_lds(S, hd, false);
         if (drop.thresh) CC_F32MFMA_LAUNCH((k_attn_fwd_f32mfma<true, true>), qkv, S, H, hd, scale, out, lse, drop)
@@ -2082,8 +2255,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_small(const act_t* __restrict_
 // (the backward of the other attention forms reads the fp32 output again)
 bool attn_fwd_can_image(int S, int hd) {
 #if CC_OP == 2
-    return (hd & 7) == 0 && S > 0 && !attn_f32mfma_ok(S, hd, false) && attn_fwd_lds(S, hd) <= 160 * 1024 && !attn_f32mfma_ok(S, hd, true) &&
-           attn_bwd_lds(S, hd) <= 160 * 1024;
+    const bool fwd_ok = (attn_x3mfma_on() && (hd == 64 || hd == 96 || hd == 128)) || (!attn_f32mfma_ok(S, hd, false) && attn_fwd_lds(S, hd) <= 160 * 1024);
+    return (hd & 7) == 0 && S > 0 && fwd_ok && !attn_f32mfma_ok(S, hd, true) && attn_bwd_lds(S, hd) <= 160 * 1024;
 #else
     (void)S; (void)hd;
     return false;
