@@ -743,10 +743,10 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd_mfma3(const float* __restri
     const int half = lane >> 5, q = qb * 32 + (lane & 31);
     op16_t* vh = vsm[wave][0];
     op16_t* vl = vsm[wave][1];
-    auto ld8 = [](const float* p, bool ok, float (&f)[8]) {
-        const float4 a = ok ? *reinterpret_cast<const float4*>(p) : make_float4(0, 0, 0, 0);
-        const float4 c = ok ? *reinterpret_cast<const float4*>(p + 4) : make_float4(0, 0, 0, 0);
-        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = c.x; f[5] = c.y; f[6] = c.z; f[7] = c.w;
+    auto ld8 = [](const float* p, bool ok, float (&f)[8]) {      // p is a clamped (always valid) address: load, then zero by select — no branch around the load
+        const float4 a = *reinterpret_cast<const float4*>(p), c = *reinterpret_cast<const float4*>(p + 4);
+        f[0] = ok ? a.x : 0.f; f[1] = ok ? a.y : 0.f; f[2] = ok ? a.z : 0.f; f[3] = ok ? a.w : 0.f;
+        f[4] = ok ? c.x : 0.f; f[5] = ok ? c.y : 0.f; f[6] = ok ? c.z : 0.f; f[7] = ok ? c.w : 0.f;
     };
     op16x8 qh[KK], ql[KK];
 #pragma unroll
@@ -873,6 +873,246 @@ static int attn_fwd_mfma3_launch(const float* qkv, int B, int S, int H, bool cau
         hipLaunchKernelGGL((k_attn_fwd_mfma3<HD, false>), dim3((items + 3) / 4), dim3(256), 0, st, qkv, B, S, H, scale, out, lse, drop, img);
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
+// ------------------------------------------------------------------------------------------------------------
+// Backward of the same attention as three-term bf16 MFMA products (round 4; S <= 64, head dim 64 / 96): one workgroup per (sample, head),
+// every operand staged ONCE into LDS as a hi plane and a lo plane (the GEMMs' split, kernels.hip::k_x3_split_rows' arithmetic), so that
+// every MFMA fragment is a plain 16-B read (k along the row) or a ds_read_b64_tr_b16 pair (k down the rows).  Phases, a block barrier apart:
+//   0  qkv / dO rows (fp32) -> planes Q, K, V, dO [R][LD]
+//   1  tile jobs: S = Q K^T and dP = dO V^T (fp32 scratch in the P / dS plane area)
+//   2  per row: P = exp(S scale - lse), delta = sum P dP, dS = P (dP - delta) scale -> planes P, dS [R][LDP]
+//   3  tile jobs: dQ = dS K, dK = dS^T Q, dV = P^T dO, accumulators [32 rows][32 d-columns] -> global rows (fp32, or the consumer GEMM's
+//      [hi | hi | lo] operand image).  Causal launches skip the tiles above the diagonal.
+// Replaces the fp32 VALU LDS-tile kernels (k_attn_bwd / _small) where it applies (CC_ATTN_X3MFMA=0 switches back).
+// ------------------------------------------------------------------------------------------------------------
+template <int LD>
+__device__ __forceinline__ op16x8 frag_tr_p(const op16_t* blk, int nb, int t, int lane) {      // frag_tr with the row pitch as a parameter
+    typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+    typedef __attribute__((address_space(3))) s16x4_t* lp_t;
+    const int half = lane >> 5, j = lane & 15, dsub = (lane >> 4) & 1;
+    const op16_t* p = blk + (16 * t + 4 * half + (j >> 2)) * LD + nb * 32 + 16 * dsub + 4 * (j & 3);
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)p);
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(p + 8 * LD));
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(op16x8, v);
+}
+// k-slot order of the transpose reads, for an operand whose k runs ALONG its row: elements {16 t + 4 half + 0..3} and {16 t + 8 + 4 half + 0..3}
+__device__ __forceinline__ op16x8 frag_row_p(const op16_t* row, int t, int half) {
+    const uint2 a = *reinterpret_cast<const uint2*>(row + 16 * t + 4 * half), c = *reinterpret_cast<const uint2*>(row + 16 * t + 8 + 4 * half);
+    return __builtin_bit_cast(op16x8, make_uint4(a.x, a.y, c.x, c.y));
+}
+#define CC_MFMA3(AH, AL, BH, BL, ACC) { ACC = CC_MFMA_32x32x16(AL, BH, ACC); ACC = CC_MFMA_32x32x16(AH, BL, ACC); ACC = CC_MFMA_32x32x16(AH, BH, ACC); }
+template <int HD, int NBLK> struct AttM3 {
+    static constexpr int R = 32 * NBLK, LD = AttLd<HD>::v, LDP = NBLK == 2 ? 96 : 32, SP = NBLK == 2 ? 68 : 32, NW = NBLK == 2 ? 8 : 4;
+    static constexpr int PLANE = R * LD, PPLANE = R * LDP;
+    static constexpr size_t lds = (size_t)8 * PLANE * 2 + (size_t)4 * PPLANE * 2 + R * 4;
+};
+template <int HD, int NBLK, bool CAUSAL, bool DROP>
+__global__ __launch_bounds__(NBLK == 2 ? 512 : 256, 1) void k_attn_bwd_m3(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                              const float* __restrict__ lse, int B, int S, int H, float scale,
+                                                                              float* __restrict__ dqkv, Drop drop, int img) {
+    typedef AttM3<HD, NBLK> G;
+    constexpr int R = G::R, LD = G::LD, LDP = G::LDP, SP = G::SP, NW = G::NW, NB = HD / 32, KK = HD / 16, C8 = HD / 8, NT = 64 * NW;
+    static_assert((size_t)2 * R * SP * 4 <= (size_t)4 * G::PPLANE * 2, "the fp32 scratch lives in the P / dS plane area");
+    extern __shared__ __attribute__((aligned(16))) unsigned char m3raw[];
+    op16_t* pl = reinterpret_cast<op16_t*>(m3raw);                 // planes: Qh Ql Kh Kl Vh Vl Oh Ol
+    op16_t* Qh = pl, *Ql = pl + G::PLANE, *Kh = pl + 2 * G::PLANE, *Kl = pl + 3 * G::PLANE, *Vh = pl + 4 * G::PLANE, *Vl = pl + 5 * G::PLANE;
+    op16_t* Oh = pl + 6 * G::PLANE, *Ol = pl + 7 * G::PLANE;
+    op16_t* pp = pl + 8 * G::PLANE;                                // planes: Ph Pl Dh Dl
+    op16_t* Ph = pp, *Pl = pp + G::PPLANE, *Dh = pp + 2 * G::PPLANE, *Dl = pp + 3 * G::PPLANE;
+    float* scrS = reinterpret_cast<float*>(pp);                    // phase 1 -> 2 scratch: S [R][SP], dP [R][SP]
+    float* scrD = scrS + R * SP;
+    float* lse_s = reinterpret_cast<float*>(pp + 4 * G::PPLANE);   // [R]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int D = H * HD, nitems = B * H;
+    const size_t rs = (size_t)3 * D;
+    // Persistent over the (sample, head) items of this workgroup (grid = one workgroup per CU): the NEXT item's rows are requested into
+    // registers as soon as the current item's have been written to the planes, so they travel under phases 1-3 — with one workgroup per CU
+    // (the planes fill the LDS) and every CU in the same phase, loads, arithmetic and stores otherwise took turns on an idle memory system.
+    constexpr int PER = 4 * R * C8 / NT;
+    static_assert(PER * NT == 4 * R * C8, "staging items tile the threads");
+    float4 x[PER], y[PER];
+    float lse_r = 0.f;
+    auto request = [&](int item) {
+        const int b_ = item / H, h_ = item - b_ * H;
+        const float* base = qkv + (size_t)b_ * S * rs + h_ * HD;
+        const float* dbase = dout + (size_t)b_ * S * D + h_ * HD;
+#pragma unroll
+        for (int it = 0; it < PER; it++) {
+            const int idx = tid + it * NT;
+            const int which = idx / (R * C8), rem = idx - which * (R * C8), row = rem / C8, c = rem - row * C8;
+            const float* src = which == 3 ? dbase + (size_t)min(row, S - 1) * D + c * 8 : base + which * D + (size_t)min(row, S - 1) * rs + c * 8;
+            x[it] = *reinterpret_cast<const float4*>(src);
+            y[it] = *reinterpret_cast<const float4*>(src + 4);
+        }
+        if (tid < R) lse_r = lse[((size_t)b_ * H + h_) * S + min(tid, S - 1)];
+    };
+    if ((int)blockIdx.x < nitems) request(blockIdx.x);
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int b = item / H, h = item - b * H;
+    // ---- phase 0: rows -> planes
+    {
+#pragma unroll
+        for (int it = 0; it < PER; it++) {
+            const int idx = tid + it * NT;
+            const int which = idx / (R * C8), rem = idx - which * (R * C8), row = rem / C8, c = rem - row * C8;
+            const bool ok = row < S;
+            const float f[8] = {ok ? x[it].x : 0.f, ok ? x[it].y : 0.f, ok ? x[it].z : 0.f, ok ? x[it].w : 0.f,
+                                ok ? y[it].x : 0.f, ok ? y[it].y : 0.f, ok ? y[it].z : 0.f, ok ? y[it].w : 0.f};
+            op16x8 hi, lo;
+            x3_split8(f, hi, lo);
+            *reinterpret_cast<op16x8*>(pl + (2 * which) * G::PLANE + row * LD + c * 8) = hi;
+            *reinterpret_cast<op16x8*>(pl + (2 * which + 1) * G::PLANE + row * LD + c * 8) = lo;
+        }
+        if (tid < R) lse_s[tid] = tid < S ? lse_r : 0.f;
+    }
+    if (item + (int)gridDim.x < nitems) request(item + gridDim.x);
+    __syncthreads();
+    // ---- phase 1: jobs (tile (i, j), product)
+    {
+        constexpr int NTILE = CAUSAL ? NBLK * (NBLK + 1) / 2 : NBLK * NBLK;
+        for (int job = wave; job < 2 * NTILE; job += NW) {
+            const int prod = job & 1, tl = job >> 1;
+            int i, j;
+            if (CAUSAL) { i = tl == 0 ? 0 : 1; j = tl == 2 ? 1 : 0; if (NBLK == 1) { i = 0; j = 0; } }
+            else { i = tl / NBLK; j = tl % NBLK; }
+            const op16_t* ah = (prod ? Oh : Qh) + (i * 32 + l31) * LD + 8 * half;
+            const op16_t* al = (prod ? Ol : Ql) + (i * 32 + l31) * LD + 8 * half;
+            const op16_t* bh = (prod ? Vh : Kh) + (j * 32 + l31) * LD + 8 * half;
+            const op16_t* bl = (prod ? Vl : Kl) + (j * 32 + l31) * LD + 8 * half;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < KK; kk++) {
+                const op16x8 a_h = *reinterpret_cast<const op16x8*>(ah + kk * 16), a_l = *reinterpret_cast<const op16x8*>(al + kk * 16);
+                const op16x8 b_h = *reinterpret_cast<const op16x8*>(bh + kk * 16), b_l = *reinterpret_cast<const op16x8*>(bl + kk * 16);
+                CC_MFMA3(a_h, a_l, b_h, b_l, acc)
+            }
+            float* dst = (prod ? scrD : scrS) + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; r++) dst[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * SP] = acc[r];
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: a group of R lanes owns a row
+    {
+        constexpr int RPP = 64 / R, ROWS = R / (NW * RPP);      // rows per wave-pass, passes per wave
+        static_assert(ROWS * NW * RPP == R, "row passes tile the block");
+        const int key = lane % R;
+        float pm[ROWS], ds[ROWS];
+#pragma unroll
+        for (int it = 0; it < ROWS; it++) {
+            const int q = (it * NW + wave) * RPP + lane / R;
+            const bool ok = q < S && key < S && (!CAUSAL || key <= q);
+            const float sv = scrS[q * SP + key], dv = scrD[q * SP + key];
+            const float p = ok ? __expf(sv * scale - lse_s[q]) : 0.f;
+            const float mk = DROP ? drop_mul(drop, ((unsigned)(b * H + h) * S + min(q, S - 1)) * S + min(key, S - 1)) : 1.f;
+            const float dpm = ok ? dv * mk : 0.f;
+            float dl = p * dpm;
+#pragma unroll
+            for (int o = R / 2; o > 0; o >>= 1) dl += __shfl_xor(dl, o, 64);
+            ds[it] = ok ? p * (dpm - dl) * scale : 0.f;
+            pm[it] = p * mk;
+        }
+        __syncthreads();                                       // every S / dP value is in registers: the area becomes the P / dS planes
+#pragma unroll
+        for (int it = 0; it < ROWS; it++) {
+            const int q = (it * NW + wave) * RPP + lane / R;
+            const op16_t ph = f2op(pm[it]), dh = f2op(ds[it]);
+            float phf, dhf, t0;
+            unpack2((unsigned)ph, phf, t0);
+            unpack2((unsigned)dh, dhf, t0);
+            Ph[q * LDP + key] = ph;
+            Pl[q * LDP + key] = f2op(pm[it] - phf);
+            Dh[q * LDP + key] = dh;
+            Dl[q * LDP + key] = f2op(ds[it] - dhf);
+        }
+    }
+    __syncthreads();
+    // ---- phase 3: jobs (kind, row block, 32-column block of d)
+    for (int job = wave; job < 3 * NBLK * NB; job += NW) {
+        const int kind = job / (NBLK * NB), rem = job - kind * (NBLK * NB), blk = rem / NB, nb = rem - blk * NB;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+        if (kind == 0) {                                        // dQ[q][d] = sum over keys dS[q][key] K[key][d]
+            const int jn = CAUSAL ? blk + 1 : NBLK;
+            for (int j = 0; j < jn; j++)
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const op16x8 a_h = frag_row_p(Dh + (blk * 32 + l31) * LDP + j * 32, t, half), a_l = frag_row_p(Dl + (blk * 32 + l31) * LDP + j * 32, t, half);
+                    const op16x8 b_h = frag_tr_p<LD>(Kh + j * 32 * LD, nb, t, lane), b_l = frag_tr_p<LD>(Kl + j * 32 * LD, nb, t, lane);
+                    CC_MFMA3(a_h, a_l, b_h, b_l, acc)
+                }
+        } else {                                                // dK[key][d] = sum over q dS[q][key] Q[q][d];  dV[key][d] = sum over q P[q][key] dO[q][d]
+            const op16_t* Ah = kind == 1 ? Dh : Ph, *Al = kind == 1 ? Dl : Pl, *Bh = kind == 1 ? Qh : Oh, *Bl = kind == 1 ? Ql : Ol;
+            for (int i = CAUSAL ? blk : 0; i < NBLK; i++)
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const op16x8 a_h = frag_tr_p<LDP>(Ah + i * 32 * LDP, blk, t, lane), a_l = frag_tr_p<LDP>(Al + i * 32 * LDP, blk, t, lane);
+                    const op16x8 b_h = frag_tr_p<LD>(Bh + i * 32 * LD, nb, t, lane), b_l = frag_tr_p<LD>(Bl + i * 32 * LD, nb, t, lane);
+                    CC_MFMA3(a_h, a_l, b_h, b_l, acc)
+                }
+        }
+        const int d = nb * 32 + l31;
+        if (img) {                                              // rows of 9 D 16-bit elements: [hi (q k v) | hi | lo]
+            op16_t* r3 = reinterpret_cast<op16_t*>(dqkv) + (size_t)b * S * 9 * D + kind * D + h * HD + d;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const op16_t vh = f2op(acc[r]);
+                float vhf, t0;
+                unpack2((unsigned)vh, vhf, t0);
+                const op16_t vl = f2op(acc[r] - vhf);
+                if (row < S) {
+                    op16_t* o3 = r3 + (size_t)row * 9 * D;
+                    o3[0] = vh;
+                    o3[3 * D] = vh;
+                    o3[6 * D] = vl;
+                }
+            }
+        } else {
+            float* o1 = dqkv + (size_t)b * S * rs + kind * D + h * HD + d;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < S) o1[(size_t)row * rs] = acc[r];
+            }
+        }
+    }
+    __syncthreads();                                            // the planes are rewritten by the next item's phase 0
+    }
+}
+template <int HD, int NBLK>
+static int attn_bwd_m3_launch(const float* qkv, const float* dout, const float* lse, int B, int S, int H, bool causal, float* dqkv, hipStream_t st,
+                              Drop drop, int img) {
+    typedef AttM3<HD, NBLK> G;
+    const float scale = 1.0f / sqrtf((float)HD);
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return CC_ERR_STATE;
+        ncu = pr.multiProcessorCount;
+    }
+    const int per_cu = (int)((size_t)160 * 1024 / G::lds);       // resident workgroups per CU (LDS-limited)
+    const dim3 grid(min(B * H, ncu * max(1, per_cu))), blk(64 * G::NW);
+#define CC_M3_LAUNCH(C, DR)                                                                                                              \
+    {                                                                                                                                    \
+        if (G::lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_attn_bwd_m3<HD, NBLK, C, DR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds); \
+        hipLaunchKernelGGL((k_attn_bwd_m3<HD, NBLK, C, DR>), grid, blk, G::lds, st, qkv, dout, lse, B, S, H, scale, dqkv, drop, img);          \
+    }
+    if (drop.thresh) {
+        if (!causal) return CC_ERR_SHAPE;
+        CC_M3_LAUNCH(true, true)
+    } else if (causal) CC_M3_LAUNCH(true, false)
+    else CC_M3_LAUNCH(false, false)
+#undef CC_M3_LAUNCH
+    return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+}
+static bool attn_x3mfma_on();
+static bool attn_bwd_m3_ok(int S, int hd) { return attn_x3mfma_on() && (hd == 64 || hd == 96) && S > 0 && S <= 64; }
 static bool attn_x3mfma_on() {
     static const bool on = !(getenv("CC_ATTN_X3MFMA") && atoi(getenv("CC_ATTN_X3MFMA")) == 0) && !getenv("CC_ATTN_F32MFMA");
     return on;
@@ -2256,7 +2496,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_small(const act_t* __restrict_
 bool attn_fwd_can_image(int S, int hd) {
 #if CC_OP == 2
     const bool fwd_ok = (attn_x3mfma_on() && (hd == 64 || hd == 96 || hd == 128)) || (!attn_f32mfma_ok(S, hd, false) && attn_fwd_lds(S, hd) <= 160 * 1024);
-    return (hd & 7) == 0 && S > 0 && fwd_ok && !attn_f32mfma_ok(S, hd, true) && attn_bwd_lds(S, hd) <= 160 * 1024;
+    return (hd & 7) == 0 && S > 0 && fwd_ok && (attn_bwd_m3_ok(S, hd) || (!attn_f32mfma_ok(S, hd, true) && attn_bwd_lds(S, hd) <= 160 * 1024));
 #else
     (void)S; (void)hd;
     return false;
@@ -2265,7 +2505,7 @@ bool attn_fwd_can_image(int S, int hd) {
 // bf16x3: whether attn_bwd will honour an x3_emit_image(dqkv) request for this shape (only the LDS-tile VALU kernel writes images)
 bool attn_bwd_can_image(int S, int hd) {
 #if CC_OP == 2
-    return (hd & 7) == 0 && S > 0 && !attn_f32mfma_ok(S, hd, true) && attn_bwd_lds(S, hd) <= 160 * 1024;
+    return (hd & 7) == 0 && S > 0 && (attn_bwd_m3_ok(S, hd) || (!attn_f32mfma_ok(S, hd, true) && attn_bwd_lds(S, hd) <= 160 * 1024));
 #else
     (void)S; (void)hd;
     return false;
@@ -2292,6 +2532,12 @@ int attn_bwd(const act_t* qkv, const act_t* dout, const act_t* o, const float* l
     if (drop.thresh && (!kX3 || !causal)) return CC_ERR_SHAPE;          // dropout on the VALU kernel: the bf16x3 build's GPT-2 path only
     const float scale = 1.0f / sqrtf((float)hd);
 #if CC_OP == 2
+    if (attn_bwd_m3_ok(S, hd)) {                                         // three bf16 MFMA terms per product
+        if (hd == 64) return S <= 32 ? attn_bwd_m3_launch<64, 1>(qkv, dout, lse, B, S, H, causal, dqkv, st, drop, img)
+                                     : attn_bwd_m3_launch<64, 2>(qkv, dout, lse, B, S, H, causal, dqkv, st, drop, img);
+        return S <= 32 ? attn_bwd_m3_launch<96, 1>(qkv, dout, lse, B, S, H, causal, dqkv, st, drop, img)
+                       : attn_bwd_m3_launch<96, 2>(qkv, dout, lse, B, S, H, causal, dqkv, st, drop, img);
+    }
     if (attn_f32mfma_ok(S, hd, true)) {
         const size_t sh = attn_f32mfma_lds(S, hd, true);
         if (drop.thresh) CC_F32MFMA_LAUNCH((k_attn_bwd_f32mfma<true, true>), qkv, dout, lse, S, H, hd, scale, dqkv, drop)
