@@ -995,38 +995,51 @@ __global__ __launch_bounds__(NBLK == 2 ? 512 : 256, 1) void k_attn_bwd_m3(const 
         }
     }
     __syncthreads();
-    // ---- phase 2: a group of R lanes owns a row
+    // ---- phase 2: a thread owns 8 consecutive keys of a row (R / 8 neighbouring lanes share the row)
     {
-        constexpr int RPP = 64 / R, ROWS = R / (NW * RPP);      // rows per wave-pass, passes per wave
-        static_assert(ROWS * NW * RPP == R, "row passes tile the block");
-        const int key = lane % R;
-        float pm[ROWS], ds[ROWS];
+        constexpr int CPR = R / 8;                                // chunks (threads) per row
+        const int q = tid / CPR, c = tid - q * CPR;
+        const bool act = q < R;                                   // R = 32: 128 of the 256 threads
+        float pm[8], ds[8];
+        {
+            float sv[8], dv[8];
+            const float* ps = scrS + (act ? q : 0) * SP + c * 8;
+            const float* pd = scrD + (act ? q : 0) * SP + c * 8;
+            const float4 s0 = *reinterpret_cast<const float4*>(ps), s1 = *reinterpret_cast<const float4*>(ps + 4);
+            const float4 d0 = *reinterpret_cast<const float4*>(pd), d1 = *reinterpret_cast<const float4*>(pd + 4);
+            sv[0] = s0.x; sv[1] = s0.y; sv[2] = s0.z; sv[3] = s0.w; sv[4] = s1.x; sv[5] = s1.y; sv[6] = s1.z; sv[7] = s1.w;
+            dv[0] = d0.x; dv[1] = d0.y; dv[2] = d0.z; dv[3] = d0.w; dv[4] = d1.x; dv[5] = d1.y; dv[6] = d1.z; dv[7] = d1.w;
+            const float lq = lse_s[act ? q : 0];
+            float dpm[8], dl = 0.f;
 #pragma unroll
-        for (int it = 0; it < ROWS; it++) {
-            const int q = (it * NW + wave) * RPP + lane / R;
-            const bool ok = q < S && key < S && (!CAUSAL || key <= q);
-            const float sv = scrS[q * SP + key], dv = scrD[q * SP + key];
-            const float p = ok ? __expf(sv * scale - lse_s[q]) : 0.f;
-            const float mk = DROP ? drop_mul(drop, ((unsigned)(b * H + h) * S + min(q, S - 1)) * S + min(key, S - 1)) : 1.f;
-            const float dpm = ok ? dv * mk : 0.f;
-            float dl = p * dpm;
+            for (int e = 0; e < 8; e++) {
+                const int key = c * 8 + e;
+                const bool ok = act && q < S && key < S && (!CAUSAL || key <= q);
+                const float pe = ok ? __expf(sv[e] * scale - lq) : 0.f;
+                const float mk = DROP ? drop_mul(drop, ((unsigned)(b * H + h) * S + min(q, S - 1)) * S + min(key, S - 1)) : 1.f;
+                dpm[e] = ok ? dv[e] * mk : 0.f;
+                dl += pe * dpm[e];
+                pm[e] = pe;                                       // mask applied below, after delta
+                ds[e] = mk;
+            }
 #pragma unroll
-            for (int o = R / 2; o > 0; o >>= 1) dl += __shfl_xor(dl, o, 64);
-            ds[it] = ok ? p * (dpm - dl) * scale : 0.f;
-            pm[it] = p * mk;
+            for (int o = CPR / 2; o > 0; o >>= 1) dl += __shfl_xor(dl, o, 64);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float mk = ds[e];
+                ds[e] = pm[e] * (dpm[e] - dl) * scale;            // pm = 0 where masked
+                pm[e] *= mk;
+            }
         }
-        __syncthreads();                                       // every S / dP value is in registers: the area becomes the P / dS planes
-#pragma unroll
-        for (int it = 0; it < ROWS; it++) {
-            const int q = (it * NW + wave) * RPP + lane / R;
-            const op16_t ph = f2op(pm[it]), dh = f2op(ds[it]);
-            float phf, dhf, t0;
-            unpack2((unsigned)ph, phf, t0);
-            unpack2((unsigned)dh, dhf, t0);
-            Ph[q * LDP + key] = ph;
-            Pl[q * LDP + key] = f2op(pm[it] - phf);
-            Dh[q * LDP + key] = dh;
-            Dl[q * LDP + key] = f2op(ds[it] - dhf);
+        __syncthreads();                                          // every S / dP value is in registers: the area becomes the P / dS planes
+        if (act) {
+            op16x8 ph, plo, dh, dlo;
+            x3_split8(pm, ph, plo);
+            x3_split8(ds, dh, dlo);
+            *reinterpret_cast<op16x8*>(Ph + q * LDP + c * 8) = ph;
+            *reinterpret_cast<op16x8*>(Pl + q * LDP + c * 8) = plo;
+            *reinterpret_cast<op16x8*>(Dh + q * LDP + c * 8) = dh;
+            *reinterpret_cast<op16x8*>(Dl + q * LDP + c * 8) = dlo;
         }
     }
     __syncthreads();
@@ -1057,19 +1070,25 @@ __global__ __launch_bounds__(NBLK == 2 ? 512 : 256, 1) void k_attn_bwd_m3(const 
         }
         const int d = nb * 32 + l31;
         if (img) {                                              // rows of 9 D 16-bit elements: [hi (q k v) | hi | lo]
-            op16_t* r3 = reinterpret_cast<op16_t*>(dqkv) + (size_t)b * S * 9 * D + kind * D + h * HD + d;
+            // lanes d, d + 1 trade one value per register pair: the even lane stores row r's two columns, the odd lane row r + 1's — 4-byte
+            // stores (64 lanes x 4 B = two 64-B row segments per instruction) instead of 2-byte ones
+            const int odd = lane & 1;
+            op16_t* r3 = reinterpret_cast<op16_t*>(dqkv) + (size_t)b * S * 9 * D + kind * D + h * HD + (d & ~1);
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const op16_t vh = f2op(acc[r]);
-                float vhf, t0;
-                unpack2((unsigned)vh, vhf, t0);
-                const op16_t vl = f2op(acc[r] - vhf);
+            for (int rp = 0; rp < 8; rp++) {
+                const float v0 = acc[2 * rp], v1 = acc[2 * rp + 1];
+                const float got = __shfl_xor(odd ? v0 : v1, 1, 64);
+                const float a0 = odd ? got : v0, a1 = odd ? v1 : got;           // columns d & ~1, (d & ~1) + 1 of this lane's row
+                const int row = blk * 32 + ((2 * rp) & 3) + 8 * ((2 * rp) >> 2) + 4 * half + odd;
+                const unsigned hi = pack2op(a0, a1);
+                float h0, h1;
+                unpack2(hi, h0, h1);
+                const unsigned lo = pack2op(a0 - h0, a1 - h1);
                 if (row < S) {
                     op16_t* o3 = r3 + (size_t)row * 9 * D;
-                    o3[0] = vh;
-                    o3[3 * D] = vh;
-                    o3[6 * D] = vl;
+                    *reinterpret_cast<unsigned*>(o3) = hi;
+                    *reinterpret_cast<unsigned*>(o3 + 3 * D) = hi;
+                    *reinterpret_cast<unsigned*>(o3 + 6 * D) = lo;
                 }
             }
         } else {
