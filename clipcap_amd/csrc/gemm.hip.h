@@ -817,7 +817,8 @@ __device__ __forceinline__ int h_tt_g(int k) { return (k & 3) | (((k >> 3) & 1) 
 #define H_ISSUE(T, IS_A)                                                                                                 \
     {                                                                                                                    \
         char* st_ = smem + ((T) % H_NS) * SSTAGE + ((IS_A) ? 0 : SBM * H_BK * 2);                                      \
-        const int k0_ = kbeg + (T)*H_BK;                                                                                 \
+        int k0_ = kbeg + (T)*H_BK;                                                                                       \
+        if constexpr (X3F) k0_ = ((T) >> 1) * H_BK + (((T) & 1) ? ((IS_A) ? 2 * x3k_ : x3k_) : 0);   /* hi stage, then lo stage of the same K chunk */ \
         _Pragma("unroll") for (int i_ = 0; i_ < ((IS_A) ? NI / 2 : NJ); i_++) {                                              \
             const int seg = wn + 4 * i_;                        /* 2 NI (A) or 4 NJ (B) segments of 1 KiB */                \
             const op16_t* src;                                                                                           \
@@ -865,7 +866,7 @@ __device__ __forceinline__ op16x8 h_tt_oper(const HTTFrag& f) {
             _Pragma("unroll") for (int j_ = 0; j_ < NJ; j_++) bfr[j_] = *reinterpret_cast<const op16x8*>(cb_ + h_lds_off(bcol + j_ * 16 + frow, fchunk)); \
         }                                                                                                                \
     }
-#define H_MFMA()                                                                                                         \
+#define H_MFMA(T)                                                                                                        \
     {                                                                                                      \
         if constexpr (TT) {                                                                                              \
             _Pragma("unroll") for (int i_ = 0; i_ < NI; i_++) af[i_] = h_tt_oper(taf[i_]);                                 \
@@ -874,6 +875,23 @@ __device__ __forceinline__ op16x8 h_tt_oper(const HTTFrag& f) {
         __builtin_amdgcn_s_setprio(1);                                                                                   \
         _Pragma("unroll") for (int i_ = 0; i_ < NI; i_++) _Pragma("unroll") for (int j_ = 0; j_ < NJ; j_++)                \
             acc[i_][j_] = CC_MFMA_16x16x32(bfr[j_], af[i_], acc[i_][j_]);                \
+        __builtin_amdgcn_s_setprio(0);                                                                                   \
+    }
+// X3F: the lo stage of a K chunk — its fragments go to their own registers, its MFMA segment is A_hi B_lo + A_lo B_hi
+#define H_LOADF_LO(T)                                                                                                    \
+    {                                                                                                                    \
+        const char* ca_ = smem + ((T) % H_NS) * SSTAGE;                                                                 \
+        const char* cb_ = ca_ + SBM * H_BK * 2;                                                                         \
+        _Pragma("unroll") for (int i_ = 0; i_ < NI; i_++) af2[X3F ? i_ : 0] = *reinterpret_cast<const op16x8*>(ca_ + h_lds_off(arow + i_ * 16 + frow, fchunk)); \
+        _Pragma("unroll") for (int j_ = 0; j_ < NJ; j_++) bf2[X3F ? j_ : 0] = *reinterpret_cast<const op16x8*>(cb_ + h_lds_off(bcol + j_ * 16 + frow, fchunk)); \
+    }
+#define H_MFMA_LO()                                                                                                      \
+    {                                                                                                                    \
+        __builtin_amdgcn_s_setprio(1);                                                                                   \
+        _Pragma("unroll") for (int i_ = 0; i_ < NI; i_++) _Pragma("unroll") for (int j_ = 0; j_ < NJ; j_++)                \
+            acc[i_][j_] = CC_MFMA_16x16x32(bf2[X3F ? j_ : 0], af[i_], acc[i_][j_]);                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < NI; i_++) _Pragma("unroll") for (int j_ = 0; j_ < NJ; j_++)                \
+            acc[i_][j_] = CC_MFMA_16x16x32(bfr[j_], af2[X3F ? i_ : 0], acc[i_][j_]);                                       \
         __builtin_amdgcn_s_setprio(0);                                                                                   \
     }
 #define H_SEGEND()                                                                                                       \
@@ -905,11 +923,16 @@ __device__ unsigned long long cc_stamp_buf[2 * 8];
 #endif
 // body shared by the single-problem kernels and the grouped weight-gradient kernel: `tile` = logical tile of this block inside its
 // problem (XCD remap applied by the caller), `zslice` = its K slice
-template <class Epi, int NJ, bool TT, int NI = 8>
+// X3F (bf16x3 build, 256 x 192 form, one K slice): the operands are the [hi | hi | lo] / [hi | lo | hi] images over K' = 3 K.  Instead of walking
+// K' as three passes (hi hi, hi lo, lo hi: three stages of DMA and fragment reads per K chunk), a chunk is TWO stages — its hi tiles, then
+// its lo tiles — and the lo stage's MFMA segment runs A_hi B_lo + A_lo B_hi with the hi fragments kept in registers: 2/3 of the DMA bytes,
+// fragment reads and segment hand-offs for the same 3 MFMA products.  (44 more registers: fits the 178-register 256 x 192 form only.)
+template <class Epi, int NJ, bool TT, int NI = 8, bool X3F = false>
 __device__ __forceinline__ void gemm_stag256_body(const op16_t* __restrict__ A, const op16_t* __restrict__ B, const GemmShape& g, const Epi& epi,
                                                   int tile, int zslice, char* smem) {
     static_assert(NJ >= 2 && NJ <= 4 && (NI == 8 || NI == 10), "wave tile is (16 NI) x (16 NJ)");
     static_assert(!TT || (NJ == 4 && NI == 8), "the K-strided image is laid out for 256 x 256 tiles");
+    static_assert(!X3F || (!TT && NJ == 3 && NI == 8), "the fused split-bf16 form is the 256 x 192 NT kernel's");
     constexpr int BN = 64 * NJ, SBM = 32 * NI, SSTAGE = (SBM + H_BN) * H_BK * 2;      // NI = 10: 320-row tiles, 36 KiB stages
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -920,7 +943,9 @@ __device__ __forceinline__ void gemm_stag256_body(const op16_t* __restrict__ A, 
     tile_coords(tile, tiles_m, tiles_n, g.group_m, tm, tn);
     const int m0 = tm * SBM, n0 = tn * BN;
     const int kbeg = zslice * g.k_chunk;                      // split-K slice (k_chunk is a multiple of 64)
-    const int nk = (min(g.K, kbeg + g.k_chunk) - kbeg) / H_BK;
+    const int x3k_ = g.K / 3;                                 // X3F: the logical K (g.K = K' = 3 K, one slice)
+    (void)x3k_;
+    const int nk = X3F ? 2 * (x3k_ / H_BK) : (min(g.K, kbeg + g.k_chunk) - kbeg) / H_BK;
     f32x4 acc[NI][NJ];
 #pragma unroll
     for (int i = 0; i < NI; i++)
@@ -930,7 +955,7 @@ __device__ __forceinline__ void gemm_stag256_body(const op16_t* __restrict__ A, 
     // 12800 x 768 launch then travel while the first operand tiles are in flight, instead of joining the store burst at the end of a
     // single-round launch.  Issued before the first DMA so that every later counted vmcnt wait implies these loads have landed.
     // (256 x 192 form only: the 256-wide forms have no registers to spare for the address arithmetic — 276 / 564 B of scratch measured)
-    constexpr bool kAccInit = epi_acc_init<Epi>::value && NJ == 3 && NI == 8;
+    constexpr bool kAccInit = epi_acc_init<Epi>::value && NJ == 3 && NI == 8 && !X3F;      // (the fused split-bf16 form has no registers to spare either: 54 spilled)
     if constexpr (kAccInit) {
         if (zslice == 0 && epi.init_from_input()) {
             const int q_ = lane >> 4, rl_ = lane & 15;
@@ -941,6 +966,8 @@ __device__ __forceinline__ void gemm_stag256_body(const op16_t* __restrict__ A, 
         }
     }
     op16x8 af[NI], bfr[NJ];
+    op16x8 af2[X3F ? NI : 1], bf2[X3F ? NJ : 1];              // X3F: the lo stage's fragments
+    (void)af2; (void)bf2;
     HTTFrag taf[TT ? NI : 1], tbf[TT ? NJ : 1];
     (void)taf; (void)tbf;
     const int frow = lane & 15, fchunk = lane >> 4;
@@ -949,6 +976,55 @@ __device__ __forceinline__ void gemm_stag256_body(const op16_t* __restrict__ A, 
     const int tt_gx = h_tt_g(8 * fchunk + (frow >> 2)) << 1;
     (void)tt_base; (void)tt_gx;
     H_STAMP_DECL
+    if constexpr (X3F) {
+        // two stages per K chunk, parity known at compile time (a run-time parity test in one loop body kept both fragment sets and their
+        // copies live: 171-285 spilled registers)
+#define H_G0_STEP(T, LOADF, MFMA)                                                                                        \
+        {                                                                                                                \
+            LOADF(T);                                                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                                           \
+            if ((T) + H_NS - 1 < nk) H_ISSUE((T) + H_NS - 1, true);                                                      \
+            H_SEGEND();                                                                                                  \
+            MFMA;                                                                                                        \
+            H_WAIT(T, NI / 2);                                                                                           \
+            H_SEGEND();                                                                                                  \
+        }
+#define H_G1_STEP(T, LOADF, MFMA_PREV)                                                                                   \
+        {                                                                                                                \
+            MFMA_PREV;                                                                                                   \
+            H_SEGEND();                                                                                                  \
+            LOADF(T);                                                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                                           \
+            if ((T) + H_NS - 1 < nk) H_ISSUE((T) + H_NS - 1, false);                                                     \
+            H_WAIT(T, NJ);                                                                                               \
+            H_SEGEND();                                                                                                  \
+        }
+        if (grp == 0) {
+            H_ISSUE(0, true);
+            if (nk > 1) H_ISSUE(1, true);
+            if (nk > 2) H_ISSUE(2, true);
+            H_WAIT(-1, NI / 2);
+            H_SEGEND();
+            for (int t = 0; t < nk; t += 2) {
+                H_G0_STEP(t, H_LOADF, H_MFMA(t))
+                H_G0_STEP(t + 1, H_LOADF_LO, H_MFMA_LO())
+            }
+            H_SEGEND();
+        } else {
+            H_ISSUE(0, false);
+            if (nk > 1) H_ISSUE(1, false);
+            if (nk > 2) H_ISSUE(2, false);
+            H_WAIT(-1, NJ);
+            H_SEGEND();
+            for (int t = 0; t < nk; t += 2) {
+                H_G1_STEP(t, H_LOADF, if (t >= 1) H_MFMA_LO())
+                H_G1_STEP(t + 1, H_LOADF_LO, H_MFMA(t))
+            }
+            H_MFMA_LO(); H_SEGEND();
+        }
+#undef H_G0_STEP
+#undef H_G1_STEP
+    } else
     if (grp == 0) {
         H_ISSUE(0, true);
         if (nk > 1) H_ISSUE(1, true);
@@ -974,7 +1050,7 @@ __device__ __forceinline__ void gemm_stag256_body(const op16_t* __restrict__ A, 
             H_STAMP(2)                                 // fragment reads + wait
             H_SEGEND();
             H_STAMP(3)                                 // barrier (end of read segment)
-            H_MFMA();
+            H_MFMA(t);
             H_STAMP(4)                                 // MFMA issue
             H_WAIT(t, NI / 2);
             H_STAMP(5)                                 // vmcnt wait
@@ -991,7 +1067,7 @@ __device__ __forceinline__ void gemm_stag256_body(const op16_t* __restrict__ A, 
         H_SEGEND();
         H_STAMP(0)
         for (int t = 0; t < nk; t++) {
-            if (t >= 1) H_MFMA();
+            if (t >= 1) H_MFMA(t - 1);
             H_STAMP(4)
             H_SEGEND();
             H_STAMP(6)
@@ -1014,7 +1090,7 @@ __device__ __forceinline__ void gemm_stag256_body(const op16_t* __restrict__ A, 
             H_SEGEND();
             H_STAMP(3)
         }
-        H_MFMA(); H_SEGEND();
+        H_MFMA(nk - 1); H_SEGEND();
     }
     H_STAMP(0)
     if constexpr (epi_acc_init<Epi>::value && !kAccInit) {      // forms that did not start from the input: the epilogue adds it as before
@@ -1027,10 +1103,10 @@ __device__ __forceinline__ void gemm_stag256_body(const op16_t* __restrict__ A, 
     H_STAMP(7)                                         // epilogue
     H_STAMP_OUT
 }
-template <class Epi, int NJ, bool TT = false, int NI = 8>
+template <class Epi, int NJ, bool TT = false, int NI = 8, bool X3F = false>
 __global__ __launch_bounds__(512, 1) void gemm_nt_stag256_kernel(const op16_t* __restrict__ A, const op16_t* __restrict__ B, GemmShape g, Epi epi) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    gemm_stag256_body<Epi, NJ, TT, NI>(A, B, g, epi, xcd_remap(blockIdx.x, gridDim.x), (int)blockIdx.z, smem);
+    gemm_stag256_body<Epi, NJ, TT, NI, X3F>(A, B, g, epi, xcd_remap(blockIdx.x, gridDim.x), (int)blockIdx.z, smem);
 }
 #undef H_STAMP_DECL
 #undef H_STAMP
@@ -1038,6 +1114,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_stag256_kernel(const op16_t* _
 #undef H_ISSUE
 #undef H_LOADF
 #undef H_MFMA
+#undef H_LOADF_LO
+#undef H_MFMA_LO
 #undef H_SEGEND
 #undef H_WAIT
 
@@ -1711,7 +1789,19 @@ inline int launch_gemm(int al, int bl, const op16_t* A, int lda, const op16_t* B
     }
         if (nj == 4 && ni == 8) CC_LAUNCH_STAG(4, 8)
         else if (nj == 4) CC_LAUNCH_STAG(4, 10)
-        else if constexpr (!epi_row_strip<Epi>::value) CC_LAUNCH_STAG(3, 8)
+        else if constexpr (!epi_row_strip<Epi>::value) {
+            bool fused = false;
+            if constexpr (kX3) {       // bf16x3 build: every NT launch carries operand images over K' = 3 K — the fused two-stage form (gemm_stag256_body, X3F)
+                static const bool x3f_on = !(getenv("CC_X3_FUSED") && atoi(getenv("CC_X3_FUSED")) == 0);
+                if (x3f_on && ksplit == 1 && (K % (3 * H_BK)) == 0) {
+                    static bool attr_ = false;
+                    if (!attr_) { (void)hipFuncSetAttribute((const void*)gemm_nt_stag256_kernel<Epi, 3, false, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr_ = true; }
+                    hipLaunchKernelGGL((gemm_nt_stag256_kernel<Epi, 3, false, 8, true>), gr, dim3(512), sh, st, A, B, g, epi);
+                    fused = true;
+                }
+            }
+            if (!fused) CC_LAUNCH_STAG(3, 8)
+        }
 #undef CC_LAUNCH_STAG
     } else
 #ifdef CC_GEMM_ABLATION
