@@ -425,6 +425,78 @@ __global__ __launch_bounds__(G_THREADS, 2) void gemm_nt_glds_kernel(const op16_t
     gemm_epilogue(acc, smem, wave, lane, m0 + wm * 64, n0 + wn * 64, epi);
 }
 
+// bf16x3 build: the same kernel in the fused two-stage form of gemm_stag256_body<X3F> — a K chunk of 64 is its hi tiles
+// (A image columns [c, c + 64), B image columns [c, c + 64)), then its lo tiles (A: 2 K + c, B: K + c); the hi stage's fragments stay in
+// registers (64 of them: two 32-deep sub-steps x (4 + 4) fragments) and the lo stage runs A_hi B_lo + A_lo B_hi.  g.K is K' = 3 K, one slice.
+template <class Epi>
+__global__ __launch_bounds__(G_THREADS, 2) void gemm_nt_glds_x3f_kernel(const op16_t* __restrict__ A, const op16_t* __restrict__ B,
+                                                                         GemmShape g, Epi epi) {
+    __shared__ __attribute__((aligned(1024))) char smem[4 * G_TILE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (g.N + G_BN - 1) / G_BN, tiles_m = (g.M + G_BM - 1) / G_BM;
+    int tm, tn;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, g.group_m, tm, tn);
+    const int m0 = tm * G_BM, n0 = tn * G_BN;
+    const int Kl = g.K / 3, nc = Kl / G_BK;                   // logical K, chunks
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fchunk = lane >> 4;
+    op16x8 ah[2][4], bh[2][4];
+#define X3F_ISSUE(C, LO, BUF)                                                                                            \
+    {                                                                                                                    \
+        glds_tile(A, g.lda, g.M, m0, (C)*G_BK + ((LO) ? 2 * Kl : 0), (BUF), wave, lane);                                 \
+        glds_tile(B, g.ldb, g.N, n0, (C)*G_BK + ((LO) ? Kl : 0), (BUF) + G_TILE_BYTES, wave, lane);                      \
+    }
+    char* buf0 = smem;
+    char* buf1 = smem + 2 * G_TILE_BYTES;
+    X3F_ISSUE(0, 0, buf0)
+    for (int c = 0; c < nc; c++) {
+        // ---- hi stage (buffer 0); the lo tiles of this chunk travel meanwhile
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        X3F_ISSUE(c, 1, buf1)
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) ah[ks][i] = *reinterpret_cast<const op16x8*>(buf0 + g_lds_off(wm * 64 + i * 16 + frow, ks * 4 + fchunk));
+#pragma unroll
+            for (int j = 0; j < 4; j++) bh[ks][j] = *reinterpret_cast<const op16x8*>(buf0 + G_TILE_BYTES + g_lds_off(wn * 64 + j * 16 + frow, ks * 4 + fchunk));
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = CC_MFMA_16x16x32(ah[ks][i], bh[ks][j], acc[i][j]);
+        }
+        // ---- lo stage (buffer 1); the next chunk's hi tiles travel meanwhile
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (c + 1 < nc) X3F_ISSUE(c + 1, 0, buf0)
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            op16x8 al[4], bl[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) al[i] = *reinterpret_cast<const op16x8*>(buf1 + g_lds_off(wm * 64 + i * 16 + frow, ks * 4 + fchunk));
+#pragma unroll
+            for (int j = 0; j < 4; j++) bl[j] = *reinterpret_cast<const op16x8*>(buf1 + G_TILE_BYTES + g_lds_off(wn * 64 + j * 16 + frow, ks * 4 + fchunk));
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = CC_MFMA_16x16x32(ah[ks][i], bl[j], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = CC_MFMA_16x16x32(al[i], bh[ks][j], acc[i][j]);
+        }
+    }
+#undef X3F_ISSUE
+    __syncthreads();
+    gemm_epilogue(acc, smem, wave, lane, m0 + wm * 64, n0 + wn * 64, epi);
+}
+
 // Small grids (<= one 128 x 128 tile per CU): the same kernel with FOUR LDS stages (128 KiB, one block per CU by construction) and
 // three K-tiles of DMA in flight behind a counted vmcnt.  With a single block per CU the 2-stage kernel above exposes a full
 // L2/HBM round trip per K-step (s_waitcnt vmcnt(0) with nothing else on the CU to run): mapper GEMMs (M = 5120) ran 12-24 K-steps
@@ -1824,8 +1896,17 @@ inline int launch_gemm(int al, int bl, const op16_t* A, int lda, const op16_t* B
         }
         if (g_gemm_small_x2) hipLaunchKernelGGL((gemm_nt_glds4x2_kernel<Epi>), grid, dim3(2 * G_THREADS), sh4, st, A, B, g, epi);
         else hipLaunchKernelGGL((gemm_nt_glds4_kernel<Epi>), grid, dim3(G_THREADS), sh4, st, A, B, g, epi);
-    } else if (al == 0 && bl == 0 && (K % G_BK) == 0)
-        hipLaunchKernelGGL((gemm_nt_glds_kernel<Epi>), grid, dim3(G_THREADS), 0, st, A, B, g, epi);
+    } else if (al == 0 && bl == 0 && (K % G_BK) == 0) {
+        bool fused = false;
+        if constexpr (kX3) {       // bf16x3 build: operand images over K' = 3 K -> the fused two-stage form
+            static const bool x3f_on = !(getenv("CC_X3_FUSED") && atoi(getenv("CC_X3_FUSED")) == 0);
+            if (x3f_on && ksplit == 1 && (K % (3 * G_BK)) == 0) {
+                hipLaunchKernelGGL((gemm_nt_glds_x3f_kernel<Epi>), grid, dim3(G_THREADS), 0, st, A, B, g, epi);
+                fused = true;
+            }
+        }
+        if (!fused) hipLaunchKernelGGL((gemm_nt_glds_kernel<Epi>), grid, dim3(G_THREADS), 0, st, A, B, g, epi);
+    }
     else if (al == 0 && bl == 0)
         hipLaunchKernelGGL((gemm_bf16_kernel<0, 0, Epi>), grid, dim3(G_THREADS), 0, st, A, B, g, epi);
     else if (al == 0 && bl == 1)
