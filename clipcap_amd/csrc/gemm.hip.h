@@ -635,6 +635,100 @@ __global__ __launch_bounds__(2 * G_THREADS, 1) void gemm_nt_glds4x2_kernel(const
     }
 }
 
+// bf16x3 build: the 8-wave small-grid kernel in the fused two-stage form (gemm_stag256_body<X3F>): hi stage, lo stage, hi fragments retained
+template <class Epi>
+__global__ __launch_bounds__(2 * G_THREADS, 1) void gemm_nt_glds4x2_x3f_kernel(const op16_t* __restrict__ A, const op16_t* __restrict__ B,
+                                                                            GemmShape g, Epi epi) {
+    extern __shared__ __attribute__((aligned(1024))) char smem4[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, w4 = wave & 3;
+    const int wm = w4 >> 1, wn = w4 & 1;
+    const int tiles_n = (g.N + G_BN - 1) / G_BN, tiles_m = (g.M + G_BM - 1) / G_BM;
+    int tm, tn;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, g.group_m, tm, tn);
+    const int m0 = tm * G_BM, n0 = tn * G_BN;
+    const int Kl = g.K / 3;                                   // logical K (g.K = K' = 3 K, one slice)
+    const int nk = 2 * (Kl / G_BK);                           // a K chunk = its hi stage, then its lo stage
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // group 0 streams the A tile, group 1 the B tile: 4 DMA instructions per wave and K-tile
+#define G4_ISSUE(T)                                                                                                      \
+    {                                                                                                                    \
+        char* st_ = smem4 + ((T) & 3) * 2 * G_TILE_BYTES;                                                                \
+        if (grp == 0) glds_tile(A, g.lda, g.M, m0, ((T) >> 1) * G_BK + (((T) & 1) ? 2 * Kl : 0), st_, w4, lane);           \
+        else glds_tile(B, g.ldb, g.N, n0, ((T) >> 1) * G_BK + (((T) & 1) ? Kl : 0), st_ + G_TILE_BYTES, w4, lane);       \
+    }
+    G4_ISSUE(0);
+    if (nk > 1) G4_ISSUE(1);
+    if (nk > 2) G4_ISSUE(2);
+    const int frow = lane & 15, fchunk = lane >> 4;
+#define G4_WAIT(KT)                                                                                                      \
+    {                                                                                                                    \
+        const int rem_ = min(nk - 1, (KT) + 2) - (KT);                                                                   \
+        if (rem_ >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                  \
+        else if (rem_ == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                             \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                            \
+        __builtin_amdgcn_s_barrier();                                                                                    \
+        if ((KT) + 3 < nk) G4_ISSUE((KT) + 3);                                                                           \
+    }
+    op16x8 af[4], bfr[4];
+    for (int kt = 0; kt < nk; kt += 2) {
+        G4_WAIT(kt)
+        const char* cur = smem4 + (kt & 3) * 2 * G_TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; i++) af[i] = *reinterpret_cast<const op16x8*>(cur + g_lds_off(wm * 64 + i * 16 + frow, grp * 4 + fchunk));
+#pragma unroll
+        for (int j = 0; j < 4; j++) bfr[j] = *reinterpret_cast<const op16x8*>(cur + G_TILE_BYTES + g_lds_off(wn * 64 + j * 16 + frow, grp * 4 + fchunk));
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = CC_MFMA_16x16x32(af[i], bfr[j], acc[i][j]);
+        G4_WAIT(kt + 1)
+        const char* cur2 = smem4 + ((kt + 1) & 3) * 2 * G_TILE_BYTES;
+        op16x8 al[4], bl[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) al[i] = *reinterpret_cast<const op16x8*>(cur2 + g_lds_off(wm * 64 + i * 16 + frow, grp * 4 + fchunk));
+#pragma unroll
+        for (int j = 0; j < 4; j++) bl[j] = *reinterpret_cast<const op16x8*>(cur2 + G_TILE_BYTES + g_lds_off(wn * 64 + j * 16 + frow, grp * 4 + fchunk));
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = CC_MFMA_16x16x32(af[i], bl[j], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = CC_MFMA_16x16x32(al[i], bfr[j], acc[i][j]);
+    }
+#undef G4_WAIT
+#undef G4_ISSUE
+    __syncthreads();
+    // exchange: 8 float4 per thread each way, [tile][thread] so that a wave's ds_write/read_b128 is contiguous
+    f32x4* xch = reinterpret_cast<f32x4*>(smem4 + 4 * 2 * G_TILE_BYTES / 2) + grp * (8 * G_THREADS) + (tid & (G_THREADS - 1));
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) xch[(i * 4 + j) * G_THREADS] = grp ? acc[i][j] : acc[2 + i][j];
+    __syncthreads();
+    const f32x4* xin = reinterpret_cast<const f32x4*>(smem4 + 4 * 2 * G_TILE_BYTES / 2) + (grp ^ 1) * (8 * G_THREADS) + (tid & (G_THREADS - 1));
+    if (grp == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] += xin[(i * 4 + j) * G_THREADS];
+        gemm_epilogue<Epi, 0, 2>(acc, smem4, wave, lane, m0 + wm * 64, n0 + wn * 64, epi);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[2 + i][j] += xin[(i * 4 + j) * G_THREADS];
+        gemm_epilogue<Epi, 2, 4>(acc, smem4, wave, lane, m0 + wm * 64, n0 + wn * 64, epi);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Skinny NT kernel for decode-sized M (a few hundred rows): block tile 64 x (64 NJ), 4 waves as 2 x 2, wave tile 32 x 32 NJ on
 // v_mfma_f32_32x32x16_bf16.  Why not the 128 x 128 kernels: at M = 320 they give 24-96 blocks, and ONE block's K-step is bound by
@@ -1894,7 +1988,18 @@ inline int launch_gemm(int al, int bl, const op16_t* A, int lda, const op16_t* B
             (void)hipFuncSetAttribute((const void*)gemm_nt_glds4x2_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh4);
             attr = true;
         }
-        if (g_gemm_small_x2) hipLaunchKernelGGL((gemm_nt_glds4x2_kernel<Epi>), grid, dim3(2 * G_THREADS), sh4, st, A, B, g, epi);
+        bool fused = false;
+        if constexpr (kX3) {
+            static const bool x3f_on = !(getenv("CC_X3_FUSED") && atoi(getenv("CC_X3_FUSED")) == 0);
+            if (g_gemm_small_x2 && x3f_on && ksplit == 1 && (K % (3 * G_BK)) == 0) {
+                static bool attr2 = false;
+                if (!attr2) { (void)hipFuncSetAttribute((const void*)gemm_nt_glds4x2_x3f_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh4); attr2 = true; }
+                hipLaunchKernelGGL((gemm_nt_glds4x2_x3f_kernel<Epi>), grid, dim3(2 * G_THREADS), sh4, st, A, B, g, epi);
+                fused = true;
+            }
+        }
+        if (fused) {}
+        else if (g_gemm_small_x2) hipLaunchKernelGGL((gemm_nt_glds4x2_kernel<Epi>), grid, dim3(2 * G_THREADS), sh4, st, A, B, g, epi);
         else hipLaunchKernelGGL((gemm_nt_glds4_kernel<Epi>), grid, dim3(G_THREADS), sh4, st, A, B, g, epi);
     } else if (al == 0 && bl == 0 && (K % G_BK) == 0) {
         bool fused = false;
