@@ -984,7 +984,7 @@ __device__ __forceinline__ int h_tt_g(int k) { return (k & 3) | (((k >> 3) & 1) 
     {                                                                                                                    \
         char* st_ = smem + ((T) % H_NS) * SSTAGE + ((IS_A) ? 0 : SBM * H_BK * 2);                                      \
         int k0_ = kbeg + (T)*H_BK;                                                                                       \
-        if constexpr (X3F) k0_ = ((T) >> 1) * H_BK + (((T) & 1) ? ((IS_A) ? 2 * x3k_ : x3k_) : 0);   /* hi stage, then lo stage of the same K chunk */ \
+        if constexpr (X3F) k0_ = (x3c0_ + ((T) >> 1)) * H_BK + (((T) & 1) ? ((IS_A) ? 2 * x3k_ : x3k_) : 0);   /* hi stage, then lo stage of the same K chunk */ \
         _Pragma("unroll") for (int i_ = 0; i_ < ((IS_A) ? NI / 2 : NJ); i_++) {                                              \
             const int seg = wn + 4 * i_;                        /* 2 NI (A) or 4 NJ (B) segments of 1 KiB */                \
             const op16_t* src;                                                                                           \
@@ -1109,9 +1109,11 @@ __device__ __forceinline__ void gemm_stag256_body(const op16_t* __restrict__ A, 
     tile_coords(tile, tiles_m, tiles_n, g.group_m, tm, tn);
     const int m0 = tm * SBM, n0 = tn * BN;
     const int kbeg = zslice * g.k_chunk;                      // split-K slice (k_chunk is a multiple of 64)
-    const int x3k_ = g.K / 3;                                 // X3F: the logical K (g.K = K' = 3 K, one slice)
-    (void)x3k_;
-    const int nk = X3F ? 2 * (x3k_ / H_BK) : (min(g.K, kbeg + g.k_chunk) - kbeg) / H_BK;
+    const int x3k_ = g.K / 3;                                 // X3F: the logical K (g.K = K' = 3 K); K slices are ranges of its 32-wide chunks
+    const int x3nc_ = x3k_ / H_BK, x3per_ = (x3nc_ + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int x3c0_ = zslice * x3per_, x3c1_ = min(x3nc_, x3c0_ + x3per_);
+    (void)x3c0_;
+    const int nk = X3F ? 2 * max(0, x3c1_ - x3c0_) : (min(g.K, kbeg + g.k_chunk) - kbeg) / H_BK;
     f32x4 acc[NI][NJ];
 #pragma unroll
     for (int i = 0; i < NI; i++)
@@ -1166,7 +1168,7 @@ __device__ __forceinline__ void gemm_stag256_body(const op16_t* __restrict__ A, 
             H_SEGEND();                                                                                                  \
         }
         if (grp == 0) {
-            H_ISSUE(0, true);
+            if (nk > 0) H_ISSUE(0, true);                    // (an empty K slice writes a zero slab)
             if (nk > 1) H_ISSUE(1, true);
             if (nk > 2) H_ISSUE(2, true);
             H_WAIT(-1, NI / 2);
@@ -1177,7 +1179,7 @@ __device__ __forceinline__ void gemm_stag256_body(const op16_t* __restrict__ A, 
             }
             H_SEGEND();
         } else {
-            H_ISSUE(0, false);
+            if (nk > 0) H_ISSUE(0, false);
             if (nk > 1) H_ISSUE(1, false);
             if (nk > 2) H_ISSUE(2, false);
             H_WAIT(-1, NJ);
@@ -1186,7 +1188,8 @@ __device__ __forceinline__ void gemm_stag256_body(const op16_t* __restrict__ A, 
                 H_G1_STEP(t, H_LOADF, if (t >= 1) H_MFMA_LO())
                 H_G1_STEP(t + 1, H_LOADF_LO, H_MFMA(t))
             }
-            H_MFMA_LO(); H_SEGEND();
+            if (nk > 0) H_MFMA_LO();
+            H_SEGEND();
         }
 #undef H_G0_STEP
 #undef H_G1_STEP
@@ -1892,6 +1895,11 @@ template <> struct epi_row_strip<EpiLMHeadExp> { static constexpr bool value = t
 template <class Epi>
 inline int launch_gemm_s64(const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, int ksplit, int nj, const Epi& epi, int* ks_eff,
                            hipStream_t st);
+// bf16x3 build: the fused two-stage forms of the NT kernels (gemm_stag256_body<X3F>, gemm_nt_glds_x3f_kernel, gemm_nt_glds4x2_x3f_kernel); CC_X3_FUSED=0: A/B switch
+inline bool x3_fused_on() {
+    static const bool on = kX3 && !(getenv("CC_X3_FUSED") && atoi(getenv("CC_X3_FUSED")) == 0);
+    return on;
+}
 template <class Epi>
 inline int launch_gemm(int al, int bl, const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K,
                        int ksplit, const Epi& epi, hipStream_t st, int tile = -2, int group_m = 0) {   // tile: -2 = process-wide mode / chooser, else as cc_gemm_tile_mode; group_m: row tiles per ordering group (0 = default)
@@ -1958,8 +1966,8 @@ inline int launch_gemm(int al, int bl, const op16_t* A, int lda, const op16_t* B
         else if constexpr (!epi_row_strip<Epi>::value) {
             bool fused = false;
             if constexpr (kX3) {       // bf16x3 build: every NT launch carries operand images over K' = 3 K — the fused two-stage form (gemm_stag256_body, X3F)
-                static const bool x3f_on = !(getenv("CC_X3_FUSED") && atoi(getenv("CC_X3_FUSED")) == 0);
-                if (x3f_on && ksplit == 1 && (K % (3 * H_BK)) == 0) {
+                const bool x3f_on = x3_fused_on();
+                if (x3f_on && (K % (3 * H_BK)) == 0 && ksplit <= K / (3 * H_BK)) {     // (K slices: ranges of the logical K's chunks, every slice non-empty)
                     static bool attr_ = false;
                     if (!attr_) { (void)hipFuncSetAttribute((const void*)gemm_nt_stag256_kernel<Epi, 3, false, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr_ = true; }
                     hipLaunchKernelGGL((gemm_nt_stag256_kernel<Epi, 3, false, 8, true>), gr, dim3(512), sh, st, A, B, g, epi);
@@ -1990,7 +1998,7 @@ inline int launch_gemm(int al, int bl, const op16_t* A, int lda, const op16_t* B
         }
         bool fused = false;
         if constexpr (kX3) {
-            static const bool x3f_on = !(getenv("CC_X3_FUSED") && atoi(getenv("CC_X3_FUSED")) == 0);
+            const bool x3f_on = x3_fused_on();
             if (g_gemm_small_x2 && x3f_on && ksplit == 1 && (K % (3 * G_BK)) == 0) {
                 static bool attr2 = false;
                 if (!attr2) { (void)hipFuncSetAttribute((const void*)gemm_nt_glds4x2_x3f_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh4); attr2 = true; }
@@ -2004,7 +2012,7 @@ inline int launch_gemm(int al, int bl, const op16_t* A, int lda, const op16_t* B
     } else if (al == 0 && bl == 0 && (K % G_BK) == 0) {
         bool fused = false;
         if constexpr (kX3) {       // bf16x3 build: operand images over K' = 3 K -> the fused two-stage form
-            static const bool x3f_on = !(getenv("CC_X3_FUSED") && atoi(getenv("CC_X3_FUSED")) == 0);
+            const bool x3f_on = x3_fused_on();
             if (x3f_on && ksplit == 1 && (K % (3 * G_BK)) == 0) {
                 hipLaunchKernelGGL((gemm_nt_glds_x3f_kernel<Epi>), grid, dim3(G_THREADS), 0, st, A, B, g, epi);
                 fused = true;

@@ -414,9 +414,26 @@ int gemm_nt_deepk(const act_t* Aa, int lda, const op16_t* B, int ldb, int M, int
     e.zstride = slab;
     // tile order: an XCD's share of the grid (tiles / 8 consecutive logical tiles per K slice) should hold whole row panels, so that the
     // column tiles of a panel run side by side on one L2 and the deep A panel is fetched once, not once per column tile
-    const int tiles_n = (N + H_BN - 1) / H_BN;
-    const int gm = std::max(1, (int)((tiles + 7) / 8) / tiles_n);
-    const int rc = launch_gemm(0, 0, A, lda, B, ldb, M, N, K, ks, e, st, 4, gm);
+    int tile = 4, tiles_n = (N + H_BN - 1) / H_BN;
+    long tl = tiles;
+    if (kX3 && x3_fused_on() && (K % (3 * H_BK)) == 0) {
+        // bf16x3: the fused two-stage form lives on the 256 x 192 kernel (gemm_stag256_body<X3F>): its tile count, and the slice count
+        // that minimises rounds x chunks per slice (whole rounds of 256 workgroups)
+        tile = 3;
+        tiles_n = (N + 191) / 192;
+        tl = (long)((M + H_BM - 1) / H_BM) * tiles_n;
+        const int nc = K / (3 * H_BK);
+        long best = -1;
+        int best_ks = ks;
+        for (int k2 = 1; k2 <= 8 && (size_t)k2 <= fit && k2 <= nc / 32; k2++) {
+            const long cost = ((tl * k2 + 255) / 256) * ((nc + k2 - 1) / k2);
+            if (best < 0 || cost < best) { best = cost; best_ks = k2; }
+        }
+        ks = best_ks;
+        if (ks < 2) return CC_ERR_SHAPE;
+    }
+    const int gm = std::max(1, (int)((tl + 7) / 8) / tiles_n);
+    const int rc = launch_gemm(0, 0, A, lda, B, ldb, M, N, K, ks, e, st, tile, gm);
     if (rc != CC_OK) return rc;
     const int kt = K / G_BK, per = (kt + ks - 1) / ks, ks_eff = (kt + per - 1) / per;
     const size_t n8 = (size_t)M * (N >> 3);
