@@ -256,3 +256,34 @@ def test_x3_module_autograd_paths_vs_reference_gradients():
             wm = max(wm, float((p.grad.cpu() - r).norm() / r.norm().clamp_min(1e-12)))
     print(f"split-bf16 autograd paths: GPT-2 worst relative gradient error {worst:.2e}, mapper {wm:.2e}")
     assert worst <= 2e-3 and wm <= 2e-3
+
+
+@pytest.mark.parametrize("B,S,H,hd,causal", [(3, 50, 2, 64, 1), (2, 20, 3, 96, 0), (2, 64, 2, 64, 1), (2, 33, 1, 96, 1), (1, 32, 2, 64, 0),
+                                             (2, 1, 2, 64, 1), (2, 7, 1, 128, 0), (1, 61, 2, 96, 0), (2, 75, 1, 64, 1), (1, 180, 2, 96, 0),
+                                             (2, 17, 2, 32, 1), (3, 40, 2, 128, 1)])
+def test_x3_attention_kernels_vs_fp32(B, S, H, hd, causal):
+    """cc_attention_fwd / _bwd in the split-bf16 build (fp32 tensors): the three-term MFMA kernels (k_attn_fwd_mfma3 for head dim 64 / 96 /
+    128; k_attn_bwd_m3 for head dim 64 / 96, S <= 64 — one and two 32-row blocks, ragged last block) and the fp32 VALU kernels they fall
+    back to (head dim 32, head dim 128 backward, S = 75 / 180) against fp32 torch: output and lse to 2e-4, gradients to 5e-4 of their scale
+    (every product carries ~16 mantissa bits per operand)."""
+    from tests.test_gpu_kernels import _attn_ref, _lib, _p, _st
+    torch.manual_seed(S * 7 + hd + causal)
+    D = H * hd
+    qkv = torch.randn(B * S, 3 * D, device="cuda")
+    out = torch.full((B * S, D), float("nan"), device="cuda")
+    lse = torch.empty(B, H, S, device="cuda")
+    assert _lib().cc_attention_fwd(2, _p(qkv), B, S, H, hd, causal, _p(out), _p(lse), _st()) == 0
+    qkv_r = qkv.clone().requires_grad_(True)
+    ref, lse_ref = _attn_ref(qkv_r, B, S, H, hd, causal)
+    torch.cuda.synchronize()
+    assert (lse - lse_ref).abs().max().item() <= 2e-4
+    assert (out.view(B, S, D) - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
+    dout = torch.randn(B * S, D, device="cuda")
+    dqkv = torch.full_like(qkv, float("nan"))
+    delta = torch.empty(B * H * S, device="cuda")
+    assert _lib().cc_attention_bwd(2, _p(qkv), _p(dout), _p(out), _p(lse), _p(delta), B, S, H, hd, causal, _p(dqkv), _st()) == 0
+    ref.backward(dout.view(B, S, D))
+    torch.cuda.synchronize()
+    g = qkv_r.grad
+    assert torch.isfinite(dqkv).all()
+    assert (dqkv - g).abs().max().item() <= 5e-4 * max(1.0, g.abs().max().item()), (dqkv - g).abs().max().item()
