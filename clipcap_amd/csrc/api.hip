@@ -285,7 +285,7 @@ void gpt2_carve(const cc_gpt2_cfg* c, int B, int T, int cap, int mode, void* ws,
     w.row_map = cv.take<int>(Mh);
     if (keep) {
         const int npart = c->Vp / 64;
-        w.logits16 = cv.take<act_t>(Mc * c->Vp);
+        w.logits16 = cv.take<act_t>(Mc * c->Vp * ((kX3 && !full) ? 3 : 2) / 2);               // bf16x3, frozen LM: E as an operand image (lm_exp_form)
         w.pmax = cv.take<float>(Mc * npart);
         w.psum = cv.take<float>(Mc * npart);
         w.tgt_logit = cv.take<float>(Mc);
@@ -545,9 +545,14 @@ static bool x3_img_on() {
 #if CC_OP == 2
 static bool gpt2_bwd_images(const cc_gpt2_shape* s) { return s->mode == 1 && x3_img_on() && s->p_resid == 0.f && s->p_attn == 0.f && s->p_embd == 0.f; }
 #endif
-static bool lm_exp_form() {
-    static const bool on = (CC_OP == 0) && []() { const char* e = getenv("CC_LM_EXPFORM"); return !e || atoi(e) != 0; }();
-    return on;
+// bf16x3: the exponential form for frozen-LM runs (round 4) — E leaves the GEMM as the [hi | hi | lo] operand image of the input-gradient
+// GEMM (in the logits buffer, 1.5x), so neither fp32 logits nor the softmax-gradient pass over them exist; the full finetune keeps the
+// logit form (its tied weight gradient reads the fp32 gradient).
+static bool lm_exp_form(const cc_gpt2_shape* s) {
+    static const bool env = []() { const char* e = getenv("CC_LM_EXPFORM"); return !e || atoi(e) != 0; }();
+    if (CC_OP == 0) return env;
+    if (CC_OP == 2) return env && x3_img_on() && s->mode == 1;
+    return false;
 }
 static bool shape_ok(const cc_gpt2_cfg* c, const cc_gpt2_shape* s) {
     return s && s->B > 0 && s->T > 0 && s->L >= 0 && s->L <= s->T && s->cap >= s->T - s->L && s->mode >= 0 && s->mode <= 2 && s->T <= c->NPOS &&
@@ -772,8 +777,12 @@ int CC_API(cc_lmhead_ce_fwd)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const
     CC_TRY(ce_targets(reinterpret_cast<const long long*>(tokens), w.target, w.row_map, s->B, cap, s->L, s->T, st));
     // ln_f only on the rows the loss reads: L-1 .. T-2 of every sample (model.py:108)
     CC_TRY(ln_fwd(w.x[c->NL], D, w.row_map, w32 + o.lnf_w, w32 + o.lnf_b, w.hf16, nullptr, w.meanf, w.rstdf, Mc, D, st));
-    const bool ef = lm_exp_form();
-    if (ef) CC_TRY(lm_tgt_ref(w.hf16, W16(w16, o.wte), D, w.target, w.cref, Mc, st));
+    const bool ef = lm_exp_form(s);
+    const op16_t* wte_rows = kX3 ? reinterpret_cast<const op16_t*>(w32 + o.wte) : W16(w16, o.wte);      // rows read elementwise: bf16x3 takes the fp32 master
+    if (ef) CC_TRY(lm_tgt_ref(w.hf16, wte_rows, D, w.target, w.cref, Mc, st));
+#if CC_OP == 2
+    if (ef) x3_emit_image(w.logits16, c->Vp);
+#endif
     CC_TIMED(CC_SITE_LMHEAD_FWD, st, gemm_lmhead(w.hf16, D, W16(w16, o.wte), D, Mc, c->Vp, c->V, D, w.logits16, c->Vp, w.pmax, w.psum, npart, w.target, w.tgt_logit, st,
                                                  ef ? w.cref : nullptr));
     CC_TRY(ce_rows(w.pmax, w.psum, npart, w.target, ef ? w.cref : w.tgt_logit, w.lse_row, w.row_loss, stats, Mc, st));   // cref IS the target logit
@@ -794,14 +803,15 @@ int CC_API(cc_lmhead_ce_bwd)(const cc_gpt2_cfg* c, const cc_gpt2_shape* s, const
     const bool full = s->mode == 2;
     // exponential form: logits16 holds E = exp(logit - cref); d logits = r E - w onehot is never written — the row factors go into the
     // GEMMs' finishing passes (EpiLMHead comment).  Otherwise: the in-place softmax-gradient pass over the stored logits.
-    const bool ef = lm_exp_form();
-    const LmFix fix{w.lmfac, w.target, W16(w16, o.wte)};
+    const bool ef = lm_exp_form(s);
+    const LmFix fix{w.lmfac, w.target, kX3 ? reinterpret_cast<const op16_t*>(w32 + o.wte) : W16(w16, o.wte)};
     if (ef) CC_TRY(lm_rowfac(w.cref, w.lse_row, w.target, denom, loss_scale, w.lmfac, Mc, st));
     const act_t* dlog = w.logits16;            // the A operand of the input-gradient GEMM
 #if CC_OP == 2
     // frozen LM: nothing but that GEMM reads d logits -> the softmax-gradient pass writes its [hi | hi | lo] operand image straight into the
     // call's operand scratch (sized for exactly this image, gpt2_carve) instead of fp32 values a split pass would re-read
     op16_t* dimg = (!ef && !full && x3_img_on()) ? x3_scratch_block(x3_img(Mc, c->Vp)) : nullptr;
+    if (ef) dimg = reinterpret_cast<op16_t*>(w.logits16);        // exponential form: the forward GEMM wrote E there as the operand image
     if (dimg) dlog = reinterpret_cast<const act_t*>(dimg);
     if (!ef) CC_TRY(ce_dlogits(w.logits16, c->Vp, c->V, w.target, w.lse_row, denom, loss_scale, Mc, st, dimg));
 #else

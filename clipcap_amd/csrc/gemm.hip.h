@@ -1766,6 +1766,7 @@ struct EpiLMHeadExp {
     float* psum;           // [M][npart]
     const float* cref;     // [M]
     int ldc, M, V, npart;
+    int img = 0;           // bf16x3: > 0 = C receives the [hi | hi | lo] operand image of the input-gradient GEMM (rows of 3 * img elements, epi_store8)
     __device__ __forceinline__ void operator()(int row, int col, float (&v)[8]) const {
         constexpr float L2E = 1.4426950408889634f;
         const bool ok = row < M && col < ldc;
@@ -1785,7 +1786,7 @@ struct EpiLMHeadExp {
             pmax[(size_t)row * npart + blk] = col < V ? cref[row] : -INFINITY;
             psum[(size_t)row * npart + blk] = s;
         }
-        act_st8(C + (size_t)row * ldc + col, v);
+        epi_store8(C, ldc, row, col, v, img);
     }
     typedef float RowAux;                                                             // the row's reference shift
     __device__ __forceinline__ float load_row(int row) const { return row < M ? cref[row] : 0.f; }
@@ -1810,8 +1811,8 @@ struct EpiLMHeadExp {
             pmax[(size_t)row * npart + blk] = ca < V ? c : -INFINITY;
             psum[(size_t)row * npart + blk] = s;
         }
-        if (ca < ldc) act_st8(C + (size_t)row * ldc + ca, va);
-        if (cb < ldc) act_st8(C + (size_t)row * ldc + cb, vb);
+        if (ca < ldc) epi_store8(C, ldc, row, ca, va, img);
+        if (cb < ldc) epi_store8(C, ldc, row, cb, vb, img);
     }
 };
 // Decode lm_head: fp32 logits (what the beam / sampling kernels read) + the same per-(row, 64-column block) partials (max, sum of

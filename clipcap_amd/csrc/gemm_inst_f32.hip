@@ -389,7 +389,11 @@ __global__ __launch_bounds__(256) void k_deepk_finish_lm(const float* __restrict
             v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += c.x; v[5] += c.y; v[6] += c.z; v[7] += c.w;
         }
         const float r = f.fac[2 * row], w = f.fac[2 * row + 1];
+#if CC_OP == 2
+        act_ld8(reinterpret_cast<const float*>(f.wte) + (size_t)f.target[row] * N + col, b);      // bf16x3: LmFix.wte is the fp32 master
+#else
         unpack8(*reinterpret_cast<const uint4*>(f.wte + (size_t)f.target[row] * N + col), b);
+#endif
 #pragma unroll
         for (int k = 0; k < 8; k++) v[k] = r * v[k] - w * b[k];
         act_st8(out16 + (size_t)row * ldo + col, v);

@@ -9,6 +9,9 @@ int gemm_lmhead(const act_t* A, int lda, const op16_t* B, int ldb, int M, int Vp
     CC_X3_NT(A, lda, ldb, M, K, A16, 0, 0, st);
     if (cref) {      // exponential form: the caller takes the target logit from cref itself (tgt_logit unused)
         EpiLMHeadExp e{C, pmax, psum, cref, ldc, M, V, npart};
+#if CC_OP == 2
+        e.img = x3_take_emit(C);      // frozen-LM runs: E goes out as the input-gradient GEMM's operand image
+#endif
         return launch_gemm(0, 0, A16, lda, B, ldb, M, Vp, K, 1, e, st);
     }
     EpiLMHead e{C, pmax, psum, target, tgt_logit, ldc, M, V, npart};

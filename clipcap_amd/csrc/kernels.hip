@@ -2846,12 +2846,20 @@ __global__ __launch_bounds__(256) void k_lm_tgt_ref(const act_t* __restrict__ hf
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const act_t* h = hf + (size_t)row * D;
+#if CC_OP == 2
+    const float* w = reinterpret_cast<const float*>(wte) + (size_t)target[row] * D;     // bf16x3: the fp32 master row (what hi + lo stand for)
+#else
     const op16_t* w = wte + (size_t)target[row] * D;
+#endif
     float acc = 0.f;
     for (int d = lane * 8; d < D; d += 512) {
         float a[8], b[8];
         act_ld8(h + d, a);
+#if CC_OP == 2
+        act_ld8(w + d, b);
+#else
         unpack8(*reinterpret_cast<const uint4*>(w + d), b);
+#endif
 #pragma unroll
         for (int e = 0; e < 8; e++) acc += a[e] * b[e];
     }
@@ -2891,7 +2899,11 @@ __global__ __launch_bounds__(256) void k_lm_rows(act_t* __restrict__ io, const a
         if (MODE == 0) {
             float b[8];
             act_ld8(io + (size_t)row * D + c, v);
+#if CC_OP == 2
+            act_ld8(reinterpret_cast<const float*>(wte) + (size_t)target[row] * D + c, b);
+#else
             unpack8(*reinterpret_cast<const uint4*>(wte + (size_t)target[row] * D + c), b);
+#endif
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] = r * v[e] - w * b[e];
             act_st8(io + (size_t)row * D + c, v);
