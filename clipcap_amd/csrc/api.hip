@@ -124,6 +124,7 @@ struct MapperWS {
     act_t *dx16, *dx16b, *dh16, *dxn16, *datt16, *dqkv16, *dlin16;
     float* wg_scratch;
     float* adelta;
+    uint16_t* gimg;    // bf16x3 build: the [hi | hi | lo] image of the output gradient both GEMMs of a layer step read
     char* x3;          // bf16x3 build: operand-image scratch of the GEMM in flight (gemm_api.h)
     size_t x3_bytes;
     size_t bytes;
@@ -172,8 +173,12 @@ void mapper_carve(const cc_mapper_cfg* c, int B, int save, void* ws, MapperWS& w
         w.dlin16 = cv.take<act_t>((size_t)B * c->W * c->P * D);
         w.wg_scratch = cv.take<float>(WGRAD_SCRATCH_BYTES / sizeof(float));
         w.adelta = cv.take<float>((size_t)B * c->H * S);
+        // bf16x3: an output gradient is the operand of TWO GEMMs in the same image form (its layer's weight gradient and input gradient):
+        // split once into this buffer, read twice (the widest is d qkv)
+        w.gimg = kX3 ? reinterpret_cast<uint16_t*>(cv.take<char>(x3_img(M, std::max<size_t>(3 * (size_t)D, c->Hm)))) : nullptr;
     } else {
         w.dx32 = nullptr; w.dx16 = w.dx16b = w.dh16 = w.dxn16 = w.datt16 = w.dqkv16 = w.dlin16 = nullptr; w.wg_scratch = nullptr; w.adelta = nullptr;
+        w.gimg = nullptr;
     }
     w.x3 = nullptr; w.x3_bytes = 0;
     if (kX3) {
@@ -490,27 +495,51 @@ int CC_API(cc_mapper_bwd_range)(const cc_mapper_cfg* c, int32_t B, const float* 
     }
     WgradBatch wb;          // per layer: its four weight gradients as ONE grouped GEMM launch + ONE slab reduce (wgrad_flush)
     wb.defer = true;
+    // bf16x3: `G2(t, width)` = the tensor as both of its GEMMs take it — split ONCE into w.gimg ([hi | hi | lo], the form of the weight
+    // gradient's first operand and of the input gradient's A operand alike); every use re-arms the one-shot image hint
+#if CC_OP == 2
+    static const bool share = []() { const char* e = getenv("CC_X3_SHARE"); return !e || atoi(e) != 0; }();
+    int g2rc = CC_OK;
+    auto G2 = [&](const act_t* t, int width) -> const act_t* {
+        if (!share) return t;
+        g2rc = x3_split_rows(t, (size_t)width, w.gimg, M, width, 0, st);
+        return reinterpret_cast<const act_t*>(w.gimg);
+    };
+    auto USE = [&](const act_t* img) -> const act_t* { if (share) x3_expect_image(img); return img; };
+#else
+    auto G2 = [&](const act_t* t, int) -> const act_t* { return t; };
+    auto USE = [&](const act_t* img) -> const act_t* { return img; };
+    const int g2rc = CC_OK;
+#endif
     for (int l = l_hi - 1; l >= l_lo; l--) {
         const auto& y = o.layer[l];
         // fc2: y = h W2^T + b2
-        CC_TIMED(CC_SITE_MAPPER_WGRAD_FC2, st, gemm_wgrad(w.dx16, D, w.h[l], Hm, D, Hm, M, g32 + y.w2, Hm, w.wg_scratch, st, &wb));
+        const act_t* gx = G2(w.dx16, D);
+        CC_TRY(g2rc);
+        CC_TIMED(CC_SITE_MAPPER_WGRAD_FC2, st, gemm_wgrad(USE(gx), D, w.h[l], Hm, D, Hm, M, g32 + y.w2, Hm, w.wg_scratch, st, &wb));
         // fc2.bias gradient = column sums of dx16: for every layer but the top one the LN1 backward of the layer above produced
         // them together with dx16 (ln_bwd dcol); the top layer's dx16 comes from the seed
         if (l == c->N - 1) CC_TRY(colsum_bf16(w.dx16, D, M, D, g32 + y.b2, st));
-        CC_TRY(gemm_dact(0, 0, w.dx16, D, W16(w16t, y.w2), D, M, Hm, D, w.dh16, Hm, w.h[l], 1, st));          // W2^T [Hm, D]
+        CC_TRY(gemm_dact(0, 0, USE(gx), D, W16(w16t, y.w2), D, M, Hm, D, w.dh16, Hm, w.h[l], 1, st));          // W2^T [Hm, D]
         // fc1
-        CC_TRY(gemm_wgrad(w.dh16, Hm, w.xn2[l], D, Hm, D, M, g32 + y.w1, D, w.wg_scratch, st, &wb));
+        const act_t* gh = G2(w.dh16, Hm);
+        CC_TRY(g2rc);
+        CC_TRY(gemm_wgrad(USE(gh), Hm, w.xn2[l], D, Hm, D, M, g32 + y.w1, D, w.wg_scratch, st, &wb));
         CC_TRY(colsum_bf16(w.dh16, Hm, M, Hm, g32 + y.b1, st));
-        CC_TRY(gemm_bf16out(0, 0, w.dh16, Hm, W16(w16t, y.w1), Hm, M, D, Hm, w.dxn16, D, nullptr, 0, nullptr, st));   // W1^T [D, Hm]
+        CC_TRY(gemm_bf16out(0, 0, USE(gh), Hm, W16(w16t, y.w1), Hm, M, D, Hm, w.dxn16, D, nullptr, 0, nullptr, st));   // W1^T [D, Hm]
         CC_TRY(ln_bwd(w.dxn16, w.x1[l], D, nullptr, w.mean2[l], w.rstd2[l], w32 + y.n2w, w.dx32, w.dx32, w.dx16b, g32 + y.n2w,
                       g32 + y.n2b, M, D, st, g32 + y.bp));         // + project.bias gradient (column sums of dx16b)
         // project
-        CC_TRY(gemm_wgrad(w.dx16b, D, w.att[l], D, D, D, M, g32 + y.wp, D, w.wg_scratch, st, &wb));
-        CC_TRY(gemm_bf16out(0, 0, w.dx16b, D, W16(w16t, y.wp), D, M, D, D, w.datt16, D, nullptr, 0, nullptr, st));     // Wp^T
+        const act_t* gb = G2(w.dx16b, D);
+        CC_TRY(g2rc);
+        CC_TRY(gemm_wgrad(USE(gb), D, w.att[l], D, D, D, M, g32 + y.wp, D, w.wg_scratch, st, &wb));
+        CC_TRY(gemm_bf16out(0, 0, USE(gb), D, W16(w16t, y.wp), D, M, D, D, w.datt16, D, nullptr, 0, nullptr, st));     // Wp^T
         CC_TRY(attn_bwd(w.qkv[l], w.datt16, w.att[l], w.lse[l], w.adelta, B, S, H, hd, false, w.dqkv16, st));
         // fused q/kv projection (to_queries.weight ++ to_keys_values.weight = [3D, D])
-        CC_TRY(gemm_wgrad(w.dqkv16, 3 * D, w.xn1[l], D, 3 * D, D, M, g32 + y.wq, D, w.wg_scratch, st, &wb));
-        CC_TRY(gemm_bf16out(0, 0, w.dqkv16, 3 * D, W16(w16t, y.wq), 3 * D, M, D, 3 * D, w.dxn16, D, nullptr, 0, nullptr, st));  // Wqkv^T [D, 3D]
+        const act_t* gq = G2(w.dqkv16, 3 * D);
+        CC_TRY(g2rc);
+        CC_TRY(gemm_wgrad(USE(gq), 3 * D, w.xn1[l], D, 3 * D, D, M, g32 + y.wq, D, w.wg_scratch, st, &wb));
+        CC_TRY(gemm_bf16out(0, 0, USE(gq), 3 * D, W16(w16t, y.wq), 3 * D, M, D, 3 * D, w.dxn16, D, nullptr, 0, nullptr, st));  // Wqkv^T [D, 3D]
         // the deferred weight gradients read dx16 (layer input gradient), dh16, dx16b, dqkv16: all still intact here — run them
         // before the LN1 backward overwrites dx16 with the next layer's input gradient
         CC_TRY(wgrad_flush(wb, st));

@@ -147,9 +147,12 @@ int gemm_wgrad(const act_t* Xa, int ldx, const act_t* Ya, int ldy, int Mw, int N
     // The images live in the call's scratch, so nothing can be deferred to a grouped launch.
     if (Mw & 7) return CC_ERR_SHAPE;
     int rcx = CC_OK;
-    const op16_t* X = x3_operand(Xa, (size_t)ldx, K, Mw, 0, true, st, &rcx);
+    // the first operand (the output gradient) has the [hi | hi | lo] form the input-gradient GEMM of the same tensor reads as its A operand:
+    // a caller that has split it once for both passes it as an image (x3_expect_image)
+    const bool ximg = x3_take_expected(Xa);
+    const op16_t* X = ximg ? reinterpret_cast<const op16_t*>(Xa) : x3_operand(Xa, (size_t)ldx, K, Mw, 0, true, st, &rcx);
     if (!X) return rcx;
-    const op16_t* Y = x3_operand(Ya, (size_t)ldy, K, Nw, 1, false, st, &rcx);
+    const op16_t* Y = x3_operand(Ya, (size_t)ldy, K, Nw, 1, ximg, st, &rcx);
     if (!Y) return rcx;
     ldx = Mw; ldy = Nw; K *= 3;
     const bool may_defer = false;
