@@ -78,7 +78,7 @@ def train(args: Namespace, tokenizer=None, language_model=None) -> int:
     wire = grad_wire_dtype(model.transformer_mapper.engine.op_dtype, model._train_lm)
     if rank == 0:
         mode = {OP_BF16: "bf16 operands (throughput mode; --fp-precision bf16)", OP_FP16: "fp16 operands with dynamic loss-scaling (--fp-precision 16)",
-                OP_X3: "split-bf16 operands = the reference's fp32 default (--fp-precision 32/64; ~3x the bf16 step time, logits within 1e-3)"}
+                OP_X3: "split-bf16 operands = the reference's fp32 default (--fp-precision 32/64; ~2.3x the bf16 step time, logits within 1e-3)"}
         print(f"clipcap_amd: operand mode: {mode[model.transformer_mapper.engine.op_dtype]}; gradient wire: {str(wire).replace('torch.', '')}"
               + (f" over {world} ranks" if world > 1 else ""), flush=True)
     reducer = GradReducer([a.grads() for a in arenas], wire_dtype=wire) if world > 1 else None
