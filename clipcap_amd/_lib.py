@@ -95,6 +95,9 @@ SIGNATURES = {
     "cc_decode_fwd_p": (_I, [_GC, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P]),
     "cc_decode_fwd_g": (_I, [_GC, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _L, _P, _P]),
     "cc_decode_ws_check": (_I, [_GC, _I, _I, _P, _P]),
+    "cc_decode_xt_image_bytes": (_L, [_GC]),
+    "cc_decode_xt_image": (_I, [_GC, _P, _P, _P]),
+    "cc_decode_fwd_x": (_I, [_GC, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _P, _P]),
     "cc_beam_step_p": (_I, [_I, _I, _I, _P, _L, _P, _I, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "cc_decode_reorder": (_I, [_GC, _I, _I, _I, _I, _P, _P, _P, _P]),
     "cc_beam_step": (_I, [_I, _I, _I, _P, _L, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
@@ -116,6 +119,7 @@ SIGNATURES = {
     "cc_gemm_tile_mode": (_I, [_I]),
     "cc_gemm_skinny_mode": (_I, [_I]),
     "cc_decode_mode": (_I, [_I]),
+    "cc_decode_last_path": (_I, []),
     "cc_gemm_op16_f32": (_I, [_I, _I, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P]),
     "cc_layernorm_fwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "cc_attention_fwd": (_I, [_I, _P, _I, _I, _I, _I, _I, _P, _P, _P]),

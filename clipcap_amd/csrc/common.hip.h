@@ -35,6 +35,7 @@ namespace cc_shared {
 extern int g_gemm_tile_mode;   // cc_gemm_tile_mode
 extern int g_gemm_s64;         // cc_gemm_skinny_mode
 extern int g_gemm_small_x2;    // env CC_GEMM_X2
+extern int g_decode_last_path; // cc_decode_last_path
 }  // namespace cc_shared
 
 namespace CC_NS {

@@ -6,6 +6,7 @@
 #include "gemm_api.h"
 #include "kernels.h"
 #include "decode_pk.h"
+#include "decode_xt.h"
 
 using namespace CC_NS;
 
@@ -1019,6 +1020,8 @@ struct DecWS {
     size_t scratch_bytes;
     unsigned long long* pk_prof;   // [256][21] profile of the persistent layer launch (CC_PK_PROF=1)
     unsigned* pk_ctr;      // persistent layer launch (decode_pk.hip): arrival counters + error word
+    unsigned* xt_ctl;      // XCD-team engine (decode_xt.hip): control words (zeroed before every launch) + one sticky error word behind them
+    unsigned long long* xt_prof;
     int2* grp_ent;         // beam-group attention: union list [R / group][group * (pos0 + 1)] + entry counts (k_group_union)
     int* grp_cnt;
     size_t grp_ents;
@@ -1050,6 +1053,8 @@ void dec_carve(const cc_gpt2_cfg* c, int R, int Tn, void* ws, DecWS& w) {
     w.scratch = (float*)take(w.scratch_bytes);
     w.pk_ctr = (unsigned*)take((size_t)PK_CTR_WORDS * 4);
     w.pk_prof = (unsigned long long*)take((size_t)256 * 21 * 8);
+    w.xt_ctl = (unsigned*)take((size_t)(XT_CTL_WORDS + 16) * 4);
+    w.xt_prof = (unsigned long long*)take((size_t)256 * XT_PROF_WORDS * 8);
     w.grp_ents = Tn == 1 ? (size_t)R * c->NPOS + (size_t)R * 128 : 0;
     w.grp_ent = (int2*)take(w.grp_ents * sizeof(int2));
     w.grp_cnt = (int*)take((size_t)R * 4);
@@ -1080,8 +1085,12 @@ int64_t CC_API(cc_decode_part_floats)(const cc_gpt2_cfg* cfg, int32_t R) {
     return (int64_t)2 * R * ((Ns + 63) / 64);
 }
 
-int CC_API(cc_decode_fwd_g)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int32_t ctx_max, const float* w32, const uint16_t* w16,
+int CC_API(cc_decode_fwd_x)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int32_t ctx_max, const float* w32, const uint16_t* w16, const uint16_t* wimg,
                     const float* x, uint16_t* kv, const int32_t* row_map, int32_t group, void* ws, float* logits, int64_t ldl, float* lpart, void* stream);
+int CC_API(cc_decode_fwd_g)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int32_t ctx_max, const float* w32, const uint16_t* w16,
+                    const float* x, uint16_t* kv, const int32_t* row_map, int32_t group, void* ws, float* logits, int64_t ldl, float* lpart, void* stream) {
+    return CC_API(cc_decode_fwd_x)(c, R, Tn, pos0, ctx_max, w32, w16, nullptr, x, kv, row_map, group, ws, logits, ldl, lpart, stream);
+}
 
 int CC_API(cc_decode_fwd)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int32_t ctx_max, const float* w32, const uint16_t* w16,
                   const float* x, uint16_t* kv, const int32_t* row_map, void* ws, float* logits, int64_t ldl, void* stream) {
@@ -1093,7 +1102,21 @@ int CC_API(cc_decode_fwd_p)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t
     return CC_API(cc_decode_fwd_g)(c, R, Tn, pos0, ctx_max, w32, w16, x, kv, row_map, 1, ws, logits, ldl, lpart, stream);
 }
 
-int CC_API(cc_decode_fwd_g)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int32_t ctx_max, const float* w32, const uint16_t* w16,
+int64_t CC_API(cc_decode_xt_image_bytes)(const cc_gpt2_cfg* c) {
+    if (!cfg_ok(c) || c->H * 64 != c->D) return 0;
+    return xt_image_bytes(c->D, c->NL);
+}
+
+int CC_API(cc_decode_xt_image)(const cc_gpt2_cfg* c, const uint16_t* w16, uint16_t* wimg, void* stream) {
+    if (!cfg_ok(c) || !w16 || !wimg) return CC_ERR_ARG;
+    if (c->H * 64 != c->D || !xt_image_bytes(c->D, c->NL)) return CC_ERR_SHAPE;
+    const int64_t D = c->D;
+    const int64_t layer0 = (int64_t)c->Vp * D + (int64_t)c->NPOS * D;
+    const int64_t total = layer0 + (int64_t)c->NL * (12 * D * D + 13 * D) + 2 * D;
+    return xt_build_image(c->D, c->NL, layer0, total, w16, wimg, S_(stream));
+}
+
+int CC_API(cc_decode_fwd_x)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int32_t ctx_max, const float* w32, const uint16_t* w16, const uint16_t* wimg,
                     const float* x, uint16_t* kv, const int32_t* row_map, int32_t group, void* ws, float* logits, int64_t ldl, float* lpart, void* stream) {
     if (group < 1 || (R > 0 && R % group)) return CC_ERR_ARG;
     if (!cfg_ok(c) || R <= 0 || Tn <= 0 || pos0 < 0 || !w32 || !w16 || !x || !kv || !ws || !logits) return CC_ERR_ARG;
@@ -1132,7 +1155,35 @@ int CC_API(cc_decode_fwd_g)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t
     bool xn_ready = one;
     bool hf_ready = false;
     int l_first = 0;
-    if (grp_attn && one && !kX3 && (cc_shared::g_decode_mode & 2)) {
+    if (one && group >= 2) cc_shared::g_decode_last_path = 0;
+    if (grp_attn && one && !kX3 && wimg && (cc_shared::g_decode_mode & 4)) {
+        // XCD-team engine (decode_xt.hip): every XCD runs the whole stack for its own captions; CC_ERR_SHAPE = not covered -> the paths below
+        XtLaunch L{};
+        L.w32 = w32; L.wimg = reinterpret_cast<const op16_t*>(wimg); L.D = D; L.H = H; L.NL = c->NL; L.M = M; L.group = group; L.pos0 = pos0; L.ctx_max = ctx_max;
+        L.layer0 = p; L.x = w.x; L.x1 = w.x1; L.qkv = w.qkv; L.att = w.att; L.hact = w.hact; L.hf = w.hf;
+        L.kv = reinterpret_cast<act_t*>(kv); L.cache_layer = cache_layer; L.ent = w.grp_ent; L.cnt = w.grp_cnt; L.cap = grp_cap;
+        L.ctl = w.xt_ctl; L.sticky = w.xt_ctl + XT_CTL_WORDS;
+        static const bool xt_prof = getenv("CC_XT_PROF") != nullptr;
+        L.prof = xt_prof ? w.xt_prof : nullptr;
+        // probe the geometry first (no launch): the union kernel below also clears the control words
+        XtLaunch probe = L;
+        probe.ctl = nullptr;
+        if (xt_covers(probe)) {
+            switch (group) {
+#define CC_GU(G_) case G_: hipLaunchKernelGGL((k_group_union<G_>), dim3(R / group), dim3(64), 0, st, row_map, w.grp_ent, w.grp_cnt, pos0, ctx_max, grp_cap, 1, w.xt_ctl, XT_CTL_WORDS); break;
+                CC_GU(2) CC_GU(3) CC_GU(4) CC_GU(5) CC_GU(6) CC_GU(7) CC_GU(8)
+#undef CC_GU
+                default: break;
+            }
+            const int rc = decode_layers_xt(L, st);
+            if (rc != CC_OK) return rc;
+            cc_shared::g_decode_last_path = 2;
+            l_first = c->NL;
+            p += (int64_t)c->NL * (12 * (int64_t)D * D + 13 * (int64_t)D);
+            hf_ready = true;
+        }
+    }
+    if (l_first == 0 && grp_attn && one && !kX3 && (cc_shared::g_decode_mode & 2)) {
         // the whole layer stack as ONE persistent launch (decode_pk.hip); CC_ERR_SHAPE = geometry not covered -> the per-op launches below
         switch (group) {
 #define CC_GU(G_) case G_: hipLaunchKernelGGL((k_group_union<G_>), dim3(R / group), dim3(64), 0, st, row_map, w.grp_ent, w.grp_cnt, pos0, ctx_max, grp_cap, 1, w.pk_ctr, PK_CTR_WORDS); break;
@@ -1149,6 +1200,7 @@ int CC_API(cc_decode_fwd_g)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t
         L.prof = pk_prof ? w.pk_prof : nullptr;
         const int rc = decode_layers_persistent(L, st);
         if (rc == CC_OK) {
+            cc_shared::g_decode_last_path = 1;
             l_first = c->NL;
             p += (int64_t)c->NL * (12 * (int64_t)D * D + 13 * (int64_t)D);
             hf_ready = true;
@@ -1238,7 +1290,9 @@ int CC_API(cc_decode_ws_check)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, cons
     unsigned e = 0;
     if (hipStreamSynchronize(S_(stream)) != hipSuccess) return CC_ERR_LAUNCH;
     if (hipMemcpy(&e, w.pk_ctr + 7 * PK_MAX_RT, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return CC_ERR_LAUNCH;
-    return e ? CC_ERR_STATE : CC_OK;
+    unsigned e2 = 0;
+    if (hipMemcpy(&e2, w.xt_ctl + XT_CTL_WORDS, sizeof(e2), hipMemcpyDeviceToHost) != hipSuccess) return CC_ERR_LAUNCH;
+    return (e | e2) ? CC_ERR_STATE : CC_OK;
 }
 
 int CC_API(cc_decode_reorder)(const cc_gpt2_cfg* c, int32_t R_src, int32_t R_dst, int32_t ctx, int32_t ctx_max, const uint16_t* kv_src, uint16_t* kv_dst,

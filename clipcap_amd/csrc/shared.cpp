@@ -12,13 +12,16 @@ int g_gemm_tile_mode = []() { const char* e = getenv("CC_GEMM_S256"); return e ?
 int g_gemm_s64 = []() { const char* e = getenv("CC_GEMM_S64"); return e ? atoi(e) : -1; }();
 int g_gemm_small_x2 = []() { const char* e = getenv("CC_GEMM_X2"); return e ? atoi(e) : 1; }();
 // bit 0: beam-group attention step (k_decode_attn_group), bit 1: the layer stack of a group step as one persistent launch (decode_pk.hip;
-// measured slower than the per-op launches on MI355X, DESIGN.md 4.5 — kept for A/B runs).  env CC_DEC_GROUP / CC_DEC_PK preset the bits.
+// measured slower than the per-op launches on MI355X, DESIGN.md 4.5 — kept for A/B runs), bit 2: the XCD-team engine (decode_xt.hip) when cc_decode_fwd_x
+// is given a weight image.  env CC_DEC_GROUP / CC_DEC_PK / CC_DEC_XT preset the bits.
 int g_decode_mode = []() {
     const char* g = getenv("CC_DEC_GROUP");
     const char* p = getenv("CC_DEC_PK");
-    return ((g ? atoi(g) : 1) ? 1 : 0) | ((p ? atoi(p) : 0) ? 2 : 0);
+    const char* x = getenv("CC_DEC_XT");
+    return ((g ? atoi(g) : 1) ? 1 : 0) | ((p ? atoi(p) : 0) ? 2 : 0) | ((x ? atoi(x) : 0) ? 4 : 0);
 }();
 Prof g_prof;
+int g_decode_last_path = 0;
 }  // namespace cc_shared
 
 using namespace cc_shared;
@@ -35,9 +38,11 @@ int cc_gemm_tile_mode(int32_t mode) {
 
 int cc_decode_mode(int32_t mode) {
     const int old = g_decode_mode;
-    if (mode >= 0) g_decode_mode = mode & 3;
+    if (mode >= 0) g_decode_mode = mode & 7;
     return old;
 }
+
+int cc_decode_last_path(void) { return g_decode_last_path; }
 
 int cc_gemm_skinny_mode(int32_t mode) {
     const int old = g_gemm_s64;

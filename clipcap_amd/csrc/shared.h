@@ -10,6 +10,7 @@ extern int g_gemm_tile_mode;   // cc_gemm_tile_mode: -1 chooser, 0 = 128 x 128 o
 extern int g_gemm_s64;         // cc_gemm_skinny_mode
 extern int g_gemm_small_x2;    // env CC_GEMM_X2
 extern int g_decode_mode;      // cc_decode_mode
+extern int g_decode_last_path; // cc_decode_last_path
 
 // cc_prof_start / cc_prof_stop: HIP events around the launches of one call site (or of every GEMM, CC_SITE_ALL_GEMMS)
 struct Prof {

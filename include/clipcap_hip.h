@@ -56,7 +56,8 @@ extern "C" {
  * would be written out of bounds, so clipcap_amd/_lib.py refuses a library whose version differs.  Entry points ADDED since 2:
  * cc_adamw_step_cast, cc_mapper_transpose_weights, cc_gpt2_transpose_weights, cc_comm_count, cc_decode_part_floats, cc_decode_fwd_p,
  * cc_beam_step_p; since 3: cc_decode_fwd_g, cc_decode_ws_check, cc_decode_mode, cc_grad_wire_pack, cc_grad_wire_unpack,
- * cc_sample_step_lp, cc_broadcast_bucket; operand mode ADDED: CC_OP_BF16X3 */
+ * cc_sample_step_lp, cc_broadcast_bucket; round 5 (still 3: nothing existing changed): cc_decode_xt_image_bytes, cc_decode_xt_image,
+ * cc_decode_fwd_x; operand mode ADDED: CC_OP_BF16X3 */
 #define CC_ABI_VERSION 3
 int cc_abi_version(void);
 
@@ -235,6 +236,20 @@ int cc_decode_fwd_g(const cc_gpt2_cfg* cfg, int32_t R, int32_t Tnew, int32_t pos
  * wait that gives up raises an error word in `ws`.  cc_decode_ws_check synchronises `stream` and returns CC_ERR_STATE if the last step on
  * this workspace gave up (its logits are then garbage), CC_OK otherwise.  A debugging / test aid: a correct run never trips it. */
 int cc_decode_ws_check(const cc_gpt2_cfg* cfg, int32_t R, int32_t Tnew, const void* ws, void* stream);
+/* XCD-team decode engine (decode_xt.hip; bf16 / fp16 operands, D = 512 or 1024 with head dim 64): the layer stack of a single-position group
+ * step as ONE launch in which every XCD runs all layers for its own rows and the weights stream straight into registers from a
+ * fragment-ordered image — the KV-cached replacement of the per-token full re-forward of inference/base.py:80-121.
+ *   cc_decode_xt_image_bytes: size of that image for cfg (0 = width / operand type not covered by the engine);
+ *   cc_decode_xt_image:       builds it from the operand arena w16 (after cc_gpt2_sync_weights; rebuild whenever the weights change);
+ *   cc_decode_fwd_x:          cc_decode_fwd_g with the image.  wimg == NULL, or a geometry / device the engine does not cover
+ *                             (more than 48 rows per XCD, Tnew != 1, group < 2, not 8 x 32 CUs, cc_decode_mode bit 2 off), is exactly
+ *                             cc_decode_fwd_g.  Results equal cc_decode_fwd_g's to fp32 summation order.  Its waits are bounded like the
+ *                             persistent launch's; cc_decode_ws_check reports a step that gave up (sticky until the workspace is zeroed). */
+int64_t cc_decode_xt_image_bytes(const cc_gpt2_cfg* cfg);
+int cc_decode_xt_image(const cc_gpt2_cfg* cfg, const uint16_t* w16, uint16_t* wimg, void* stream);
+int cc_decode_fwd_x(const cc_gpt2_cfg* cfg, int32_t R, int32_t Tnew, int32_t pos0, int32_t ctx_max, const float* w32,
+                    const uint16_t* w16, const uint16_t* wimg, const float* x, uint16_t* kv, const int32_t* row_map, int32_t group, void* ws,
+                    float* logits, int64_t ldl, float* lpart, void* stream);
 /* reorder / expand cache rows after a beam step: kv_dst[:, :, r] = kv_src[:, :, src[r]] for positions < ctx and
  * r < R_dst (base.py:93,113: embeds.expand / embeds[next_tokens_source]); the two caches may have different row counts. */
 int cc_decode_reorder(const cc_gpt2_cfg* cfg, int32_t R_src, int32_t R_dst, int32_t ctx, int32_t ctx_max, const uint16_t* kv_src,
@@ -371,8 +386,12 @@ int cc_gemm_skinny_mode(int32_t mode);
 /* How cc_decode_fwd_g runs a single-position group step.  bit 0 (default on): beam-group attention (every distinct KV row of a group read
  * once); bit 1 (default off): the whole layer stack as ONE persistent launch with in-launch hand-offs (decode_pk.hip; bf16 / fp16 operands) —
  * results equal the per-op launches to rounding, and on MI355X it measured SLOWER than them, so it is an A/B switch, not
- * the product path.  mode < 0 only queries.  PROCESS-WIDE test knob; returns the previous mode (env CC_DEC_GROUP / CC_DEC_PK preset it). */
+ * the product path; bit 2 (default off: measured slower than the per-op launches): cc_decode_fwd_x may use the XCD-team engine when it is handed a weight image.  mode < 0 only queries.
+ * PROCESS-WIDE test knob; returns the previous mode (env CC_DEC_GROUP / CC_DEC_PK / CC_DEC_XT preset it). */
 int cc_decode_mode(int32_t mode);
+/* which path the most recent single-position group step of cc_decode_fwd_x / cc_decode_fwd_g took: 0 = launch per op, 1 = persistent launch
+ * (decode_pk.hip), 2 = XCD-team engine (decode_xt.hip).  PROCESS-WIDE test / measurement hook. */
+int cc_decode_last_path(void);
 int cc_layernorm_fwd(int32_t op_dtype, const float* x, const float* gamma, const float* beta, uint16_t* y, float* mean, float* rstd, int32_t rows,
                      int32_t D, void* stream);
 int cc_attention_fwd(int32_t op_dtype, const uint16_t* qkv, int32_t B, int32_t S, int32_t H, int32_t hd, int32_t causal, uint16_t* out, float* lse,
