@@ -218,15 +218,50 @@ inline Drop make_drop(float p, unsigned long long seed, unsigned site, unsigned 
     return d;
 }
 
+// Wave reductions on DPP (data-parallel primitives: quad_perm / row_half_mirror / row_mirror inside each row of 16 lanes, then the four
+// row results through v_readlane) instead of the xor-butterfly of __shfl_xor, which hipcc lowers to ds_bpermute_b32: six DEPENDENT LDS
+// round trips per reduction.  With many waves per SIMD those hide; where a wave runs (almost) alone — the decode finish rows, the decode
+// attention, the XCD-team engine's I/O waves — they are the kernel's latency (round 5: a LayerNorm row is two reductions = 12 trips).
+// The result is wave-uniform.  Summation order differs from the butterfly's (fp32 rounding only).  CC_WAVE_SHFL restores the old form (A/B).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_bcast(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+// sum / max over each aligned group of 8 lanes, in every lane of the group (the three xor steps 1, 2, 4 of a butterfly)
+__device__ __forceinline__ float sum8(float v) {
+#ifdef CC_WAVE_SHFL
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+#else
+    v += dpp_mov<0xB1>(v);                                  // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);                                  // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);                                 // row_half_mirror
+#endif
+    return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
+#ifdef CC_WAVE_SHFL
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+#else
+    v = sum8(v);
+    v += dpp_mov<0x140>(v);                                 // row_mirror: every lane holds its row's sum
+    return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
+#endif
 }
 __device__ __forceinline__ float wave_max(float v) {
+#ifdef CC_WAVE_SHFL
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
+#else
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
+    return fmaxf(fmaxf(lane_bcast(v, 0), lane_bcast(v, 16)), fmaxf(lane_bcast(v, 32), lane_bcast(v, 48)));
+#endif
 }
 
 // XCD-aware block order: the dispatcher places block b on XCD b%8; give each XCD a contiguous run of logical blocks (bijective for any

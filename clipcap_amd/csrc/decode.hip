@@ -353,10 +353,7 @@ __global__ __launch_bounds__(256, kX3 ? 3 : 4) void k_decode_attn_group(const ac
                 sc[b] = a;
             }
 #pragma unroll
-            for (int o = 1; o < 8; o <<= 1) {
-#pragma unroll
-                for (int b = 0; b < G; b++) sc[b] += __shfl_xor(sc[b], o);
-            }
+            for (int b = 0; b < G; b++) sc[b] = sum8(sc[b]);
 #pragma unroll
             for (int b = 0; b < 8; b++) {
                 sc[b] = (b < G && ((ek[i].y >> b) & 1)) ? sc[b] * scale : -INFINITY;

@@ -87,31 +87,6 @@ __device__ __forceinline__ float4 ldf4_sc1(const float* p) {
     const uint4 r = ld16_sc1(p);
     return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
 }
-// ---- wave reductions on DPP (no LDS): the I/O waves run alone on their SIMD slot, so the ds_bpermute chains of __shfl_xor (6 dependent LDS round
-// trips per wave_sum) are pure latency there — a LayerNorm row cost 12 of them, an attention item ~250.
-template <int CTRL>
-__device__ __forceinline__ float xt_dpp(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float xt_rdl(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
-__device__ __forceinline__ float xt_sum8(float v) {         // sum over each aligned group of 8 lanes, in every lane of the group
-    v += xt_dpp<0xB1>(v);                                   // quad_perm [1,0,3,2]
-    v += xt_dpp<0x4E>(v);                                   // quad_perm [2,3,0,1]
-    v += xt_dpp<0x141>(v);                                  // row_half_mirror
-    return v;
-}
-__device__ __forceinline__ float xt_wave_sum(float v) {     // sum over the 64 lanes, wave-uniform result
-    v = xt_sum8(v);
-    v += xt_dpp<0x140>(v);                                  // row_mirror: every lane holds its row's (16 lanes) sum
-    return (xt_rdl(v, 0) + xt_rdl(v, 16)) + (xt_rdl(v, 32) + xt_rdl(v, 48));
-}
-__device__ __forceinline__ float xt_wave_max(float v) {
-    v = fmaxf(v, xt_dpp<0xB1>(v));
-    v = fmaxf(v, xt_dpp<0x4E>(v));
-    v = fmaxf(v, xt_dpp<0x141>(v));
-    v = fmaxf(v, xt_dpp<0x140>(v));
-    return fmaxf(fmaxf(xt_rdl(v, 0), xt_rdl(v, 16)), fmaxf(xt_rdl(v, 32), xt_rdl(v, 48)));
-}
 __device__ __forceinline__ void xt_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void xt_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void xt_vm_le(int n) {      // s_waitcnt vmcnt(n), n wave-uniform; larger counts wait for 12 (conservative)
@@ -160,7 +135,7 @@ __device__ __forceinline__ bool xt_wait(unsigned* ctr, unsigned epoch, unsigned*
 }
 
 // ---- I/O waves: activation panel = LayerNorm(rows of the fp32 residual stream) as 16-bit operands, LDS rows SA bytes apart.
-// Same lane <-> element mapping and summation order as k_splitk_finish_row (decode.hip), so the statistics are bit-identical.
+// (two-pass statistics like k_splitk_finish_row; the summation order differs: fp32 rounding only)
 template <int D>
 __device__ __forceinline__ void xt_fill_ln(const float* __restrict__ src, int Rt, const float* __restrict__ gamma, const float* __restrict__ beta,
                                            char* panel, int iw, int lane, int xt_lab_aux = 16) {
@@ -203,14 +178,14 @@ __device__ __forceinline__ void xt_fill_ln(const float* __restrict__ src, int Rt
             float s = 0.f;
 #pragma unroll
             for (int it = 0; it < NV; it++) s += v[k][it].x + v[k][it].y + v[k][it].z + v[k][it].w;
-            const float mu = xt_wave_sum(s) / D;
+            const float mu = wave_sum(s) / D;
             float q = 0.f;
 #pragma unroll
             for (int it = 0; it < NV; it++) {
                 const float a = v[k][it].x - mu, bb = v[k][it].y - mu, c = v[k][it].z - mu, d = v[k][it].w - mu;
                 q += a * a + bb * bb + c * c + d * d;
             }
-            const float rs_ = rsqrtf(xt_wave_sum(q) / D + 1e-5f);
+            const float rs_ = rsqrtf(wave_sum(q) / D + 1e-5f);
             if (r < Rt) {
 #pragma unroll
                 for (int it = 0; it < NV; it++) {
@@ -300,7 +275,7 @@ __device__ __forceinline__ void xt_attn_wave(const act_t* __restrict__ qkv, act_
                 sc[b] = a;
             }
 #pragma unroll
-            for (int b = 0; b < G; b++) sc[b] = xt_sum8(sc[b]);
+            for (int b = 0; b < G; b++) sc[b] = sum8(sc[b]);
 #pragma unroll
             for (int b = 0; b < 8; b++) {
                 sc[b] = (b < G && ((msk >> b) & 1)) ? sc[b] * scale : -INFINITY;
@@ -316,7 +291,7 @@ __device__ __forceinline__ void xt_attn_wave(const act_t* __restrict__ qkv, act_
         // maximum is finite from the group that holds it on; before that group a beam's terms are all exp(-inf) = 0
 #pragma unroll
         for (int b = 0; b < G; b++) {
-            const float mn = fmaxf(mrun[b], xt_wave_max(gmx[b]));
+            const float mn = fmaxf(mrun[b], wave_max(gmx[b]));
             const float f = mrun[b] == mn ? 1.f : __expf(mrun[b] - mn);      // (-inf) - (-inf) never evaluated
             acc[b][0] *= f; acc[b][1] *= f; lsum[b] *= f;
             mrun[b] = mn;
@@ -348,7 +323,7 @@ __device__ __forceinline__ void xt_attn_wave(const act_t* __restrict__ qkv, act_
         for (int b = 0; b < G; b++) *reinterpret_cast<float2*>(red + b * HD + 2 * dp) = make_float2(acc[b][0], acc[b][1]);
     }
 #pragma unroll
-    for (int b = 0; b < G; b++) lsum[b] = xt_rdl(lsum[b], 0) + xt_rdl(lsum[b], 32);      // uniform inside each half: the halves' sums
+    for (int b = 0; b < G; b++) lsum[b] = lane_bcast(lsum[b], 0) + lane_bcast(lsum[b], 32);      // uniform inside each half: the halves' sums
     if (!hf) {
 #pragma unroll
         for (int b = 0; b < G; b++) {
@@ -672,11 +647,11 @@ __global__ __launch_bounds__(512, 2) void k_decode_xt(XtArgs a) {
                 float s = 0.f;
 #pragma unroll
                 for (int it = 0; it < NV; it++) { v[it] = ldf4_sc1(xa + (size_t)r * D + lane * 4 + it * 256); s += v[it].x + v[it].y + v[it].z + v[it].w; }
-                const float mu = xt_wave_sum(s) / D;
+                const float mu = wave_sum(s) / D;
                 float qq = 0.f;
 #pragma unroll
                 for (int it = 0; it < NV; it++) { const float e0 = v[it].x - mu, e1 = v[it].y - mu, e2 = v[it].z - mu, e3 = v[it].w - mu; qq += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3; }
-                const float rs = rsqrtf(xt_wave_sum(qq) / D + 1e-5f);
+                const float rs = rsqrtf(wave_sum(qq) / D + 1e-5f);
 #pragma unroll
                 for (int it = 0; it < NV; it++) {
                     const int c = lane * 4 + it * 256;
