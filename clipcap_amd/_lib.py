@@ -10,7 +10,11 @@ import os
 import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libclipcap_hip.so")
+# CLIPCAP_HIP_LIB selects the library: unset = the product build; "lab" = libclipcap_hip_lab.so (`make -C clipcap_amd/csrc lab`: the product plus the
+# experiment kernels and environment A/B switches, tests/lab_*.py); anything else = a path.
+_SEL = os.environ.get("CLIPCAP_HIP_LIB", "")
+LIB_PATH = os.path.join(HERE, "libclipcap_hip.so") if not _SEL else os.path.join(HERE, "libclipcap_hip_lab.so") if _SEL == "lab" else _SEL
+IS_LAB = _SEL == "lab"
 
 ERR = {0: "ok", -1: "invalid argument", -2: "unsupported shape / alignment", -3: "kernel launch failed", -4: "invalid state"}
 

@@ -37,7 +37,7 @@ struct TileScope {
     ~TileScope() { if (on) cc_shared::g_gemm_tile_mode = old; }
 };
 inline int env_tile(const char* name) {
-    const char* e = getenv(name);
+    const char* e = cc_lab_env(name);
     return e ? atoi(e) : -2;
 }
 
@@ -498,7 +498,7 @@ int CC_API(cc_mapper_bwd_range)(const cc_mapper_cfg* c, int32_t B, const float* 
     // bf16x3: `G2(t, width)` = the tensor as both of its GEMMs take it — split ONCE into w.gimg ([hi | hi | lo], the form of the weight
     // gradient's first operand and of the input gradient's A operand alike); every use re-arms the one-shot image hint
 #if CC_OP == 2
-    static const bool share = []() { const char* e = getenv("CC_X3_SHARE"); return !e || atoi(e) != 0; }();
+    static const bool share = []() { const char* e = cc_lab_env("CC_X3_SHARE"); return !e || atoi(e) != 0; }();
     int g2rc = CC_OK;
     auto G2 = [&](const act_t* t, int width) -> const act_t* {
         if (!share) return t;
@@ -562,13 +562,13 @@ namespace {
 // never materialises the softmax gradient.  fp16 lacks the exponent range, the bf16x3 build keeps fp32 logits.  CC_LM_EXPFORM=0: A/B switch.
 // c_fc forward stores gelu_new'(u) where it used to store u (CC_GELU_GRAD_FWD=0: A/B switch; forward and backward read the same setting)
 static bool gelu_grad_fwd() {
-    static const bool on = []() { const char* e = getenv("CC_GELU_GRAD_FWD"); return !e || atoi(e) != 0; }();
+    static const bool on = []() { const char* e = cc_lab_env("CC_GELU_GRAD_FWD"); return !e || atoi(e) != 0; }();
     return on;
 }
 // bf16x3, frozen LM: c_fc's forward epilogue and the gelu' input-gradient epilogue write the [hi | hi | lo] operand image of their consumer
 // GEMM directly instead of an fp32 activation that a split pass re-reads (CC_X3_IMG=0: A/B switch)
 static bool x3_img_on() {
-    static const bool on = []() { const char* e = getenv("CC_X3_IMG"); return !e || atoi(e) != 0; }();
+    static const bool on = []() { const char* e = cc_lab_env("CC_X3_IMG"); return !e || atoi(e) != 0; }();
     return on;
 }
 #if CC_OP == 2
@@ -578,7 +578,7 @@ static bool gpt2_bwd_images(const cc_gpt2_shape* s) { return s->mode == 1 && x3_
 // GEMM (in the logits buffer, 1.5x), so neither fp32 logits nor the softmax-gradient pass over them exist; the full finetune keeps the
 // logit form (its tied weight gradient reads the fp32 gradient).
 static bool lm_exp_form(const cc_gpt2_shape* s) {
-    static const bool env = []() { const char* e = getenv("CC_LM_EXPFORM"); return !e || atoi(e) != 0; }();
+    static const bool env = []() { const char* e = cc_lab_env("CC_LM_EXPFORM"); return !e || atoi(e) != 0; }();
     if (CC_OP == 0) return env;
     if (CC_OP == 2) return env && x3_img_on() && s->mode == 1;
     return false;

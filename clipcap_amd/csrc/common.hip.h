@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "lab_env.h"
 
 // ---- operand type of this build of the kernels ------------------------------------------------------------------------------
 // Every translation unit is compiled twice (Makefile): CC_OP = 0 with bf16 GEMM / attention operands (namespace cc_bf16, C symbols

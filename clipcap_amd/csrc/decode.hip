@@ -1160,7 +1160,7 @@ int CC_API(cc_decode_fwd_x)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t
         L.layer0 = p; L.x = w.x; L.x1 = w.x1; L.qkv = w.qkv; L.att = w.att; L.hact = w.hact; L.hf = w.hf;
         L.kv = reinterpret_cast<act_t*>(kv); L.cache_layer = cache_layer; L.ent = w.grp_ent; L.cnt = w.grp_cnt; L.cap = grp_cap;
         L.ctl = w.xt_ctl; L.sticky = w.xt_ctl + XT_CTL_WORDS;
-        static const bool xt_prof = getenv("CC_XT_PROF") != nullptr;
+        static const bool xt_prof = cc_lab_env("CC_XT_PROF") != nullptr;
         L.prof = xt_prof ? w.xt_prof : nullptr;
         // probe the geometry first (no launch): the union kernel below also clears the control words
         XtLaunch probe = L;
@@ -1193,7 +1193,7 @@ int CC_API(cc_decode_fwd_x)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t
         L.layer0 = p; L.x = w.x; L.x1 = w.x1; L.xn = w.xn; L.qkv = w.qkv; L.att = w.att; L.hact = w.hact; L.hf = w.hf;
         L.slab = w.scratch; L.slab_bytes = w.scratch_bytes; L.kv = reinterpret_cast<act_t*>(kv); L.cache_layer = cache_layer;
         L.ent = w.grp_ent; L.cnt = w.grp_cnt; L.cap = grp_cap; L.ctr = w.pk_ctr;
-        static const bool pk_prof = getenv("CC_PK_PROF") != nullptr;
+        static const bool pk_prof = cc_lab_env("CC_PK_PROF") != nullptr;
         L.prof = pk_prof ? w.pk_prof : nullptr;
         const int rc = decode_layers_persistent(L, st);
         if (rc == CC_OK) {

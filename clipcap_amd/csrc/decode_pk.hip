@@ -26,7 +26,7 @@
 #include "decode_pk.h"
 
 namespace CC_NS {
-#if CC_OP != 2
+#if CC_OP != 2 && defined(CC_EXPERIMENTS)      // lab build only (make lab): measured 2x slower than the per-op launches
 namespace {
 
 constexpr int PK_THREADS = 512, PK_NS = 6, PK_STAGE = 16384, PK_LDS = PK_NS * PK_STAGE;     // + 64 B behind it for the wait flag

@@ -33,7 +33,7 @@
 #include <algorithm>
 
 namespace CC_NS {
-#if CC_OP != 2
+#if CC_OP != 2 && defined(CC_EXPERIMENTS)      // lab build only (make lab): measured slower than the per-op launches
 namespace {
 
 typedef const __attribute__((address_space(1))) void* xg_t;
@@ -156,7 +156,7 @@ __device__ __forceinline__ void xt_fill_ln(const float* __restrict__ src, int Rt
             const int r = min(r0 + 4 * k, Rt - 1);
 #pragma unroll
             for (int it = 0; it < NV; it++) {
-#ifdef CC_XT_LAB
+#ifdef CC_EXPERIMENTS
                 v4u t;
                 const int vo_ = (r * D + lane * 4 + it * 256) * 4;
                 switch (xt_lab_aux) {
@@ -752,7 +752,7 @@ static bool xt_prepare(const XtLaunch& L, XtArgs& a, size_t& lds) {
     a.x = L.x; a.x1 = L.x1; a.qkv = L.qkv; a.att = L.att; a.hact = L.hact; a.hf = L.hf; a.kv = L.kv; a.cache_layer = L.cache_layer;
     a.ent = L.ent; a.cnt = L.cnt; a.ctl = L.ctl; a.sticky = L.sticky; a.prof = L.prof;
     a.rt_max = a.cpt * G;
-    { static const int aux = []() { const char* e = getenv("CC_XT_AUX"); return e ? atoi(e) : 16; }(); a.lab_aux = aux; }
+    { static const int aux = []() { const char* e = cc_lab_env("CC_XT_AUX"); return e ? atoi(e) : 16; }(); a.lab_aux = aux; }
     if (a.rt_max > 48) return false;
     a.attn_floats = XT_ATTN_WAVE_BYTES / 4;            // per I/O wave (xt_attn_wave)
     const size_t row_bytes = D == 1024 ? (size_t)XtGeo<1024>::A_ROW + XtGeo<1024>::P_ROW : (size_t)XtGeo<512>::A_ROW + XtGeo<512>::P_ROW;
@@ -775,9 +775,9 @@ int decode_layers_xt(const XtLaunch& L, hipStream_t st) {
     XtArgs a;
     size_t lds;
     if (!xt_prepare(L, a, lds) || !L.ctl || !L.sticky) return CC_ERR_SHAPE;
-#ifdef CC_XT_LAB
+#ifdef CC_EXPERIMENTS
     // lab build: ring depth from the environment (A/B runs; tools/xt_prof.py)
-    static const int ring = []() { const char* e = getenv("CC_XT_RING"); return e ? atoi(e) : 32; }();
+    static const int ring = []() { const char* e = cc_lab_env("CC_XT_RING"); return e ? atoi(e) : 32; }();
     if (L.D == 1024 && L.group == 5 && ring == 8) return xt_launch_d<1024, 8>(a, L.group, lds, st);
     if (L.D == 1024 && L.group == 5 && ring == 16) return xt_launch_d<1024, 16>(a, L.group, lds, st);
     if (L.D == 1024 && L.group == 5 && ring == 24) return xt_launch_d<1024, 24>(a, L.group, lds, st);

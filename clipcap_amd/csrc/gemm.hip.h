@@ -1898,7 +1898,7 @@ inline int launch_gemm_s64(const op16_t* A, int lda, const op16_t* B, int ldb, i
                            hipStream_t st);
 // bf16x3 build: the fused two-stage forms of the NT kernels (gemm_stag256_body<X3F>, gemm_nt_glds_x3f_kernel, gemm_nt_glds4x2_x3f_kernel); CC_X3_FUSED=0: A/B switch
 inline bool x3_fused_on() {
-    static const bool on = kX3 && !(getenv("CC_X3_FUSED") && atoi(getenv("CC_X3_FUSED")) == 0);
+    static const bool on = kX3 && !(cc_lab_env("CC_X3_FUSED") && atoi(cc_lab_env("CC_X3_FUSED")) == 0);
     return on;
 }
 template <class Epi>
@@ -1916,9 +1916,9 @@ inline int launch_gemm(int al, int bl, const op16_t* A, int lda, const op16_t* B
     }
     GemmShape g;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
-    static const int env_group = []() { const char* e = getenv("CC_GROUP_M"); return e ? atoi(e) : 0; }();
+    static const int env_group = []() { const char* e = cc_lab_env("CC_GROUP_M"); return e ? atoi(e) : 0; }();
     g.group_m = env_group > 0 ? env_group : (group_m > 0 ? group_m : 8);
-    static const int env_stagger = []() { const char* e = getenv("CC_GEMM_STAGGER"); return e ? atoi(e) : 0; }();   // tuning knob
+    static const int env_stagger = []() { const char* e = cc_lab_env("CC_GEMM_STAGGER"); return e ? atoi(e) : 0; }();   // tuning knob
     g.stagger = env_stagger;
     if (ksplit < 1) ksplit = 1;
     int kt = (K + G_BK - 1) / G_BK;
@@ -1980,7 +1980,7 @@ inline int launch_gemm(int al, int bl, const op16_t* A, int lda, const op16_t* B
 #undef CC_LAUNCH_STAG
     } else
 #ifdef CC_GEMM_ABLATION
-    static const int abl = []() { const char* e = getenv("CC_GEMM_ABL"); return e ? atoi(e) : 0; }();
+    static const int abl = []() { const char* e = cc_lab_env("CC_GEMM_ABL"); return e ? atoi(e) : 0; }();
     if (al == 0 && bl == 0 && (K % G_BK) == 0 && abl == 1) { hipLaunchKernelGGL((gemm_nt_glds_kernel<Epi, 1>), grid, dim3(G_THREADS), 0, st, A, B, g, epi); }
     else if (al == 0 && bl == 0 && (K % G_BK) == 0 && abl == 2) { hipLaunchKernelGGL((gemm_nt_glds_kernel<Epi, 2>), grid, dim3(G_THREADS), 0, st, A, B, g, epi); }
     else if (al == 0 && bl == 0 && (K % G_BK) == 0 && abl == 4) { hipLaunchKernelGGL((gemm_nt_glds_kernel<Epi, 4>), grid, dim3(G_THREADS), 0, st, A, B, g, epi); }

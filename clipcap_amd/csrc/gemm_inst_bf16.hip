@@ -11,7 +11,7 @@ int gemm_bf16out(int al, int bl, const act_t* A, int lda, const op16_t* B, int l
 #if CC_OP == 2
     e.img = x3_take_emit(C);
 #endif
-    static const bool nt = []() { const char* v = getenv("CC_PRE_NT"); return v && atoi(v) != 0; }();      // experiment switch
+    static const bool nt = []() { const char* v = cc_lab_env("CC_PRE_NT"); return v && atoi(v) != 0; }();      // experiment switch
     e.pre_nt = nt;
     return launch_gemm(al, bl, A16, lda, B, ldb, M, N, K, 1, e, st);
 }

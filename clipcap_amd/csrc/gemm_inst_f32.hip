@@ -64,8 +64,8 @@ static int wgrad_launch_group(WgradBatch& b, hipStream_t st) {
     const size_t room = WGRAD_SCRATCH_BYTES - b.used;
     // tile kernel: 256 x 256 (8 waves, fewer / fatter blocks) or 128 x 128; slice count: minimise rounds x (K-steps + fixed per-block
     // cost), rounds = ceil(blocks / CUs).  CC_WGRAD_TILE / CC_WGRAD_KS override (tuning knobs).
-    static const int force_tile = []() { const char* e = getenv("CC_WGRAD_TILE"); return e ? atoi(e) : 0; }();
-    static const int force_ks = []() { const char* e = getenv("CC_WGRAD_KS"); return e ? atoi(e) : 0; }();
+    static const int force_tile = []() { const char* e = cc_lab_env("CC_WGRAD_TILE"); return e ? atoi(e) : 0; }();
+    static const int force_ks = []() { const char* e = cc_lab_env("CC_WGRAD_KS"); return e ? atoi(e) : 0; }();
     int best_tile = 128, best_ks = 1;
     double best_cost = 1e30;
     for (int tile : {256, 128}) {
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void k_splitk_finish_row(const float* __restri
 }
 
 int skinny_single_min_tiles() {
-    static const int v = []() { const char* e = getenv("CC_SKINNY_SINGLE"); return e ? atoi(e) : 60; }();   // measured on config 5: 171 (never) / 165 (90) / 159 (60) / 160 (20) ms per decode batch
+    static const int v = []() { const char* e = cc_lab_env("CC_SKINNY_SINGLE"); return e ? atoi(e) : 60; }();   // measured on config 5: 171 (never) / 165 (90) / 159 (60) / 160 (20) ms per decode batch
     return v;
 }
 bool gemm_nt_skinny_can_fuse(int M, int N, int K, size_t scratch_bytes) {
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void k_deepk_finish_lm(const float* __restrict
 
 int gemm_nt_deepk(const act_t* Aa, int lda, const op16_t* B, int ldb, int M, int N, int K, act_t* out16, int ldo, float* scratch,
                   size_t scratch_bytes, hipStream_t st, const LmFix* fix) {
-    static const int knob = []() { const char* e = getenv("CC_DEEPK"); return e ? atoi(e) : -1; }();   // 0 = off, n > 0 = force n slices
+    static const int knob = []() { const char* e = cc_lab_env("CC_DEEPK"); return e ? atoi(e) : -1; }();   // 0 = off, n > 0 = force n slices
     if (knob == 0 || g_gemm_tile_mode == 0 || !scratch || (N & 7) || (ldo & 7) || (K % 64) || (lda & 7) || (ldb & 7)) return CC_ERR_SHAPE;
     const long tiles = (long)((M + H_BM - 1) / H_BM) * ((N + H_BN - 1) / H_BN);
     const size_t slab = (size_t)M * N;

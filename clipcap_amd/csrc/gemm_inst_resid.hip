@@ -10,7 +10,7 @@ int gemm_resid(int al, int bl, const act_t* A, int lda, const op16_t* B, int ldb
     EpiResid e{out, res, bias, ld, M, N, drop};
     // accumulators initialised from the residual (256-row kernels only read the flag): not with residual dropout, whose mask scales
     // acc + bias but not the residual; CC_RESID_INIT=0 is the A/B switch
-    static const bool init_ok = []() { const char* v = getenv("CC_RESID_INIT"); return !v || atoi(v) != 0; }();
+    static const bool init_ok = []() { const char* v = cc_lab_env("CC_RESID_INIT"); return !v || atoi(v) != 0; }();
     e.acc_init = init_ok && !drop.thresh;
     return launch_gemm(al, bl, A16, lda, B, ldb, M, N, K, 1, e, st);
 }

@@ -508,7 +508,7 @@ int ln_bwd(const act_t* dy, const float* x, int ldx, const int* row_map, const f
     // with parameter gradients every block ends with 2*D fp32 atomics: keep the block count low (one per CU) so that the
     // atomic tail (measured: it dominated at 1024 blocks) stays ~0.4 M atomics per launch, and give those blocks 8 waves
     const int nw = (dgamma && (size_t)16 * D * sizeof(float) <= 65536) ? 8 : 4;      // 8-wave reduction buffer within the 64 KiB default
-    static const int dg_grid = []() { const char* e = getenv("CC_LNBWD_GRID"); return e ? atoi(e) : 256; }();   // tuning knob
+    static const int dg_grid = []() { const char* e = cc_lab_env("CC_LNBWD_GRID"); return e ? atoi(e) : 256; }();   // tuning knob
     const int grid = std::min((rows + nw - 1) / nw, dgamma ? dg_grid : 8192);
     const size_t sh = dgamma ? (size_t)2 * nw * D * sizeof(float) : 0;
     int img = 0;
@@ -1133,7 +1133,7 @@ static int attn_bwd_m3_launch(const float* qkv, const float* dout, const float* 
 static bool attn_x3mfma_on();
 static bool attn_bwd_m3_ok(int S, int hd) { return attn_x3mfma_on() && (hd == 64 || hd == 96) && S > 0 && S <= 64; }
 static bool attn_x3mfma_on() {
-    static const bool on = !(getenv("CC_ATTN_X3MFMA") && atoi(getenv("CC_ATTN_X3MFMA")) == 0) && !getenv("CC_ATTN_F32MFMA");
+    static const bool on = !(cc_lab_env("CC_ATTN_X3MFMA") && atoi(cc_lab_env("CC_ATTN_X3MFMA")) == 0) && !cc_lab_env("CC_ATTN_F32MFMA");
     return on;
 }
 #endif   // CC_OP == 2
@@ -1746,7 +1746,7 @@ static int attn_bwd_mfma_launch(const op16_t* qkv, const op16_t* dout, const op1
     const int items = B * H * ((S + 31) / 32);
     const float scale = 1.0f / sqrtf((float)HD);
     if (drop.thresh && !causal) return CC_ERR_SHAPE;
-    static const int fused = []() { const char* e = getenv("CC_ATTN_BWD_FUSED"); return e ? atoi(e) : 1; }();   // A/B switch (0 = two-kernel path)
+    static const int fused = []() { const char* e = cc_lab_env("CC_ATTN_BWD_FUSED"); return e ? atoi(e) : 1; }();   // A/B switch (0 = two-kernel path)
     if (fused && S <= 32) {
         attn_bwd_fused_launch<HD, 1>(qkv, dout, o, lse, B, S, H, causal, dqkv, st, drop, scale);
         return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
@@ -1968,6 +1968,7 @@ static int attn_bwd_rows(const float* qkv, const float* dout, const float* o, co
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
 
+#ifdef CC_EXPERIMENTS      // lab build only (make lab): measured slower than the VALU kernels, see attn_f32mfma_ok
 // ------------------------------------------------------------------------------------------------------------
 // fp32 attention on the fp32 MATRIX pipe (round 4, an A/B option — see attn_f32mfma_ok for the measurement that keeps it off): the LDS-tile
 // kernels above with their three / five products moved from VALU dot
@@ -2173,6 +2174,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_f32mfma(const float* __restric
         }
     }
 }
+#endif   // CC_EXPERIMENTS
 static size_t attn_f32mfma_lds(int S, int hd, bool bwd) {
     const size_t RP = (size_t)((S + 31) / 32) * 32, hdp = hd + 4, Sp = RP + 4;
     return ((bwd ? 4 : 3) * RP * hdp + (bwd ? 2 : 1) * RP * Sp + (bwd ? RP : 0)) * sizeof(float);
@@ -2181,8 +2183,13 @@ static bool attn_f32mfma_ok(int S, int hd, bool bwd) {
     // OFF by default: measured on MI355X (config-2 step, split-bf16 mode, two alternations) 40.4 ms with these kernels against 38.6 ms with the
     // VALU LDS-tile kernels — the fp32 MFMA is only 2x the VALU FMA rate, and 32-row tiles pad S = 50 to 64 (1.64x the products) and skip
     // causal work per tile (3 of 4 tiles) instead of per element (51 %).  CC_ATTN_F32MFMA=1 selects them (same results: tests pass either way).
-    static const bool on = getenv("CC_ATTN_F32MFMA") != nullptr;
+#ifdef CC_EXPERIMENTS
+    static const bool on = cc_lab_env("CC_ATTN_F32MFMA") != nullptr;
     return on && S <= 96 && (hd & 31) == 0 && attn_f32mfma_lds(S, hd, bwd) <= 160 * 1024;
+#else
+    (void)S; (void)hd; (void)bwd;
+    return false;              // the product library does not carry these kernels
+#endif
 }
 #define CC_F32MFMA_LAUNCH(KERN, ...)                                                                                   \
     {                                                                                                                  \
@@ -2201,7 +2208,7 @@ int attn_fwd(const act_t* qkv, int B, int S, int H, int hd, bool causal, act_t* 
     }
 #endif
 #if CC_OP != 2
-    static const bool no_mfma = getenv("CC_ATTN_VALU") != nullptr;   // A/B switch for profiling
+    static const bool no_mfma = cc_lab_env("CC_ATTN_VALU") != nullptr;   // A/B switch for profiling
     if (!no_mfma || drop.thresh) {
         if (hd == 64) return attn_fwd_mfma_launch<64>(qkv, B, S, H, causal, out, lse, st, drop);
         if (hd == 96) return attn_fwd_mfma_launch<96>(qkv, B, S, H, causal, out, lse, st, drop);
@@ -2216,6 +2223,7 @@ int attn_fwd(const act_t* qkv, int B, int S, int H, int hd, bool causal, act_t* 
         if (hd == 96) return attn_fwd_mfma3_launch<96>(qkv, B, S, H, causal, out, lse, st, drop, img);
         return attn_fwd_mfma3_launch<128>(qkv, B, S, H, causal, out, lse, st, drop, img);
     }
+#ifdef CC_EXPERIMENTS
     if (attn_f32mfma_ok(S, hd, false)) {                                 // fp32 products on the fp32 MFMA
         const size_t sh = attn_f32mfma_lds(S, hd, false);
         if (drop.thresh) CC_F32MFMA_LAUNCH((k_attn_fwd_f32mfma<true, true>), qkv, S, H, hd, scale, out, lse, drop)
@@ -2223,6 +2231,7 @@ int attn_fwd(const act_t* qkv, int B, int S, int H, int hd, bool causal, act_t* 
         else CC_F32MFMA_LAUNCH((k_attn_fwd_f32mfma<false, false>), qkv, S, H, hd, scale, out, lse, drop)
         return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
     }
+#endif
 #endif
     const size_t sh = attn_fwd_lds(S, hd);
     if (sh > 160 * 1024) {
@@ -2541,7 +2550,7 @@ int attn_bwd(const act_t* qkv, const act_t* dout, const act_t* o, const float* l
     }
 #endif
 #if CC_OP != 2
-    static const bool no_mfma = getenv("CC_ATTN_VALU") != nullptr;
+    static const bool no_mfma = cc_lab_env("CC_ATTN_VALU") != nullptr;
     if ((!no_mfma || drop.thresh) && o && delta) {
         if (hd == 64) return attn_bwd_mfma_launch<64>(qkv, dout, o, lse, delta, B, S, H, causal, dqkv, st, drop);
         if (hd == 96) return attn_bwd_mfma_launch<96>(qkv, dout, o, lse, delta, B, S, H, causal, dqkv, st, drop);
@@ -2557,6 +2566,7 @@ int attn_bwd(const act_t* qkv, const act_t* dout, const act_t* o, const float* l
         return S <= 32 ? attn_bwd_m3_launch<96, 1>(qkv, dout, lse, B, S, H, causal, dqkv, st, drop, img)
                        : attn_bwd_m3_launch<96, 2>(qkv, dout, lse, B, S, H, causal, dqkv, st, drop, img);
     }
+#ifdef CC_EXPERIMENTS
     if (attn_f32mfma_ok(S, hd, true)) {
         const size_t sh = attn_f32mfma_lds(S, hd, true);
         if (drop.thresh) CC_F32MFMA_LAUNCH((k_attn_bwd_f32mfma<true, true>), qkv, dout, lse, S, H, hd, scale, dqkv, drop)
@@ -2564,6 +2574,7 @@ int attn_bwd(const act_t* qkv, const act_t* dout, const act_t* o, const float* l
         else CC_F32MFMA_LAUNCH((k_attn_bwd_f32mfma<false, false>), qkv, dout, lse, S, H, hd, scale, dqkv, drop)
         return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
     }
+#endif
 #endif
     const size_t sh = attn_bwd_lds(S, hd);
     if (sh > 160 * 1024) {

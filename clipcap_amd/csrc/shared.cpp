@@ -8,16 +8,16 @@
 #include <cstring>
 
 namespace cc_shared {
-int g_gemm_tile_mode = []() { const char* e = getenv("CC_GEMM_S256"); return e ? atoi(e) : -1; }();
-int g_gemm_s64 = []() { const char* e = getenv("CC_GEMM_S64"); return e ? atoi(e) : -1; }();
-int g_gemm_small_x2 = []() { const char* e = getenv("CC_GEMM_X2"); return e ? atoi(e) : 1; }();
+int g_gemm_tile_mode = []() { const char* e = cc_lab_env("CC_GEMM_S256"); return e ? atoi(e) : -1; }();
+int g_gemm_s64 = []() { const char* e = cc_lab_env("CC_GEMM_S64"); return e ? atoi(e) : -1; }();
+int g_gemm_small_x2 = []() { const char* e = cc_lab_env("CC_GEMM_X2"); return e ? atoi(e) : 1; }();
 // bit 0: beam-group attention step (k_decode_attn_group), bit 1: the layer stack of a group step as one persistent launch (decode_pk.hip;
 // measured slower than the per-op launches on MI355X, DESIGN.md 4.5 — kept for A/B runs), bit 2: the XCD-team engine (decode_xt.hip) when cc_decode_fwd_x
 // is given a weight image.  env CC_DEC_GROUP / CC_DEC_PK / CC_DEC_XT preset the bits.
 int g_decode_mode = []() {
-    const char* g = getenv("CC_DEC_GROUP");
-    const char* p = getenv("CC_DEC_PK");
-    const char* x = getenv("CC_DEC_XT");
+    const char* g = cc_lab_env("CC_DEC_GROUP");
+    const char* p = cc_lab_env("CC_DEC_PK");
+    const char* x = cc_lab_env("CC_DEC_XT");
     return ((g ? atoi(g) : 1) ? 1 : 0) | ((p ? atoi(p) : 0) ? 2 : 0) | ((x ? atoi(x) : 0) ? 4 : 0);
 }();
 Prof g_prof;

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <vector>
 
+#include "lab_env.h"
+
 namespace cc_shared {
 
 extern int g_gemm_tile_mode;   // cc_gemm_tile_mode: -1 chooser, 0 = 128 x 128 only, 3 / 4 = force 256 x 192 / 256 x 256

@@ -16,6 +16,11 @@ from clipcap_amd.inference.utils import (nucleus_distribution, repetition_penalt
                                          top_k_top_p_filtering)
 
 
+def _persistent_decode_on() -> bool:
+    from clipcap_amd import _lib
+    return bool(_lib.lib().cc_decode_mode(-1) & 6)          # bit 1: persistent layer launch, bit 2: XCD-team engine (include/clipcap_hip.h)
+
+
 def _stop_id(tokenizer) -> int:
     return tokenizer.encode(tokenizer.eos_token)[0]          # base.py:66
 
@@ -28,10 +33,14 @@ def _with_text_prefix(model, embeds, text_prefix_tokens):
 
 
 @torch.no_grad()
-def generate_beam_tokens(model, embeds: torch.Tensor, beam_size: int = 5, entry_length: int = 67, temperature: float = 1.0,
-                         stop_token: int = 50256) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """Token-level beam search for a batch of prefixes.  embeds fp32 (S, L, D).
-    Returns (tokens int64 (S, beam, n), scores (S, beam) length-normalised, seq_lengths (S, beam))."""
+def generate_beam_rounds(model, embeds: torch.Tensor, beam_size: int = 5, entry_length: int = 67, temperature: float = 1.0,
+                         stop_token: int = 50256, rounds: int = 1) -> List[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
+    """Token-level beam search for a batch of prefixes, embeds fp32 (S, L, D), as ``rounds`` consecutive generations with LIVE state —
+    the reference's ``for _ in range(number_to_generate)`` around its entry_length loop (base.py:79-130): a later round continues the beams
+    of the one before (token histories, has_stopped, seq_lengths, the KV cache), its running ``scores`` are the previous round's scores
+    already divided by seq_lengths (base.py:123 rebinds the name), beams that never stopped keep generating for another entry_length
+    tokens, and a round that starts with every beam stopped still takes one step (base.py:80-121) before it breaks.
+    Returns one (tokens int64 (S, beam, n_r), scores (S, beam) length-normalised, seq_lengths (S, beam)) per round."""
     lm = model.language_model
     g = lm.engine
     dev = g.arena.device
@@ -39,13 +48,17 @@ def generate_beam_tokens(model, embeds: torch.Tensor, beam_size: int = 5, entry_
     S, L0, D = embeds.shape
     R = S * beam_size
     V = g.dims["V"]
+    rounds = max(1, int(rounds))
+    total = rounds * entry_length
+    if L0 + total > g.dims["NPOS"]:
+        raise RuntimeError(f"{rounds} generations of {entry_length} tokens behind a {L0}-position prefix exceed n_positions = {g.dims['NPOS']}")
     wte = lm.get_input_embeddings().weight.detach()
     scores = torch.zeros(R, dtype=torch.float32, device=dev)
     seq_lengths = torch.ones(R, dtype=torch.float32, device=dev)
     has_stopped = torch.zeros(R, dtype=torch.uint8, device=dev)
     base = (torch.arange(S, device=dev, dtype=torch.int32) * beam_size).repeat_interleave(beam_size)
     # step 0: one row per sample (base.py:86-94), then fan the cache out to beam rows
-    sess = DecodeSession(g, S, L0 + entry_length)
+    sess = DecodeSession(g, S, L0 + total)
     logits0 = sess.forward(embeds)                                              # (S, V)
     lg = torch.empty(R, V, dtype=torch.float32, device=dev)
     lg[::beam_size] = logits0                                                   # row 0 of every beam set
@@ -53,40 +66,54 @@ def generate_beam_tokens(model, embeds: torch.Tensor, beam_size: int = 5, entry_
     next_tok, src = beam_step(lg, S, beam_size, temperature, True, stop_token, scores, seq_lengths, has_stopped, bufs)
     sess = sess.expand((base // beam_size).to(torch.int32), R)
     # token histories (int32, ping-pong), the next input embedding and the cache ancestry are advanced by one launch per step
-    tok = [torch.zeros(R, entry_length, dtype=torch.int32, device=dev) for _ in range(2)]
+    tok = [torch.zeros(R, total, dtype=torch.int32, device=dev) for _ in range(2)]
     x = torch.empty(R, 1, D, dtype=torch.float32, device=dev)
     sess.beam_advance(beam_size, next_tok, None, wte, 0, tok[1], tok[0], x)     # step 0: tokens = next_tokens (base.py:94)
-    n = 1
-    for step in range(1, entry_length):
-        # base.py:120-121 breaks as soon as every beam has stopped.  Steps taken after that point only append token 0 to frozen
-        # beams (scores, lengths and the truncated outputs are unchanged), so polling the flag every 4th step — one host sync
-        # instead of four — cannot change the result.
-        if step % 4 == 1 and bool(has_stopped.all()):
-            break
-        logits = sess.forward(x, partials=True, group=beam_size)                # x = wte[next_tokens] (base.py:117)
-        next_tok, src = beam_step(logits, S, beam_size, temperature, False, stop_token, scores, seq_lengths, has_stopped, bufs, sess.lpart)
-        sess.beam_advance(beam_size, next_tok, src, wte, step, tok[(step - 1) & 1], tok[step & 1], x)   # base.py:104-117
-        n = step + 1
-    tokens = tok[(n - 1) & 1][:, :n].to(torch.int64)
-    final = scores / seq_lengths                                                # base.py:123
-    return tokens.view(S, beam_size, -1), final.view(S, beam_size), seq_lengths.view(S, beam_size)
+    n = 1                                                                       # token columns written so far
+    out = []
+    for r in range(rounds):
+        for i in range(1 if r == 0 else 0, entry_length):
+            # base.py:120-121 breaks as soon as every beam has stopped.  Steps taken after that point only append token 0 to frozen
+            # beams (scores, lengths and the truncated outputs are unchanged), so polling the flag every 4th step — one host sync
+            # instead of four — cannot change the result.  (i == 0 of a later round is never skipped: the reference takes that step.)
+            if i % 4 == 1 and bool(has_stopped.all()):
+                break
+            logits = sess.forward(x, partials=True, group=beam_size)            # x = wte[next_tokens] (base.py:117)
+            next_tok, src = beam_step(logits, S, beam_size, temperature, False, stop_token, scores, seq_lengths, has_stopped, bufs, sess.lpart)
+            sess.beam_advance(beam_size, next_tok, src, wte, n, tok[(n - 1) & 1], tok[n & 1], x)   # base.py:104-117
+            n += 1
+        final = scores / seq_lengths                                            # base.py:123
+        out.append((tok[(n - 1) & 1][:, :n].to(torch.int64).view(S, beam_size, -1), final.view(S, beam_size).clone(),
+                    seq_lengths.view(S, beam_size).clone()))
+        scores.copy_(final)                                                     # the next round starts from the normalised scores (base.py:123)
+    if _persistent_decode_on():
+        sess.check()                                                            # a persistent decode launch that gave up must not go unnoticed (the flag is sticky)
+    return out
+
+
+def generate_beam_tokens(model, embeds: torch.Tensor, beam_size: int = 5, entry_length: int = 67, temperature: float = 1.0,
+                         stop_token: int = 50256) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """One generation (the reference's number_to_generate = 1): (tokens int64 (S, beam, n), scores (S, beam) length-normalised,
+    seq_lengths (S, beam))."""
+    return generate_beam_rounds(model, embeds, beam_size, entry_length, temperature, stop_token, 1)[0]
 
 
 def generate_beam(model, tokenizer: Callable, embeds: torch.Tensor, number_to_generate: int = 1,
                   text_prefix_tokens: Optional[torch.Tensor] = None, beam_size: int = 5, entry_length: int = 67,
                   temperature: float = 1.0) -> List[str]:
-    """Reference signature (base.py:55-64).  Returns the best caption per prefix row (for the reference's batch-1 input with
-    number_to_generate=1: a one-element list, exactly what base.py:125-132 returns)."""
+    """Reference signature (base.py:55-64).  For the reference's batch-1 input: ``number_to_generate`` texts, the best beam after each of
+    the consecutive generations (base.py:79-130, see generate_beam_rounds).  A batch of prefixes (S > 1, an extension — the reference is
+    batch-1) returns the best caption of every prefix row, round-major when number_to_generate > 1."""
     stop = _stop_id(tokenizer)
     embeds = _with_text_prefix(model, embeds, text_prefix_tokens)
-    tokens, scores, lengths = generate_beam_tokens(model, embeds, beam_size, entry_length, temperature, stop)
-    best = scores.argmax(dim=1)     # == argsort(descending)[0]; ties resolve to the first beam like a stable sort
     out = []
-    for s in range(tokens.shape[0]):
-        b = int(best[s])
-        n = int(lengths[s, b])
-        out.append(tokenizer.decode(tokens[s, b, :n].cpu().numpy()))
-    return out * max(1, number_to_generate) if tokens.shape[0] == 1 else out
+    for tokens, scores, lengths in generate_beam_rounds(model, embeds, beam_size, entry_length, temperature, stop, number_to_generate):
+        best = scores.argmax(dim=1)     # == argsort(descending)[0]; ties resolve to the first beam like a stable sort
+        for s in range(tokens.shape[0]):
+            b = int(best[s])
+            n = int(lengths[s, b])
+            out.append(tokenizer.decode(tokens[s, b, :n].cpu().numpy()))
+    return out
 
 
 @torch.no_grad()

@@ -11,8 +11,14 @@
  *     points keep no state and never allocate or synchronise; all work is enqueued on the caller's hipStream_t (passed
  *     as void*; NULL = default stream), so calls on different streams / from different host threads are independent.
  *     Per-step settings (GPT-2 dropout, loss scale) travel in the call's own arguments.  The only process-wide state is
- *     the test / measurement hooks at the end of this file (cc_gemm_tile_mode, cc_gemm_skinny_mode, cc_decode_mode, cc_prof_*),
- *     which the product path never touches.
+ *     the test / measurement hooks at the end of this file (cc_gemm_tile_mode, cc_gemm_skinny_mode, cc_decode_mode,
+ *     cc_decode_last_path, cc_prof_*), which the product path never touches.  libclipcap_hip.so does not read the environment
+ *     (getenv is not among its imports) and exports exactly the functions declared here (csrc/exports.map).  The kernels and A/B
+ *     code paths that were built, measured and lost — the persistent decode-layer launch, the XCD-team decode engine, fp32-MFMA
+ *     attention — and the CC_* environment switches that select them live in the LAB build only (`make -C clipcap_amd/csrc lab` ->
+ *     libclipcap_hip_lab.so, -DCC_EXPERIMENTS, csrc/lab_env.h; CLIPCAP_HIP_LIB=lab makes the Python binding load it).  In the
+ *     product library the entry points that would use them (cc_decode_mode bits 1 / 2, cc_decode_fwd_x with an image) keep the
+ *     launch-per-op path and cc_decode_xt_image_bytes returns 0.
  *   - return value: 0 = ok, <0 = error (CC_ERR_*), never throws across the ABI.
  *   - OPERAND TYPE.  GEMM / attention operands and the stored 16-bit activations are bf16 (CC_OP_BF16, default) or IEEE
  *     fp16 (CC_OP_FP16 = the reference's `--fp-precision 16`, clipcap/train/args.py:30-34), selected per model by

@@ -279,7 +279,7 @@ def beam_update(logits, scores, seq_lengths, has_stopped, *, beam_size, temperat
 
 
 def generate_beam_tokens(p, embeds, *, n_head, n_layer, beam_size=5, entry_length=67, temperature=1.0,
-                         stop_token=50256, pre="language_model.", rb=False, trace: Optional[list] = None, kv_cache: bool = False):
+                         stop_token=50256, pre="language_model.", rb=False, trace: Optional[list] = None, kv_cache: bool = False, rounds: int = 1):
     """Token-level restatement of generate_beam (inference/base.py:55-132) for one sample.
 
     embeds (1, L, D).  Full re-forward per step like the reference (:81) — the KV-cached product path must
@@ -287,6 +287,8 @@ def generate_beam_tokens(p, embeds, *, n_head, n_layer, beam_size=5, entry_lengt
     (the arithmetic of every step is unchanged; used as the "cached" CPU baseline of bench.py and to cross-check
     the cache logic).  Returns (tokens (beam, n) int64, scores (beam,), seq_lengths (beam,), order);
     the reference returns tokenizer.decode(tokens[order[0]][:int(seq_lengths[order[0]])]) (:123-130).
+    ``rounds`` > 1: the reference's number_to_generate loop (:79-130) — the entry_length loop re-entered with live state, ``scores``
+    rebound to scores / seq_lengths at the end of every round (:123); a list of those 4-tuples, one per round, is returned instead.
     """
     wte = p[pre + "transformer.wte.weight"]
     tokens = None
@@ -294,37 +296,40 @@ def generate_beam_tokens(p, embeds, *, n_head, n_layer, beam_size=5, entry_lengt
     seq_lengths = torch.ones(beam_size)
     has_stopped = torch.zeros(beam_size, dtype=torch.bool)
     past, pos, new = None, 0, embeds
-    for _ in range(entry_length):
-        if kv_cache:
-            h, past = gpt2_hidden(p, new, n_head, n_layer, pre + "transformer.", rb, past=past, pos_offset=pos)
-            pos += new.shape[1]
-            logits = (_r(h[:, -1, :], rb) @ _r(wte, rb).t())
-        else:
-            logits = gpt2_logits(p, embeds, n_head, n_layer, pre=pre, rb=rb)[:, -1, :]
-        next_tokens, src, scores, seq_lengths, has_stopped = beam_update(logits, scores, seq_lengths, has_stopped, beam_size=beam_size,
-                                                                         temperature=temperature, stop_token=stop_token)
-        if src is None:
-            embeds = embeds.expand(beam_size, *embeds.shape[1:])
-            tokens = next_tokens.unsqueeze(1)
+    results = []
+    for _round in range(max(1, rounds)):
+        for _ in range(entry_length):
             if kv_cache:
-                past = [(k.expand(beam_size, *k.shape[1:]), v.expand(beam_size, *v.shape[1:])) for k, v in past]
-        else:
-            tokens = torch.cat((tokens[src], next_tokens.unsqueeze(1)), dim=1)
-            embeds = embeds[src]
-            if kv_cache:
-                past = [(k[src], v[src]) for k, v in past]
-        nxt = wte[next_tokens].view(embeds.shape[0], 1, -1)
-        new = nxt
-        if not kv_cache:
-            embeds = torch.cat((embeds, nxt), dim=1)
-        if trace is not None:
-            trace.append(dict(tokens=tokens.clone(), scores=scores.clone(), seq_lengths=seq_lengths.clone(),
-                              has_stopped=has_stopped.clone()))
-        if has_stopped.all():
-            break
-    scores = scores / seq_lengths
-    order = scores.argsort(descending=True)
-    return tokens, scores, seq_lengths, order
+                h, past = gpt2_hidden(p, new, n_head, n_layer, pre + "transformer.", rb, past=past, pos_offset=pos)
+                pos += new.shape[1]
+                logits = (_r(h[:, -1, :], rb) @ _r(wte, rb).t())
+            else:
+                logits = gpt2_logits(p, embeds, n_head, n_layer, pre=pre, rb=rb)[:, -1, :]
+            next_tokens, src, scores, seq_lengths, has_stopped = beam_update(logits, scores, seq_lengths, has_stopped, beam_size=beam_size,
+                                                                             temperature=temperature, stop_token=stop_token)
+            if src is None:
+                embeds = embeds.expand(beam_size, *embeds.shape[1:])
+                tokens = next_tokens.unsqueeze(1)
+                if kv_cache:
+                    past = [(k.expand(beam_size, *k.shape[1:]), v.expand(beam_size, *v.shape[1:])) for k, v in past]
+            else:
+                tokens = torch.cat((tokens[src], next_tokens.unsqueeze(1)), dim=1)
+                embeds = embeds[src]
+                if kv_cache:
+                    past = [(k[src], v[src]) for k, v in past]
+            nxt = wte[next_tokens].view(embeds.shape[0], 1, -1)
+            new = nxt
+            if not kv_cache:
+                embeds = torch.cat((embeds, nxt), dim=1)
+            if trace is not None:
+                trace.append(dict(tokens=tokens.clone(), scores=scores.clone(), seq_lengths=seq_lengths.clone(),
+                                  has_stopped=has_stopped.clone()))
+            if has_stopped.all():
+                break
+        scores = scores / seq_lengths                           # :123 — the NEXT round's running scores are these
+        order = scores.argsort(descending=True)
+        results.append((tokens.clone(), scores.clone(), seq_lengths.clone(), order))
+    return results[0] if rounds <= 1 else results
 
 
 def top_k_top_p_filtering(logits: Tensor, top_k: int = 0, top_p: float = 0.0, filter_value=-float("inf")) -> Tensor:

@@ -289,6 +289,84 @@ def _main_new(only):
             print("beam_deep", i, best, d[f"beam{i}b.best"])
         np.savez_compressed(os.path.join(OUT, "beam_deep.npz"), **d)
 
+    # ---- (14) round 5 — number_to_generate > 1 (inference/base.py:79-130): the entry_length loop re-entered with LIVE state.  GPT-2-medium width,
+    #           4 layers (the beam_medium model), 3 generations of 6 tokens; run a: the stop token never appears (the beams keep growing:
+    #           6 / 12 / 18 tokens), run b: stop = the 3rd token of run a's first text (beams freeze; later rounds take one step and re-divide) ----
+    if want("beam_multi"):
+        from clipcap.inference import base as ibase
+        D, NL, n_head, V, NPOS, seed, EL, NG = 1024, 4, 16, 50257, 128, 4401, 6, 3
+        gsd = seeded.state_dict(seeded.gpt2_shapes(D, NL, V, NPOS), seed)
+        gsd["transformer.wte.weight"] = gsd["transformer.wte.weight"] * 2.0
+        lm = GPT2LMHeadModel(GPT2Config(n_embd=D, n_layer=NL, n_head=n_head, vocab_size=V, n_positions=NPOS, resid_pdrop=0.0, embd_pdrop=0.0,
+                                        attn_pdrop=0.0)).eval()
+        lm.load_state_dict({k: torch.from_numpy(v) for k, v in gsd.items()}, strict=False)
+
+        class _M5:
+            language_model = lm
+
+        d = {"cfg": np.array([D, NL, n_head, V, NPOS, seed]), "wte_scale": np.array(2.0), "param_checksum": seeded.checksum(gsd)}
+        gen = torch.Generator().manual_seed(seed + 7)
+        for i in range(2):
+            pref = torch.randn(1, 10, D, generator=gen) * 0.5
+            texts = ibase.generate_beam(_M5, FakeTokenizer(V - 1), pref, number_to_generate=NG, beam_size=5, entry_length=EL, temperature=1.0)
+            assert len(texts) == NG
+            d[f"multi{i}a.prefix"] = pref.numpy()
+            d[f"multi{i}a.meta"] = np.array([V - 1, EL, 5, NG])
+            for r, t in enumerate(texts):
+                d[f"multi{i}a.gen{r}"] = np.array([int(x) for x in t.split()], dtype=np.int64)
+            eos = int(texts[0].split()[2])
+            texts_b = ibase.generate_beam(_M5, FakeTokenizer(eos), pref, number_to_generate=NG, beam_size=5, entry_length=EL, temperature=1.0)
+            d[f"multi{i}b.prefix"] = pref.numpy()
+            d[f"multi{i}b.meta"] = np.array([eos, EL, 5, NG])
+            for r, t in enumerate(texts_b):
+                d[f"multi{i}b.gen{r}"] = np.array([int(x) for x in t.split()] if t else [], dtype=np.int64)
+            # run c: stop = the most frequent token of run a's last text — every beam runs into it, so the later rounds start with all beams stopped
+            last = [int(x) for x in texts[-1].split()]
+            eos_c = max(set(last), key=last.count)
+            texts_c = ibase.generate_beam(_M5, FakeTokenizer(eos_c), pref, number_to_generate=NG, beam_size=5, entry_length=EL, temperature=1.0)
+            d[f"multi{i}c.prefix"] = pref.numpy()
+            d[f"multi{i}c.meta"] = np.array([eos_c, EL, 5, NG])
+            for r, t in enumerate(texts_c):
+                d[f"multi{i}c.gen{r}"] = np.array([int(x) for x in t.split()] if t else [], dtype=np.int64)
+            print("beam_multi", i, [len(t.split()) for t in texts], [t for t in texts_b], "c:", eos_c, [t for t in texts_c])
+        np.savez_compressed(os.path.join(OUT, "beam_multi.npz"), **d)
+
+    # ---- (15) round 5 — beam RANKING under competition at full depth.  beam_deep's captions are degenerate (a random-init GPT-2 with tied,
+    #           scaled-up wte repeats one token: the hidden state is dominated by the last input embedding), so most of its steps are not
+    #           close calls.  Here the position embeddings are scaled x8 and wte x0.5, temperature 1.5: every step's winner changes with the
+    #           position and the captions do not repeat (asserted: >= 8 distinct tokens of 12).  24-layer GPT-2-medium, 2 prefixes x {no stop, stop mid-way} ----
+    if want("beam_varied"):
+        from clipcap.inference import base as ibase
+        D, NL, n_head, V, NPOS, seed, EL, TEMP = 1024, 24, 16, 50257, 128, 4801, 12, 1.5
+        gsd = seeded.state_dict(seeded.gpt2_shapes(D, NL, V, NPOS), seed)
+        gsd["transformer.wte.weight"] = gsd["transformer.wte.weight"] * 0.5
+        gsd["transformer.wpe.weight"] = gsd["transformer.wpe.weight"] * 8.0
+        lm = GPT2LMHeadModel(GPT2Config(n_embd=D, n_layer=NL, n_head=n_head, vocab_size=V, n_positions=NPOS, resid_pdrop=0.0, embd_pdrop=0.0,
+                                        attn_pdrop=0.0)).eval()
+        lm.load_state_dict({k: torch.from_numpy(v) for k, v in gsd.items()}, strict=False)
+
+        class _M6:
+            language_model = lm
+
+        d = {"cfg": np.array([D, NL, n_head, V, NPOS, seed]), "wte_scale": np.array(0.5), "wpe_scale": np.array(8.0), "temperature": np.array(TEMP),
+             "param_checksum": seeded.checksum(gsd)}
+        gen = torch.Generator().manual_seed(seed)
+        for i in range(2):
+            pref = torch.randn(1, 10, D, generator=gen) * 0.5
+            texts = ibase.generate_beam(_M6, FakeTokenizer(V - 1), pref, beam_size=5, entry_length=EL, temperature=TEMP)
+            best = [int(x) for x in texts[0].split()]
+            assert len(set(best)) >= 8, best
+            d[f"beam{i}a.prefix"] = pref.numpy()
+            d[f"beam{i}a.best"] = np.array(best, dtype=np.int64)
+            d[f"beam{i}a.meta"] = np.array([V - 1, EL, 5])
+            eos = best[5]
+            texts = ibase.generate_beam(_M6, FakeTokenizer(eos), pref, beam_size=5, entry_length=EL, temperature=TEMP)
+            d[f"beam{i}b.prefix"] = pref.numpy()
+            d[f"beam{i}b.best"] = np.array([int(x) for x in texts[0].split()] if texts[0] else [], dtype=np.int64)
+            d[f"beam{i}b.meta"] = np.array([eos, EL, 5])
+            print("beam_varied", i, best, d[f"beam{i}b.best"])
+        np.savez_compressed(os.path.join(OUT, "beam_varied.npz"), **d)
+
     # ---- (13) round 4 — the sentence-length penalty of no_beam.py:55-60 on rows where it FIRES: utils.py:40-51 multiplies the logits of
     #           history tokens whose VALUE equals the stop-token id, so the rows below carry history tokens whose filtered logit is exactly
     #           float(stop).  The per-step rule is the reference's own call sequence (no_beam.py:45-63) on 1-D logits. ----

@@ -1,4 +1,4 @@
-"""XCD-team decode engine (cc_decode_fwd_x with a weight image, clipcap_amd/csrc/decode_xt.hip): every XCD runs the whole GPT-2 layer stack
+"""LAB BUILD ONLY (libclipcap_hip_lab.so, run by tests/test_gpu_lab.py with CLIPCAP_HIP_LIB=lab).  XCD-team decode engine (cc_decode_fwd_x with a weight image, clipcap_amd/csrc/decode_xt.hip): every XCD runs the whole GPT-2 layer stack
 of a generated position for its own captions, the weights stream into registers from a fragment-ordered image.  Replaces the per-token
 full re-forward of the reference (clipcap/inference/base.py:80-121); must give the logits of the launch-per-op path (cc_decode_fwd_p) and
 of the re-forward for ANY beam ancestry — the bars are those of tests/test_gpu_decode_group.py."""

@@ -169,12 +169,14 @@ def test_config4_full_size_step_properties():
 
 # ---------------------------------------------------------------- configs[4]: beam decode at GPT-2-medium size ---------------
 
-def _medium_lm(n_layer, wte_scale=2.0, seed=4401, npos=128, precision=None):
+def _medium_lm(n_layer, wte_scale=2.0, seed=4401, npos=128, precision=None, wpe_scale=1.0):
     from tests import seeded
     from clipcap_amd.model.gpt2 import GPT2LM
     D, n_head, V = 1024, 16, 50257
     gsd = seeded.state_dict(seeded.gpt2_shapes(D, n_layer, V, npos), seed)
     gsd["transformer.wte.weight"] = gsd["transformer.wte.weight"] * wte_scale
+    if wpe_scale != 1.0:
+        gsd["transformer.wpe.weight"] = gsd["transformer.wpe.weight"] * wpe_scale
     lm = GPT2LM(n_embd=D, n_layer=n_layer, n_head=n_head, vocab_size=V, n_positions=npos, precision=precision)
     lm.load_state_dict({k: torch.from_numpy(v) for k, v in gsd.items()}, strict=False)
     return lm.to("cuda"), gsd
@@ -306,6 +308,106 @@ def test_beam_deep_24_layers_tokens_vs_reference_and_oracle():
     for case in cases:
         got = mine(case)
         assert np.array_equal(got, g[case + ".best"]), (case, got, g[case + ".best"])
+    lm.set_precision("bf16")
+
+
+def test_beam_varied_24_layers_ranking_under_competition():
+    """tests/golden/beam_varied.npz: the reference's generate_beam (inference/base.py:55-132) on the seeded 24-layer GPT-2-medium with the
+    position embeddings x8, wte x0.5 and temperature 1.5 — captions that do NOT repeat (>= 8 distinct tokens of 12, asserted by the
+    generator), i.e. beam ranking with real competition at full depth (beam_deep's captions repeat one token).  split-bf16 operands (the
+    reference's precision): token-exact against the reference; bf16 operands: token-exact against the like-for-like oracle."""
+    from types import SimpleNamespace
+    from clipcap_amd.inference.base import generate_beam_tokens
+    g = load_golden("beam_varied")
+    D, NL, n_head, V, NPOS, seed = [int(v) for v in g["cfg"]]
+    temp = float(g["temperature"])
+    assert NL == 24
+    lm, gsd = _medium_lm(NL, float(g["wte_scale"]), seed, NPOS, wpe_scale=float(g["wpe_scale"]))
+    assert np.array_equal(__import__("tests.seeded", fromlist=["checksum"]).checksum(gsd), g["param_checksum"])
+    model = SimpleNamespace(language_model=lm)
+    sd = {"language_model." + k: torch.from_numpy(v) for k, v in gsd.items()}
+    cases = ("beam0a", "beam0b", "beam1a", "beam1b")
+    for case in cases:
+        assert len(set(int(t) for t in g[case[:-1] + "a.best"])) >= 8
+
+    def mine(case):
+        eos, entry, beam = [int(v) for v in g[case + ".meta"]]
+        toks, scores, lens = generate_beam_tokens(model, torch.from_numpy(g[case + ".prefix"]).cuda(), beam, entry, temp, eos)
+        b = int(scores[0].argmax())
+        return toks[0, b, : int(lens[0, b])].cpu().numpy()
+
+    exact_ref = 0
+    for case in cases:
+        eos, entry, beam = [int(v) for v in g[case + ".meta"]]
+        got = mine(case)
+        exact_ref += int(np.array_equal(got, g[case + ".best"]))
+        if case in ("beam0a", "beam1b"):       # the like-for-like oracle re-forwards 24 layers per step on the host: two runs keep the test short
+            ot, osc, ol, order = O.generate_beam_tokens(sd, torch.from_numpy(g[case + ".prefix"]), n_head=n_head, n_layer=NL, beam_size=beam,
+                                                        entry_length=entry, stop_token=eos, temperature=temp, rb=True)
+            want = ot[order[0]][: int(ol[order[0]])].numpy()
+            assert np.array_equal(got, want), (case, got, want)
+    print(f"beam_varied, bf16 operands: {exact_ref} / 4 captions equal the reference's")
+    lm.set_precision(32)
+    for case in cases:
+        got = mine(case)
+        assert np.array_equal(got, g[case + ".best"]), (case, got, g[case + ".best"])
+    lm.set_precision("bf16")
+
+
+def test_beam_number_to_generate_rounds_vs_reference():
+    """number_to_generate > 1 (inference/base.py:79-130): the entry_length loop re-entered with live state — beams that never stopped keep
+    growing (6 / 12 / 18 tokens), stopped beams freeze, scores are divided by seq_lengths once more per round.  tests/golden/beam_multi.npz =
+    the reference's three generations for 2 prefixes x {stop never seen, stop mid-way, a stop every beam runs into}.  split-bf16 operands:
+    every generation token-exact against the reference; bf16 operands: token-exact against the like-for-like oracle."""
+    from types import SimpleNamespace
+    from clipcap_amd.inference.base import generate_beam, generate_beam_rounds
+    g = load_golden("beam_multi")
+    D, NL, n_head, V, NPOS, seed = [int(v) for v in g["cfg"]]
+    lm, gsd = _medium_lm(NL, float(g["wte_scale"]), seed, NPOS)
+    model = SimpleNamespace(language_model=lm)
+    sd = {"language_model." + k: torch.from_numpy(v) for k, v in gsd.items()}
+    cases = [f"multi{i}{c}" for i in range(2) for c in "abc"]
+
+    def mine(case):
+        eos, entry, beam, ng = [int(v) for v in g[case + ".meta"]]
+        out = []
+        for toks, scores, lens in generate_beam_rounds(model, torch.from_numpy(g[case + ".prefix"]).cuda(), beam, entry, 1.0, eos, ng):
+            b = int(scores[0].argmax())
+            out.append(toks[0, b, : int(lens[0, b])].cpu().numpy())
+        return out
+
+    exact = total = 0
+    for case in cases:
+        eos, entry, beam, ng = [int(v) for v in g[case + ".meta"]]
+        got = mine(case)
+        assert len(got) == ng
+        res = O.generate_beam_tokens(sd, torch.from_numpy(g[case + ".prefix"]), n_head=n_head, n_layer=NL, beam_size=beam, entry_length=entry,
+                                     stop_token=eos, rb=True, rounds=ng)
+        for r in range(ng):
+            ot, osc, ol, order = res[r]
+            want = ot[order[0]][: int(ol[order[0]])].numpy()
+            assert np.array_equal(got[r], want), (case, r, got[r], want)
+            exact += int(np.array_equal(got[r], g[f"{case}.gen{r}"]))
+            total += 1
+    print(f"beam_multi, bf16 operands: {exact} / {total} generations equal the reference's")
+    assert exact >= total - 3, (exact, total)
+
+    class Tok:                                   # the reference-signature entry point returns one text per generation
+        eos_token = "<eos>"
+        def __init__(self, e): self.e = e
+        def encode(self, s): return [self.e]
+        def decode(self, ids): return " ".join(str(int(i)) for i in ids)
+
+    lm.set_precision(32)
+    for case in cases:
+        eos, entry, beam, ng = [int(v) for v in g[case + ".meta"]]
+        got = mine(case)
+        for r in range(ng):
+            assert np.array_equal(got[r], g[f"{case}.gen{r}"]), (case, r, got[r], g[f"{case}.gen{r}"])
+    case = cases[2]
+    eos, entry, beam, ng = [int(v) for v in g[case + ".meta"]]
+    texts = generate_beam(model, Tok(eos), torch.from_numpy(g[case + ".prefix"]).cuda(), number_to_generate=ng, beam_size=beam, entry_length=entry)
+    assert texts == [" ".join(str(int(t)) for t in g[f"{case}.gen{r}"]) for r in range(ng)]
     lm.set_precision("bf16")
 
 

@@ -3,9 +3,8 @@ beam group read every distinct (cache row, position) of their ancestry tables on
 those of the per-row kernel (cc_decode_fwd_p) and of the full re-forward the reference does (inference/base.py:80-121) for ANY
 ancestry table: shared prefixes, partially shared histories, rows that share nothing, rows that name other groups' cache rows.
 
-The same sweep also runs with cc_decode_mode bit 1 set: the whole layer stack of a group step as ONE persistent launch whose workgroups
-hand activations over through arrival counters (clipcap_amd/csrc/decode_pk.hip) — an A/B switch (measured slower than the per-op launches,
-DESIGN.md 4.5), held to the same bars, plus cc_decode_ws_check (no hand-off gave up)."""
+(The persistent-launch forms of the layer stack — decode_pk.hip, decode_xt.hip — are lab-build code: tests/lab_decode_pk.py, tests/lab_decode_xt.py,
+run by tests/test_gpu_lab.py against libclipcap_hip_lab.so.)"""
 import pytest
 import torch
 
@@ -74,22 +73,6 @@ def test_group_attention_medium_width_320_rows(precision):
     tol = 1e-4 if precision == 32 else 4e-3
     w = _lockstep(lm, 64, 5, 10, 6, tol, seed=11)
     print(f"precision {precision}: worst |group - per-row| / scale = {w:.2e}")
-
-
-@pytest.mark.parametrize("precision,S,G,NL", [(None, 64, 5, 3), (16, 64, 5, 2), (None, 13, 3, 2), (None, 32, 8, 2), (None, 7, 2, 2), (32, 64, 5, 2)])
-def test_persistent_layer_launch_equals_per_op_launches(precision, S, G, NL):
-    """cc_decode_mode bit 1: one persistent launch per position (decode_pk.hip) against the per-row launches and the full re-forward —
-    320 rows, ragged row tiles (39 / 14 rows), group widths 2 / 3 / 5 / 8; split-bf16 operands keep the per-op path (the flag is then a
-    no-op and the result must not change)."""
-    from clipcap_amd import _lib
-    from tests.test_gpu_configs import _medium_lm
-    lm, _ = _medium_lm(NL, precision=precision)
-    old = _lib.lib().cc_decode_mode(3)
-    try:
-        w = _lockstep(lm, S, G, 10, 6, 1e-4 if precision == 32 else 4e-3, seed=100 + S)
-    finally:
-        _lib.lib().cc_decode_mode(old)
-    print(f"persistent launch, precision {precision}, {S} x {G} rows, {NL} layers: worst |persistent - per-row launches| / scale = {w:.2e}")
 
 
 def test_group_hint_is_ignored_where_it_does_not_apply():

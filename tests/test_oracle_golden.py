@@ -293,3 +293,45 @@ def test_beam_search_medium_depth():
                                                        entry_length=entry, stop_token=eos)
         best = toks[order[0]][: int(lens[order[0]])].numpy()
         assert np.array_equal(best, g[case + ".best"]), (case, best, g[case + ".best"])
+
+
+def test_beam_search_number_to_generate_rounds():
+    """inference/base.py:79-130 with number_to_generate = 3 (tests/golden/beam_multi.npz): the oracle's ``rounds`` reproduces the reference's
+    three consecutive generations — beams that keep growing, beams frozen mid-way, and rounds that start with every beam stopped."""
+    from tests import seeded
+    g = load_golden("beam_multi")
+    D, NL, n_head, V, NPOS, seed = [int(v) for v in g["cfg"]]
+    gsd = seeded.state_dict(seeded.gpt2_shapes(D, NL, V, NPOS), seed)
+    gsd["transformer.wte.weight"] = gsd["transformer.wte.weight"] * float(g["wte_scale"])
+    assert np.array_equal(seeded.checksum(gsd), g["param_checksum"])
+    sd = {"language_model." + k: torch.from_numpy(v) for k, v in gsd.items()}
+    torch.set_num_threads(max(1, min(8, torch.get_num_threads())))
+    for case in ("multi0a", "multi0c", "multi1b", "multi1c"):
+        eos, entry, beam, ng = [int(v) for v in g[case + ".meta"]]
+        res = O.generate_beam_tokens(sd, torch.from_numpy(g[case + ".prefix"]), n_head=n_head, n_layer=NL, beam_size=beam, entry_length=entry,
+                                     stop_token=eos, rounds=ng, kv_cache=True)
+        assert len(res) == ng
+        for r, (toks, sc, lens, order) in enumerate(res):
+            best = toks[order[0]][: int(lens[order[0]])].numpy()
+            assert np.array_equal(best, g[f"{case}.gen{r}"]), (case, r, best, g[f"{case}.gen{r}"])
+
+
+def test_beam_search_varied_captions_medium_depth():
+    """tests/golden/beam_varied.npz (24 layers, wpe x8, wte x0.5, temperature 1.5): the reference's non-repeating caption of prefix 0,
+    without and with a stop token — beam ranking under competition at full depth (the other prefix is covered by the GPU tests)."""
+    from tests import seeded
+    g = load_golden("beam_varied")
+    D, NL, n_head, V, NPOS, seed = [int(v) for v in g["cfg"]]
+    gsd = seeded.state_dict(seeded.gpt2_shapes(D, NL, V, NPOS), seed)
+    gsd["transformer.wte.weight"] = gsd["transformer.wte.weight"] * float(g["wte_scale"])
+    gsd["transformer.wpe.weight"] = gsd["transformer.wpe.weight"] * float(g["wpe_scale"])
+    assert np.array_equal(seeded.checksum(gsd), g["param_checksum"])
+    sd = {"language_model." + k: torch.from_numpy(v) for k, v in gsd.items()}
+    torch.set_num_threads(max(1, min(8, torch.get_num_threads())))
+    for case in ("beam0a", "beam0b"):
+        eos, entry, beam = [int(v) for v in g[case + ".meta"]]
+        assert len(set(int(t) for t in g["beam0a.best"])) >= 8
+        toks, sc, lens, order = O.generate_beam_tokens(sd, torch.from_numpy(g[case + ".prefix"]), n_head=n_head, n_layer=NL, beam_size=beam,
+                                                       entry_length=entry, stop_token=eos, temperature=float(g["temperature"]), kv_cache=True)
+        best = toks[order[0]][: int(lens[order[0]])].numpy()
+        assert np.array_equal(best, g[case + ".best"]), (case, best, g[case + ".best"])
