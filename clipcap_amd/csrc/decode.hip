@@ -435,13 +435,12 @@ __global__ void k_last_rows(int* __restrict__ map, int R, int Tn) {
     if (i < R) map[i] = i * Tn + Tn - 1;
 }
 
-__global__ void k_embed_tokens(const float* __restrict__ wte, const int* __restrict__ tok, float* __restrict__ out, int R, int D) {
+__global__ void k_embed_tokens(const float* __restrict__ wte, const int* __restrict__ tok, float* __restrict__ out, int R, int D, int rows) {
     const int d4n = D >> 2;
     const size_t total = (size_t)R * d4n;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % d4n), r = (int)(i / d4n);
-        int id = tok[r];
-        if (id < 0) id = 0;
+        const int id = min(max(tok[r], 0), rows - 1);       // never reads outside wte (callers validate ids; an out-of-range id must not fault the device)
         reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(wte + (size_t)id * D)[c];
     }
 }
@@ -1371,7 +1370,7 @@ int CC_API(cc_beam_step_p)(int32_t S, int32_t beam, int32_t V, const float* logi
 int CC_API(cc_embed_tokens)(const cc_gpt2_cfg* c, int32_t R, const float* w32, const int32_t* tokens, float* out, void* stream) {
     if (!cfg_ok(c) || R <= 0 || !w32 || !tokens || !out) return CC_ERR_ARG;
     const size_t total = (size_t)R * (c->D >> 2);
-    hipLaunchKernelGGL(k_embed_tokens, dim3((int)std::min<size_t>((total + 255) / 256, 2048)), dim3(256), 0, S_(stream), w32, tokens, out, R, c->D);
+    hipLaunchKernelGGL(k_embed_tokens, dim3((int)std::min<size_t>((total + 255) / 256, 2048)), dim3(256), 0, S_(stream), w32, tokens, out, R, c->D, c->Vp);
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
 

@@ -3160,13 +3160,16 @@ int x3_split_multi(const X3SplitBatch& b, hipStream_t st) {
 namespace {
 struct X3Scratch { char* base = nullptr; size_t bytes = 0, used = 0; };
 thread_local X3Scratch g_x3;
-}  // namespace
-void x3_set_scratch(void* base, size_t bytes) { g_x3.base = static_cast<char*>(base); g_x3.bytes = bytes; g_x3.used = 0; }
-namespace {
 thread_local const void* g_x3_expect = nullptr;
 thread_local const void* g_x3_emit = nullptr;
 thread_local int g_x3_emit_w = 0;
 }  // namespace
+// every C-ABI entry sets the call's scratch first: a one-shot image hint armed by an earlier call that returned early (an error path between
+// arm and take) must not reach this call's producers / consumers through a recycled workspace pointer
+void x3_set_scratch(void* base, size_t bytes) {
+    g_x3.base = static_cast<char*>(base); g_x3.bytes = bytes; g_x3.used = 0;
+    g_x3_expect = nullptr; g_x3_emit = nullptr; g_x3_emit_w = 0;
+}
 // the call's operand-image scratch as one block (a producer kernel writes the NEXT GEMM's A image there itself); nullptr when it does not fit
 op16_t* x3_scratch_block(size_t bytes) { return (g_x3.base && bytes <= g_x3.bytes) ? reinterpret_cast<op16_t*>(g_x3.base) : nullptr; }
 void x3_expect_image(const void* a) { g_x3_expect = a; }

@@ -120,16 +120,23 @@ class _Arena:
         self.zero = (rank, ranges, gather)
 
     def full_moments(self):
-        """(m, v) over the whole arena — with sharded optimizer state a COLLECTIVE (every rank calls it): the owners' slices gathered."""
+        """(m, v) over the whole arena.  Replicated state: the device tensors themselves.  Sharded state (ZeRO stage 1): a COLLECTIVE (every
+        rank calls it) that moves one owner's slice at a time through a slice-sized device buffer into HOST tensors — peak device memory is
+        one slice, not two more full-size arenas on every rank (which is what sharding was meant to save)."""
         if self.zero is None or self.m is None:
             return self.m, self.v
         rank, ranges, gather = self.zero
         lo, hi = ranges[rank]
         out = []
         for t in (self.m, self.v):
-            full = torch.zeros(self.n, dtype=torch.float32, device=self.device)
-            full[lo:hi].copy_(t)
-            gather(full, ranges)
+            full = torch.empty(self.n, dtype=torch.float32)                  # host
+            for r, (a, b) in enumerate(ranges):
+                if b <= a:
+                    continue
+                piece = t if r == rank else torch.empty(b - a, dtype=torch.float32, device=self.device)
+                gather(piece, [(0, b - a) if q == r else (0, 0) for q in range(len(ranges))])     # one broadcast: owner r's slice
+                full[a:b].copy_(piece)
+                del piece
             out.append(full)
         return out[0], out[1]
 

@@ -26,8 +26,8 @@ _GROUPS = {
     "data": [
         ("--input-dataset", str, "./dataset/", "Preprocessed dataset folder (embeddings/*.npy, captions/*.parquet, encoder_config.yaml)."),
         ("--output-folder", str, "./models/", "Where checkpoints and the model config are written."),
-        ("--reader-max-piece-size", int, 50, "Accepted for compatibility with the embedding-reader flags."),
-        ("--reader-parallel-pieces", int, 10, "Accepted for compatibility with the embedding-reader flags."),
+        ("--reader-max-piece-size", int, 50, "MB of embeddings one reader worker loads (and tokenises) at a time (embedding-reader's max_piece_size)."),
+        ("--reader-parallel-pieces", int, 10, "Pieces read / tokenised concurrently by background workers, delivered in order (embedding-reader's parallel_pieces; 0 = on the training thread)."),
     ],
     "deepspeed": [
         ("--enable-deepspeed", bool, False, "No DeepSpeed here (one process per GPU + RCCL always); kept for its one numerical effect in the reference: "

@@ -4,14 +4,26 @@ with a ``caption`` column) — the contract of clipcap/train/dataloader.py:11-66
 
     batch = (tokens int64 (B, max_token_length) right-padded with -1 / truncated, embeds float32 (B, E))
 
-The reference delegates to the un-vendored ``embedding_reader`` package; this is a native reader: ``np.load(mmap_mode="r")``
-per shard, pyarrow for captions, contiguous per-rank row ranges (the reference does not shard at all, dataloader.py:84-91),
-pinned host staging and an async H2D copy on a side stream so the next batch uploads while the current step runs.
+The reference delegates to the un-vendored ``embedding_reader`` package, which reads ``parallel_pieces`` pieces of at most
+``max_piece_size`` MB concurrently and hands batches out in order (dataloader.py:32-37, 53-63).  This is a native reader with the same two
+knobs: ``np.load(mmap_mode="r")`` per shard, pyarrow for captions, contiguous per-rank row ranges (the reference does not shard at all,
+dataloader.py:84-91); a bounded background pipeline of ``reader_parallel_pieces`` workers, each reading + tokenising + padding one PIECE
+(consecutive global batches, at most ``reader_max_piece_size`` MB of embeddings) at a time, delivered strictly in order — worker PROCESSES
+(spawned once, reused across epochs) whenever the tokenizer can be pickled: the tokenizers library does not tokenise concurrently from
+several threads of one interpreter (measured: 4 threads = 4 sequential calls), and 256 captions cost ~6 ms of it per 10 ms step; threads
+otherwise; persistent
+pinned staging buffers and an async H2D copy on a side stream (DevicePrefetcher), so that the training thread does no shard I/O and no
+tokenisation between launches (bench.py --mode e2e measures what is left).
 """
 from __future__ import annotations
 
 import glob
+import multiprocessing
 import os
+import pickle
+import threading
+from collections import OrderedDict, deque
+from concurrent.futures import ProcessPoolExecutor, ThreadPoolExecutor
 from typing import Iterator, List, Optional, Tuple
 
 import numpy as np
@@ -33,13 +45,22 @@ class ShardIndex:
         self.count = int(self.starts[-1])
         self.dimension = int(self.arrays[0].shape[-1])
         self.sample_shape = tuple(self.arrays[0].shape[1:])
-        self._caps: dict = {}
+        self._caps: "OrderedDict[int, List[str]]" = OrderedDict()      # a few decoded caption shards (worker threads read concurrently)
+        self._caps_lock = threading.Lock()
 
     def _captions(self, shard: int) -> List[str]:
-        if shard not in self._caps:
-            import pyarrow.parquet as pq
-            self._caps = {shard: pq.read_table(self.cap_files[shard], columns=["caption"]).column("caption").to_pylist()}
-        return self._caps[shard]
+        with self._caps_lock:
+            caps = self._caps.get(shard)
+            if caps is not None:
+                self._caps.move_to_end(shard)
+                return caps
+        import pyarrow.parquet as pq
+        caps = pq.read_table(self.cap_files[shard], columns=["caption"]).column("caption").to_pylist()
+        with self._caps_lock:
+            self._caps[shard] = caps
+            while len(self._caps) > 4:
+                self._caps.popitem(last=False)
+        return caps
 
     def rows(self, lo: int, hi: int) -> Tuple[np.ndarray, List[str]]:
         embs, caps = [], []
@@ -61,19 +82,42 @@ def pad_tokens(ids: List[int], max_token_length: int) -> np.ndarray:
     return out
 
 
+_WORKER_DS = None      # reader worker process: its own sequential EmbedDataset (own mmaps, own tokenizer copy)
+
+
+def _reader_worker_init(kwargs: dict) -> None:
+    global _WORKER_DS
+    try:
+        torch.set_num_threads(1)
+    except RuntimeError:
+        pass
+    _WORKER_DS = EmbedDataset(**kwargs)
+
+
+def _reader_worker_piece(lo: int, hi: int):
+    """One piece in a worker process: numpy arrays travel back (cheaper to pickle than tensors)."""
+    return [(t.numpy(), e.numpy()) for t, e in _WORKER_DS.load_piece(lo, hi)]
+
+
 class EmbedDataset(torch.utils.data.IterableDataset):
     """Same constructor arguments as the reference's EmbedDataset (dataloader.py:16-17) + rank/world for sharding."""
 
     def __init__(self, data_path: str = "./dataset/", language_model: str = "gpt2-xl", batch_size: int = 256,
                  reader_max_piece_size: int = 50, reader_parallel_pieces: int = 10, max_token_length: int = 64, tokenizer=None,
-                 rank: int = 0, world_size: int = 1) -> None:
+                 rank: int = 0, world_size: int = 1, reader_backend: str = "auto") -> None:
+        """``reader_backend``: "process" / "thread" / "auto" (processes when the tokenizer pickles, see the module docstring)."""
         super().__init__()
+        self.data_path, self.language_model = data_path, language_model
+        self.reader_backend = reader_backend
+        self._pool = None
         if tokenizer is None:
             from clipcap_amd.model.model import get_tokenizer
             tokenizer = get_tokenizer(language_model)
         self.tokenizer = tokenizer
         self.batch_size = batch_size
         self.max_token_length = max_token_length
+        self.reader_max_piece_size = reader_max_piece_size          # MB of embeddings read (and tokenised) by one worker at a time
+        self.reader_parallel_pieces = reader_parallel_pieces        # pieces in flight = worker threads (<= 0: everything on the caller's thread)
         self.index = ShardIndex(data_path)
         self.encoder_embedding_size = self.index.dimension
         self.rank, self.world_size = rank, world_size
@@ -88,25 +132,142 @@ class EmbedDataset(torch.utils.data.IterableDataset):
     def encode(self, captions: List[str]) -> np.ndarray:
         enc = self.tokenizer.batch_encode_plus(captions)["input_ids"] if hasattr(self.tokenizer, "batch_encode_plus") \
             else [self.tokenizer.encode(c) for c in captions]
-        return np.stack([pad_tokens(ids, self.max_token_length) for ids in enc])
+        # dataloader.py:41-50 for the whole piece at once (right-pad with -1 / truncate) without a Python-level loop over tokens: the workers
+        # share the interpreter lock with the training thread, so everything here is one C-level pass (chain -> fromiter -> fancy index)
+        import itertools
+        L, n = self.max_token_length, len(enc)
+        lens = np.fromiter(map(len, enc), dtype=np.int64, count=n)
+        flat = np.fromiter(itertools.chain.from_iterable(enc), dtype=np.int64, count=int(lens.sum()))
+        rows = np.repeat(np.arange(n), lens)
+        cols = np.arange(flat.size) - np.repeat(np.cumsum(lens) - lens, lens)
+        keep = cols < L
+        out = np.full((n, L), -1, dtype=np.int64)
+        out[rows[keep], cols[keep]] = flat[keep]
+        return out
 
-    def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
+    MAX_BATCHES_PER_PIECE = 8      # a piece is also bounded in batches, so that the first batch of an epoch is not behind 50 MB of tokenisation
+
+    def pieces(self) -> List[Tuple[int, int]]:
+        """Global row ranges [lo, hi) of the pieces of one epoch: whole global batches (the last one may be partial), at most
+        reader_max_piece_size MB of embeddings and MAX_BATCHES_PER_PIECE batches each.  Identical on every rank."""
+        gb = self.batch_size * self.world_size
+        row_bytes = 4 * int(np.prod(self.index.sample_shape))
+        k = max(1, min(self.MAX_BATCHES_PER_PIECE, int(self.reader_max_piece_size * (1 << 20)) // max(1, gb * row_bytes)))
+        out = []
+        for lo in range(0, self.index.count, gb * k):
+            out.append((lo, min(self.index.count, lo + gb * k)))
+        return out
+
+    def load_piece(self, lo: int, hi: int) -> List[Tuple[torch.Tensor, torch.Tensor]]:
+        """This rank's batches of the global rows [lo, hi): shard reads, ONE tokeniser call for the whole piece, padding."""
         from clipcap_amd.train.ddp import shard_range
         gb = self.batch_size * self.world_size
-        for lo in range(0, self.index.count, gb):
-            hi = min(self.index.count, lo + gb)
-            if hi - lo < self.world_size:          # fewer rows than ranks: no rank takes this step (see __len__)
+        embs, caps, counts = [], [], []
+        for b0 in range(lo, hi, gb):
+            b1 = min(hi, b0 + gb)
+            if b1 - b0 < self.world_size:          # fewer rows than ranks: no rank takes this step (see __len__)
                 break
-            a, b = shard_range(hi - lo, self.rank, self.world_size)
-            emb, caps = self.index.rows(lo + a, lo + b)
-            yield torch.from_numpy(self.encode(caps)), torch.from_numpy(np.ascontiguousarray(emb))
+            a, b = shard_range(b1 - b0, self.rank, self.world_size)
+            e, c = self.index.rows(b0 + a, b0 + b)
+            embs.append(e)
+            caps += c
+            counts.append(b - a)
+        if not counts:
+            return []
+        toks = self.encode(caps)
+        out, at = [], 0
+        for e, n in zip(embs, counts):
+            out.append((torch.from_numpy(toks[at:at + n]), torch.from_numpy(np.ascontiguousarray(e))))
+            at += n
+        return out
+
+    def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
+        pieces = self.pieces()
+        par = int(self.reader_parallel_pieces)
+        if par <= 0:
+            for lo, hi in pieces:
+                yield from self.load_piece(lo, hi)
+            return
+        # bounded, ordered: at most `par` pieces are being read / tokenised ahead of the consumer; results are handed out in piece order
+        ex, own = self._executor(par)
+        conv = (lambda bs: [(torch.from_numpy(t), torch.from_numpy(e)) for t, e in bs]) if isinstance(ex, ProcessPoolExecutor) else (lambda bs: bs)
+        fn = _reader_worker_piece if isinstance(ex, ProcessPoolExecutor) else self.load_piece
+        pending: deque = deque()
+        it = iter(pieces)
+        try:
+            for _ in range(par):
+                nxt = next(it, None)
+                if nxt is None:
+                    break
+                pending.append(ex.submit(fn, *nxt))
+            first = True
+            while pending:
+                fut = pending.popleft()
+                try:
+                    # a worker process that cannot start (an un-importable __main__, a tokenizer that unpickles badly) must not hang the run
+                    batches = conv(fut.result(timeout=300 if first and not own else None))
+                except Exception as e:       # BrokenProcessPool, TimeoutError, an exception raised in the worker
+                    if own:
+                        raise
+                    import warnings
+                    warnings.warn(f"clipcap_amd reader: worker processes failed ({type(e).__name__}: {e}); reading on threads instead")
+                    self.close()
+                    self.reader_backend = "thread"
+                    done = len(pieces) - len(pending) - 1 - sum(1 for _ in it)          # pieces already delivered
+                    for lo, hi in pieces[done:]:
+                        yield from self.load_piece(lo, hi)
+                    return
+                first = False
+                nxt = next(it, None)
+                if nxt is not None:
+                    pending.append(ex.submit(fn, *nxt))
+                yield from batches
+        finally:
+            for f in pending:
+                f.cancel()
+            if own:
+                ex.shutdown(wait=True, cancel_futures=True)
+
+    def _executor(self, par: int):
+        """(executor, caller_owns_it).  The process pool is created once and kept for the following epochs (a spawned worker imports torch:
+        seconds, once); a thread pool is per epoch."""
+        backend = self.reader_backend
+        if backend == "auto":
+            try:
+                pickle.dumps(self.tokenizer)
+                backend = "process"
+            except Exception:      # a tokenizer that cannot travel (a local class, an object holding handles): threads
+                backend = "thread"
+        if backend == "thread":
+            return ThreadPoolExecutor(max_workers=par, thread_name_prefix="clipcap-reader"), True
+        if self._pool is None or self._pool[1] != par:
+            self.close()
+            kwargs = dict(data_path=self.data_path, language_model=self.language_model, batch_size=self.batch_size,
+                          reader_max_piece_size=self.reader_max_piece_size, reader_parallel_pieces=0, max_token_length=self.max_token_length,
+                          tokenizer=self.tokenizer, rank=self.rank, world_size=self.world_size)
+            # spawn, not fork: the parent holds a HIP runtime and (in train()) RCCL threads
+            ex = ProcessPoolExecutor(max_workers=par, mp_context=multiprocessing.get_context("spawn"), initializer=_reader_worker_init, initargs=(kwargs,))
+            self._pool = (ex, par)
+        return self._pool[0], False
+
+    def close(self) -> None:
+        if self._pool is not None:
+            self._pool[0].shutdown(wait=False, cancel_futures=True)
+            self._pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def get_dataloader(data_path: str = "./dataset/", language_model: str = "gpt2-xl", batch_size: int = 256, tokenizer=None, rank: int = 0,
-                   world_size: int = 1):
+                   world_size: int = 1, reader_max_piece_size: int = 50, reader_parallel_pieces: int = 10, max_token_length: int = 64):
     """Returns (iterable of batches, encoder_embedding_size) like dataloader.py:69-92."""
     ds = EmbedDataset(data_path=data_path, language_model=language_model, batch_size=batch_size, tokenizer=tokenizer, rank=rank,
-                      world_size=world_size)
+                      world_size=world_size, reader_max_piece_size=reader_max_piece_size, reader_parallel_pieces=reader_parallel_pieces,
+                      max_token_length=max_token_length)
     return ds, ds.encoder_embedding_size
 
 
@@ -123,15 +284,30 @@ def trim_padding(tokens: torch.Tensor, multiple: int = 8) -> torch.Tensor:
 
 
 class DevicePrefetcher:
-    """Uploads batch i+1 (pinned staging + non_blocking copy on a side stream) while batch i is being consumed; trims the
-    all-padding tail of the token batch on the host first (``trim_padding``)."""
+    """Uploads batch i+1 while batch i is being consumed: the all-padding tail of the token batch is trimmed on the host (``trim_padding``),
+    the batch is copied into one of ``depth`` PERSISTENT pinned staging buffers (a fresh ``pin_memory()`` per batch is a hipHostMalloc per
+    step) and sent with a non-blocking copy on a side stream; a staging buffer is reused only after the copy that read it has finished."""
 
-    def __init__(self, it, device, trim: bool = True):
+    def __init__(self, it, device, trim: bool = True, depth: int = 2):
         self.it = iter(it)
         self.trim = trim
         self.device = torch.device(device)
         self.stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
+        self._slots = [None] * max(2, depth)       # (pinned token bytes, pinned embedding bytes, event of the last copy out of them)
+        self._n = 0
         self._next = self._load()
+
+    def _staged(self, slot, which, t: torch.Tensor) -> torch.Tensor:
+        need = t.numel() * t.element_size()
+        buf = slot[which]
+        if buf is None or buf.numel() < need:
+            buf = torch.empty(max(need, 1), dtype=torch.uint8).pin_memory()
+            slot[which] = buf
+        view = buf[:need].view(t.dtype).view(t.shape)
+        # a plain single-threaded memcpy: torch's copy_ splits half a megabyte over the intra-op thread pool, and waking that pool from the
+        # training loop cost 5-25 ms per step on a 256-core host (tools/e2e_host_profile.py) against 5 us for the copy itself
+        np.copyto(view.numpy(), t.numpy())
+        return view
 
     def _load(self):
         try:
@@ -142,8 +318,18 @@ class DevicePrefetcher:
             tokens = trim_padding(tokens)
         if self.stream is None:
             return tokens, emb
+        i = self._n % len(self._slots)
+        self._n += 1
+        if self._slots[i] is None:
+            self._slots[i] = [None, None, torch.cuda.Event()]
+        slot = self._slots[i]
+        if slot[0] is not None:
+            slot[2].synchronize()                   # the H2D copy that last read these staging buffers is done
+        pt, pe = self._staged(slot, 0, tokens), self._staged(slot, 1, emb)
         with torch.cuda.stream(self.stream):
-            return tokens.pin_memory().to(self.device, non_blocking=True), emb.pin_memory().to(self.device, non_blocking=True)
+            out = pt.to(self.device, non_blocking=True), pe.to(self.device, non_blocking=True)
+            slot[2].record(self.stream)
+        return out
 
     def __iter__(self):
         return self

@@ -120,10 +120,16 @@ def zero_stage(strategy: Optional[str]) -> int:
     (they are what the kernels read), so every stage >= 1 shards the optimizer state — the largest of the three for AdamW."""
     if not strategy:
         return 0
-    s = str(strategy).lower()
-    for d in "321":
-        if d in s:
-            return 1
+    s = str(strategy).strip().lower()
+    import re
+    if s == "deepspeed":                       # Lightning's plain "deepspeed" strategy is ZeRO stage 2
+        return 1
+    m = re.fullmatch(r"(?:deepspeed_)?(?:stage_)?([0-3])(?:_offload(?:_nvme)?)?", s) or re.fullmatch(r"zero_?([0-3])", s)
+    if m:
+        return 1 if int(m.group(1)) >= 1 else 0
+    import warnings
+    warnings.warn(f"--deepspeed-strategy {strategy!r} is not one of Lightning's DeepSpeed strategy names (deepspeed, deepspeed_stage_1/2/3[_offload]); "
+                  "optimizer state stays replicated")
     return 0
 
 

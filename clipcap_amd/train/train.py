@@ -32,7 +32,9 @@ def grad_wire_dtype(op_dtype: int, train_lm: bool) -> torch.dtype:
     return torch.bfloat16
 
 
-def train(args: Namespace, tokenizer=None, language_model=None) -> int:
+def train(args: Namespace, tokenizer=None, language_model=None, step_hook=None) -> int:
+    """``step_hook(step, model)`` (optional, not in the reference): called after every optimizer step has been enqueued — a measurement hook
+    (bench.py --mode e2e times the loop with it), never used by ``python -m clipcap_amd.train``."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -46,7 +48,10 @@ def train(args: Namespace, tokenizer=None, language_model=None) -> int:
     with open(Path(args.input_dataset) / "encoder_config.yaml", "r") as f:      # train.py:26-29
         encoder_config = EncoderConfig(**yaml.safe_load(f))
     dataset, encoder_embedding_size = get_dataloader(args.input_dataset, args.language_model, args.batch_size, tokenizer=tokenizer,
-                                                     rank=rank, world_size=world)
+                                                     rank=rank, world_size=world,
+                                                     reader_max_piece_size=getattr(args, "reader_max_piece_size", 50),
+                                                     reader_parallel_pieces=getattr(args, "reader_parallel_pieces", 10),
+                                                     max_token_length=getattr(args, "max_token_length", 64))
     encoder_config.encoder_embedding_size = encoder_embedding_size
     args.total_steps = len(dataset) * args.epochs                                # train.py:40
     config = Config.from_args(args)
@@ -101,6 +106,8 @@ def train(args: Namespace, tokenizer=None, language_model=None) -> int:
         for batch in DevicePrefetcher(dataset, device):
             loss = model.fused_step(batch, lr=args.optimizer_lr * sched(step), reducer=reducer)
             step += 1
+            if step_hook is not None:
+                step_hook(step, model)
             if rank == 0 and step % max(1, args.logging_frequency) == 0:
                 val = float(loss)
                 print(f"epoch {epoch} step {step}/{args.total_steps} loss {val:.4f}", flush=True)

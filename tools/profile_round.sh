@@ -38,4 +38,19 @@ cp $ROOT/profiles/pmc_constants.json $OUT/pmc_constants.json
 rm -rf $OUT/prof_pmc_train_* $OUT/prof_pmc_decode_*
 # the training step in the split-bf16 (fp32 parity) mode
 run_trace x3_train python $ROOT/bench.py --precision 32 --steps 6 --warmup 2 --no-cpu-baseline --no-sub-benches --no-roofline-pass
+# MFMA utilisation (north_star: "rocprof counters reporting ... MFMA utilisation"): SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE in their own passes over the
+# bf16 step, the split-bf16 step and one beam decode; tools/mfma_util.py -> <tag>_mfma_utilisation.md and the "mfma_busy" entry of pmc_constants.json
+for leg in train x3_train decode; do
+    case $leg in
+        train) CMD="python $ROOT/bench.py --steps 2 --warmup 1 --regions 1 --no-cpu-baseline --no-sub-benches --no-roofline-pass" ;;
+        x3_train) CMD="python $ROOT/bench.py --precision 32 --steps 2 --warmup 1 --regions 1 --no-cpu-baseline --no-sub-benches --no-roofline-pass" ;;
+        decode) CMD="python $ROOT/bench.py --mode decode --steps 1 --warmup 1" ;;
+    esac
+    rm -rf $OUT/prof_mfma_$leg
+    rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format rocpd -d $OUT/prof_mfma_$leg -- $CMD > /dev/null 2>&1
+done
+python $ROOT/tools/mfma_util.py train=$(find $OUT/prof_mfma_train -name "*.db" | head -1) x3_train=$(find $OUT/prof_mfma_x3_train -name "*.db" | head -1) \
+    decode=$(find $OUT/prof_mfma_decode -name "*.db" | head -1) --json $ROOT/profiles/pmc_constants.json > $OUT/${TAG}_mfma_utilisation.md
+cp $ROOT/profiles/pmc_constants.json $OUT/pmc_constants.json
+rm -rf $OUT/prof_mfma_*
 cd $ROOT
