@@ -843,7 +843,8 @@ def main():
     if world > 1:
         rccl_ranks = (comm.count() if comm is not None else torch.distributed.get_world_size()) if backend == "nccl" else 0
         torch.distributed.destroy_process_group()
-        print(f"[bench rank {rank}] left the process group", file=sys.stderr, flush=True)
+        sys.stderr.write(f"[bench rank {rank}] left the process group\n")      # one write: eight ranks share the pipe
+        sys.stderr.flush()
     if rank != 0:
         return
     value = B * world * args.steps / dt

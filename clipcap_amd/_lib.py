@@ -99,9 +99,11 @@ SIGNATURES = {
     "cc_decode_fwd_p": (_I, [_GC, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P]),
     "cc_decode_fwd_g": (_I, [_GC, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _L, _P, _P]),
     "cc_decode_ws_check": (_I, [_GC, _I, _I, _P, _P]),
+    "cc_decode_image_bytes": (_L, [_GC]),
+    "cc_decode_image": (_I, [_GC, _P, _P, _P]),
     "cc_decode_xt_image_bytes": (_L, [_GC]),
     "cc_decode_xt_image": (_I, [_GC, _P, _P, _P]),
-    "cc_decode_fwd_x": (_I, [_GC, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _P, _P]),
+    "cc_decode_fwd_x": (_I, [_GC, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _P, _P]),
     "cc_beam_step_p": (_I, [_I, _I, _I, _P, _L, _P, _I, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "cc_decode_reorder": (_I, [_GC, _I, _I, _I, _I, _P, _P, _P, _P]),
     "cc_beam_step": (_I, [_I, _I, _I, _P, _L, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P]),

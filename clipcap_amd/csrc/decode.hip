@@ -1082,10 +1082,11 @@ int64_t CC_API(cc_decode_part_floats)(const cc_gpt2_cfg* cfg, int32_t R) {
 }
 
 int CC_API(cc_decode_fwd_x)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int32_t ctx_max, const float* w32, const uint16_t* w16, const uint16_t* wimg,
-                    const float* x, uint16_t* kv, const int32_t* row_map, int32_t group, void* ws, float* logits, int64_t ldl, float* lpart, void* stream);
+                    const uint16_t* wteam, const float* x, uint16_t* kv, const int32_t* row_map, int32_t group, void* ws, float* logits, int64_t ldl, float* lpart,
+                    void* stream);
 int CC_API(cc_decode_fwd_g)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int32_t ctx_max, const float* w32, const uint16_t* w16,
                     const float* x, uint16_t* kv, const int32_t* row_map, int32_t group, void* ws, float* logits, int64_t ldl, float* lpart, void* stream) {
-    return CC_API(cc_decode_fwd_x)(c, R, Tn, pos0, ctx_max, w32, w16, nullptr, x, kv, row_map, group, ws, logits, ldl, lpart, stream);
+    return CC_API(cc_decode_fwd_x)(c, R, Tn, pos0, ctx_max, w32, w16, nullptr, nullptr, x, kv, row_map, group, ws, logits, ldl, lpart, stream);
 }
 
 int CC_API(cc_decode_fwd)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int32_t ctx_max, const float* w32, const uint16_t* w16,
@@ -1096,6 +1097,32 @@ int CC_API(cc_decode_fwd)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t p
 int CC_API(cc_decode_fwd_p)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int32_t ctx_max, const float* w32, const uint16_t* w16,
                     const float* x, uint16_t* kv, const int32_t* row_map, void* ws, float* logits, int64_t ldl, float* lpart, void* stream) {
     return CC_API(cc_decode_fwd_g)(c, R, Tn, pos0, ctx_max, w32, w16, x, kv, row_map, 1, ws, logits, ldl, lpart, stream);
+}
+
+// fragment-ordered images of the four GEMM weights of every block, at their arena offsets (include/clipcap_hip.h)
+int64_t CC_API(cc_decode_image_bytes)(const cc_gpt2_cfg* c) {
+    if (!cfg_ok(c) || kX3 || (c->D % 64)) return 0;
+    const int64_t D = c->D;
+    return 2 * ((int64_t)c->Vp * D + (int64_t)c->NPOS * D + (int64_t)c->NL * (12 * D * D + 13 * D) + 2 * D);
+}
+
+int CC_API(cc_decode_image)(const cc_gpt2_cfg* c, const uint16_t* w16, uint16_t* wimg, void* stream) {
+    if (!cfg_ok(c) || !w16 || !wimg) return CC_ERR_ARG;
+    if (kX3 || (c->D % 64)) return CC_ERR_SHAPE;
+    const int64_t D = c->D;
+    const int64_t layer0 = (int64_t)c->Vp * D + (int64_t)c->NPOS * D;
+    const int64_t total = layer0 + (int64_t)c->NL * (12 * D * D + 13 * D) + 2 * D;
+    const op16_t* w16t = reinterpret_cast<const op16_t*>(w16) + total;       // transposed Conv1D weights: [N][K], K contiguous
+    op16_t* img = reinterpret_cast<op16_t*>(wimg);
+    for (int l = 0; l < c->NL; l++) {
+        const int64_t base = layer0 + (int64_t)l * (12 * D * D + 13 * D);
+        const int64_t aw = base + 2 * D, pw = aw + 3 * D * D + 3 * D, fw = pw + D * D + 3 * D, p2w = fw + 4 * D * D + 4 * D;
+        CC_TRY(skinny_image(w16t + aw, img + aw, 3 * c->D, c->D, S_(stream)));
+        CC_TRY(skinny_image(w16t + pw, img + pw, c->D, c->D, S_(stream)));
+        CC_TRY(skinny_image(w16t + fw, img + fw, 4 * c->D, c->D, S_(stream)));
+        CC_TRY(skinny_image(w16t + p2w, img + p2w, c->D, 4 * c->D, S_(stream)));
+    }
+    return CC_OK;
 }
 
 int64_t CC_API(cc_decode_xt_image_bytes)(const cc_gpt2_cfg* c) {
@@ -1113,7 +1140,8 @@ int CC_API(cc_decode_xt_image)(const cc_gpt2_cfg* c, const uint16_t* w16, uint16
 }
 
 int CC_API(cc_decode_fwd_x)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int32_t ctx_max, const float* w32, const uint16_t* w16, const uint16_t* wimg,
-                    const float* x, uint16_t* kv, const int32_t* row_map, int32_t group, void* ws, float* logits, int64_t ldl, float* lpart, void* stream) {
+                    const uint16_t* wteam, const float* x, uint16_t* kv, const int32_t* row_map, int32_t group, void* ws, float* logits, int64_t ldl, float* lpart,
+                    void* stream) {
     if (group < 1 || (R > 0 && R % group)) return CC_ERR_ARG;
     if (!cfg_ok(c) || R <= 0 || Tn <= 0 || pos0 < 0 || !w32 || !w16 || !x || !kv || !ws || !logits) return CC_ERR_ARG;
     const int Ns = std::min(c->Vp, (c->V + 7) / 8 * 8);
@@ -1152,10 +1180,10 @@ int CC_API(cc_decode_fwd_x)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t
     bool hf_ready = false;
     int l_first = 0;
     if (one && group >= 2) cc_shared::g_decode_last_path = 0;
-    if (grp_attn && one && !kX3 && wimg && (cc_shared::g_decode_mode & 4)) {
+    if (grp_attn && one && !kX3 && wteam && (cc_shared::g_decode_mode & 4)) {
         // XCD-team engine (decode_xt.hip): every XCD runs the whole stack for its own captions; CC_ERR_SHAPE = not covered -> the paths below
         XtLaunch L{};
-        L.w32 = w32; L.wimg = reinterpret_cast<const op16_t*>(wimg); L.D = D; L.H = H; L.NL = c->NL; L.M = M; L.group = group; L.pos0 = pos0; L.ctx_max = ctx_max;
+        L.w32 = w32; L.wimg = reinterpret_cast<const op16_t*>(wteam); L.D = D; L.H = H; L.NL = c->NL; L.M = M; L.group = group; L.pos0 = pos0; L.ctx_max = ctx_max;
         L.layer0 = p; L.x = w.x; L.x1 = w.x1; L.qkv = w.qkv; L.att = w.att; L.hact = w.hact; L.hf = w.hf;
         L.kv = reinterpret_cast<act_t*>(kv); L.cache_layer = cache_layer; L.ent = w.grp_ent; L.cnt = w.grp_cnt; L.cap = grp_cap;
         L.ctl = w.xt_ctl; L.sticky = w.xt_ctl + XT_CTL_WORDS;
@@ -1204,6 +1232,8 @@ int CC_API(cc_decode_fwd_x)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t
             return rc;
         }
     }
+    // fragment-ordered weight image (cc_decode_image): the K-over-the-waves GEMMs then load the weight operand global -> VGPR
+    const op16_t* bimg = (!kX3 && wimg && (cc_shared::g_decode_mode & 8)) ? reinterpret_cast<const op16_t*>(wimg) : nullptr;
     for (int l = l_first; l < c->NL; l++) {
         const int64_t l1w = p; p += D;
         const int64_t l1b = p; p += D;
@@ -1225,9 +1255,9 @@ int CC_API(cc_decode_fwd_x)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t
         const bool f_qkv = gemm_nt_skinny_can_fuse(M, 3 * D, D, w.scratch_bytes) &&
                            ((M + 127) / 128) * ((3 * D + 127) / 128) < skinny_single_min_tiles();
         SkinnyFuse fq;
-        fq.kcache = kc; fq.vcache = vc; fq.Tn = Tn; fq.pos0 = pos0; fq.ctx_max = ctx_max;
-        CC_TRY(gemm_nt_skinny(w.xn, D, w16t + (size_t)PL * aw, D, M, 3 * D, D, w32 + ab, 0, nullptr, nullptr, w.qkv, 3 * D, w.scratch, w.scratch_bytes, st,
-                              f_qkv ? &fq : nullptr));
+        if (f_qkv) { fq.kcache = kc; fq.vcache = vc; fq.Tn = Tn; fq.pos0 = pos0; fq.ctx_max = ctx_max; }
+        fq.bimg = bimg ? bimg + aw : nullptr;
+        CC_TRY(gemm_nt_skinny(w.xn, D, w16t + (size_t)PL * aw, D, M, 3 * D, D, w32 + ab, 0, nullptr, nullptr, w.qkv, 3 * D, w.scratch, w.scratch_bytes, st, &fq));
         if (grp_attn) {
             const int ng = R / group, app = f_qkv ? 0 : 1;
 #define CC_GRP(G_)                                                                                                                            \
@@ -1250,18 +1280,21 @@ int CC_API(cc_decode_fwd_x)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t
         // attn.c_proj + residual (+ fused ln_2)
         const bool f_d = gemm_nt_skinny_can_fuse(M, D, D, w.scratch_bytes) && gemm_nt_skinny_can_fuse(M, D, 4 * D, w.scratch_bytes);
         SkinnyFuse f2;
-        f2.ln_gamma = w32 + l2w; f2.ln_beta = w32 + l2b; f2.ln_out16 = w.xn;
-        CC_TRY(gemm_nt_skinny(w.att, D, w16t + (size_t)PL * pw, D, M, D, D, w32 + pb, 0, w.x, w.x1, nullptr, D, w.scratch, w.scratch_bytes, st, f_d ? &f2 : nullptr));
+        if (f_d) { f2.ln_gamma = w32 + l2w; f2.ln_beta = w32 + l2b; f2.ln_out16 = w.xn; }
+        f2.bimg = bimg ? bimg + pw : nullptr;
+        CC_TRY(gemm_nt_skinny(w.att, D, w16t + (size_t)PL * pw, D, M, D, D, w32 + pb, 0, w.x, w.x1, nullptr, D, w.scratch, w.scratch_bytes, st, &f2));
         if (!f_d) CC_TRY(ln_fwd(w.x1, D, nullptr, w32 + l2w, w32 + l2b, w.xn, nullptr, nullptr, nullptr, M, D, st));
-        CC_TRY(gemm_nt_skinny(w.xn, D, w16t + (size_t)PL * fw, D, M, 4 * D, D, w32 + fb, 2, nullptr, nullptr, w.hact, 4 * D, w.scratch, w.scratch_bytes, st));
+        SkinnyFuse f3;
+        f3.bimg = bimg ? bimg + fw : nullptr;
+        CC_TRY(gemm_nt_skinny(w.xn, D, w16t + (size_t)PL * fw, D, M, 4 * D, D, w32 + fb, 2, nullptr, nullptr, w.hact, 4 * D, w.scratch, w.scratch_bytes, st, &f3));
         // mlp.c_proj + residual (+ fused ln_1 of the next layer: its parameters sit right behind this layer's in the arena)
         // (after the LAST layer p points at ln_f: with one new position per row the finishing pass normalises straight into hf)
         const bool last = l + 1 == c->NL;
         const bool f_next = f_d && (!last || one);
         SkinnyFuse f1;
-        f1.ln_gamma = w32 + p; f1.ln_beta = w32 + p + D; f1.ln_out16 = last ? w.hf : w.xn;       // p now points at layer l+1's ln_1.weight (or ln_f)
-        CC_TRY(gemm_nt_skinny(w.hact, 4 * D, w16t + (size_t)PL * p2w, 4 * D, M, D, 4 * D, w32 + p2b, 0, w.x1, w.x, nullptr, D, w.scratch, w.scratch_bytes, st,
-                              f_next ? &f1 : nullptr));
+        if (f_next) { f1.ln_gamma = w32 + p; f1.ln_beta = w32 + p + D; f1.ln_out16 = last ? w.hf : w.xn; }      // p now points at layer l+1's ln_1.weight (or ln_f)
+        f1.bimg = bimg ? bimg + p2w : nullptr;
+        CC_TRY(gemm_nt_skinny(w.hact, 4 * D, w16t + (size_t)PL * p2w, 4 * D, M, D, 4 * D, w32 + p2b, 0, w.x1, w.x, nullptr, D, w.scratch, w.scratch_bytes, st, &f1));
         xn_ready = f_next && !last;
         hf_ready = f_next && last;
     }

@@ -946,6 +946,151 @@ __global__ __launch_bounds__(G_THREADS, 2) void gemm_nt_s64kw_kernel(const op16_
     }
 }
 
+// The same 64 x 64 / K-over-the-waves kernel with the WEIGHT operand taken out of LDS (round 5): B comes from a
+// fragment-ordered image (k_skinny_image, cc_decode_image) — per (64-column tile, 64-k tile, wave = 16-k quarter, 32-column half) one 1-KiB
+// piece in which lane l holds W[n0 + 32 i + (l & 31)][k0 + 16 w + 8 (l >> 5) .. + 7], i.e. exactly the lane's v_mfma_f32_32x32x16 operand —
+// and is loaded global -> VGPR, fully coalesced, three K-tiles ahead.  No DMA, no LDS write, no ds_read for B: the LDS carries the 8-KiB
+// activation stage only (half the DMA bytes and half the fragment reads of gemm_nt_s64kw_kernel, whose K-step the fragment reads bound).
+// The B loads are inline asm beside the LDS-DMA of A (hipcc drains the DMA queue at any ordinary VGPR load it sees next to a
+// global_load_lds), so both queues are counted by hand: per K-tile a wave issues 2 DMA + 2 B loads, in order; tile t is complete when at
+// most 4 * (tiles issued after t) operations are outstanding.  The B registers are a ring of 4 tiles with static indices (loop unrolled x 4).
+// In the decode chain the weights are COLD (708 MB per generated position stream from HBM once; the hot-cache micro-benchmark hides it): a
+// block's K loop is then a chain of HBM round trips, nk / (tiles in flight) of them — 16 tiles at 3 in flight = 5-6 round trips of ~2 us.
+// With B in registers the prefetch depth costs registers only, not LDS: a ring of RB K-tiles (2 KiB per wave and tile).  For the depth to
+// be real the B loads must not share a vmcnt queue with the activation DMA (loads return in order: waiting for the A stage of tile t would
+// also wait for every B tile requested before it), so a FIFTH wave issues all of the A DMA (and owns its waits); waves 0-3 issue nothing
+// but their B fragments and count them exactly: vmcnt(2 (RB - 1)).
+typedef unsigned kb_u32x4 __attribute__((ext_vector_type(4)));
+template <class Epi, int RB>
+__global__ __launch_bounds__(320, RB == 16 ? 2 : 3) void gemm_nt_s64kwb_kernel(const op16_t* __restrict__ A, const op16_t* __restrict__ Bimg, GemmShape g, Epi epi) {
+    static_assert(RB == 4 || RB == 8 || RB == 16, "ring depth");
+    extern __shared__ __attribute__((aligned(1024))) char smkb[];
+    constexpr int STAGE = 64 * 128;                       // one activation stage: 64 rows x 128 B; four of them, then reused by the epilogue (64 KiB)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = (g.N + 63) / 64, tiles_m = (g.M + 63) / 64;
+    int tm, tn;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, g.group_m, tm, tn);
+    const int m0 = tm * 64, n0 = tn * 64;
+    const int kbeg = blockIdx.z * g.k_chunk;
+    const int nk = (min(g.K, kbeg + g.k_chunk) - kbeg) / G_BK;
+    const int ktot = g.K / G_BK;
+    const int last = nk - 1;
+    const int ngrp = (nk + RB - 1) / RB;                  // whole groups of RB steps; the steps beyond the last K-tile only keep the counts
+    if (wave == 4) {
+        // ---- loader wave: the activation stages (8 DMA instructions each), three K-tiles ahead
+#define KB_A(T, U)                                                                                                                    \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) {                                                                                \
+        const int row_ = i_ * 8 + (lane >> 3);                                                                                        \
+        const int chunk_ = (lane & 7) ^ ((row_ >> 1) & 7) ^ ((row_ >> 4) & 3);                                                        \
+        const op16_t* src_ = A + (size_t)min(m0 + row_, g.M - 1) * g.lda + kbeg + (T)*G_BK + chunk_ * 8;                              \
+        __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(smkb + (U)*STAGE + i_ * 1024), 16, 0, 0);                             \
+    }
+        KB_A(0, 0)
+        KB_A(min(1, last), 1)
+        KB_A(min(2, last), 2)
+        for (int t = 0; t < ngrp * RB; t++) {
+            s_wait_vm<16>();                               // tile t has landed (t + 1, t + 2 may be in flight)
+            __builtin_amdgcn_s_barrier();
+            KB_A(min(t + 3, last), (t + 3) & 3)            // that stage held K-tile t - 1: every wave is past it
+        }
+#undef KB_A
+        s_wait_vm<0>();
+    } else {
+        // this wave's two fragments of K-tile t: Bimg + (((tn * ktot + kbeg / 64 + t) * 4 + wave) * 2 + i) * 512 elements
+        const op16_t* bptr = Bimg + ((size_t)(tn * ktot + kbeg / G_BK) * 4 + wave) * 1024 + lane * 8;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+        // The ring registers must never pass through a copy: an asm load is asynchronous behind the compiler's back, so a v_mov of a ring
+        // register (a PHI at a branch that issues conditionally, or at the exit into a separate tail block) reads it before the data lands
+        // and frees it for other values that the landing load then overwrites (measured: a fault on the first shape whose K-tile count was
+        // not a multiple of the unroll).  So: ONE loop of whole groups, every step issues its two loads (K-tile index clamped), the wait is a
+        // constant, and only the fragment reads + MFMAs of a step beyond the last K-tile are skipped (a branch over the accumulators only).
+        kb_u32x4 br[RB][2];
+#define KB_B(T, U)                                                                                                                    \
+    {                                                                                                                                 \
+        const op16_t* bp_ = bptr + (size_t)(T)*4096;                                                                                  \
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(br[U][0]) : "v"(bp_) : "memory");                                       \
+        asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(br[U][1]) : "v"(bp_) : "memory");                           \
+    }
+#pragma unroll
+        for (int t = 0; t < RB; t++) KB_B(min(t, last), t)
+        const int frow = lane & 31, ch = wave * 2 + (lane >> 5);
+        for (int kt0 = 0; kt0 < ngrp * RB; kt0 += RB) {
+#pragma unroll
+            for (int u = 0; u < RB; u++) {
+                const int kt = kt0 + u;
+                if constexpr (RB == 4) asm volatile("s_waitcnt vmcnt(6)" : "+v"(br[u][0]), "+v"(br[u][1])::"memory");
+                else if constexpr (RB == 8) asm volatile("s_waitcnt vmcnt(14)" : "+v"(br[u][0]), "+v"(br[u][1])::"memory");
+                else asm volatile("s_waitcnt vmcnt(30)" : "+v"(br[u][0]), "+v"(br[u][1])::"memory");
+                __builtin_amdgcn_s_barrier();
+                if (kt <= last) {
+                    const char* cur_ = smkb + (kt & 3) * STAGE;
+                    const op16x8 a0_ = *reinterpret_cast<const op16x8*>(cur_ + g_lds_off(frow, ch));
+                    const op16x8 a1_ = *reinterpret_cast<const op16x8*>(cur_ + g_lds_off(32 + frow, ch));
+                    const op16x8 b0_ = __builtin_bit_cast(op16x8, br[u][0]), b1_ = __builtin_bit_cast(op16x8, br[u][1]);
+                    acc[0][0] = CC_MFMA_32x32x16(a0_, b0_, acc[0][0]);
+                    acc[0][1] = CC_MFMA_32x32x16(a0_, b1_, acc[0][1]);
+                    acc[1][0] = CC_MFMA_32x32x16(a1_, b0_, acc[1][0]);
+                    acc[1][1] = CC_MFMA_32x32x16(a1_, b1_, acc[1][1]);
+                }
+                KB_B(min(kt + RB, last), u)                 // the slot just consumed
+            }
+        }
+#undef KB_B
+        // the (redundant) loads still in flight land in the ring registers: they stay the ring's until this wait
+#pragma unroll
+        for (int u = 0; u < RB; u++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(br[u][0]), "+v"(br[u][1])::"memory");
+        // partial tiles -> LDS (after every wave has left the K loop: the stages are dead)
+        __builtin_amdgcn_s_barrier();
+        float* part = reinterpret_cast<float*>(smkb);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) part[((wave * 4 + i * 2 + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+    }
+    if (wave == 4) __builtin_amdgcn_s_barrier();           // (the loader's share of the barrier above)
+    __syncthreads();
+    if (wave < 4) {
+        const float* part = reinterpret_cast<const float*>(smkb);
+#pragma unroll
+        for (int ps = 0; ps < 2; ps++) {
+            const int row = wave * 16 + ps * 8 + (lane >> 3), c8 = lane & 7;
+            const int rr = row & 31, reg = (rr >> 3) * 4 + (rr & 3), ls = (c8 & 3) * 8 + 32 * ((rr >> 2) & 1), tile = (row >> 5) * 2 + (c8 >> 2);
+            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int pw = 0; pw < 4; pw++) {
+                const float* src = part + ((pw * 4 + tile) * 16 + reg) * 64 + ls;
+                const float4 x = *reinterpret_cast<const float4*>(src), y = *reinterpret_cast<const float4*>(src + 4);
+                v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w; v[4] += y.x; v[5] += y.y; v[6] += y.z; v[7] += y.w;
+            }
+            epi(m0 + row, n0 + c8 * 8, v);
+        }
+    }
+}
+// the image a 64-column x 64-k tile of W [N][K] takes in cc_decode_image: element offset of (tile column tn, K-tile kt, wave w, half i, lane l)
+// = (((tn * (K / 64) + kt) * 4 + w) * 2 + i) * 512 + l * 8 — a permutation of the matrix, so the image has the matrix's size
+static __global__ __launch_bounds__(256) void k_skinny_image(const op16_t* __restrict__ W, op16_t* __restrict__ img, int N, int K) {
+    const size_t total = (size_t)N * K / 8;
+    const int ktot = K / 64;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int l = (int)(e & 63);
+        size_t f = e >> 6;
+        const int i = (int)(f & 1); f >>= 1;
+        const int w = (int)(f & 3); f >>= 2;
+        const int kt = (int)(f % ktot), tn = (int)(f / ktot);
+        const op16_t* src = W + (size_t)(tn * 64 + i * 32 + (l & 31)) * K + kt * 64 + w * 16 + (l >> 5) * 8;
+        reinterpret_cast<kb_u32x4*>(img)[e] = *reinterpret_cast<const kb_u32x4*>(src);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // 256-row kernels for large outputs: 8 waves, wave tile 128 x 16 NJ (8 x NJ MFMA tiles; block tile 256 x 256 for NJ = 4,
 // 256 x 192 for NJ = 3), K-tile 32, FOUR LDS stages of 32 KiB.  Per FLOP the 256 x 256 form moves half the L2->LDS bytes and
@@ -1895,7 +2040,7 @@ template <> struct epi_row_strip<EpiLMHeadExp> { static constexpr bool value = t
 // ------------------------------------------------------------------------------------------------
 template <class Epi>
 inline int launch_gemm_s64(const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, int ksplit, int nj, const Epi& epi, int* ks_eff,
-                           hipStream_t st);
+                           hipStream_t st, const op16_t* Bimg = nullptr);
 // bf16x3 build: the fused two-stage forms of the NT kernels (gemm_stag256_body<X3F>, gemm_nt_glds_x3f_kernel, gemm_nt_glds4x2_x3f_kernel); CC_X3_FUSED=0: A/B switch
 inline bool x3_fused_on() {
     static const bool on = kX3 && !(cc_lab_env("CC_X3_FUSED") && atoi(cc_lab_env("CC_X3_FUSED")) == 0);
@@ -2036,7 +2181,7 @@ inline int launch_gemm(int al, int bl, const op16_t* A, int lda, const op16_t* B
 // (epi must be an EpiF32 in slab mode when ksplit > 1).  *ks_eff returns the effective slice count.
 template <class Epi>
 inline int launch_gemm_s64(const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, int ksplit, int nj, const Epi& epi, int* ks_eff,
-                           hipStream_t st) {
+                           hipStream_t st, const op16_t* Bimg) {
     if ((K % G_BK) || (lda & 7) || (ldb & 7) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return CC_ERR_SHAPE;
     GemmShape g;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
@@ -2057,7 +2202,12 @@ inline int launch_gemm_s64(const op16_t* A, int lda, const op16_t* B, int ldb, i
         hipLaunchKernelGGL((gemm_nt_s64_kernel<Epi, NJ_, NS_, KG_>), dim3((unsigned)(tm * ((N + 64 * (NJ_) - 1) / (64 * (NJ_)))), 1, (unsigned)ksplit), \
                            dim3(G_THREADS * (KG_)), sh, st, A, B, g, epi);                                               \
     }
-    if (nj == 3) {                   // K split over the waves (gemm_nt_s64kw_kernel)
+    if (nj == 3 && Bimg && (N % 64) == 0 && ((uintptr_t)Bimg & 15) == 0) {      // ... with the weight operand global -> VGPR from its fragment-ordered image
+        constexpr size_t sh = (size_t)4 * 128 * 128;      // (the epilogue's partial tiles need the 64 KiB)
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_s64kwb_kernel<Epi, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr = true; }
+        hipLaunchKernelGGL((gemm_nt_s64kwb_kernel<Epi, 4>), dim3((unsigned)(tm * (N / 64)), 1, (unsigned)ksplit), dim3(320), sh, st, A, Bimg, g, epi);
+    } else if (nj == 3) {                   // K split over the waves (gemm_nt_s64kw_kernel)
         constexpr size_t sh = (size_t)4 * 128 * 128;
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_s64kw_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr = true; }

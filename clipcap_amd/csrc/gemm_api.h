@@ -101,7 +101,9 @@ struct SkinnyFuse {
     act_t* kcache = nullptr;           // qkv rows (N == 3*D): columns [D,2D) -> kcache, [2D,3D) -> vcache at (r*ctx_max + pos0 + t)*D
     act_t* vcache = nullptr;
     int Tn = 1, pos0 = 0, ctx_max = 0;
+    const op16_t* bimg = nullptr;      // the weight's fragment-ordered image (k_skinny_image; cc_decode_image): B is then loaded global -> VGPR where the form allows
 };
+int skinny_image(const op16_t* W, op16_t* img, int N, int K, hipStream_t st);
 int gemm_nt_skinny(const act_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, const float* bias, int act, const float* res,
                    float* out32, act_t* out16, int ldo, float* scratch, size_t scratch_bytes, hipStream_t st,
                    const SkinnyFuse* fuse = nullptr);

@@ -453,6 +453,12 @@ int gemm_nt_deepk(const act_t* Aa, int lda, const op16_t* B, int ldb, int M, int
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
 
+int skinny_image(const op16_t* W, op16_t* img, int N, int K, hipStream_t st) {
+    if ((N % 64) || (K % 64) || !W || !img) return CC_ERR_SHAPE;
+    hipLaunchKernelGGL(k_skinny_image, dim3(1024), dim3(256), 0, st, W, img, N, K);
+    return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+}
+
 int gemm_nt_skinny(const act_t* Aa, int lda, const op16_t* B, int ldb, int M, int N, int K, const float* bias, int act, const float* res,
                    float* out32, act_t* out16, int ldo, float* scratch, size_t scratch_bytes, hipStream_t st, const SkinnyFuse* fuse) {
     cc_shared::ProfScope _all(cc_shared::SITE_ALL_GEMMS, st, 2.0 * M * N * (double)K);
@@ -463,6 +469,7 @@ int gemm_nt_skinny(const act_t* Aa, int lda, const op16_t* B, int ldb, int M, in
     const size_t slab = (size_t)M * N;
     const bool can_slab = scratch && slab && (K % G_BK) == 0 && scratch_bytes >= slab * sizeof(float);
     const bool fused = fuse && (fuse->ln_out16 || fuse->kcache);
+    const op16_t* bimg = (fuse && !kX3) ? fuse->bimg : nullptr;
     // decode-sized M: 64 x 64 tiles (gemm_nt_s64_kernel) put 2.5-5x the blocks on the chip; a block's K loop is bound by what one CU
     // can pull through its L2->LDS path (~57 GB/s measured), so the job is to have every CU pulling
     const bool s64 = g_gemm_s64 != 0 && (K % G_BK) == 0 && M <= 640 && tiles <= 256 && (lda & 7) == 0 && (ldb & 7) == 0;
@@ -491,10 +498,10 @@ int gemm_nt_skinny(const act_t* Aa, int lda, const op16_t* B, int ldb, int M, in
         if (fused) return CC_ERR_SHAPE;                    // callers only request fusion when the slab path is available
         if (s64) {
             const int form = s64_form(1);
-            if (res) { EpiResid e{out32, res, bias, ldo, M, N}; return launch_gemm_s64(A, lda, B, ldb, M, N, K, 1, form, e, nullptr, st); }
-            if (out16) { EpiBF16 e{out16, nullptr, bias, ldo, M, N, act}; return launch_gemm_s64(A, lda, B, ldb, M, N, K, 1, form, e, nullptr, st); }
+            if (res) { EpiResid e{out32, res, bias, ldo, M, N}; return launch_gemm_s64(A, lda, B, ldb, M, N, K, 1, form, e, nullptr, st, bimg); }
+            if (out16) { EpiBF16 e{out16, nullptr, bias, ldo, M, N, act}; return launch_gemm_s64(A, lda, B, ldb, M, N, K, 1, form, e, nullptr, st, bimg); }
             EpiF32 e{out32, bias, ldo, M, N, 0, 1.0f};
-            return launch_gemm_s64(A, lda, B, ldb, M, N, K, 1, form, e, nullptr, st);
+            return launch_gemm_s64(A, lda, B, ldb, M, N, K, 1, form, e, nullptr, st, bimg);
         }
         if (res) { EpiResid e{out32, res, bias, ldo, M, N}; return launch_gemm(0, 0, A, lda, B, ldb, M, N, K, 1, e, st); }
         if (out16) { EpiBF16 e{out16, nullptr, bias, ldo, M, N, act}; return launch_gemm(0, 0, A, lda, B, ldb, M, N, K, 1, e, st); }
@@ -503,7 +510,7 @@ int gemm_nt_skinny(const act_t* Aa, int lda, const op16_t* B, int ldb, int M, in
     }
     EpiF32 e{scratch, nullptr, N, M, N, 3, 1.0f};
     e.zstride = slab;
-    int rc = s64 ? launch_gemm_s64(A, lda, B, ldb, M, N, K, ks, s64_form(ks), e, nullptr, st) : launch_gemm(0, 0, A, lda, B, ldb, M, N, K, ks, e, st);
+    int rc = s64 ? launch_gemm_s64(A, lda, B, ldb, M, N, K, ks, s64_form(ks), e, nullptr, st, bimg) : launch_gemm(0, 0, A, lda, B, ldb, M, N, K, ks, e, st);
     if (rc != CC_OK) return rc;
     const int kt = K / G_BK, per = (kt + ks - 1) / ks, ks_eff = (kt + per - 1) / per;
     if (N <= 3072 && (N & 3) == 0) {

@@ -384,27 +384,33 @@ class Gpt2Engine:
             return _lib.lib().cc_gpt2_transpose_weights(C.byref(self.cfg), w16, st)
         return _lib.lib().cc_gpt2_sync_weights(C.byref(self.cfg), w32, w16, st)
 
-    def decode_image(self) -> Optional[torch.Tensor]:
-        """Fragment-ordered weight image of the XCD-team decode engine (cc_decode_xt_image; include/clipcap_hip.h), rebuilt whenever the
-        operand copy changes; None when the engine does not cover this model (width, operand type) or is switched off (cc_decode_mode bit 2)."""
+    def decode_images(self) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+        """(wimg, wteam) for cc_decode_fwd_x (include/clipcap_hip.h), rebuilt whenever the operand copy changes:
+        wimg  — the block GEMM weights in MFMA fragment order (cc_decode_image; cc_decode_mode bit 3): the decode GEMMs whose K is split over
+                the waves load the weight operand global -> VGPR from it;
+        wteam — the XCD-team engine's image (cc_decode_xt_image; lab build, cc_decode_mode bit 2).
+        None where the library does not cover this model (width, operand type), the switch is off, or the build lacks the engine."""
         a = self.arena
         l = _lib.lib()
-        if a.device.type != "cuda" or not (l.cc_decode_mode(-1) & 4):
-            return None
+        mode = l.cc_decode_mode(-1)
+        if a.device.type != "cuda" or not (mode & 12):
+            return None, None
         a.sync_bf16()
-        key = (a._w16_version, a.op_dtype, a.w16.data_ptr())
-        if getattr(self, "_xt_key", None) != key:
-            nbytes = l.cc_decode_xt_image_bytes(C.byref(self.cfg))
-            if nbytes <= 0:
-                self._xt_img = None
-            else:
-                img = getattr(self, "_xt_img", None)
-                if img is None or img.numel() * 2 != nbytes or img.device != a.device:
-                    img = torch.empty(nbytes // 2, dtype=a.w16.dtype, device=a.device)
-                check(l.cc_decode_xt_image(C.byref(self.cfg), _p(a.w16), _p(img), _stream(a.device)), "cc_decode_xt_image")
-                self._xt_img = img
-            self._xt_key = key
-        return self._xt_img
+        key = (a._w16_version, a.op_dtype, a.w16.data_ptr(), mode & 12)
+        if getattr(self, "_img_key", None) != key:
+            out = []
+            for bit, nbytes_fn, build_fn, name in ((8, l.cc_decode_image_bytes, l.cc_decode_image, "cc_decode_image"),
+                                                  (4, l.cc_decode_xt_image_bytes, l.cc_decode_xt_image, "cc_decode_xt_image")):
+                nbytes = nbytes_fn(C.byref(self.cfg)) if mode & bit else 0
+                if nbytes <= 0:
+                    out.append(None)
+                    continue
+                img = torch.empty(nbytes // 2, dtype=a.w16.dtype, device=a.device)
+                check(build_fn(C.byref(self.cfg), _p(a.w16), _p(img), _stream(a.device)), name)
+                out.append(img)
+            self._imgs = tuple(out)
+            self._img_key = key
+        return self._imgs
 
     def shapes(self) -> List[Tuple[str, int, Tuple[int, ...]]]:
         d = self.dims
@@ -665,9 +671,9 @@ class DecodeSession:
                 self._lpart = torch.empty(n, dtype=torch.float32, device=g.arena.device)
             self.lpart = (self._lpart, self._lpart.numel() // (2 * self.R))
         grp = int(group) if self.R % max(1, int(group)) == 0 else 1
-        wimg = g.decode_image() if (tn == 1 and grp >= 2) else None      # XCD-team engine: single-position group steps only
+        wimg, wteam = g.decode_images() if tn == 1 else (None, None)     # weight images: single-position steps (M = rows x beams)
         check(_lib.lib().cc_decode_fwd_x(C.byref(g.cfg), Ra, tn, self.pos, self.ctx_max, _p(g.arena.w32), _p(g.arena.w16),
-                                        _p(wimg) if wimg is not None else None, _p(x), _p(self.kv),
+                                        _p(wimg) if wimg is not None else None, _p(wteam) if (wteam is not None and grp >= 2) else None, _p(x), _p(self.kv),
                                         _p(self.row_map), grp, _p(self._workspace(tn)), _p(logits), Vp,
                                         _p(self._lpart) if partials else None, _stream(g.arena.device)), "cc_decode_fwd_x")
         self.pos += tn
