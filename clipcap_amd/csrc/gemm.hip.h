@@ -2086,7 +2086,14 @@ inline int launch_gemm(int al, int bl, const op16_t* A, int lda, const op16_t* B
         const long tm = (M + H_BM - 1) / H_BM, t128 = (long)grid.x;
         const long t256 = tm * ((N + 255) / 256), t192 = tm * ((N + 191) / 192), t320 = (long)((M + 319) / 320) * ((N + 255) / 256);
         const double c128 = t128 <= 256 ? 16384.0 / 0.75 : (double)((t128 + 511) / 512) * 32768.0;
-        const double c256 = (double)((t256 + 255) / 256) * 65536.0 / 1.2, c192 = (double)((t192 + 255) / 256) * 49152.0 / 1.15;
+        double c192 = (double)((t192 + 255) / 256) * 49152.0 / 1.15;
+        const double c256 = (double)((t256 + 255) / 256) * 65536.0 / 1.2;
+        if constexpr (kX3) {
+            // bf16x3 build: only the 256 x 192 form has the fused two-stage loop (2/3 of the stages of the three-pass walk over K' = 3 K that the
+            // 256-wide forms run), so its rate advantage belongs in the cost (round 5; CC_X3_CHOOSE192=0 in the lab build: the round-4 chooser)
+            static const bool pref192 = []() { const char* e = cc_lab_env("CC_X3_CHOOSE192"); return !e || atoi(e) != 0; }();
+            if (pref192 && x3_fused_on() && ksplit == 1 && (K % (3 * H_BK)) == 0) c192 /= 1.45;
+        }
         const double c320 = (double)((t320 + 255) / 256) * 81920.0 / 1.3;
         constexpr bool can192 = !epi_row_strip<Epi>::value;   // the lm_head partials assume 64-column wave strips
         // the activation-gradient epilogue (aux tile read + gelu' + store) is not hidden at one block per CU: 12800 x 3072 x 768 measured

@@ -15,7 +15,7 @@ int g_gemm_small_x2 = []() { const char* e = cc_lab_env("CC_GEMM_X2"); return e 
 // measured slower than the per-op launches on MI355X, DESIGN.md 4.5 — kept for A/B runs), bit 2: the XCD-team engine (decode_xt.hip) when cc_decode_fwd_x
 // is given a weight image, bit 3: the K-split decode GEMMs take their weight operand global -> VGPR from the fragment-ordered image of cc_decode_image
 // (gemm_nt_s64kwb_kernel; bit-identical results; with the weights cold from HBM, as in the chain, 1-3 % slower than both operands through LDS —
-// profiles/r05_d_*; default off).  env CC_DEC_GROUP / CC_DEC_PK / CC_DEC_XT preset bits 0-2.
+// DESIGN.md 4.5, tools/ab_decode_mode.py; default off).  env CC_DEC_GROUP / CC_DEC_PK / CC_DEC_XT preset bits 0-2.
 int g_decode_mode = []() {
     const char* g = cc_lab_env("CC_DEC_GROUP");
     const char* p = cc_lab_env("CC_DEC_PK");

@@ -11,5 +11,7 @@ hdr() { echo "# round ${TAG#r}: $1"; echo; }
 { hdr "\`rocprofv3 --kernel-trace --pmc FETCH_SIZE\` / \`--pmc WRITE_SIZE\` (one counter per pass) on \`python bench.py --steps 2 --warmup 1 --regions 1 --no-cpu-baseline --no-sub-benches --no-roofline-pass\` (3 steps); KB per dispatch; gfx950 correction: FETCH_SIZE x2 for wide coalesced reads (MI355X_MICROARCH.md, HBM section).  Totals and the source hash of the build: profiles/pmc_constants.json"; echo "## FETCH_SIZE"; echo '```'; cat $G/${TAG}_pmc_FETCH_SIZE.txt; echo '```'; echo; echo "## WRITE_SIZE"; echo '```'; cat $G/${TAG}_pmc_WRITE_SIZE.txt; echo '```'; } > $P/${TAG}_e_pmc_fetch_write_train.md
 { hdr "the same two counter passes on \`python bench.py --mode decode --steps 1 --warmup 1\` (3 decodes x 67 positions); KB per dispatch"; echo "## FETCH_SIZE"; echo '```'; cat $G/${TAG}_decode_pmc_FETCH_SIZE.txt; echo '```'; echo; echo "## WRITE_SIZE"; echo '```'; cat $G/${TAG}_decode_pmc_WRITE_SIZE.txt; echo '```'; } > $P/${TAG}_f_pmc_fetch_write_decode.md
 { hdr "the config-2 training step with split-bf16 operands: \`rocprofv3 --kernel-trace -- python bench.py --precision 32 --steps 6 --warmup 2 --no-cpu-baseline --no-sub-benches --no-roofline-pass\`"; cat $G/${TAG}_x3_train.md; } > $P/${TAG}_g_train_step_split_bf16_kernel_stats.md
+[ -f $G/${TAG}_mfma_utilisation.md ] && { hdr "MFMA pipe utilisation: \`rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE\` (own passes) over the bf16 step, the split-bf16 step and one beam decode; busy = SQ_VALU_MFMA_BUSY_CYCLES / 32 / GRBM_GUI_ACTIVE per dispatch, cycle-weighted (tools/mfma_util.py)"; cat $G/${TAG}_mfma_utilisation.md; } > $P/${TAG}_i_mfma_utilisation.md
+[ -f $G/${TAG}_vendor_gemm_trace.md ] && { hdr "vendor GEMM (hipBLASLt through torch.matmul) vs this library, GPU-side dispatch durations, one shape per process: \`python tools/vendor_gemm_trace.py\` (measuring stick only; nothing in the product calls a vendor GEMM)"; cat $G/${TAG}_vendor_gemm_trace.md; } > $P/${TAG}_j_vendor_gemm_trace.md
 cp $G/pmc_constants.json $P/pmc_constants.json
 ls -la $P | grep ${TAG}_

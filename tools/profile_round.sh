@@ -18,18 +18,18 @@ run_trace() {  # name, command...
 }
 run_trace train $TRAIN
 run_trace mapper python $ROOT/bench.py --mode mapper --steps 10 --warmup 3
-run_trace decode python $ROOT/bench.py --mode decode --steps 1 --warmup 1
+run_trace decode python $ROOT/bench.py --mode decode --steps 1 --warmup 1 --regions 1
 # counter passes: one TCC counter per pass; the databases are kept until pmc_constants.py has read them
 for ctr in FETCH_SIZE WRITE_SIZE; do
     rm -rf $OUT/prof_pmc_train_$ctr
     rocprofv3 --kernel-trace --pmc $ctr --output-format rocpd -d $OUT/prof_pmc_train_$ctr -- python $ROOT/bench.py --steps 2 --warmup 1 --regions 1 --no-cpu-baseline --no-sub-benches --no-roofline-pass > /dev/null 2>&1
     python $ROOT/tools/rocpd_pmc.py $(find $OUT/prof_pmc_train_$ctr -name "*.db" | head -1) > $OUT/${TAG}_pmc_$ctr.txt
 done
-# decode: the same two counter passes on the beam-5 decode (bench.py --mode decode --steps 1 --warmup 1 = 3 decodes: warm-up, timed, and the
+# decode: the same two counter passes on the beam-5 decode (bench.py --mode decode --steps 1 --warmup 1 --regions 1 = 3 decodes: warm-up, timed, and the
 # untimed one that counts the distinct KV rows; per generated position = totals / (3 decodes x 67 positions))
 for ctr in FETCH_SIZE WRITE_SIZE; do
     rm -rf $OUT/prof_pmc_decode_$ctr
-    rocprofv3 --kernel-trace --pmc $ctr --output-format rocpd -d $OUT/prof_pmc_decode_$ctr -- python $ROOT/bench.py --mode decode --steps 1 --warmup 1 > /dev/null 2>&1
+    rocprofv3 --kernel-trace --pmc $ctr --output-format rocpd -d $OUT/prof_pmc_decode_$ctr -- python $ROOT/bench.py --mode decode --steps 1 --warmup 1 --regions 1 > /dev/null 2>&1
     python $ROOT/tools/rocpd_pmc.py $(find $OUT/prof_pmc_decode_$ctr -name "*.db" | head -1) > $OUT/${TAG}_decode_pmc_$ctr.txt
 done
 python $ROOT/tools/pmc_constants.py $TAG $(find $OUT/prof_pmc_train_FETCH_SIZE -name "*.db" | head -1) $(find $OUT/prof_pmc_train_WRITE_SIZE -name "*.db" | head -1) 3 \
@@ -44,7 +44,7 @@ for leg in train x3_train decode; do
     case $leg in
         train) CMD="python $ROOT/bench.py --steps 2 --warmup 1 --regions 1 --no-cpu-baseline --no-sub-benches --no-roofline-pass" ;;
         x3_train) CMD="python $ROOT/bench.py --precision 32 --steps 2 --warmup 1 --regions 1 --no-cpu-baseline --no-sub-benches --no-roofline-pass" ;;
-        decode) CMD="python $ROOT/bench.py --mode decode --steps 1 --warmup 1" ;;
+        decode) CMD="python $ROOT/bench.py --mode decode --steps 1 --warmup 1 --regions 1" ;;
     esac
     rm -rf $OUT/prof_mfma_$leg
     rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format rocpd -d $OUT/prof_mfma_$leg -- $CMD > /dev/null 2>&1

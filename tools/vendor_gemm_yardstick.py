@@ -48,12 +48,13 @@ def timed(f, flops):
 
 
 def main():
-    only = sys.argv[1:]
+    only = [a for a in sys.argv[1:] if a != "--exact"]
+    exact = "--exact" in sys.argv[1:]            # tools/vendor_gemm_trace.py: one shape per process, labels matched whole
     print("| site | M | N | K | vendor bf16-out us (TFLOP/s) | vendor fp32-acc check | ours (chooser, fp32 out) us (TFLOP/s) | ours / vendor |")
     print("|---|---|---|---|---|---|---|---|")
     lib.cc_gemm_tile_mode(-1)
     for (label, M, N, K) in SHAPES:
-        if only and not any(o in label for o in only):
+        if only and not (label in only if exact else any(o in label for o in only)):
             continue
         torch.manual_seed(0)
         A = torch.randn(M, K, device="cuda").bfloat16()
