@@ -203,7 +203,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[4][4], char* smem, in
 //   Epi::strip(...)                  row-strip functors (NJ == 4): both column groups of the row at once
 template <class Epi, int NI, int NJ>
 __device__ __forceinline__ void gemm_epilogue_regs(f32x4 (&acc)[NI][NJ], int lane, int row0, int col0, const Epi& epi) {
-    static_assert(NI % 2 == 0, "leftover column tiles pair along i");
+    static_assert(NI % 2 == 0 || NJ % 2 == 0, "leftover column tiles pair along i");
     const int q = lane >> 4, rl = lane & 15;
 #define G_PAIR(X, Y, V)                                                                                                  \
     _Pragma("unroll") for (int r_ = 0; r_ < 4; r_++) {                                                                   \
@@ -946,6 +946,87 @@ __global__ __launch_bounds__(G_THREADS, 2) void gemm_nt_s64kw_kernel(const op16_
     }
 }
 
+// 80 x 64 tiles, K split over the waves (round 5): the wave-quantisation fix for c_fc at M = 320.  With 64 x 64 tiles 320 x 4096 is 320 blocks
+// on 256 CUs — 64 CUs carry two blocks and the launch takes as long as they do (12.7 us against 9.2 us for c_attn's 240 single blocks of the
+// same depth); 320 rows as FOUR 80-row tiles are exactly 4 x 64 = 256 blocks, one per CU (hipBLASLt's pick for the shape, MT64x96, makes the
+// same trade the other way round: 215 blocks; profiles/r05_j_*).  The LDS image of A is 96 rows (three 32-row MFMA fragments; the DMA clamps
+// rows beyond M, rows 80-95 of a tile belong to the next tile and their products are dropped), a stage is 20 KiB, the cross-wave reduction
+// of the 4 x 6 partial tiles needs 96 KiB.  Otherwise gemm_nt_s64kw_kernel: every wave computes the whole tile for one 16-k quarter of a K-tile.
+template <class Epi>
+__global__ __launch_bounds__(G_THREADS, 1) void gemm_nt_s80kw_kernel(const op16_t* __restrict__ A, const op16_t* __restrict__ B, GemmShape g, Epi epi) {
+    extern __shared__ __attribute__((aligned(1024))) char smk8[];
+    constexpr int NS = 4, STAGE = (96 + 64) * 128, P = 5, BMT = 80;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = (g.N + 63) / 64, tiles_m = (g.M + BMT - 1) / BMT;
+    int tm, tn;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, g.group_m, tm, tn);
+    const int m0 = tm * BMT, n0 = tn * 64;
+    const int kbeg = blockIdx.z * g.k_chunk;
+    const int nk = (min(g.K, kbeg + g.k_chunk) - kbeg) / G_BK;
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+#define KW_ISSUE(T, SLOT) glds_pair<96, 64, 4>(A, g.lda, g.M, m0, B, g.ldb, g.N, n0, kbeg + (T)*G_BK, smk8 + (SLOT) * STAGE, wave, lane)
+#pragma unroll
+    for (int t = 0; t < NS - 1; t++)
+        if (t < nk) KW_ISSUE(t, t);
+    const int frow = lane & 31, ch = wave * 2 + (lane >> 5);
+    int slot = 0, islot = NS - 1;
+    for (int kt = 0; kt < nk; kt++) {
+        const int rem = min(nk - 1, kt + NS - 2) - kt;
+        if (rem >= 2) s_wait_vm<2 * P>();
+        else if (rem == 1) s_wait_vm<P>();
+        else s_wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        const char* cur = smk8 + slot * STAGE;
+        op16x8 a[3], b[2];
+#pragma unroll
+        for (int i = 0; i < 3; i++) a[i] = *reinterpret_cast<const op16x8*>(cur + g_lds_off(i * 32 + frow, ch));
+#pragma unroll
+        for (int j = 0; j < 2; j++) b[j] = *reinterpret_cast<const op16x8*>(cur + 96 * 128 + g_lds_off(j * 32 + frow, ch));
+        if (kt + NS - 1 < nk) KW_ISSUE(kt + NS - 1, islot);       // after the reads are issued: the DMA issue cycles hide their latency
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) acc[i][j] = CC_MFMA_32x32x16(a[i], b[j], acc[i][j]);
+        slot = slot + 1 == NS ? 0 : slot + 1;
+        islot = islot + 1 == NS ? 0 : islot + 1;
+    }
+#undef KW_ISSUE
+    __syncthreads();
+    // partial tiles -> LDS as [wave][tile 2i+j][register][lane] floats (96 KiB); element (row, col) of a 32 x 32 tile sits in register
+    // 4 (row>>3) + (row&3) of lane (col&31) + 32 ((row>>2)&1), so 8 consecutive columns are 8 consecutive floats
+    float* part = reinterpret_cast<float*>(smk8);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) part[((wave * 6 + i * 2 + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+    __syncthreads();
+    // 80 rows x 8 column groups of 8 = 640 items over 256 threads
+#pragma unroll
+    for (int ps = 0; ps < 3; ps++) {
+        const int item = ps * G_THREADS + tid, row = item >> 3, c8 = item & 7;
+        if (row < BMT) {
+            const int rr = row & 31, reg = (rr >> 3) * 4 + (rr & 3), ls = (c8 & 3) * 8 + 32 * ((rr >> 2) & 1), tile = (row >> 5) * 2 + (c8 >> 2);
+            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int pw = 0; pw < 4; pw++) {
+                const float* src = part + ((pw * 6 + tile) * 16 + reg) * 64 + ls;
+                const float4 x = *reinterpret_cast<const float4*>(src), y = *reinterpret_cast<const float4*>(src + 4);
+                v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w; v[4] += y.x; v[5] += y.y; v[6] += y.z; v[7] += y.w;
+            }
+            epi(m0 + row, n0 + c8 * 8, v);
+        }
+    }
+}
+
 // The same 64 x 64 / K-over-the-waves kernel with the WEIGHT operand taken out of LDS (round 5): B comes from a
 // fragment-ordered image (k_skinny_image, cc_decode_image) — per (64-column tile, 64-k tile, wave = 16-k quarter, 32-column half) one 1-KiB
 // piece in which lane l holds W[n0 + 32 i + (l & 31)][k0 + 16 w + 8 (l >> 5) .. + 7], i.e. exactly the lane's v_mfma_f32_32x32x16 operand —
@@ -1130,8 +1211,8 @@ __device__ __forceinline__ int h_tt_g(int k) { return (k & 3) | (((k >> 3) & 1) 
         char* st_ = smem + ((T) % H_NS) * SSTAGE + ((IS_A) ? 0 : SBM * H_BK * 2);                                      \
         int k0_ = kbeg + (T)*H_BK;                                                                                       \
         if constexpr (X3F) k0_ = (x3c0_ + ((T) >> 1)) * H_BK + (((T) & 1) ? ((IS_A) ? 2 * x3k_ : x3k_) : 0);   /* hi stage, then lo stage of the same K chunk */ \
-        _Pragma("unroll") for (int i_ = 0; i_ < ((IS_A) ? NI / 2 : NJ); i_++) {                                              \
-            const int seg = wn + 4 * i_;                        /* 2 NI (A) or 4 NJ (B) segments of 1 KiB */                \
+        _Pragma("unroll") for (int i_ = 0; i_ < ((IS_A) ? (NI + 1) / 2 : NJ); i_++) {                                        \
+            const int seg = (IS_A) ? min(wn + 4 * i_, 2 * NI - 1) : wn + 4 * i_;   /* 2 NI (A) or 4 NJ (B) segments of 1 KiB; odd NI: two waves re-issue the last one (same bytes, same place) so that every wave counts the same DMA instructions */ \
             const op16_t* src;                                                                                           \
             if constexpr (TT) {                                                                                          \
                 const int kr = seg * 2 + (lane >> 5);           /* 2 k-rows of 512 B per segment */                       \
@@ -1241,7 +1322,7 @@ __device__ unsigned long long cc_stamp_buf[2 * 8];
 template <class Epi, int NJ, bool TT, int NI = 8, bool X3F = false>
 __device__ __forceinline__ void gemm_stag256_body(const op16_t* __restrict__ A, const op16_t* __restrict__ B, const GemmShape& g, const Epi& epi,
                                                   int tile, int zslice, char* smem) {
-    static_assert(NJ >= 2 && NJ <= 4 && (NI == 8 || NI == 10), "wave tile is (16 NI) x (16 NJ)");
+    static_assert(NJ >= 2 && NJ <= 4 && (NI == 8 || NI == 10 || (NI == 5 && NJ == 4)), "wave tile is (16 NI) x (16 NJ)");
     static_assert(!TT || (NJ == 4 && NI == 8), "the K-strided image is laid out for 256 x 256 tiles");
     static_assert(!X3F || (!TT && NJ == 3 && NI == 8), "the fused split-bf16 form is the 256 x 192 NT kernel's");
     constexpr int BN = 64 * NJ, SBM = 32 * NI, SSTAGE = (SBM + H_BN) * H_BK * 2;      // NI = 10: 320-row tiles, 36 KiB stages
@@ -1268,7 +1349,7 @@ __device__ __forceinline__ void gemm_stag256_body(const op16_t* __restrict__ A, 
     // 12800 x 768 launch then travel while the first operand tiles are in flight, instead of joining the store burst at the end of a
     // single-round launch.  Issued before the first DMA so that every later counted vmcnt wait implies these loads have landed.
     // (256 x 192 form only: the 256-wide forms have no registers to spare for the address arithmetic — 276 / 564 B of scratch measured)
-    constexpr bool kAccInit = epi_acc_init<Epi>::value && NJ == 3 && NI == 8 && !X3F;      // (the fused split-bf16 form has no registers to spare either: 54 spilled)
+    constexpr bool kAccInit = epi_acc_init<Epi>::value && ((NJ == 3 && NI == 8) || NI == 5) && !X3F;      // (the fused split-bf16 form has no registers to spare either: 54 spilled)
     if constexpr (kAccInit) {
         if (zslice == 0 && epi.init_from_input()) {
             const int q_ = lane >> 4, rl_ = lane & 15;
@@ -1299,7 +1380,7 @@ __device__ __forceinline__ void gemm_stag256_body(const op16_t* __restrict__ A, 
             if ((T) + H_NS - 1 < nk) H_ISSUE((T) + H_NS - 1, true);                                                      \
             H_SEGEND();                                                                                                  \
             MFMA;                                                                                                        \
-            H_WAIT(T, NI / 2);                                                                                           \
+            H_WAIT(T, (NI + 1) / 2);                                                                                           \
             H_SEGEND();                                                                                                  \
         }
 #define H_G1_STEP(T, LOADF, MFMA_PREV)                                                                                   \
@@ -1316,7 +1397,7 @@ __device__ __forceinline__ void gemm_stag256_body(const op16_t* __restrict__ A, 
             if (nk > 0) H_ISSUE(0, true);                    // (an empty K slice writes a zero slab)
             if (nk > 1) H_ISSUE(1, true);
             if (nk > 2) H_ISSUE(2, true);
-            H_WAIT(-1, NI / 2);
+            H_WAIT(-1, (NI + 1) / 2);
             H_SEGEND();
             for (int t = 0; t < nk; t += 2) {
                 H_G0_STEP(t, H_LOADF, H_MFMA(t))
@@ -1344,7 +1425,7 @@ __device__ __forceinline__ void gemm_stag256_body(const op16_t* __restrict__ A, 
         if (nk > 1) H_ISSUE(1, true);
         if (nk > 2) H_ISSUE(2, true);
         if (H_NS > 4 && nk > 3) H_ISSUE(3, true);
-        H_WAIT(-1, NI / 2);
+        H_WAIT(-1, (NI + 1) / 2);
         H_SEGEND();
         H_STAMP(0)                                     // prologue
         for (int t = 0; t < nk; t++) {
@@ -1366,7 +1447,7 @@ __device__ __forceinline__ void gemm_stag256_body(const op16_t* __restrict__ A, 
             H_STAMP(3)                                 // barrier (end of read segment)
             H_MFMA(t);
             H_STAMP(4)                                 // MFMA issue
-            H_WAIT(t, NI / 2);
+            H_WAIT(t, (NI + 1) / 2);
             H_STAMP(5)                                 // vmcnt wait
             H_SEGEND();
             H_STAMP(6)                                 // barrier (end of MFMA segment)
@@ -2076,31 +2157,34 @@ inline int launch_gemm(int al, int bl, const op16_t* A, int lda, const op16_t* B
     // cost = rounds x tile area / rate, the 128 x 128 kernel counted with 2 co-resident blocks per CU (measured table: DESIGN.md 4.1).
     // The 320 x 256 form (10 row tiles per wave, 36-KiB stages) does 1.25x the MFMAs per K-step at 1.13-1.27x the step time: it wins
     // where it saves a round (12800 x 3072: 480 tiles = 2 rounds instead of 3; the lm_head: 25 instead of 31).
-    // g_gemm_tile_mode (cc_gemm_tile_mode / CC_GEMM_S256) = 0 (never) / 3 / 4 / 5 (force 256x192 / 256x256 / 320x256) overrides it for
+    // g_gemm_tile_mode (cc_gemm_tile_mode / CC_GEMM_S256) = 0 (never) / 3 / 4 / 5 / 6 (force 256x192 / 256x256 / 320x256 / 160x256) overrides it for
     // tests and tools/gemm_tiles.py.
     const int s256 = tile != -2 ? tile : g_gemm_tile_mode;
     int nj = 0, ni = 8;
+    constexpr bool can160 = !kX3 && !epi_row_strip<Epi>::value && !std::is_same<Epi, EpiDAct>::value;      // the 160 x 256 form (below)
     // K slices (blockIdx.z) on the 256-row kernels only for the slab-writing fp32 epilogue and only when the caller names the tile
     constexpr bool zsplit_ok = std::is_same<Epi, EpiF32>::value;
     if (al == 0 && bl == 0 && (K % H_BK) == 0 && (ksplit == 1 || (zsplit_ok && tile > 0)) && s256 != 0) {
         const long tm = (M + H_BM - 1) / H_BM, t128 = (long)grid.x;
         const long t256 = tm * ((N + 255) / 256), t192 = tm * ((N + 191) / 192), t320 = (long)((M + 319) / 320) * ((N + 255) / 256);
         const double c128 = t128 <= 256 ? 16384.0 / 0.75 : (double)((t128 + 511) / 512) * 32768.0;
-        double c192 = (double)((t192 + 255) / 256) * 49152.0 / 1.15;
-        const double c256 = (double)((t256 + 255) / 256) * 65536.0 / 1.2;
-        if constexpr (kX3) {
-            // bf16x3 build: only the 256 x 192 form has the fused two-stage loop (2/3 of the stages of the three-pass walk over K' = 3 K that the
-            // 256-wide forms run), so its rate advantage belongs in the cost (round 5; CC_X3_CHOOSE192=0 in the lab build: the round-4 chooser)
-            static const bool pref192 = []() { const char* e = cc_lab_env("CC_X3_CHOOSE192"); return !e || atoi(e) != 0; }();
-            if (pref192 && x3_fused_on() && ksplit == 1 && (K % (3 * H_BK)) == 0) c192 /= 1.45;
-        }
+        // (bf16x3 build, round 5: crediting the 256 x 192 form with its fused two-stage loop — c192 / 1.45, which moves c_attn / c_fc forward from
+        // the three-pass 256-wide forms to 3-4 rounds of fused 192-wide tiles — measured 28.55 -> 30.1 ms per step, two alternations: reverted)
+        const double c256 = (double)((t256 + 255) / 256) * 65536.0 / 1.2, c192 = (double)((t192 + 255) / 256) * 49152.0 / 1.15;
         const double c320 = (double)((t320 + 255) / 256) * 81920.0 / 1.3;
         constexpr bool can192 = !epi_row_strip<Epi>::value;   // the lm_head partials assume 64-column wave strips
         // the activation-gradient epilogue (aux tile read + gelu' + store) is not hidden at one block per CU: 12800 x 3072 x 768 measured
         // 106.6 us on 320 x 256 vs 97.3 on 128 x 128 (two co-resident blocks), while the plain / gelu-forward epilogues gain (90 -> 78 us)
         // (also with the forward-stored derivative, act 3 — a single multiply —, the 128 x 128 kernel stays ahead: 12.31 vs 12.44 ms per step)
         constexpr bool can320 = !std::is_same<Epi, EpiDAct>::value;
-        if (s256 == 5 || (can320 && s256 < 0 && c320 < 0.98 * c128 && c320 < c256 && (!can192 || c320 < c192))) { nj = 4; ni = 10; }
+        // (round 5) 160 x 256 (5 row tiles per wave, 26-KiB stages): for the N = 768 launches at M = 12800 it is 240 tiles on the 256 CUs where
+        // 256 x 192 is 200 — hipBLASLt's pick for these shapes too (MT160x256, profiles/r05_j_*).  A single-round launch takes one tile's
+        // latency, so the smaller tile is the shorter launch whenever both fit one round; never for the bf16x3 build (its fused form is 192-wide).
+        const long t160 = (long)((M + 159) / 160) * ((N + 255) / 256);
+        const double c160 = (double)((t160 + 255) / 256) * 40960.0 / 1.1;
+        static const bool s160_on = []() { const char* e = cc_lab_env("CC_GEMM_S160"); return !e || atoi(e) != 0; }();
+        if (can160 && (s256 == 6 || (s256 < 0 && s160_on && ksplit == 1 && c160 < 0.98 * c128 && c160 < 0.98 * c256 && c160 < 0.98 * c320 && (!can192 || c160 < 0.98 * c192)))) { nj = 4; ni = 5; }
+        else if (s256 == 5 || (can320 && s256 < 0 && c320 < 0.98 * c128 && c320 < c256 && (!can192 || c320 < c192))) { nj = 4; ni = 10; }
         else if (s256 == 4 || (s256 < 0 && c256 < 0.98 * c128 && (!can192 || c256 <= c192))) nj = 4;
         else if (can192 && (s256 == 3 || (s256 < 0 && c192 < 0.98 * c128))) nj = 3;
     }
@@ -2115,6 +2199,7 @@ inline int launch_gemm(int al, int bl, const op16_t* A, int lda, const op16_t* B
         hipLaunchKernelGGL((gemm_nt_stag256_kernel<Epi, NJ_, false, NI_>), gr, dim3(512), sh, st, A, B, g, epi);        \
     }
         if (nj == 4 && ni == 8) CC_LAUNCH_STAG(4, 8)
+        else if (nj == 4 && ni == 5) { if constexpr (can160) CC_LAUNCH_STAG(4, 5) }
         else if (nj == 4) CC_LAUNCH_STAG(4, 10)
         else if constexpr (!epi_row_strip<Epi>::value) {
             bool fused = false;
@@ -2184,7 +2269,7 @@ inline int launch_gemm(int al, int bl, const op16_t* A, int lda, const op16_t* B
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
 
-// Skinny NT launcher (gemm_nt_s64_kernel): K % 64 == 0; nj = 1 (64 x 64 tiles) or 2 (64 x 128); K split over blockIdx.z
+// Skinny NT launcher (gemm_nt_s64_kernel): K % 64 == 0; nj = 1 (64 x 64 tiles), 2 (64 x 128), 3 (64 x 64, K over the waves) or 4 (80 x 64, K over the waves); K split over blockIdx.z
 // (epi must be an EpiF32 in slab mode when ksplit > 1).  *ks_eff returns the effective slice count.
 template <class Epi>
 inline int launch_gemm_s64(const op16_t* A, int lda, const op16_t* B, int ldb, int M, int N, int K, int ksplit, int nj, const Epi& epi, int* ks_eff,
@@ -2214,6 +2299,11 @@ inline int launch_gemm_s64(const op16_t* A, int lda, const op16_t* B, int ldb, i
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_s64kwb_kernel<Epi, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr = true; }
         hipLaunchKernelGGL((gemm_nt_s64kwb_kernel<Epi, 4>), dim3((unsigned)(tm * (N / 64)), 1, (unsigned)ksplit), dim3(320), sh, st, A, Bimg, g, epi);
+    } else if (nj == 4) {                   // 80 x 64 tiles, K split over the waves (gemm_nt_s80kw_kernel)
+        constexpr size_t sh = (size_t)4 * 6 * 16 * 64 * sizeof(float);      // the epilogue's partial tiles: 96 KiB (the four 20-KiB stages fit inside)
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_s80kw_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr = true; }
+        hipLaunchKernelGGL((gemm_nt_s80kw_kernel<Epi>), dim3((unsigned)(((M + 79) / 80) * ((N + 63) / 64)), 1, (unsigned)ksplit), dim3(G_THREADS), sh, st, A, B, g, epi);
     } else if (nj == 3) {                   // K split over the waves (gemm_nt_s64kw_kernel)
         constexpr size_t sh = (size_t)4 * 128 * 128;
         static bool attr = false;

@@ -490,9 +490,14 @@ int gemm_nt_skinny(const act_t* Aa, int lda, const op16_t* B, int ldb, int M, in
     if (can_slab) { const size_t fit = scratch_bytes / (slab * sizeof(float)); if ((size_t)ks > fit) ks = (int)fit; }
     // K split over the waves of a block (gemm_nt_s64kw_kernel): pays from ~14 K-tiles per block, and only on grids of at most one
     // block per CU (320 x 3072 x 1024: 9.0 -> 8.3 us, 320 x 1024 x 4096 in one slice: 23.6 -> 18.4 us; c_fc's 320 blocks: no gain)
+    // (round 5) a single-slice grid of 257-320 64 x 64 tiles that is <= 256 tiles of 80 x 64 (c_fc at M = 320: 5 x 64 -> 4 x 64) takes the
+    // 80-row form of the same kernel: one block per CU instead of two on a quarter of them (CC_SKINNY_80=0 in the lab build: off)
+    static const bool s80_on = []() { const char* e = cc_lab_env("CC_SKINNY_80"); return !e || atoi(e) != 0; }();
     auto s64_form = [&](int slices) {
-        const int t64 = ((M + 63) / 64) * ((N + 63) / 64);
-        return (K / G_BK / (slices > 0 ? slices : 1) >= 14 && (long)t64 * slices <= 256 && g_gemm_s64 != 1) ? 3 : 1;
+        const int t64 = ((M + 63) / 64) * ((N + 63) / 64), t80 = ((M + 79) / 80) * ((N + 63) / 64);
+        if (g_gemm_s64 == 1 || K / G_BK / (slices > 0 ? slices : 1) < 14) return 1;
+        if ((long)t64 * slices <= 256) return 3;
+        return (s80_on && slices <= 1 && t80 <= 256) ? 4 : 1;      // (no weight-image variant: both operand paths run this kernel)
     };
     if (!can_slab || (ks <= 1 && !fused)) {
         if (fused) return CC_ERR_SHAPE;                    // callers only request fusion when the slab path is available

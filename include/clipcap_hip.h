@@ -386,12 +386,12 @@ int cc_gemm_op16_f32(int32_t op_dtype, int32_t al, int32_t bl, const uint16_t* A
 int64_t cc_wgrad_scratch_bytes(void);
 int cc_gemm_wgrad(int32_t op_dtype, const uint16_t* X, int32_t ldx, const uint16_t* Y, int32_t ldy, int32_t Mw, int32_t Nw, int32_t K, float* dW, int32_t ldw,
                   float* scratch, void* stream);
-/* PROCESS-WIDE test knob.  NT GEMM tile choice: -1 = cost-model chooser (default), 0 = 128x128 kernels only (also for cc_gemm_wgrad), 3 / 4 / 5 =
- * force the 256x192 / 256x256 / 320x256 kernel wherever it is legal.  Returns the previous mode.  For tests and tools/gemm_bench.py only. */
+/* PROCESS-WIDE test knob.  NT GEMM tile choice: -1 = cost-model chooser (default), 0 = 128x128 kernels only (also for cc_gemm_wgrad), 3 / 4 / 5 / 6 =
+ * force the 256x192 / 256x256 / 320x256 / 160x256 kernel wherever it is legal.  Returns the previous mode.  For tests and tools/gemm_bench.py only. */
 int cc_gemm_tile_mode(int32_t mode);
 /* Decode-sized NT GEMMs (M <= 640 rows: cc_decode_fwd's c_attn / c_proj / c_fc at rows x beams = 320) run on 64-row tiles
- * (gemm_nt_s64_kernel).  -1 = default (those call sites only), 0 = never, 1 / 2 = additionally route cc_gemm_bf16_f32's NT launches with
- * M <= 1024 through the 64 x 64 / 64 x 128 / 64 x 64 K-split-over-waves (3) form.  PROCESS-WIDE test knob; returns the previous mode.  For tests and
+ * (gemm_nt_s64_kernel).  -1 = default (those call sites only), 0 = never, 1 / 2 / 3 / 4 = additionally route cc_gemm_bf16_f32's NT launches with
+ * M <= 1024 through the 64 x 64 / 64 x 128 / 64 x 64 K-split-over-waves (3) / 80 x 64 K-split-over-waves (4) form.  PROCESS-WIDE test knob; returns the previous mode.  For tests and
  * tools/small_gemm_bench.py. */
 int cc_gemm_skinny_mode(int32_t mode);
 /* How cc_decode_fwd_g runs a single-position group step.  bit 0 (default on): beam-group attention (every distinct KV row of a group read

@@ -56,10 +56,10 @@ def test_gemm_layouts(al, bl, M, N, K):
     assert torch.isnan(Cm[:, N:]).all()   # nothing written outside the N columns
 
 
-@pytest.mark.parametrize("mode", [3, 4, 5])
+@pytest.mark.parametrize("mode", [3, 4, 5, 6])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 32), (8, 8, 32), (520, 200, 96), (1000, 392, 1024), (300, 776, 160), (640, 512, 64), (330, 248, 128)])
 def test_gemm_nt_256_row_tiles(mode, M, N, K):
-    """the 256 x 192 / 256 x 256 / 320 x 256 group-staggered NT kernels (forced: the chooser would pick 128 x 128 at these sizes)"""
+    """the 256 x 192 / 256 x 256 / 320 x 256 / 160 x 256 (mode 6) group-staggered NT kernels (forced: the chooser would pick 128 x 128 at these sizes)"""
     torch.manual_seed(M + N + K + mode)
     dev = "cuda"
     A = _bf(torch.randn(M, K, device=dev))
@@ -79,12 +79,13 @@ def test_gemm_nt_256_row_tiles(mode, M, N, K):
     assert torch.isnan(Cm[:, N:]).all()
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
 @pytest.mark.parametrize("M,N,K,ks", [(320, 1024, 1024, 1), (320, 3072, 1024, 1), (5, 2304, 768, 3), (333, 1000, 256, 1), (64, 64, 64, 1),
-                                      (640, 4096, 1024, 1), (77, 200, 4096, 6), (1, 8, 128, 2)])
+                                      (640, 4096, 1024, 1), (77, 200, 4096, 6), (1, 8, 128, 2), (320, 4096, 1024, 1), (81, 72, 192, 1)])
 def test_gemm_nt_skinny_64_row_tiles(mode, M, N, K, ks):
-    """the 64 x 64 / 64 x 128 decode-sized NT kernels (32x32x16 MFMA; mode 3: the 64 x 64 form with K split over the waves), single pass
-    and with K slices (atomic accumulation into a non-zero C), ragged M / N edges and a padded leading dimension"""
+    """the 64 x 64 / 64 x 128 decode-sized NT kernels (32x32x16 MFMA; mode 3: the 64 x 64 form with K split over the waves; mode 4: its
+    80 x 64 form, four row tiles for M = 320), single pass and with K slices (atomic accumulation into a non-zero C), ragged M / N edges and
+    a padded leading dimension"""
     torch.manual_seed(M + N + K + mode)
     dev = "cuda"
     A = _bf(torch.randn(M, K, device=dev))
