@@ -938,6 +938,27 @@ def main():
         out["fp32_parity_mode"] = {"operands": "split bf16 (hi*hi + hi*lo + lo*hi), fp32 activations", "flag": "--fp-precision 32",
                                    "ms_per_step": round(ms3, 3), "samples_per_s": round(B / ms3 * 1e3, 1), "steps": k3,
                                    "slowdown_vs_bf16": round(ms3 / ms_per_step, 2), "final_loss": round(float(loss3.item()), 4)}
+        # and with IEEE fp16 operands (--fp-precision 16, the reference's AMP mode; device-side dynamic loss scaling inside the step): the
+        # middle point of the precision / throughput curve — full-depth logits 2.0e-3 from the reference (bf16 1.5e-2, split bf16 4e-5;
+        # tests/test_gpu_fp16.py, tests/test_gpu_x3.py assert these)
+        try:
+            me.set_precision(16)
+            ge.set_precision(16)
+            for i in range(nxt + 3 + k3, nxt + 6 + k3):
+                one_step(i)
+            sync()
+            t0 = time.perf_counter()
+            for i in range(nxt + 6 + k3, nxt + 6 + 2 * k3):
+                loss16 = one_step(i)
+            sync()
+            ms16 = (time.perf_counter() - t0) / k3 * 1e3
+            out["fp16_mode"] = {"operands": "IEEE fp16, dynamic loss scaling on the device", "flag": "--fp-precision 16", "ms_per_step": round(ms16, 3),
+                                "samples_per_s": round(B / ms16 * 1e3, 1), "steps": k3, "slowdown_vs_bf16": round(ms16 / ms_per_step, 2),
+                                "final_loss": round(float(loss16.item()), 4),
+                                "logits_vs_reference": {"bf16": 1.5e-2, "fp16": 2.0e-3, "split_bf16": 4e-5, "bar": 1e-3,
+                                                        "source": "full-depth configs[1] fixtures of the reference, asserted in tests/test_gpu_configs.py / test_gpu_fp16.py / test_gpu_x3.py"}}
+        except Exception as e:      # never lose the headline line to the extra
+            out["fp16_mode"] = {"error": f"{type(e).__name__}: {e}"}
         me.set_precision("bf16")
         ge.set_precision("bf16")
     if not args.no_cpu_baseline:

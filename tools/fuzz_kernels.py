@@ -18,15 +18,19 @@ def main():
     t0, n, fails = time.time(), 0, []
     while time.time() - t0 < budget:
         K.OP[0], K.OP[1] = rng.choice([(0, torch.bfloat16), (1, torch.float16)])
-        kind = rng.choice(["attn", "attn", "tile", "tile", "layout", "wgrad", "ln"])
+        kind = rng.choice(["attn", "attn", "tile", "tile", "skinny", "layout", "wgrad", "ln"])
         try:
             if kind == "attn":
                 hd = rng.choice([64, 96, 128, 64, 96])
                 args = (rng.randint(1, 5), rng.randint(1, 100), rng.randint(1, 5), hd, rng.randint(0, 1), 1)
                 K.test_attention_fwd_bwd(*args)
             elif kind == "tile":
-                args = (rng.choice([3, 4, 5]), 8 * rng.randint(1, 150), 8 * rng.randint(1, 120), 32 * rng.randint(1, 40))
+                args = (rng.choice([3, 4, 5, 6, 6]), 8 * rng.randint(1, 150), 8 * rng.randint(1, 120), 32 * rng.randint(1, 40))
                 K.test_gemm_nt_256_row_tiles(*args)
+            elif kind == "skinny":      # the decode-sized 64-row / 80-row tile kernels (round 5: mode 4 = 80 x 64, K over the waves), single pass and K slices
+                ks = rng.choice([1, 1, 1, 2, 3])
+                args = (rng.choice([1, 2, 3, 4, 4]), rng.randint(1, 640), 8 * rng.randint(1, 520), 64 * ks * rng.randint(1, 24), ks)
+                K.test_gemm_nt_skinny_64_row_tiles(*args)
             elif kind == "layout":
                 al, bl = rng.choice([(0, 0), (0, 1), (1, 1)])
                 args = (al, bl, 8 * rng.randint(1, 130), 8 * rng.randint(1, 100), 8 * rng.randint(1, 140))
