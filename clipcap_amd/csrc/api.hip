@@ -122,6 +122,10 @@ struct MapperWS {
     // backward scratch
     float* dx32;
     act_t *dx16, *dx16b, *dh16, *dxn16, *datt16, *dqkv16, *dlin16;
+    // per-layer copies of the four output gradients that are weight-gradient operands (round 5): with them every layer's weight gradients can
+    // wait for ONE grouped launch at the end of the backward call (gdx[l] = d x[l+1], the gradient entering layer l from above).  The bf16x3
+    // build splits operands per call and keeps the single buffers: there every entry aliases them.
+    act_t *gdx[MAX_LAYERS], *gdxb[MAX_LAYERS], *gdh[MAX_LAYERS], *gdqkv[MAX_LAYERS];
     float* wg_scratch;
     float* adelta;
     uint16_t* gimg;    // bf16x3 build: the [hi | hi | lo] image of the output gradient both GEMMs of a layer step read
@@ -171,6 +175,13 @@ void mapper_carve(const cc_mapper_cfg* c, int B, int save, void* ws, MapperWS& w
         w.datt16 = cv.take<act_t>(M * D);
         w.dqkv16 = cv.take<act_t>(M * 3 * D);
         w.dlin16 = cv.take<act_t>((size_t)B * c->W * c->P * D);
+        for (int l = 0; l < c->N; l++) {
+            const bool own = !kX3;                       // every layer its own (a deferred weight gradient reads them at the END of the call)
+            w.gdx[l] = own ? cv.take<act_t>(M * D) : w.dx16;
+            w.gdxb[l] = own ? cv.take<act_t>(M * D) : w.dx16b;
+            w.gdh[l] = own ? cv.take<act_t>(M * c->Hm) : w.dh16;
+            w.gdqkv[l] = own ? cv.take<act_t>(M * 3 * D) : w.dqkv16;
+        }
         w.wg_scratch = cv.take<float>(WGRAD_SCRATCH_BYTES / sizeof(float));
         w.adelta = cv.take<float>((size_t)B * c->H * S);
         // bf16x3: an output gradient is the operand of TWO GEMMs in the same image form (its layer's weight gradient and input gradient):
@@ -179,6 +190,7 @@ void mapper_carve(const cc_mapper_cfg* c, int B, int save, void* ws, MapperWS& w
     } else {
         w.dx32 = nullptr; w.dx16 = w.dx16b = w.dh16 = w.dxn16 = w.datt16 = w.dqkv16 = w.dlin16 = nullptr; w.wg_scratch = nullptr; w.adelta = nullptr;
         w.gimg = nullptr;
+        for (int l = 0; l < c->N; l++) w.gdx[l] = w.gdxb[l] = w.gdh[l] = w.gdqkv[l] = nullptr;
     }
     w.x3 = nullptr; w.x3_bytes = 0;
     if (kX3) {
@@ -491,10 +503,20 @@ int CC_API(cc_mapper_bwd_range)(const cc_mapper_cfg* c, int32_t B, const float* 
     if (l_hi == c->N) {   // seed: d x[N][:, PP:, :] = dout, rows [0:PP] = 0
         if (hipMemsetAsync(w.dx32, 0, (size_t)M * D * sizeof(float), st) != hipSuccess) return CC_ERR_LAUNCH;
         CC_TRY(copy_rows(dout, (size_t)c->L * D, w.dx32 + (size_t)PP * D, (size_t)S * D, c->L * D, B, st));
-        CC_TRY(f32_to_act(w.dx32, w.dx16, (size_t)M * D, st));
+        if (c->N > 0) CC_TRY(f32_to_act(w.dx32, w.gdx[c->N - 1], (size_t)M * D, st));      // (a mapper without layers has no 16-bit consumer)
     }
-    WgradBatch wb;          // per layer: its four weight gradients as ONE grouped GEMM launch + ONE slab reduce (wgrad_flush)
+    // The weight gradients are off the dependency chain.  bf16 / fp16 builds (round 5): every layer of this call parks its four problems and
+    // ONE grouped launch at the end runs them all — whole-K 256 x 256 tiles that add into dW in their epilogue (8 layers: 576 tiles), no K
+    // slices, no slabs, no per-layer reduce launch; their operands live in per-layer buffers (MapperWS::gd*).  A caller that wants the
+    // gradients of a layer range early (the DDP reducer's 2-layer slices) gets them at the end of ITS call: the flush is per call.
+    // bf16x3 build: per layer, as before (operand images are split per GEMM call).
+    WgradBatch wb;
     wb.defer = true;
+    constexpr bool kDeferAll = !kX3;
+    static const bool defer_all_on = []() { const char* e = cc_lab_env("CC_MAPPER_WGRAD_DEFER"); return !e || atoi(e) != 0; }();     // lab build: A/B switch
+    const bool defer_all = kDeferAll && defer_all_on && 4 * (l_hi - l_lo) <= 32;
+    if (defer_all) { wb.direct = true; wb.cap = 4 * (l_hi - l_lo); }
+    ColsumBatch cs;
     // bf16x3: `G2(t, width)` = the tensor as both of its GEMMs take it — split ONCE into w.gimg ([hi | hi | lo], the form of the weight
     // gradient's first operand and of the input gradient's A operand alike); every use re-arms the one-shot image hint
 #if CC_OP == 2
@@ -513,39 +535,49 @@ int CC_API(cc_mapper_bwd_range)(const cc_mapper_cfg* c, int32_t B, const float* 
 #endif
     for (int l = l_hi - 1; l >= l_lo; l--) {
         const auto& y = o.layer[l];
+        act_t* dx16 = w.gdx[l];                                   // d x[l+1]: written by the seed / by the LN1 backward of layer l + 1
+        act_t* dx16b = w.gdxb[l];
+        act_t* dh16 = w.gdh[l];
+        act_t* dqkv16 = w.gdqkv[l];
+        // d x[l] in 16 bits: the gradient entering layer l - 1.  Below layer 0 nobody reads it (the linear's gradient comes from dx32), and it
+        // must NOT land in a buffer a deferred weight gradient still has to read: it goes to the attention-gradient scratch, dead by then
+        act_t* dx16_below = l > 0 ? w.gdx[l - 1] : w.datt16;
         // fc2: y = h W2^T + b2
-        const act_t* gx = G2(w.dx16, D);
+        const act_t* gx = G2(dx16, D);
         CC_TRY(g2rc);
         CC_TIMED(CC_SITE_MAPPER_WGRAD_FC2, st, gemm_wgrad(USE(gx), D, w.h[l], Hm, D, Hm, M, g32 + y.w2, Hm, w.wg_scratch, st, &wb));
         // fc2.bias gradient = column sums of dx16: for every layer but the top one the LN1 backward of the layer above produced
         // them together with dx16 (ln_bwd dcol); the top layer's dx16 comes from the seed
-        if (l == c->N - 1) CC_TRY(colsum_bf16(w.dx16, D, M, D, g32 + y.b2, st));
-        CC_TRY(gemm_dact(0, 0, USE(gx), D, W16(w16t, y.w2), D, M, Hm, D, w.dh16, Hm, w.h[l], 1, st));          // W2^T [Hm, D]
+        if (l == c->N - 1) CC_TRY(colsum_bf16(dx16, D, M, D, g32 + y.b2, st));
+        CC_TRY(gemm_dact(0, 0, USE(gx), D, W16(w16t, y.w2), D, M, Hm, D, dh16, Hm, w.h[l], 1, st));          // W2^T [Hm, D]
         // fc1
-        const act_t* gh = G2(w.dh16, Hm);
+        const act_t* gh = G2(dh16, Hm);
         CC_TRY(g2rc);
         CC_TRY(gemm_wgrad(USE(gh), Hm, w.xn2[l], D, Hm, D, M, g32 + y.w1, D, w.wg_scratch, st, &wb));
-        CC_TRY(colsum_bf16(w.dh16, Hm, M, Hm, g32 + y.b1, st));
+        if (defer_all) cs.add(dh16, g32 + y.b1);                  // fc1.bias gradient: with the deferred weight gradients, one launch for all layers
+        else CC_TRY(colsum_bf16(dh16, Hm, M, Hm, g32 + y.b1, st));
         CC_TRY(gemm_bf16out(0, 0, USE(gh), Hm, W16(w16t, y.w1), Hm, M, D, Hm, w.dxn16, D, nullptr, 0, nullptr, st));   // W1^T [D, Hm]
-        CC_TRY(ln_bwd(w.dxn16, w.x1[l], D, nullptr, w.mean2[l], w.rstd2[l], w32 + y.n2w, w.dx32, w.dx32, w.dx16b, g32 + y.n2w,
+        CC_TRY(ln_bwd(w.dxn16, w.x1[l], D, nullptr, w.mean2[l], w.rstd2[l], w32 + y.n2w, w.dx32, w.dx32, dx16b, g32 + y.n2w,
                       g32 + y.n2b, M, D, st, g32 + y.bp));         // + project.bias gradient (column sums of dx16b)
         // project
-        const act_t* gb = G2(w.dx16b, D);
+        const act_t* gb = G2(dx16b, D);
         CC_TRY(g2rc);
         CC_TRY(gemm_wgrad(USE(gb), D, w.att[l], D, D, D, M, g32 + y.wp, D, w.wg_scratch, st, &wb));
         CC_TRY(gemm_bf16out(0, 0, USE(gb), D, W16(w16t, y.wp), D, M, D, D, w.datt16, D, nullptr, 0, nullptr, st));     // Wp^T
-        CC_TRY(attn_bwd(w.qkv[l], w.datt16, w.att[l], w.lse[l], w.adelta, B, S, H, hd, false, w.dqkv16, st));
+        CC_TRY(attn_bwd(w.qkv[l], w.datt16, w.att[l], w.lse[l], w.adelta, B, S, H, hd, false, dqkv16, st));
         // fused q/kv projection (to_queries.weight ++ to_keys_values.weight = [3D, D])
-        const act_t* gq = G2(w.dqkv16, 3 * D);
+        const act_t* gq = G2(dqkv16, 3 * D);
         CC_TRY(g2rc);
         CC_TRY(gemm_wgrad(USE(gq), 3 * D, w.xn1[l], D, 3 * D, D, M, g32 + y.wq, D, w.wg_scratch, st, &wb));
         CC_TRY(gemm_bf16out(0, 0, USE(gq), 3 * D, W16(w16t, y.wq), 3 * D, M, D, 3 * D, w.dxn16, D, nullptr, 0, nullptr, st));  // Wqkv^T [D, 3D]
-        // the deferred weight gradients read dx16 (layer input gradient), dh16, dx16b, dqkv16: all still intact here — run them
-        // before the LN1 backward overwrites dx16 with the next layer's input gradient
-        CC_TRY(wgrad_flush(wb, st));
-        CC_TRY(ln_bwd(w.dxn16, w.x[l], D, nullptr, w.mean1[l], w.rstd1[l], w32 + y.n1w, w.dx32, w.dx32, w.dx16, g32 + y.n1w,
+        // per-layer form: the deferred weight gradients read dx16, dh16, dx16b, dqkv16 — run them before the LN1 backward overwrites dx16
+        // with the next layer's input gradient (with per-layer buffers nothing is overwritten and the flush waits for the end of the call)
+        if (!defer_all) CC_TRY(wgrad_flush(wb, st));
+        CC_TRY(ln_bwd(w.dxn16, w.x[l], D, nullptr, w.mean1[l], w.rstd1[l], w32 + y.n1w, w.dx32, w.dx32, dx16_below, g32 + y.n1w,
                       g32 + y.n1b, M, D, st, l > 0 ? g32 + o.layer[l - 1].b2 : nullptr));   // + fc2.bias gradient of the layer below
     }
+    CC_TRY(wgrad_flush(wb, st));
+    CC_TRY(colsum_bf16_multi(cs, Hm, M, Hm, st));
     if (l_lo > 0) return CC_OK;
     // prefix_const, pos_embeddings, linear
     CC_TRY(batch_sum(w.dx32 + (size_t)PP * D, (size_t)S * D, g32 + o.prefix, c->L * D, B, st));

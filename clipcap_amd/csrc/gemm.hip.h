@@ -2339,31 +2339,37 @@ inline int launch_gemm_tt256(const op16_t* A, int lda, const op16_t* B, int ldb,
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
 
-// Grouped form: up to 4 independent weight-gradient problems (one mapper / GPT-2 layer's dW's) in ONE launch.  The blocks of all
+// Grouped form: up to 32 independent weight-gradient problems (one mapper / GPT-2 layer's dW's, or — round 5 — all layers of a mapper backward) in ONE launch.  The blocks of all
 // problems and all their K slices form one 1-D grid (problem i owns logical blocks [first[i], first[i+1]), slice-major inside), so the
 // launch fills the CUs with ONE tail instead of four, and the per-launch floor is paid once.  Each problem writes fp32 slabs (C of
 // its functor + slice * zstride) that the batched slab reduce folds into dW.
+constexpr int TT_GROUP_MAX = 32;
 struct TTGroup {
-    const op16_t* A[4];
-    const op16_t* B[4];
-    GemmShape g[4];
-    float* slab[4];        // slab base of problem i (slice z at + z * zstride[i]); row stride = g[i].N
-    size_t zstride[4];
-    int first[5];          // logical block ranges
+    const op16_t* A[TT_GROUP_MAX];
+    const op16_t* B[TT_GROUP_MAX];
+    GemmShape g[TT_GROUP_MAX];
+    float* slab[TT_GROUP_MAX];        // slab base of problem i (slice z at + z * zstride[i]); direct mode: dW itself
+    size_t zstride[TT_GROUP_MAX];
+    int ldc[TT_GROUP_MAX];            // row stride of the output (slab: g[i].N; direct: ldw)
+    int first[TT_GROUP_MAX + 1];      // logical block ranges
     int n;
+    int mode;                         // EpiF32 mode of every problem: 0 = store into the slab, 1 = dW += tile (one K slice, no slab, no reduce)
 };
+__device__ __forceinline__ int tt_group_find(const TTGroup& grp, int L) {
+    int i = 0;
+    for (int k = 1; k < grp.n; k++)
+        if (L >= grp.first[k]) i = k;
+    return i;
+}
 static __global__ __launch_bounds__(G_THREADS, 1) void gemm_tt_glds4_group_kernel(TTGroup grp) {
     extern __shared__ __attribute__((aligned(1024))) char smemt[];
     const int L = xcd_remap(blockIdx.x, gridDim.x);
-    int i = 0;
-#pragma unroll
-    for (int k = 1; k < 4; k++)
-        if (k < grp.n && L >= grp.first[k]) i = k;
+    const int i = tt_group_find(grp, L);
     const GemmShape g = grp.g[i];
     const int tiles = ((g.M + G_BM - 1) / G_BM) * ((g.N + G_BN - 1) / G_BN);
     const int local = L - grp.first[i];
     const int z = local / tiles, tile = local - z * tiles;
-    EpiF32 e{grp.slab[i] + (size_t)z * grp.zstride[i], nullptr, g.N, g.M, g.N, 0, 1.0f};
+    EpiF32 e{grp.slab[i] + (size_t)z * grp.zstride[i], nullptr, grp.ldc[i], g.M, g.N, grp.mode, 1.0f};
     gemm_tt_glds4_body(grp.A[i], grp.B[i], g, e, tile, z, smemt);
 }
 // the same grouping on the 256 x 256 transpose-read kernel (8 waves, one block per CU): fewer, fatter blocks — wins when the group's
@@ -2371,15 +2377,12 @@ static __global__ __launch_bounds__(G_THREADS, 1) void gemm_tt_glds4_group_kerne
 static __global__ __launch_bounds__(512, 1) void gemm_tt_stag256_group_kernel(TTGroup grp) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int L = xcd_remap(blockIdx.x, gridDim.x);
-    int i = 0;
-#pragma unroll
-    for (int k = 1; k < 4; k++)
-        if (k < grp.n && L >= grp.first[k]) i = k;
+    const int i = tt_group_find(grp, L);
     const GemmShape g = grp.g[i];
     const int tiles = ((g.M + H_BM - 1) / H_BM) * ((g.N + H_BN - 1) / H_BN);
     const int local = L - grp.first[i];
     const int z = local / tiles, tile = local - z * tiles;
-    EpiF32 e{grp.slab[i] + (size_t)z * grp.zstride[i], nullptr, g.N, g.M, g.N, 0, 1.0f};
+    EpiF32 e{grp.slab[i] + (size_t)z * grp.zstride[i], nullptr, grp.ldc[i], g.M, g.N, grp.mode, 1.0f};
     gemm_stag256_body<EpiF32, 4, true>(grp.A[i], grp.B[i], g, e, tile, z, smem);
 }
 inline int launch_gemm_tt256_group(const TTGroup& grp, hipStream_t st) {

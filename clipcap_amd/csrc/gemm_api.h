@@ -82,8 +82,13 @@ struct WgradBatch {
     // operand unchanged until the flush.
     bool defer = false;
     struct Deferred { const op16_t* X; const op16_t* Y; int ldx, ldy, Mw, Nw, K; float* dW; int ldw; };      // (never used in the bf16x3 build: operands are split per call)
-    Deferred d[4];
+    Deferred d[32];
     int nd = 0;
+    int cap = 4;          // deferred problems per grouped launch (<= 32)
+    // direct = true (round 5; with defer): the deferred problems run as ONE launch with a single K slice per tile that adds into dW in its
+    // epilogue — no slabs, no reduce launch; meant for many problems at once (all layers of a mapper backward: 576 tiles of 256 x 256),
+    // where whole-K tiles still fill the CUs.  The caller keeps every operand unchanged until the flush.
+    bool direct = false;
     float* scratch = nullptr;
 };
 int wgrad_flush(WgradBatch& b, hipStream_t st);

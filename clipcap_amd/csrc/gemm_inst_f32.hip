@@ -55,7 +55,30 @@ static int wgrad_launch_group(WgradBatch& b, hipStream_t st) {
     if (b.nd == 0) return CC_OK;
     TTGroup grp;
     grp.n = b.nd;
+    grp.mode = 0;
     const int K = b.d[0].K;
+    if (b.direct) {
+        // one K slice per tile, dW += tile in the epilogue: the 256 x 256 kernel when K allows it (a block walks the whole K: 160 steps at K = 5120)
+        double fl = 0.0;
+        for (int i = 0; i < b.nd; i++) fl += 2.0 * b.d[i].Mw * b.d[i].Nw * (double)K;
+        cc_shared::ProfScope _alld(cc_shared::SITE_ALL_GEMMS, st, fl);
+        const bool t256 = (K % H_BK) == 0;
+        const int tile = t256 ? 256 : 128;
+        const int kt64 = (K + G_BK - 1) / G_BK;
+        int first = 0;
+        for (int i = 0; i < b.nd; i++) {
+            const auto& d = b.d[i];
+            grp.A[i] = d.X; grp.B[i] = d.Y;
+            grp.g[i] = GemmShape{d.Mw, d.Nw, d.K, d.ldx, d.ldy, kt64 * G_BK, 8, 0};
+            grp.slab[i] = d.dW; grp.zstride[i] = 0; grp.ldc[i] = d.ldw;
+            grp.first[i] = first;
+            first += ((d.Mw + tile - 1) / tile) * ((d.Nw + tile - 1) / tile);
+        }
+        for (int i = b.nd; i <= TT_GROUP_MAX; i++) grp.first[i] = first;
+        grp.mode = 1;
+        b.nd = 0;
+        return t256 ? launch_gemm_tt256_group(grp, st) : launch_gemm_tt128_group(grp, st);
+    }
     double flops = 0.0;
     for (int i = 0; i < b.nd; i++) flops += 2.0 * b.d[i].Mw * b.d[i].Nw * (double)K;
     cc_shared::ProfScope _all(cc_shared::SITE_ALL_GEMMS, st, flops);
@@ -98,15 +121,14 @@ static int wgrad_launch_group(WgradBatch& b, hipStream_t st) {
         const int tiles = ((d.Mw + best_tile - 1) / best_tile) * ((d.Nw + best_tile - 1) / best_tile);
         grp.A[i] = d.X; grp.B[i] = d.Y;
         grp.g[i] = GemmShape{d.Mw, d.Nw, d.K, d.ldx, d.ldy, per64 * G_BK, 8, 0};
-        grp.slab[i] = sc; grp.zstride[i] = slab;
+        grp.slab[i] = sc; grp.zstride[i] = slab; grp.ldc[i] = d.Nw;
         grp.first[i] = first;
         first += tiles * ks;
         b.it[b.n++] = WgradBatch::Item{sc, slab, ks, d.Nw, d.dW, d.ldw, slab / 4};
         b.used += (size_t)ks * slab * sizeof(float);
         b.used = (b.used + 255) & ~size_t(255);
     }
-    grp.first[b.nd] = first;
-    for (int i = b.nd + 1; i < 5; i++) grp.first[i] = first;
+    for (int i = b.nd; i <= TT_GROUP_MAX; i++) grp.first[i] = first;
     b.nd = 0;
     return best_tile == 256 ? launch_gemm_tt256_group(grp, st) : launch_gemm_tt128_group(grp, st);
 }
@@ -178,7 +200,8 @@ int gemm_wgrad(const act_t* Xa, int ldx, const act_t* Ya, int ldy, int Mw, int N
         slab_bytes <= WGRAD_SCRATCH_BYTES && (batch->nd == 0 || batch->d[0].K == K)) {
         size_t pending = 0;
         for (int i = 0; i < batch->nd; i++) pending += (((size_t)batch->d[i].Mw * batch->d[i].Nw * sizeof(float)) + 255) & ~size_t(255);
-        if (batch->nd == 4 || batch->n + batch->nd >= 8 || batch->used + pending + slab_bytes > WGRAD_SCRATCH_BYTES) {
+        const int cap = std::min(std::max(batch->cap, 1), 32);
+        if (batch->nd == cap || (!batch->direct && (batch->n + batch->nd >= 8 || batch->used + pending + slab_bytes > WGRAD_SCRATCH_BYTES))) {
             const int rcf = wgrad_flush(*batch, st);
             if (rcf != CC_OK) return rcf;
         }

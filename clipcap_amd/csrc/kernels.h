@@ -34,6 +34,8 @@ int ln_bwd(const act_t* dy, const float* x, int ldx, const int* row_map, const f
 // dcol (needs dgamma, dx16, no row_map): += column sums of the 16-bit dx16 (a bias gradient).  dmask: dropout mask applied to the
 // 16-bit copy dx16 only (element index row * D + col; dx32 stays unmasked) — the residual dropout of the c_proj that consumes dx16.
 int colsum_bf16(const act_t* X, int ld, int M, int N, float* out, hipStream_t st);
+struct ColsumBatch { const act_t* X[32]; float* out[32]; int n = 0; void add(const act_t* x, float* o) { X[n] = x; out[n] = o; n++; } };
+int colsum_bf16_multi(const ColsumBatch& b, int ld, int M, int N, hipStream_t st);      // out[i][c] += sum_r X[i][r][c] for n equally shaped matrices, one launch
 
 int attn_probs(const act_t* qkv, int B, int S, int H, int hd, float* out, hipStream_t st);
 int attn_fwd(const act_t* qkv, int B, int S, int H, int hd, bool causal, act_t* out, float* lse, hipStream_t st, Drop drop = Drop());

@@ -555,6 +555,45 @@ __global__ __launch_bounds__(256) void k_colsum_bf16(const act_t* __restrict__ X
         if (c < N) __hip_atomic_fetch_add(out + c, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
+// the same column sums for up to 32 equally shaped matrices in one launch (blockIdx.z = matrix): the mapper backward's per-layer
+// fc1.bias gradients, deferred to the end of the call together with the weight gradients (round 5)
+__global__ __launch_bounds__(256) void k_colsum_bf16_multi(ColsumBatch b, int ld, int M, int N, int rows_per_slice) {
+    __shared__ float red[32][65];
+    const act_t* __restrict__ X = b.X[blockIdx.z];
+    float* __restrict__ out = b.out[blockIdx.z];
+    const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int col = blockIdx.x * 64 + cg * 8;
+    const int r0 = blockIdx.y * rows_per_slice, r1 = min(M, r0 + rows_per_slice);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (col < N) {
+        for (int r = r0 + rl; r < r1; r += 32) {
+            float f[8];
+            act_ld8(X + (size_t)r * ld + col, f);
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc[e] += f[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) red[rl][cg * 8 + e] = acc[e];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; r++) s += red[r][threadIdx.x];
+        const int c = blockIdx.x * 64 + threadIdx.x;
+        if (c < N) __hip_atomic_fetch_add(out + c, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+int colsum_bf16_multi(const ColsumBatch& b, int ld, int M, int N, hipStream_t st) {
+    if ((N & 7) || (ld & 7) || b.n < 0 || b.n > 32) return CC_ERR_SHAPE;
+    if (M <= 0 || N <= 0 || b.n == 0) return CC_OK;
+    const int cb = (N + 63) / 64;
+    int slices = std::max(1, std::min((M + 255) / 256, std::max(1, 1024 / (cb * b.n))));
+    const int rps = ((M + slices - 1) / slices + 31) / 32 * 32;
+    slices = (M + rps - 1) / rps;
+    hipLaunchKernelGGL(k_colsum_bf16_multi, dim3(cb, slices, b.n), dim3(256), 0, st, b, ld, M, N, rps);
+    return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+}
 int colsum_bf16(const act_t* X, int ld, int M, int N, float* out, hipStream_t st) {
     if ((N & 7) || (ld & 7)) return CC_ERR_SHAPE;
     if (M <= 0 || N <= 0) return CC_OK;

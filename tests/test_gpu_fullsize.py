@@ -105,3 +105,59 @@ def test_full_size_full_finetune_with_dropout_properties():
     eng.zero_grad()
     plain = float(eng.forward_backward(tokens, embeds))
     assert abs(plain - l0) > 1e-4                  # dropout is actually on
+
+
+def test_full_size_mapper_gradients_vs_oracle_and_layer_slices():
+    """The mapper at the FULL config-2 size (B = 256 -> M = 5120 rows, 3 layers to keep the CPU oracle in seconds): at this M the backward takes
+    the grouped weight-gradient path that small-shape tests never reach (K >= 1024) — round 5: every layer's weight gradients parked until ONE
+    launch at the end of the call.  (1) every gradient tensor against the oracle's autograd with bf16 rounding points; (2) the single-call
+    backward against the layer-sliced backward (1, 2 and 3 layers per cc_mapper_bwd_range call): the same kernels on the same operands, so
+    equal up to the order of fp32 atomics — a deferred launch that reads an operand a later layer has overwritten shows up in both."""
+    from clipcap_amd.engine import MapperEngine
+    from oracle import clipcap_oracle as O
+    torch.manual_seed(17)
+    E, D, P, L, H, N, B = 512, 768, 10, 10, 8, 3, 256
+    eng = MapperEngine(E, D, L, P, H, N, device="cuda")
+    views = eng.views(eng.arena.w32)
+    sd = {}
+    for k, v in views.items():
+        if k.endswith("norm1.weight") or k.endswith("norm2.weight"):
+            t = 1.0 + 0.1 * torch.randn(v.shape)
+        elif k == "prefix_const":
+            t = torch.randn(v.shape)
+        elif k.endswith(".bias"):
+            t = 0.05 * torch.randn(v.shape)
+        else:
+            t = torch.randn(v.shape) / (v.shape[-1] ** 0.5)
+        sd[k] = t
+        v.copy_(t)
+    eng.arena.mark_dirty() if hasattr(eng.arena, "mark_dirty") else None
+    x = torch.randn(B, E)
+    out = eng.forward(x.cuda(), save=True)
+    dout = (2.0 * out / out.numel())
+
+    def grads(group):
+        eng.arena.grads().zero_()
+        if group == 0:
+            eng.backward(dout)
+        else:
+            eng.backward(dout, on_layers_done=lambda lo, hi: None, group=group)
+        torch.cuda.synchronize()
+        return eng.arena.g32.clone()
+
+    g_single = grads(0)
+    for group in (1, 2, 3):
+        r = _rel(grads(group), g_single)
+        assert r <= 1e-5, (group, r)
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.mapper_forward(sdr, x, projection_length=P, num_heads=H, num_layers=N, rb=True)
+    ref.square().mean().backward()
+    eng.arena.g32.copy_(g_single)
+    gv = eng.views(eng.arena.g32)
+    worst = ("", 0.0)
+    for k in sd:
+        r = _rel(gv[k].cpu(), sdr[k].grad)
+        if r > worst[1]:
+            worst = (k, r)
+        assert r <= 3e-2, (k, r)
+    print(f"full-size mapper (3 layers, B = 256): worst relative gradient error vs oracle(bf16 points) {worst[1]:.3e} ({worst[0]})")
