@@ -514,7 +514,10 @@ int CC_API(cc_mapper_bwd_range)(const cc_mapper_cfg* c, int32_t B, const float* 
     wb.defer = true;
     constexpr bool kDeferAll = !kX3;
     static const bool defer_all_on = []() { const char* e = cc_lab_env("CC_MAPPER_WGRAD_DEFER"); return !e || atoi(e) != 0; }();     // lab build: A/B switch
-    const bool defer_all = kDeferAll && defer_all_on && 4 * (l_hi - l_lo) <= 32;
+    // Whole-K tiles fill the CUs worse than the per-layer launches' K slices (8 layers: 576 tiles = 2.25 rounds, 75 % against 84 %); what the
+    // deferred launch saves — the slab traffic and reduce launches — does not grow with the row count, the fill loss does: measured ahead at
+    // B = 256 (M = 5120: 2.63 -> 2.50 ms), even at B = 1024, behind at B = 4096 (28.4 -> 29.9 ms).  Crossover ~ 15 k rows.
+    const bool defer_all = kDeferAll && defer_all_on && 4 * (l_hi - l_lo) <= 32 && M <= 12288;
     if (defer_all) { wb.direct = true; wb.cap = 4 * (l_hi - l_lo); }
     ColsumBatch cs;
     // bf16x3: `G2(t, width)` = the tensor as both of its GEMMs take it — split ONCE into w.gimg ([hi | hi | lo], the form of the weight
