@@ -514,10 +514,12 @@ int CC_API(cc_mapper_bwd_range)(const cc_mapper_cfg* c, int32_t B, const float* 
     wb.defer = true;
     constexpr bool kDeferAll = !kX3;
     static const bool defer_all_on = []() { const char* e = cc_lab_env("CC_MAPPER_WGRAD_DEFER"); return !e || atoi(e) != 0; }();     // lab build: A/B switch
-    // Whole-K tiles fill the CUs worse than the per-layer launches' K slices (8 layers: 576 tiles = 2.25 rounds, 75 % against 84 %); what the
-    // deferred launch saves — the slab traffic and reduce launches — does not grow with the row count, the fill loss does: measured ahead at
-    // B = 256 (M = 5120: 2.63 -> 2.50 ms), even at B = 1024, behind at B = 4096 (28.4 -> 29.9 ms).  Crossover ~ 15 k rows.
-    const bool defer_all = kDeferAll && defer_all_on && 4 * (l_hi - l_lo) <= 32 && M <= 12288;
+    // Whole-K tiles fill the CUs worse than the per-layer launches' K slices (8 layers: 576 tiles = 2.25 rounds); the launch therefore cuts the
+    // tiles beyond its last full round into K slices (TTGroup::whole / split: 2 rounds + 64 tiles x 4 slices, slabs + a small reduce).  What the
+    // deferred launch saves does not grow with the row count, what is left of the fill loss does: ahead at B = 256 (M = 5120: 2.63 -> 2.50 ms)
+    // and B = 1024 (7.64 -> 7.43), behind at B = 4096 (28.04 -> 28.35) — calls above 40 960 rows keep the per-layer form.
+    static const int defer_rows = []() { const char* e = cc_lab_env("CC_MAPPER_DEFER_ROWS"); return e ? atoi(e) : 40960; }();      // lab build: the row limit
+    const bool defer_all = kDeferAll && defer_all_on && 4 * (l_hi - l_lo) <= 32 && M <= defer_rows;
     if (defer_all) { wb.direct = true; wb.cap = 4 * (l_hi - l_lo); }
     ColsumBatch cs;
     // bf16x3: `G2(t, width)` = the tensor as both of its GEMMs take it — split ONCE into w.gimg ([hi | hi | lo], the form of the weight

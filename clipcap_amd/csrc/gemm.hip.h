@@ -2354,6 +2354,12 @@ struct TTGroup {
     int first[TT_GROUP_MAX + 1];      // logical block ranges
     int n;
     int mode;                         // EpiF32 mode of every problem: 0 = store into the slab, 1 = dW += tile (one K slice, no slab, no reduce)
+    // direct mode, 256 x 256 kernel: the tiles beyond the last FULL round of the chip (physical blocks >= `whole`, dispatched last) are cut into
+    // `split` K slices each, so the launch ends with a short round of all CUs instead of a long round of a few (8 mapper layers: 576 tiles =
+    // 2 full rounds + 64 tiles x 4 slices).  The slices store compact 256 x 256 fp32 slabs into `tail` (unit u at + u * 65536) and
+    // gemm_tt_tail_reduce_kernel adds them into dW (fp32 atomics for the same job measured 2.54 -> 2.84 ms on the mapper).  whole < 0: off.
+    int whole = -1, split = 1;
+    float* tail = nullptr;
 };
 __device__ __forceinline__ int tt_group_find(const TTGroup& grp, int L) {
     int i = 0;
@@ -2376,6 +2382,33 @@ static __global__ __launch_bounds__(G_THREADS, 1) void gemm_tt_glds4_group_kerne
 // tiles x slices fill the CUs in one round (a mapper layer: 72 tiles x 3 slices)
 static __global__ __launch_bounds__(512, 1) void gemm_tt_stag256_group_kernel(TTGroup grp) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
+    if (grp.whole >= 0) {
+        // direct mode with a K-sliced tail: logical tile index from the PHYSICAL block index (dispatch order decides what runs last)
+        const int b = (int)blockIdx.x;
+        const bool cut = b >= grp.whole;
+        const int Lt = cut ? grp.whole + (b - grp.whole) / grp.split : xcd_remap(b, grp.whole);
+        const int i = tt_group_find(grp, Lt);
+        GemmShape g = grp.g[i];
+        int z = 0;
+        if (cut) {
+            z = (b - grp.whole) % grp.split;
+            const int kt = (g.K + G_BK - 1) / G_BK;
+            g.k_chunk = ((kt + grp.split - 1) / grp.split) * G_BK;
+        }
+        if (!cut) {
+            EpiF32 e{grp.slab[i], nullptr, grp.ldc[i], g.M, g.N, 1, 1.0f};
+            gemm_stag256_body<EpiF32, 4, true>(grp.A[i], grp.B[i], g, e, Lt - grp.first[i], 0, smem);
+        } else {
+            // compact slab of this (tile, slice): element (row, col) of the tile at (row - m0) * 256 + (col - n0)
+            const int tiles_n = (g.N + H_BN - 1) / H_BN, tiles_m = (g.M + H_BM - 1) / H_BM;
+            int tm, tn;
+            tile_coords(Lt - grp.first[i], tiles_m, tiles_n, g.group_m, tm, tn);
+            float* sl = grp.tail + (size_t)(b - grp.whole) * (H_BM * H_BN) - ((size_t)tm * H_BM * H_BN + (size_t)tn * H_BN);
+            EpiF32 e{sl, nullptr, H_BN, g.M, g.N, 0, 1.0f};
+            gemm_stag256_body<EpiF32, 4, true>(grp.A[i], grp.B[i], g, e, Lt - grp.first[i], z, smem);
+        }
+        return;
+    }
     const int L = xcd_remap(blockIdx.x, gridDim.x);
     const int i = tt_group_find(grp, L);
     const GemmShape g = grp.g[i];
@@ -2385,11 +2418,39 @@ static __global__ __launch_bounds__(512, 1) void gemm_tt_stag256_group_kernel(TT
     EpiF32 e{grp.slab[i] + (size_t)z * grp.zstride[i], nullptr, grp.ldc[i], g.M, g.N, grp.mode, 1.0f};
     gemm_stag256_body<EpiF32, 4, true>(grp.A[i], grp.B[i], g, e, tile, z, smem);
 }
+// dW += sum of the K-slice slabs of the cut tiles (16 workgroups per cut tile, 16 rows each: with one per tile the 64-workgroup launch ran at 0.8 TB/s)
+static __global__ __launch_bounds__(256) void gemm_tt_tail_reduce_kernel(TTGroup grp) {
+    const int ct = (int)blockIdx.x >> 4, rb = ((int)blockIdx.x & 15) * (H_BM / 16);
+    const int Lt = grp.whole + ct;
+    const int i = tt_group_find(grp, Lt);
+    const GemmShape g = grp.g[i];
+    const int tiles_n = (g.N + H_BN - 1) / H_BN, tiles_m = (g.M + H_BM - 1) / H_BM;
+    int tm, tn;
+    tile_coords(Lt - grp.first[i], tiles_m, tiles_n, g.group_m, tm, tn);
+    const int m0 = tm * H_BM, n0 = tn * H_BN;
+    const float* sl = grp.tail + (size_t)ct * grp.split * (H_BM * H_BN);
+    float* dW = grp.slab[i];
+    const int ldw = grp.ldc[i];
+    for (int q = threadIdx.x; q < (H_BM / 16) * H_BN / 4; q += 256) {
+        const int r = rb + q / (H_BN / 4), c = (q % (H_BN / 4)) * 4;
+        if (m0 + r >= g.M || n0 + c >= g.N) continue;
+        float4 a = *reinterpret_cast<const float4*>(sl + (size_t)r * H_BN + c);
+        for (int z = 1; z < grp.split; z++) {
+            const float4 v = *reinterpret_cast<const float4*>(sl + (size_t)z * (H_BM * H_BN) + (size_t)r * H_BN + c);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        float* d = dW + (size_t)(m0 + r) * ldw + n0 + c;
+        const float4 o = *reinterpret_cast<const float4*>(d);
+        *reinterpret_cast<float4*>(d) = make_float4(o.x + a.x, o.y + a.y, o.z + a.z, o.w + a.w);
+    }
+}
 inline int launch_gemm_tt256_group(const TTGroup& grp, hipStream_t st) {
     constexpr size_t sh = (size_t)H_NS * H_STAGE;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tt_stag256_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr = true; }
-    hipLaunchKernelGGL(gemm_tt_stag256_group_kernel, dim3((unsigned)grp.first[grp.n]), dim3(512), sh, st, grp);
+    const unsigned blocks = grp.whole >= 0 ? (unsigned)(grp.whole + (grp.first[grp.n] - grp.whole) * grp.split) : (unsigned)grp.first[grp.n];
+    hipLaunchKernelGGL(gemm_tt_stag256_group_kernel, dim3(blocks), dim3(512), sh, st, grp);
+    if (grp.whole >= 0) hipLaunchKernelGGL(gemm_tt_tail_reduce_kernel, dim3((unsigned)(grp.first[grp.n] - grp.whole) * 16), dim3(256), 0, st, grp);
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
 inline int launch_gemm_tt128_group(const TTGroup& grp, hipStream_t st) {

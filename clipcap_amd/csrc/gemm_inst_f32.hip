@@ -76,6 +76,18 @@ static int wgrad_launch_group(WgradBatch& b, hipStream_t st) {
         }
         for (int i = b.nd; i <= TT_GROUP_MAX; i++) grp.first[i] = first;
         grp.mode = 1;
+        if (t256) {
+            // the tail beyond the last full round of 256 workgroups: K slices + atomics, so that it is a short round of every CU
+            // (CC_WGRAD_TAIL=0 in the lab build: whole tiles only)
+            static const bool tail_on = []() { const char* e = cc_lab_env("CC_WGRAD_TAIL"); return !e || atoi(e) != 0; }();
+            const int full = (first / 256) * 256, rem = first - full;
+            int sp = rem > 0 ? 256 / rem : 1;
+            sp = std::min(sp, std::min(8, std::max(1, (K / H_BK) / 16)));      // at least 16 K-steps per slice
+            // (the slices' slabs: rem x sp x 256 KiB <= 64 MiB of the scratch, which a direct batch does not use otherwise)
+            if (tail_on && full > 0 && sp >= 2 && b.scratch && b.n == 0 && (size_t)rem * sp * H_BM * H_BN * sizeof(float) <= WGRAD_SCRATCH_BYTES) {
+                grp.whole = full; grp.split = sp; grp.tail = b.scratch;
+            }
+        }
         b.nd = 0;
         return t256 ? launch_gemm_tt256_group(grp, st) : launch_gemm_tt128_group(grp, st);
     }

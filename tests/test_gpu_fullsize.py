@@ -107,8 +107,10 @@ def test_full_size_full_finetune_with_dropout_properties():
     assert abs(plain - l0) > 1e-4                  # dropout is actually on
 
 
-def test_full_size_mapper_gradients_vs_oracle_and_layer_slices():
-    """The mapper at the FULL config-2 size (B = 256 -> M = 5120 rows, 3 layers to keep the CPU oracle in seconds): at this M the backward takes
+@pytest.mark.parametrize("N", [3, 8])
+def test_full_size_mapper_gradients_vs_oracle_and_layer_slices(N):
+    """The mapper at the FULL config-2 size (B = 256 -> M = 5120 rows; 3 layers = 216 weight-gradient tiles, one round; 8 layers = 576 tiles = two
+    full rounds of whole-K tiles + a K-sliced tail added with atomics): at this M the backward takes
     the grouped weight-gradient path that small-shape tests never reach (K >= 1024) — round 5: every layer's weight gradients parked until ONE
     launch at the end of the call.  (1) every gradient tensor against the oracle's autograd with bf16 rounding points; (2) the single-call
     backward against the layer-sliced backward (1, 2 and 3 layers per cc_mapper_bwd_range call): the same kernels on the same operands, so
@@ -116,7 +118,7 @@ def test_full_size_mapper_gradients_vs_oracle_and_layer_slices():
     from clipcap_amd.engine import MapperEngine
     from oracle import clipcap_oracle as O
     torch.manual_seed(17)
-    E, D, P, L, H, N, B = 512, 768, 10, 10, 8, 3, 256
+    E, D, P, L, H, B = 512, 768, 10, 10, 8, 256
     eng = MapperEngine(E, D, L, P, H, N, device="cuda")
     views = eng.views(eng.arena.w32)
     sd = {}
@@ -160,4 +162,4 @@ def test_full_size_mapper_gradients_vs_oracle_and_layer_slices():
         if r > worst[1]:
             worst = (k, r)
         assert r <= 3e-2, (k, r)
-    print(f"full-size mapper (3 layers, B = 256): worst relative gradient error vs oracle(bf16 points) {worst[1]:.3e} ({worst[0]})")
+    print(f"full-size mapper ({N} layers, B = 256): worst relative gradient error vs oracle(bf16 points) {worst[1]:.3e} ({worst[0]})")
