@@ -1514,6 +1514,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_stag256_kernel(const op16_t* _
 #undef H_SEGEND
 #undef H_WAIT
 
+#include "gemm_q4.hip.h"
+
 // ------------------------------------------------------------------------------------------------
 // TT 128 x 128 kernel (both operands K-strided, weight gradients below the 256-row kernel's break-even): the 4-stage small-grid
 // pipeline above with the K-strided staging and transpose reads of the 256-row TT kernel.  LDS stage = A [64 k][128 cols] |
