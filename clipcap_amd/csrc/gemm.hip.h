@@ -2185,7 +2185,7 @@ inline int launch_gemm(int al, int bl, const op16_t* A, int lda, const op16_t* B
         const long t160 = (long)((M + 159) / 160) * ((N + 255) / 256);
         const double c160 = (double)((t160 + 255) / 256) * 40960.0 / 1.1;
         static const bool s160_on = []() { const char* e = cc_lab_env("CC_GEMM_S160"); return !e || atoi(e) != 0; }();
-        if (can160 && (s256 == 6 || (s256 < 0 && s160_on && ksplit == 1 && c160 < 0.98 * c128 && c160 < 0.98 * c256 && c160 < 0.98 * c320 && (!can192 || c160 < 0.98 * c192)))) { nj = 4; ni = 5; }
+        if (can160 && (s256 == 6 || s256 == 7 || (s256 < 0 && s160_on && ksplit == 1 && c160 < 0.98 * c128 && c160 < 0.98 * c256 && c160 < 0.98 * c320 && (!can192 || c160 < 0.98 * c192)))) { nj = 4; ni = 5; }
         else if (s256 == 5 || (can320 && s256 < 0 && c320 < 0.98 * c128 && c320 < c256 && (!can192 || c320 < c192))) { nj = 4; ni = 10; }
         else if (s256 == 4 || (s256 < 0 && c256 < 0.98 * c128 && (!can192 || c256 <= c192))) nj = 4;
         else if (can192 && (s256 == 3 || (s256 < 0 && c192 < 0.98 * c128))) nj = 3;
@@ -2201,7 +2201,33 @@ inline int launch_gemm(int al, int bl, const op16_t* A, int lda, const op16_t* B
         hipLaunchKernelGGL((gemm_nt_stag256_kernel<Epi, NJ_, false, NI_>), gr, dim3(512), sh, st, A, B, g, epi);        \
     }
         if (nj == 4 && ni == 8) CC_LAUNCH_STAG(4, 8)
-        else if (nj == 4 && ni == 5) { if constexpr (can160) CC_LAUNCH_STAG(4, 5) }
+        else if (nj == 4 && ni == 5) {
+            if constexpr (can160) {
+                // (round 6) the 160 x 256 launches go to the persistent 4-wave kernel with 64-deep full-line stages (gemm_q4.hip.h) wherever K fits its
+                // ring: three stages for K % 192 == 0, two for K % 128 == 0; byte offsets inside an operand are 32-bit there.  Measured against the
+                // staggered 160 x 256 kernel (profiles/r06_b): 12800 x 768 x 3072 58.9 -> 52.8 us, x 2304 44.2 -> 41.7, x 768 20.2 -> 21.2 (plain functor:
+                // 57.1 -> 49.7, 43.7 -> 38.5, 20.6 -> 19.8).  cc_gemm_tile_mode 6 keeps the staggered kernel, 7 forces this one.
+                static const bool q4_on = []() { const char* e = cc_lab_env("CC_GEMM_Q4"); return !e || atoi(e) != 0; }();
+                const bool fits32 = (size_t)M * (size_t)lda * 2 < 0xffff0000ull && (size_t)N * (size_t)ldb * 2 < 0xffff0000ull;
+                const int ns = (K % 192 == 0 && K >= 384) ? 3 : ((K % 128 == 0 && K >= 256) ? 2 : 0);
+                if (ns && fits32 && ksplit == 1 && s256 != 6 && (q4_on || s256 == 7)) {
+                    static const int ncu = []() { int n = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+                    const int tiles = ((M + 159) / 160) * ((N + 255) / 256);
+                    const dim3 gq((unsigned)(tiles < ncu ? tiles : ncu));
+                    if (ns == 3) {
+                        constexpr size_t shq = (size_t)3 * (160 + 256) * 128;
+                        static bool attr_ = false;
+                        if (!attr_) { (void)hipFuncSetAttribute((const void*)gemm_nt_q4_kernel<Epi, 5, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shq); attr_ = true; }
+                        hipLaunchKernelGGL((gemm_nt_q4_kernel<Epi, 5, 3>), gq, dim3(256), shq, st, A, B, g, epi);
+                    } else {
+                        constexpr size_t shq = (size_t)2 * (160 + 256) * 128;
+                        static bool attr_ = false;
+                        if (!attr_) { (void)hipFuncSetAttribute((const void*)gemm_nt_q4_kernel<Epi, 5, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shq); attr_ = true; }
+                        hipLaunchKernelGGL((gemm_nt_q4_kernel<Epi, 5, 2>), gq, dim3(256), shq, st, A, B, g, epi);
+                    }
+                } else CC_LAUNCH_STAG(4, 5)
+            }
+        }
         else if (nj == 4) CC_LAUNCH_STAG(4, 10)
         else if constexpr (!epi_row_strip<Epi>::value) {
             bool fused = false;

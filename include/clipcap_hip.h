@@ -387,7 +387,9 @@ int64_t cc_wgrad_scratch_bytes(void);
 int cc_gemm_wgrad(int32_t op_dtype, const uint16_t* X, int32_t ldx, const uint16_t* Y, int32_t ldy, int32_t Mw, int32_t Nw, int32_t K, float* dW, int32_t ldw,
                   float* scratch, void* stream);
 /* PROCESS-WIDE test knob.  NT GEMM tile choice: -1 = cost-model chooser (default), 0 = 128x128 kernels only (also for cc_gemm_wgrad), 3 / 4 / 5 / 6 =
- * force the 256x192 / 256x256 / 320x256 / 160x256 kernel wherever it is legal.  Returns the previous mode.  For tests and tools/gemm_bench.py only. */
+ * force the 256x192 / 256x256 / 320x256 / 160x256 (8-wave staggered) kernel wherever it is legal; 7 = 160x256 on the persistent 4-wave kernel with the
+ * instruction-level K loop (what the chooser launches for that tile when K % 128 == 0 and K >= 256), the staggered one otherwise.  Returns the previous
+ * mode.  For tests and tools/gemm_bench.py only. */
 int cc_gemm_tile_mode(int32_t mode);
 /* Decode-sized NT GEMMs (M <= 640 rows: cc_decode_fwd's c_attn / c_proj / c_fc at rows x beams = 320) run on 64-row tiles
  * (gemm_nt_s64_kernel).  -1 = default (those call sites only), 0 = never, 1 / 2 / 3 / 4 = additionally route cc_gemm_bf16_f32's NT launches with

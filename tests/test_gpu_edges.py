@@ -137,7 +137,7 @@ def test_decode_row_count_paths_agree():
             assert d.abs().max().item() <= 8e-3 * scale and d.pow(2).mean().sqrt().item() <= 2e-3 * scale
 
 
-@pytest.mark.parametrize("mode", [0, 3, 4, 5])
+@pytest.mark.parametrize("mode", [0, 3, 4, 5, 6, 7])
 def test_whole_step_under_every_forced_gemm_tile(mode):
     """The NT tile chooser picks by size, so small tests never reach the 256- / 320-row kernels through the model: force each tile
     (cc_gemm_tile_mode) for every NT GEMM of a training step — residual, gelu', lm_head + cross-entropy epilogues included — and

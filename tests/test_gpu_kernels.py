@@ -56,10 +56,14 @@ def test_gemm_layouts(al, bl, M, N, K):
     assert torch.isnan(Cm[:, N:]).all()   # nothing written outside the N columns
 
 
-@pytest.mark.parametrize("mode", [3, 4, 5, 6])
-@pytest.mark.parametrize("M,N,K", [(256, 256, 32), (8, 8, 32), (520, 200, 96), (1000, 392, 1024), (300, 776, 160), (640, 512, 64), (330, 248, 128)])
+@pytest.mark.parametrize("mode", [3, 4, 5, 6, 7])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 32), (8, 8, 32), (520, 200, 96), (1000, 392, 1024), (300, 776, 160), (640, 512, 64), (330, 248, 128),
+                                   (520, 776, 768), (161, 264, 384), (300, 520, 256), (6400, 2048, 384), (3000, 768, 2304)])
 def test_gemm_nt_256_row_tiles(mode, M, N, K):
-    """the 256 x 192 / 256 x 256 / 320 x 256 / 160 x 256 (mode 6) group-staggered NT kernels (forced: the chooser would pick 128 x 128 at these sizes)"""
+    """the 256 x 192 / 256 x 256 / 320 x 256 / 160 x 256 (mode 6) group-staggered NT kernels (forced: the chooser would pick 128 x 128 at these sizes)
+    and (mode 7) the persistent 4-wave 160 x 256 kernel with the instruction-level K loop (gemm_q4.hip.h): three 64-deep stages for K % 192 == 0,
+    two for K % 128 == 0 (shortest legal K of either ring included), the staggered kernel for any other K; 6400 x 2048 = 320 tiles > one per CU, so
+    workgroups walk more than one tile and the cross-tile prefetch is live."""
     torch.manual_seed(M + N + K + mode)
     dev = "cuda"
     A = _bf(torch.randn(M, K, device=dev))

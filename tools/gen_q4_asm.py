@@ -13,7 +13,7 @@ A stage is consumed in two half-steps of 32 K-columns; fragments are double-buff
 
 The tile's statement = head (NS stages; the first `b` barrier waits on nothing: its stage was awaited before the previous tile's
 epilogue), main loop (NS stages per iteration), tail (NS stages whose DMA instructions stream the NEXT tile's first NS stages).
-All registers are constraint operands (accumulators "=&a", fragments "v"), so hipcc allocates them and nothing inside the statement is
+All registers are constraint operands (accumulators "+a", fragments "v"), so hipcc allocates them and nothing inside the statement is
 visible to its scheduler.  Hazards handled in the text: SALU write of M0 -> LDS-DMA needs one wait state (an MFMA sits between), the
 statement opens with s_nop 4 (fresh readfirstlane SGPRs read by VMEM) and ends with s_nop 7 x 2 (MFMA result -> compiler's accvgpr reads).
 
@@ -53,7 +53,7 @@ class Gen:
     def fb(self, s, j):
         return "%%[b%d_%d]" % (s, j)
 
-    def half(self, buf, kk, vm, dma, zero_c=False):
+    def half(self, buf, kk, vm, dma):
         """Half-step kk (0 = a, 1 = b) of the stage in ring buffer `buf`; vm: None = LDS wait only; dma: issue ND DMA instructions into `buf`."""
         ni = self.ni
         if vm is None:
@@ -88,13 +88,13 @@ class Gen:
         for j in range(8):
             for i in range(ni):
                 c = self.acc(i, j)
-                self.emit("Q4_MFMA \" %s, %s, %s, %s\\n\"" % (c, self.fb(kk, j), self.fa(kk, i), "0" if zero_c else c))
+                self.emit("Q4_MFMA \" %s, %s, %s, %s\\n\"" % (c, self.fb(kk, j), self.fa(kk, i), c))
                 for f in slots[k]:
                     self.emit(f)
                 k += 1
 
     def stage(self, buf, first=False):
-        self.half(buf, 0, None, False, zero_c=first)
+        self.half(buf, 0, None, False)
         self.half(buf, 1, None if first else (self.ns - 2) * self.nd, True)
 
     def set_offsets(self, src, add):
@@ -143,7 +143,7 @@ class Gen:
         n_acc = 0
         for j in range(8):
             for i in range(ni):
-                cons = "=&a" if n_acc < 64 else "=&v"      # the AGPR half holds 64 accumulator tiles
+                cons = "+a" if n_acc < 64 else "+v"        # the AGPR half holds 64 accumulator tiles; the kernel zeroes them or starts them from the functor's additive input
                 outs.append("[c%d_%d] \"%s\"(acc[%d][%d][%d])" % (i, j, cons, j >> 2, i, j & 3))
                 n_acc += 1
         for i in range(ni):
