@@ -1717,6 +1717,33 @@ struct EpiBF16 {
     }
 };
 
+// C(bf16) = acc + bias and nothing else: EpiBF16 without its run-time switches (activation, pre-activation copy, operand image).  The 36
+// input-gradient launches and the 12 c_attn launches of a GPT-2 step are this; with the switches tested per 8-column unit the epilogue of the
+// 256-row kernels is an unrolled branch tree (round 6, tools/probes/q4_bench.hip: 12800 x 768 x 3072 on the 4-wave kernel 52.8 -> 49.7 us).
+struct EpiBF16Plain {
+    act_t* C;
+    const float* bias;  // nullable
+    int ldc, M, Ns;
+    __device__ __forceinline__ void operator()(int row, int col, float (&v)[8]) const {
+        if (row >= M || col >= Ns) return;
+        if (bias) {
+            const float4 b0 = *reinterpret_cast<const float4*>(bias + col);
+            const float4 b1 = *reinterpret_cast<const float4*>(bias + col + 4);
+            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        }
+        act_st8(C + (size_t)row * ldc + col, v);
+    }
+    static constexpr bool kPre = false;
+    __device__ __forceinline__ void pre4(int, int, f32x4&) const {}
+    __device__ __forceinline__ void bias8(int col, float (&b)[8]) const { load_bias8(bias, col, Ns, b); }
+    __device__ __forceinline__ void fin(int row, int col, float (&v)[8], const float (&b)[8]) const {
+        if (row >= M || col >= Ns) return;
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] += b[e];
+        act_st8(C + (size_t)row * ldc + col, v);
+    }
+};
+
 // out(fp32) = res + drop(acc + bias)   (residual stream update; out may alias res; drop = residual dropout, off unless drop.thresh)
 struct EpiResid {
     float* out;

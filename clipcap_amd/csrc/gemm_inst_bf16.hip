@@ -13,6 +13,12 @@ int gemm_bf16out(int al, int bl, const act_t* A, int lda, const op16_t* B, int l
 #endif
     static const bool nt = []() { const char* v = cc_lab_env("CC_PRE_NT"); return v && atoi(v) != 0; }();      // experiment switch
     e.pre_nt = nt;
+    // plain launches (no activation, no pre-activation copy, no operand image): the functor without run-time switches
+    static const bool plain_on = []() { const char* v = cc_lab_env("CC_EPI_PLAIN"); return !v || atoi(v) != 0; }();
+    if (plain_on && act == 0 && !pre && e.img == 0) {
+        EpiBF16Plain p{C, bias, ldc, M, N};
+        return launch_gemm(al, bl, A16, lda, B, ldb, M, N, K, 1, p, st);
+    }
     return launch_gemm(al, bl, A16, lda, B, ldb, M, N, K, 1, e, st);
 }
 }  // namespace CC_NS
