@@ -1655,7 +1655,10 @@ __device__ __forceinline__ void epi_store8(act_t* C, int ldc, int row, int col, 
 #endif
     act_st8(C + (size_t)row * ldc + col, v);
 }
-struct EpiBF16 {
+// ACT / PRE >= 0 fix the run-time switches `act` / `pre` at compile time (PRE: 0 = no copy, 1 = copy, 2 = non-temporal copy): with them tested per
+// 8-column unit the unrolled epilogue of the 256-row kernels is a branch tree (round 6: c_fc forward 78.2 -> 74.9 us on the 320 x 256 kernel)
+template <int ACT = -1, int PRE = -1>
+struct EpiBF16T {
     act_t* C;
     act_t* pre;         // nullable
     const float* bias;  // nullable
@@ -1663,6 +1666,9 @@ struct EpiBF16 {
     int act;            // 0 none, 1 relu, 2 gelu_new, 3 gelu_new with `pre` receiving gelu_new'(u) instead of u (the backward's multiplier)
     bool pre_nt = false; // act 3: `pre` is read only by the backward pass -> non-temporal stores
     int img = 0;         // bf16x3: > 0 = write C as the consumer's operand image with this row width (epi_store8)
+    __device__ __forceinline__ int act_() const { return ACT >= 0 ? ACT : act; }
+    __device__ __forceinline__ bool has_pre() const { return PRE >= 0 ? PRE != 0 : pre != nullptr; }
+    __device__ __forceinline__ bool nt_() const { return PRE >= 0 ? PRE == 2 : pre_nt; }
     __device__ __forceinline__ void operator()(int row, int col, float (&v)[8]) const {
         if (row >= M || col >= Ns) return;
         if (bias) {
@@ -1670,17 +1676,17 @@ struct EpiBF16 {
             const float4 b1 = *reinterpret_cast<const float4*>(bias + col + 4);
             v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
         }
-        if (act == 3) {
+        if (act_() == 3) {
             float dg[8];
 #pragma unroll
             for (int e = 0; e < 8; e++) gelu_new_both(v[e], v[e], dg[e]);
-            if (pre) { if (pre_nt) act_st8_nt(pre + (size_t)row * ldc + col, dg); else act_st8(pre + (size_t)row * ldc + col, dg); }
+            if (has_pre()) { if (nt_()) act_st8_nt(pre + (size_t)row * ldc + col, dg); else act_st8(pre + (size_t)row * ldc + col, dg); }
         } else {
-            if (pre) act_st8(pre + (size_t)row * ldc + col, v);
-            if (act == 1) {
+            if (has_pre()) act_st8(pre + (size_t)row * ldc + col, v);
+            if (act_() == 1) {
 #pragma unroll
                 for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
-            } else if (act == 2) {
+            } else if (act_() == 2) {
 #pragma unroll
                 for (int e = 0; e < 8; e++) v[e] = gelu_new_f(v[e]);
             }
@@ -1698,17 +1704,17 @@ struct EpiBF16 {
         if (row >= M || col >= Ns) return;
 #pragma unroll
         for (int e = 0; e < 8; e++) v[e] += b[e];
-        if (act == 3) {
+        if (act_() == 3) {
             float dg[8];
 #pragma unroll
             for (int e = 0; e < 8; e++) gelu_new_both(v[e], v[e], dg[e]);
-            if (pre) { if (pre_nt) act_st8_nt(pre + (size_t)row * ldc + col, dg); else act_st8(pre + (size_t)row * ldc + col, dg); }
+            if (has_pre()) { if (nt_()) act_st8_nt(pre + (size_t)row * ldc + col, dg); else act_st8(pre + (size_t)row * ldc + col, dg); }
         } else {
-            if (pre) act_st8(pre + (size_t)row * ldc + col, v);
-            if (act == 1) {
+            if (has_pre()) act_st8(pre + (size_t)row * ldc + col, v);
+            if (act_() == 1) {
 #pragma unroll
                 for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
-            } else if (act == 2) {
+            } else if (act_() == 2) {
 #pragma unroll
                 for (int e = 0; e < 8; e++) v[e] = gelu_new_f(v[e]);
             }
@@ -1716,6 +1722,7 @@ struct EpiBF16 {
         epi_store8(C, ldc, row, col, v, img);
     }
 };
+using EpiBF16 = EpiBF16T<>;
 
 // C(bf16) = acc + bias and nothing else: EpiBF16 without its run-time switches (activation, pre-activation copy, operand image).  The 36
 // input-gradient launches and the 12 c_attn launches of a GPT-2 step are this; with the switches tested per 8-column unit the epilogue of the
@@ -1862,21 +1869,23 @@ struct EpiF32 {
 };
 
 // C(bf16) = acc * act'(aux)   (dgrad through relu: aux = post-activation h; through gelu_new: aux = pre-activation u)
-struct EpiDAct {
+template <int ACT = -1>      // ACT >= 0 fixes `act` at compile time (the training step's launches are all act 3)
+struct EpiDActT {
     act_t* C;
     const act_t* aux;
     int ldc, M, Ns;
     int act;  // 1 relu (aux = post-activation), 2 gelu_new (aux = pre-activation u), 3 multiply by aux (= gelu_new'(u) stored by the forward)
     int img = 0;   // bf16x3: > 0 = write C as the consumer's operand image (epi_store8); aux keeps the plain [M][ldc] layout
+    __device__ __forceinline__ int act_() const { return ACT >= 0 ? ACT : act; }
     __device__ __forceinline__ void operator()(int row, int col, float (&v)[8]) const {
         if (row >= M || col >= Ns) return;
         const size_t o = (size_t)row * ldc + col;
         float a[8];
         act_ld8(aux + o, a);
-        if (act == 1) {
+        if (act_() == 1) {
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] = a[e] > 0.f ? v[e] : 0.f;
-        } else if (act == 3) {
+        } else if (act_() == 3) {
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] *= a[e];
         } else {
@@ -1893,10 +1902,10 @@ struct EpiDAct {
         if (row >= M || col >= Ns) return;
         float a[8];
         act_unpack8(ax, a);
-        if (act == 1) {
+        if (act_() == 1) {
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] = a[e] > 0.f ? v[e] : 0.f;
-        } else if (act == 3) {
+        } else if (act_() == 3) {
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] *= a[e];
         } else {
@@ -1911,7 +1920,7 @@ struct EpiDAct {
         float x[4];
         act_unpack4(act_ldraw4(aux + (size_t)row * ldc + col), x[0], x[1], x[2], x[3]);
 #pragma unroll
-        for (int e = 0; e < 4; e++) a[e] = act == 1 ? (x[e] > 0.f ? a[e] : 0.f) : (act == 3 ? a[e] * x[e] : a[e] * gelu_new_grad(x[e]));
+        for (int e = 0; e < 4; e++) a[e] = act_() == 1 ? (x[e] > 0.f ? a[e] : 0.f) : (act_() == 3 ? a[e] * x[e] : a[e] * gelu_new_grad(x[e]));
     }
     __device__ __forceinline__ void bias8(int, float (&b)[8]) const {
 #pragma unroll
@@ -1922,6 +1931,9 @@ struct EpiDAct {
         epi_store8(C, ldc, row, col, v, img);
     }
 };
+using EpiDAct = EpiDActT<>;
+template <class E> struct epi_is_dact { static constexpr bool value = false; };
+template <int A> struct epi_is_dact<EpiDActT<A>> { static constexpr bool value = true; };
 
 // lm_head: bf16 logits + per-(row, 64-column block) softmax partials from the fp32 accumulators + exact target logit.
 struct EpiLMHead {
@@ -2190,7 +2202,7 @@ inline int launch_gemm(int al, int bl, const op16_t* A, int lda, const op16_t* B
     // tests and tools/gemm_tiles.py.
     const int s256 = tile != -2 ? tile : g_gemm_tile_mode;
     int nj = 0, ni = 8;
-    constexpr bool can160 = !kX3 && !epi_row_strip<Epi>::value && !std::is_same<Epi, EpiDAct>::value;      // the 160 x 256 form (below)
+    constexpr bool can160 = !kX3 && !epi_row_strip<Epi>::value && !epi_is_dact<Epi>::value;      // the 160 x 256 form (below)
     // K slices (blockIdx.z) on the 256-row kernels only for the slab-writing fp32 epilogue and only when the caller names the tile
     constexpr bool zsplit_ok = std::is_same<Epi, EpiF32>::value;
     if (al == 0 && bl == 0 && (K % H_BK) == 0 && (ksplit == 1 || (zsplit_ok && tile > 0)) && s256 != 0) {
@@ -2205,7 +2217,7 @@ inline int launch_gemm(int al, int bl, const op16_t* A, int lda, const op16_t* B
         // the activation-gradient epilogue (aux tile read + gelu' + store) is not hidden at one block per CU: 12800 x 3072 x 768 measured
         // 106.6 us on 320 x 256 vs 97.3 on 128 x 128 (two co-resident blocks), while the plain / gelu-forward epilogues gain (90 -> 78 us)
         // (also with the forward-stored derivative, act 3 — a single multiply —, the 128 x 128 kernel stays ahead: 12.31 vs 12.44 ms per step)
-        constexpr bool can320 = !std::is_same<Epi, EpiDAct>::value;
+        constexpr bool can320 = !epi_is_dact<Epi>::value;
         // (round 5) 160 x 256 (5 row tiles per wave, 26-KiB stages): for the N = 768 launches at M = 12800 it is 240 tiles on the 256 CUs where
         // 256 x 192 is 200 — hipBLASLt's pick for these shapes too (MT160x256, profiles/r05_j_*).  A single-round launch takes one tile's
         // latency, so the smaller tile is the shorter launch whenever both fit one round; never for the bf16x3 build (its fused form is 192-wide).

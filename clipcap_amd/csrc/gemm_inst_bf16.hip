@@ -19,6 +19,11 @@ int gemm_bf16out(int al, int bl, const act_t* A, int lda, const op16_t* B, int l
         EpiBF16Plain p{C, bias, ldc, M, N};
         return launch_gemm(al, bl, A16, lda, B, ldb, M, N, K, 1, p, st);
     }
+    static const bool spec_on = []() { const char* v = cc_lab_env("CC_EPI_SPEC"); return !v || atoi(v) != 0; }();
+    if (spec_on && act == 3 && pre && !nt && e.img == 0) {       // c_fc forward of the training step: gelu_new, gelu' stored beside
+        EpiBF16T<3, 1> g3{C, pre, bias, ldc, M, N, 3};
+        return launch_gemm(al, bl, A16, lda, B, ldb, M, N, K, 1, g3, st);
+    }
     return launch_gemm(al, bl, A16, lda, B, ldb, M, N, K, 1, e, st);
 }
 }  // namespace CC_NS
