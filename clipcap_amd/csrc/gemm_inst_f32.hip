@@ -539,7 +539,14 @@ int gemm_nt_skinny(const act_t* Aa, int lda, const op16_t* B, int ldb, int M, in
         if (s64) {
             const int form = s64_form(1);
             if (res) { EpiResid e{out32, res, bias, ldo, M, N}; return launch_gemm_s64(A, lda, B, ldb, M, N, K, 1, form, e, nullptr, st, bimg); }
-            if (out16) { EpiBF16 e{out16, nullptr, bias, ldo, M, N, act}; return launch_gemm_s64(A, lda, B, ldb, M, N, K, 1, form, e, nullptr, st, bimg); }
+            if (out16) {
+                // decode's c_attn (plain) and c_fc (gelu_new) launches: the functors without run-time switches (round 6)
+                static const bool spec_on = []() { const char* v = cc_lab_env("CC_EPI_SPEC"); return !v || atoi(v) != 0; }();
+                if (spec_on && act == 0) { EpiBF16Plain e{out16, bias, ldo, M, N}; return launch_gemm_s64(A, lda, B, ldb, M, N, K, 1, form, e, nullptr, st, bimg); }
+                if (spec_on && act == 2) { EpiBF16T<2, 0> e{out16, nullptr, bias, ldo, M, N, 2}; return launch_gemm_s64(A, lda, B, ldb, M, N, K, 1, form, e, nullptr, st, bimg); }
+                EpiBF16 e{out16, nullptr, bias, ldo, M, N, act};
+                return launch_gemm_s64(A, lda, B, ldb, M, N, K, 1, form, e, nullptr, st, bimg);
+            }
             EpiF32 e{out32, bias, ldo, M, N, 0, 1.0f};
             return launch_gemm_s64(A, lda, B, ldb, M, N, K, 1, form, e, nullptr, st, bimg);
         }
