@@ -1081,12 +1081,13 @@ int64_t CC_API(cc_decode_part_floats)(const cc_gpt2_cfg* cfg, int32_t R) {
     return (int64_t)2 * R * ((Ns + 63) / 64);
 }
 
-int CC_API(cc_decode_fwd_x)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int32_t ctx_max, const float* w32, const uint16_t* w16, const uint16_t* wimg,
-                    const uint16_t* wteam, const float* x, uint16_t* kv, const int32_t* row_map, int32_t group, void* ws, float* logits, int64_t ldl, float* lpart,
-                    void* stream);
+// the decode step behind every entry point; wimg / wteam: lab build only (include/clipcap_hip_lab.h: cc_decode_fwd_x), NULL in the product
+static int decode_fwd_impl(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int32_t ctx_max, const float* w32, const uint16_t* w16, const uint16_t* wimg,
+                           const uint16_t* wteam, const float* x, uint16_t* kv, const int32_t* row_map, int32_t group, void* ws, float* logits, int64_t ldl, float* lpart,
+                           void* stream);
 int CC_API(cc_decode_fwd_g)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int32_t ctx_max, const float* w32, const uint16_t* w16,
                     const float* x, uint16_t* kv, const int32_t* row_map, int32_t group, void* ws, float* logits, int64_t ldl, float* lpart, void* stream) {
-    return CC_API(cc_decode_fwd_x)(c, R, Tn, pos0, ctx_max, w32, w16, nullptr, nullptr, x, kv, row_map, group, ws, logits, ldl, lpart, stream);
+    return decode_fwd_impl(c, R, Tn, pos0, ctx_max, w32, w16, nullptr, nullptr, x, kv, row_map, group, ws, logits, ldl, lpart, stream);
 }
 
 int CC_API(cc_decode_fwd)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int32_t ctx_max, const float* w32, const uint16_t* w16,
@@ -1099,7 +1100,8 @@ int CC_API(cc_decode_fwd_p)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t
     return CC_API(cc_decode_fwd_g)(c, R, Tn, pos0, ctx_max, w32, w16, x, kv, row_map, 1, ws, logits, ldl, lpart, stream);
 }
 
-// fragment-ordered images of the four GEMM weights of every block, at their arena offsets (include/clipcap_hip.h)
+#ifdef CC_EXPERIMENTS      // ---- lab build only: the entry points of include/clipcap_hip_lab.h ----
+// fragment-ordered images of the four GEMM weights of every block, at their arena offsets
 int64_t CC_API(cc_decode_image_bytes)(const cc_gpt2_cfg* c) {
     if (!cfg_ok(c) || kX3 || (c->D % 64)) return 0;
     const int64_t D = c->D;
@@ -1142,6 +1144,13 @@ int CC_API(cc_decode_xt_image)(const cc_gpt2_cfg* c, const uint16_t* w16, uint16
 int CC_API(cc_decode_fwd_x)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int32_t ctx_max, const float* w32, const uint16_t* w16, const uint16_t* wimg,
                     const uint16_t* wteam, const float* x, uint16_t* kv, const int32_t* row_map, int32_t group, void* ws, float* logits, int64_t ldl, float* lpart,
                     void* stream) {
+    return decode_fwd_impl(c, R, Tn, pos0, ctx_max, w32, w16, wimg, wteam, x, kv, row_map, group, ws, logits, ldl, lpart, stream);
+}
+#endif  // CC_EXPERIMENTS
+
+static int decode_fwd_impl(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t pos0, int32_t ctx_max, const float* w32, const uint16_t* w16, const uint16_t* wimg,
+                           const uint16_t* wteam, const float* x, uint16_t* kv, const int32_t* row_map, int32_t group, void* ws, float* logits, int64_t ldl, float* lpart,
+                           void* stream) {
     if (group < 1 || (R > 0 && R % group)) return CC_ERR_ARG;
     if (!cfg_ok(c) || R <= 0 || Tn <= 0 || pos0 < 0 || !w32 || !w16 || !x || !kv || !ws || !logits) return CC_ERR_ARG;
     const int Ns = std::min(c->Vp, (c->V + 7) / 8 * 8);

@@ -1042,6 +1042,7 @@ __global__ __launch_bounds__(G_THREADS, 1) void gemm_nt_s80kw_kernel(const op16_
 // also wait for every B tile requested before it), so a FIFTH wave issues all of the A DMA (and owns its waits); waves 0-3 issue nothing
 // but their B fragments and count them exactly: vmcnt(2 (RB - 1)).
 typedef unsigned kb_u32x4 __attribute__((ext_vector_type(4)));
+#ifdef CC_EXPERIMENTS   // lab build only (round 5: bit-identical, 1-3 % slower in the real decode chain — HISTORY.md)
 template <class Epi, int RB>
 __global__ __launch_bounds__(320, RB == 16 ? 2 : 3) void gemm_nt_s64kwb_kernel(const op16_t* __restrict__ A, const op16_t* __restrict__ Bimg, GemmShape g, Epi epi) {
     static_assert(RB == 4 || RB == 8 || RB == 16, "ring depth");
@@ -1171,6 +1172,8 @@ static __global__ __launch_bounds__(256) void k_skinny_image(const op16_t* __res
         reinterpret_cast<kb_u32x4*>(img)[e] = *reinterpret_cast<const kb_u32x4*>(src);
     }
 }
+
+#endif  // CC_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------------------
 // 256-row kernels for large outputs: 8 waves, wave tile 128 x 16 NJ (8 x NJ MFMA tiles; block tile 256 x 256 for NJ = 4,
@@ -2361,12 +2364,17 @@ inline int launch_gemm_s64(const op16_t* A, int lda, const op16_t* B, int ldb, i
         hipLaunchKernelGGL((gemm_nt_s64_kernel<Epi, NJ_, NS_, KG_>), dim3((unsigned)(tm * ((N + 64 * (NJ_) - 1) / (64 * (NJ_)))), 1, (unsigned)ksplit), \
                            dim3(G_THREADS * (KG_)), sh, st, A, B, g, epi);                                               \
     }
+#ifdef CC_EXPERIMENTS
     if (nj == 3 && Bimg && (N % 64) == 0 && ((uintptr_t)Bimg & 15) == 0) {      // ... with the weight operand global -> VGPR from its fragment-ordered image
         constexpr size_t sh = (size_t)4 * 128 * 128;      // (the epilogue's partial tiles need the 64 KiB)
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_s64kwb_kernel<Epi, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr = true; }
         hipLaunchKernelGGL((gemm_nt_s64kwb_kernel<Epi, 4>), dim3((unsigned)(tm * (N / 64)), 1, (unsigned)ksplit), dim3(320), sh, st, A, Bimg, g, epi);
-    } else if (nj == 4) {                   // 80 x 64 tiles, K split over the waves (gemm_nt_s80kw_kernel)
+    } else
+#else
+    (void)Bimg;
+#endif
+    if (nj == 4) {                   // 80 x 64 tiles, K split over the waves (gemm_nt_s80kw_kernel)
         constexpr size_t sh = (size_t)4 * 6 * 16 * 64 * sizeof(float);      // the epilogue's partial tiles: 96 KiB (the four 20-KiB stages fit inside)
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_s80kw_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr = true; }

@@ -488,11 +488,13 @@ int gemm_nt_deepk(const act_t* Aa, int lda, const op16_t* B, int ldb, int M, int
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
 
+#ifdef CC_EXPERIMENTS
 int skinny_image(const op16_t* W, op16_t* img, int N, int K, hipStream_t st) {
     if ((N % 64) || (K % 64) || !W || !img) return CC_ERR_SHAPE;
     hipLaunchKernelGGL(k_skinny_image, dim3(1024), dim3(256), 0, st, W, img, N, K);
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
+#endif
 
 int gemm_nt_skinny(const act_t* Aa, int lda, const op16_t* B, int ldb, int M, int N, int K, const float* bias, int act, const float* res,
                    float* out32, act_t* out16, int ldo, float* scratch, size_t scratch_bytes, hipStream_t st, const SkinnyFuse* fuse) {

@@ -35,7 +35,19 @@ def _r(t: Tensor, rb) -> Tensor:
     if rb == "bf16x3":      # split operand of the kernels' bf16x3 build: hi = bf16(x), lo = bf16(x - hi); the operand is worth hi + lo
         hi = t.to(torch.bfloat16).to(t.dtype)
         return hi + (t - hi).to(torch.bfloat16).to(t.dtype)
+    if rb == "fp16x2":      # split fp16 operand: hi = fp16(x), lo = fp16(x - hi)
+        hi = t.to(torch.float16).to(t.dtype)
+        return hi + (t - hi).to(torch.float16).to(t.dtype)
     return t.to(torch.float16 if rb == "fp16" else torch.bfloat16).to(t.dtype)
+
+
+def _m(rb, site: str):
+    """Per-site rounding mode (tools/diag/site_error_budget.py): rb may be a dict {site class: mode, "default": mode} with the site
+    classes "mapper", "c_attn", "attn" (stored qkv and the probabilities fed to P V), "attn.c_proj", "c_fc", "mlp.c_proj", "lm_head";
+    any other rb applies to every site."""
+    if isinstance(rb, dict):
+        return rb.get(site, rb.get("default", False))
+    return rb
 
 
 def _linear(x: Tensor, w: Tensor, b: Optional[Tensor], rb: bool) -> Tensor:
@@ -94,6 +106,7 @@ def mapper_forward(p: Dict[str, Tensor], x: Tensor, *, projection_length: int, n
     cat learned prefix_const (L,D) -> N layers -> rows [W*P:].
     """
     bsz = x.shape[0]
+    rb = _m(rb, "mapper")
     wgt, bias = p[pre + "linear.weight"], p[pre + "linear.bias"]
     proj = _linear(x, wgt, bias, rb).reshape(bsz, window * projection_length, -1)
     if (pre + "pos_embeddings") in p:
@@ -137,7 +150,7 @@ def gpt2_block_forward(p, pre, x, n_head, rb=False, past_kv=None, drop=None, lay
     bsz, t, d = x.shape
     hd = d // n_head
     h = F.layer_norm(x, (d,), p[pre + "ln_1.weight"], p[pre + "ln_1.bias"], 1e-5)
-    qkv = _r(_conv1d(h, p[pre + "attn.c_attn.weight"], p[pre + "attn.c_attn.bias"], rb), rb)
+    qkv = _r(_conv1d(h, p[pre + "attn.c_attn.weight"], p[pre + "attn.c_attn.bias"], _m(rb, "c_attn")), _m(rb, "attn"))
     q, k, v = qkv.split(d, dim=2)
     q = q.reshape(bsz, t, n_head, hd).transpose(1, 2)
     k = k.reshape(bsz, t, n_head, hd).transpose(1, 2)
@@ -154,14 +167,14 @@ def gpt2_block_forward(p, pre, x, n_head, rb=False, past_kv=None, drop=None, lay
     att = att.softmax(dim=-1)
     if drop is not None and drop.get("p_attn", 0.0) > 0:
         att = att * drop["attn"][layer] / (1.0 - drop["p_attn"])
-    a = _r((_r(att, rb) @ v).transpose(1, 2).reshape(bsz, t, d), rb)
-    y = _conv1d(a, p[pre + "attn.c_proj.weight"], p[pre + "attn.c_proj.bias"], rb)
+    a = _r((_r(att, _m(rb, "attn")) @ v).transpose(1, 2).reshape(bsz, t, d), _m(rb, "attn.c_proj"))
+    y = _conv1d(a, p[pre + "attn.c_proj.weight"], p[pre + "attn.c_proj.bias"], _m(rb, "attn.c_proj"))
     if drop is not None and drop.get("p_resid", 0.0) > 0:
         y = y * drop["resid_attn"][layer] / (1.0 - drop["p_resid"])
     x = x + y
     h = F.layer_norm(x, (d,), p[pre + "ln_2.weight"], p[pre + "ln_2.bias"], 1e-5)
-    h = _r(gelu_new(_conv1d(h, p[pre + "mlp.c_fc.weight"], p[pre + "mlp.c_fc.bias"], rb)), rb)
-    y = _conv1d(h, p[pre + "mlp.c_proj.weight"], p[pre + "mlp.c_proj.bias"], rb)
+    h = _r(gelu_new(_conv1d(h, p[pre + "mlp.c_fc.weight"], p[pre + "mlp.c_fc.bias"], _m(rb, "c_fc"))), _m(rb, "mlp.c_proj"))
+    y = _conv1d(h, p[pre + "mlp.c_proj.weight"], p[pre + "mlp.c_proj.bias"], _m(rb, "mlp.c_proj"))
     if drop is not None and drop.get("p_resid", 0.0) > 0:
         y = y * drop["resid_mlp"][layer] / (1.0 - drop["p_resid"])
     x = x + y
@@ -190,7 +203,7 @@ def gpt2_hidden(p, inputs_embeds, n_head, n_layer, pre="transformer.", rb=False,
 def gpt2_logits(p, inputs_embeds, n_head, n_layer, pre="", rb=False, drop=None):
     """GPT2LMHeadModel.forward (hf :650-725): logits = hidden @ wte^T (tied, :638, :703)."""
     h, _ = gpt2_hidden(p, inputs_embeds, n_head, n_layer, pre + "transformer.", rb, drop=drop)
-    return _r(h, rb) @ _r(p[pre + "transformer.wte.weight"], rb).t()
+    return _r(h, _m(rb, "lm_head")) @ _r(p[pre + "transformer.wte.weight"], _m(rb, "lm_head")).t()
 
 
 # --------------------------------------------------------------------------------------------------
