@@ -472,9 +472,11 @@ class _BpeTokenizer:
         return self.t.decode([int(i) for i in ids])
 
 
-def _write_e2e_dataset(root, rows, E, shards=4, seed=77):
+def _write_e2e_dataset(root, rows, E, shards=4, seed=77, words_lo=44, words_hi=60):
     """The reference's on-disk layout (clipcap/preprocess/writer.py:49-75): embeddings/*.npy, captions/*.parquet, encoder_config.yaml.
-    Captions: 4..25 words (mean 11, like COCO's) drawn from 3000 synthetic words."""
+    Captions: words_lo..words_hi words drawn from 3000 synthetic words.  Every word is at least one token, so a caption of >= 44 words is
+    cut to the headline's 40 tokens by max_token_length (dataloader.py:41-63) and every batch has the headline shape [B, 40] — the reader
+    tokenises MORE text than a 40-token caption holds (round 5 wrote 4..25 words: batches trimmed to 24 columns)."""
     import pyarrow as pa
     import pyarrow.parquet as pq
     import yaml
@@ -489,7 +491,7 @@ def _write_e2e_dataset(root, rows, E, shards=4, seed=77):
     for s in range(shards):
         n = rows // shards
         np.save(os.path.join(root, "embeddings", f"img_emb_{s:04d}.npy"), rng.standard_normal((n, E), dtype=np.float32))
-        lens = np.clip(np.rint(rng.normal(11, 3, n)), 4, 25).astype(int)
+        lens = rng.integers(words_lo, words_hi + 1, n)
         idx = rng.choice(len(words), size=int(lens.sum()), p=freq)
         caps, at = [], 0
         for ln in lens:
@@ -507,7 +509,7 @@ def _write_e2e_dataset(root, rows, E, shards=4, seed=77):
     return sample
 
 
-def e2e_bench(args, device):
+def e2e_bench(args, device, max_tokens=None):
     """The REAL train() loop (clipcap_amd/train/train.py; reference clipcap/train/train.py:17-93 over dataloader.py:11-66) on a synthetic dataset
     in the reference's on-disk layout: >= 200 k rows, npy embedding shards + parquet captions, a real BPE tokenizer, BASELINE configs[1]'s
     model.  Timed from step `warm` to the last step of the epoch through train()'s step hook (the loop itself is untouched); right after the
@@ -524,10 +526,11 @@ def e2e_bench(args, device):
     out = {}
     with tempfile.TemporaryDirectory(prefix="clipcap_e2e_") as tmp:
         t0 = time.perf_counter()
-        sample = _write_e2e_dataset(os.path.join(tmp, "ds"), rows, c["E"])
+        max_tokens = int(max_tokens or c["cap"])        # 40 = the headline; 64 = the reference's default padding (--max-token-length, no trimming possible)
+        sample = _write_e2e_dataset(os.path.join(tmp, "ds"), rows, c["E"], words_lo=max_tokens + 4, words_hi=max_tokens + 20)
         tok = _BpeTokenizer(sample)
         out["dataset"] = {"rows": rows, "embedding_shards": 4, "E": c["E"], "write_and_tokenizer_train_s": round(time.perf_counter() - t0, 1),
-                          "tokenizer": f"byte-level BPE ({tok.t.get_vocab_size()} tokens, tokenizers library), captions 4..25 words"}
+                          "tokenizer": f"byte-level BPE ({tok.t.get_vocab_size()} tokens, tokenizers library), captions {max_tokens + 4}..{max_tokens + 20} words cut to {max_tokens} tokens"}
         torch.manual_seed(1234)
         lm = GPT2LM(n_embd=c["D"], n_layer=c["n_layer"], n_head=c["n_head"], vocab_size=c["V"], n_positions=c["npos"])
         a = add_model_args(add_training_args(argparse.ArgumentParser())).parse_args([
@@ -536,7 +539,7 @@ def e2e_bench(args, device):
             "--transformer-layers", str(c["N"]), "--transformer-attention-heads", str(c["H"]), "--logging-frequency", "1000000",
             "--checkpoint-filename-prefix", "e2e", "--reader-parallel-pieces", str(args.reader_parallel_pieces),
             "--reader-max-piece-size", "50", "--device", str(device.index or 0)])
-        a.max_token_length = c["cap"]
+        a.max_token_length = max_tokens
         n_steps = rows // B
         warm = min(50, n_steps // 4)
         st = {}
@@ -917,6 +920,10 @@ def main():
         torch.cuda.empty_cache()
         try:
             out["e2e_train"] = e2e_bench(argparse.Namespace(batch=0, steps=0, reader_parallel_pieces=10), device)
+            # the same loop at the reference's 64-column padding (captions longer than 64 tokens: nothing to trim)
+            p64 = e2e_bench(argparse.Namespace(batch=0, steps=0, reader_parallel_pieces=10), device, max_tokens=64)
+            out["e2e_train_pad64"] = {k: p64[k] for k in ("ms_per_step", "samples_per_s", "device_resident_replay_ms_per_step", "ratio_to_device_resident",
+                                                          "gpu_idle_fraction", "batch_shapes_tokens_embeds", "steps_timed")}
         except Exception as e:      # never lose the headline line to the extra
             out["e2e_train"] = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()

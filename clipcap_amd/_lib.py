@@ -98,12 +98,6 @@ SIGNATURES = {
     "cc_decode_part_floats": (_L, [_GC, _I]),
     "cc_decode_fwd_p": (_I, [_GC, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P]),
     "cc_decode_fwd_g": (_I, [_GC, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _L, _P, _P]),
-    "cc_decode_ws_check": (_I, [_GC, _I, _I, _P, _P]),
-    "cc_decode_image_bytes": (_L, [_GC]),
-    "cc_decode_image": (_I, [_GC, _P, _P, _P]),
-    "cc_decode_xt_image_bytes": (_L, [_GC]),
-    "cc_decode_xt_image": (_I, [_GC, _P, _P, _P]),
-    "cc_decode_fwd_x": (_I, [_GC, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _P, _P]),
     "cc_beam_step_p": (_I, [_I, _I, _I, _P, _L, _P, _I, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "cc_decode_reorder": (_I, [_GC, _I, _I, _I, _I, _P, _P, _P, _P]),
     "cc_beam_step": (_I, [_I, _I, _I, _P, _L, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
@@ -125,7 +119,6 @@ SIGNATURES = {
     "cc_gemm_tile_mode": (_I, [_I]),
     "cc_gemm_skinny_mode": (_I, [_I]),
     "cc_decode_mode": (_I, [_I]),
-    "cc_decode_last_path": (_I, []),
     "cc_gemm_op16_f32": (_I, [_I, _I, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P]),
     "cc_layernorm_fwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "cc_attention_fwd": (_I, [_I, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
@@ -138,6 +131,17 @@ SIGNATURES = {
     "cc_comm_count": (_I, [_P, C.POINTER(_I)]),
     "cc_prof_start": (_I, [_I, _I]),
     "cc_prof_stop": (_I, [C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(_I)]),
+}
+
+# include/clipcap_hip_lab.h: entry points of the LAB library only (CLIPCAP_HIP_LIB=lab); the product library does not export them
+LAB_SIGNATURES = {
+    "cc_decode_ws_check": (_I, [_GC, _I, _I, _P, _P]),
+    "cc_decode_image_bytes": (_L, [_GC]),
+    "cc_decode_image": (_I, [_GC, _P, _P, _P]),
+    "cc_decode_xt_image_bytes": (_L, [_GC]),
+    "cc_decode_xt_image": (_I, [_GC, _P, _P, _P]),
+    "cc_decode_fwd_x": (_I, [_GC, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _P, _P]),
+    "cc_decode_last_path": (_I, []),
 }
 
 ABI_VERSION = 3       # CC_ABI_VERSION of include/clipcap_hip.h this binding was written against
@@ -164,7 +168,8 @@ def lib() -> C.CDLL:
                 l = C.CDLL(LIB_PATH)
             except OSError as e:  # pragma: no cover
                 raise HipExtensionMissing(f"cannot load {LIB_PATH}: {e}") from e
-            for name, (res, args) in SIGNATURES.items():
+            sigs = dict(SIGNATURES, **LAB_SIGNATURES) if IS_LAB else SIGNATURES
+            for name, (res, args) in sigs.items():
                 fn = getattr(l, name)
                 fn.restype = res
                 fn.argtypes = args

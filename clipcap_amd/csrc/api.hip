@@ -112,6 +112,7 @@ void mapper_offsets(const cc_mapper_cfg* c, MapperOff& o) {
     o.total = p;
 }
 
+constexpr int kDeferRows = 40960;      // cc_mapper_bwd_range defers the weight gradients of a call up to this many rows (and 8 layers)
 struct MapperWS {
     act_t* emb16;
     float* lin_tmp;
@@ -126,6 +127,7 @@ struct MapperWS {
     // wait for ONE grouped launch at the end of the backward call (gdx[l] = d x[l+1], the gradient entering layer l from above).  The bf16x3
     // build splits operands per call and keeps the single buffers: there every entry aliases them.
     act_t *gdx[MAX_LAYERS], *gdxb[MAX_LAYERS], *gdh[MAX_LAYERS], *gdqkv[MAX_LAYERS];
+    bool own_grads;     // every layer has its own copies (else they alias the single dx16 / dx16b / dh16 / dqkv16 buffers and weight gradients flush per layer)
     float* wg_scratch;
     float* adelta;
     uint16_t* gimg;    // bf16x3 build: the [hi | hi | lo] image of the output gradient both GEMMs of a layer step read
@@ -175,8 +177,11 @@ void mapper_carve(const cc_mapper_cfg* c, int B, int save, void* ws, MapperWS& w
         w.datt16 = cv.take<act_t>(M * D);
         w.dqkv16 = cv.take<act_t>(M * 3 * D);
         w.dlin16 = cv.take<act_t>((size_t)B * c->W * c->P * D);
+        // per-layer copies only where cc_mapper_bwd_range can defer (<= kDeferRows rows and <= 8 layers): a B = 4096 call would otherwise
+        // carry (N - 1) x M x (5 D + Hm) unused 16-bit elements (~6 GB at D = 768, N = 8) — ADVICE r5
+        w.own_grads = !kX3 && M <= (size_t)kDeferRows && c->N <= 8;
         for (int l = 0; l < c->N; l++) {
-            const bool own = !kX3;                       // every layer its own (a deferred weight gradient reads them at the END of the call)
+            const bool own = w.own_grads;                // every layer its own (a deferred weight gradient reads them at the END of the call)
             w.gdx[l] = own ? cv.take<act_t>(M * D) : w.dx16;
             w.gdxb[l] = own ? cv.take<act_t>(M * D) : w.dx16b;
             w.gdh[l] = own ? cv.take<act_t>(M * c->Hm) : w.dh16;
@@ -191,6 +196,7 @@ void mapper_carve(const cc_mapper_cfg* c, int B, int save, void* ws, MapperWS& w
         w.dx32 = nullptr; w.dx16 = w.dx16b = w.dh16 = w.dxn16 = w.datt16 = w.dqkv16 = w.dlin16 = nullptr; w.wg_scratch = nullptr; w.adelta = nullptr;
         w.gimg = nullptr;
         for (int l = 0; l < c->N; l++) w.gdx[l] = w.gdxb[l] = w.gdh[l] = w.gdqkv[l] = nullptr;
+        w.own_grads = false;
     }
     w.x3 = nullptr; w.x3_bytes = 0;
     if (kX3) {
@@ -518,8 +524,8 @@ int CC_API(cc_mapper_bwd_range)(const cc_mapper_cfg* c, int32_t B, const float* 
     // tiles beyond its last full round into K slices (TTGroup::whole / split: 2 rounds + 64 tiles x 4 slices, slabs + a small reduce).  What the
     // deferred launch saves does not grow with the row count, what is left of the fill loss does: ahead at B = 256 (M = 5120: 2.63 -> 2.50 ms)
     // and B = 1024 (7.64 -> 7.43), behind at B = 4096 (28.04 -> 28.35) — calls above 40 960 rows keep the per-layer form.
-    static const int defer_rows = []() { const char* e = cc_lab_env("CC_MAPPER_DEFER_ROWS"); return e ? atoi(e) : 40960; }();      // lab build: the row limit
-    const bool defer_all = kDeferAll && defer_all_on && 4 * (l_hi - l_lo) <= 32 && M <= defer_rows;
+    static const int defer_rows = []() { const char* e = cc_lab_env("CC_MAPPER_DEFER_ROWS"); return e ? std::min(atoi(e), kDeferRows) : kDeferRows; }();      // lab build: a lower row limit
+    const bool defer_all = kDeferAll && defer_all_on && w.own_grads && 4 * (l_hi - l_lo) <= 32 && M <= defer_rows;
     if (defer_all) { wb.direct = true; wb.cap = 4 * (l_hi - l_lo); }
     ColsumBatch cs;
     // bf16x3: `G2(t, width)` = the tensor as both of its GEMMs take it — split ONCE into w.gimg ([hi | hi | lo], the form of the weight

@@ -224,6 +224,10 @@ inline Drop make_drop(float p, unsigned long long seed, unsigned site, unsigned 
 // round trips per reduction.  With many waves per SIMD those hide; where a wave runs (almost) alone — the decode finish rows, the decode
 // attention, the XCD-team engine's I/O waves — they are the kernel's latency (round 5: a LayerNorm row is two reductions = 12 trips).
 // The result is wave-uniform.  Summation order differs from the butterfly's (fp32 rounding only).  CC_WAVE_SHFL restores the old form (A/B).
+// PRECONDITION: the FULL wave calls these (EXEC = all 64 lanes) — update_dpp with old = 0 / bound_ctrl off substitutes 0 for an
+// inactive source lane (wrong for wave_max of negative values) and v_readlane of an inactive lane returns stale register contents.  Every call
+// site here is wave-uniform (block sizes are multiples of 64, no early exit before a reduction); a kernel that cannot guarantee that must build
+// with CC_WAVE_SHFL, whose shuffles degrade per lane instead.
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));

@@ -3,6 +3,9 @@
 // Decode is HBM-bound (every weight byte is read once per step); the GEMMs reuse gemm.hip.h, attention over the
 // cache is one wave per (row, head, new position).
 #include "../../include/clipcap_hip.h"
+#ifdef CC_EXPERIMENTS
+#include "../../include/clipcap_hip_lab.h"
+#endif
 #include "gemm_api.h"
 #include "kernels.h"
 #include "decode_pk.h"
@@ -1321,6 +1324,7 @@ static int decode_fwd_impl(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, int32_t 
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
 
+#ifdef CC_EXPERIMENTS
 int CC_API(cc_decode_ws_check)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, const void* ws, void* stream) {
     if (!cfg_ok(c) || R <= 0 || Tn <= 0 || !ws) return CC_ERR_ARG;
     DecWS w;
@@ -1332,6 +1336,7 @@ int CC_API(cc_decode_ws_check)(const cc_gpt2_cfg* c, int32_t R, int32_t Tn, cons
     if (hipMemcpy(&e2, w.xt_ctl + XT_CTL_WORDS, sizeof(e2), hipMemcpyDeviceToHost) != hipSuccess) return CC_ERR_LAUNCH;
     return (e | e2) ? CC_ERR_STATE : CC_OK;
 }
+#endif
 
 int CC_API(cc_decode_reorder)(const cc_gpt2_cfg* c, int32_t R_src, int32_t R_dst, int32_t ctx, int32_t ctx_max, const uint16_t* kv_src, uint16_t* kv_dst,
                       const int32_t* src, void* stream) {

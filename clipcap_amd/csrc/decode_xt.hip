@@ -33,7 +33,7 @@
 #include <algorithm>
 
 namespace CC_NS {
-#if CC_OP != 2 && defined(CC_EXPERIMENTS)      // lab build only (make lab): measured slower than the per-op launches
+#if CC_OP != 2 && defined(CC_EXPERIMENTS)      // lab build only (make lab): measured slower than the per-op launches (HISTORY.md 4.5)
 namespace {
 
 typedef const __attribute__((address_space(1))) void* xg_t;

@@ -1191,7 +1191,7 @@ static __global__ __launch_bounds__(256) void k_skinny_image(const op16_t* __res
 // NT LDS image [row][32 k] (64-B rows) with the bank-group-exact XOR key h_swz below.
 // ------------------------------------------------------------------------------------------------
 #ifndef CC_STAG_READ_FIRST
-#define CC_STAG_READ_FIRST 1   // fragment reads of tile t are issued before the DMA of tile t+3: the DMA issue stalls (queue back-pressure) then cover the read latency; +1-2 % on the K <= 4096 shapes, A/B in DESIGN 4.5
+#define CC_STAG_READ_FIRST 1   // fragment reads of tile t are issued before the DMA of tile t+3: the DMA issue stalls (queue back-pressure) then cover the read latency; +1-2 % on the K <= 4096 shapes, A/B in HISTORY.md 4.5
 #endif
 constexpr int H_BM = 256, H_BN = 256, H_BK = 32, H_NS = 4, H_STAGE = (H_BM + H_BN) * H_BK * 2;   // 32 KiB per stage, 128 KiB total (5 stages = all 160 KiB measured 2-3 % slower)
 // The B tile may be narrower: NJ MFMA column tiles per wave -> block tile 256 x (64 NJ); NJ = 3 gives 256 x 192 for N = 768-like widths.
@@ -2247,7 +2247,7 @@ inline int launch_gemm(int al, int bl, const op16_t* A, int lda, const op16_t* B
             if constexpr (can160) {
                 // (round 6) the 160 x 256 launches go to the persistent 4-wave kernel with 64-deep full-line stages (gemm_q4.hip.h) wherever K fits its
                 // ring: three stages for K % 192 == 0, two for K % 128 == 0; byte offsets inside an operand are 32-bit there.  Measured against the
-                // staggered 160 x 256 kernel (profiles/r06_b): 12800 x 768 x 3072 58.9 -> 52.8 us, x 2304 44.2 -> 41.7, x 768 20.2 -> 21.2 (plain functor:
+                // staggered 160 x 256 kernel (profiles/r06_l): 12800 x 768 x 3072 58.9 -> 52.8 us, x 2304 44.2 -> 41.7, x 768 20.2 -> 21.2 (plain functor:
                 // 57.1 -> 49.7, 43.7 -> 38.5, 20.6 -> 19.8).  cc_gemm_tile_mode 6 keeps the staggered kernel, 7 forces this one.
                 static const bool q4_on = []() { const char* e = cc_lab_env("CC_GEMM_Q4"); return !e || atoi(e) != 0; }();
                 const bool fits32 = (size_t)M * (size_t)lda * 2 < 0xffff0000ull && (size_t)N * (size_t)ldb * 2 < 0xffff0000ull;

@@ -1,5 +1,8 @@
 // Variant-independent part of the C ABI: version, the process-wide test knobs and the measurement hooks (include/clipcap_hip.h).
 #include "../../include/clipcap_hip.h"
+#ifdef CC_EXPERIMENTS
+#include "../../include/clipcap_hip_lab.h"
+#endif
 #include "shared.h"
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -12,10 +15,10 @@ int g_gemm_tile_mode = []() { const char* e = cc_lab_env("CC_GEMM_S256"); return
 int g_gemm_s64 = []() { const char* e = cc_lab_env("CC_GEMM_S64"); return e ? atoi(e) : -1; }();
 int g_gemm_small_x2 = []() { const char* e = cc_lab_env("CC_GEMM_X2"); return e ? atoi(e) : 1; }();
 // bit 0: beam-group attention step (k_decode_attn_group), bit 1: the layer stack of a group step as one persistent launch (decode_pk.hip;
-// measured slower than the per-op launches on MI355X, DESIGN.md 4.5 — kept for A/B runs), bit 2: the XCD-team engine (decode_xt.hip) when cc_decode_fwd_x
+// measured slower than the per-op launches on MI355X, HISTORY.md 4.5 — kept for A/B runs), bit 2: the XCD-team engine (decode_xt.hip) when cc_decode_fwd_x
 // is given a weight image, bit 3: the K-split decode GEMMs take their weight operand global -> VGPR from the fragment-ordered image of cc_decode_image
 // (gemm_nt_s64kwb_kernel; bit-identical results; with the weights cold from HBM, as in the chain, 1-3 % slower than both operands through LDS —
-// DESIGN.md 4.5, tools/ab_decode_mode.py; default off).  env CC_DEC_GROUP / CC_DEC_PK / CC_DEC_XT preset bits 0-2.
+// HISTORY.md 4.5, tools/ab_decode_mode.py; default off).  env CC_DEC_GROUP / CC_DEC_PK / CC_DEC_XT preset bits 0-2.
 int g_decode_mode = []() {
     const char* g = cc_lab_env("CC_DEC_GROUP");
     const char* p = cc_lab_env("CC_DEC_PK");
@@ -44,7 +47,9 @@ int cc_decode_mode(int32_t mode) {
     return old;
 }
 
+#ifdef CC_EXPERIMENTS
 int cc_decode_last_path(void) { return g_decode_last_path; }
+#endif
 
 int cc_gemm_skinny_mode(int32_t mode) {
     const int old = g_gemm_s64;

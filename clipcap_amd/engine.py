@@ -385,12 +385,15 @@ class Gpt2Engine:
         return _lib.lib().cc_gpt2_sync_weights(C.byref(self.cfg), w32, w16, st)
 
     def decode_images(self) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
-        """(wimg, wteam) for cc_decode_fwd_x (include/clipcap_hip.h), rebuilt whenever the operand copy changes:
+        """LAB LIBRARY ONLY (CLIPCAP_HIP_LIB=lab; (None, None) with the product library).  (wimg, wteam) for cc_decode_fwd_x
+        (include/clipcap_hip_lab.h), rebuilt whenever the operand copy changes:
         wimg  — the block GEMM weights in MFMA fragment order (cc_decode_image; cc_decode_mode bit 3): the decode GEMMs whose K is split over
                 the waves load the weight operand global -> VGPR from it;
         wteam — the XCD-team engine's image (cc_decode_xt_image; lab build, cc_decode_mode bit 2).
         None where the library does not cover this model (width, operand type), the switch is off, or the build lacks the engine."""
         a = self.arena
+        if not _lib.IS_LAB:
+            return None, None
         l = _lib.lib()
         mode = l.cc_decode_mode(-1)
         if a.device.type != "cuda" or not (mode & 12):
@@ -671,18 +674,23 @@ class DecodeSession:
                 self._lpart = torch.empty(n, dtype=torch.float32, device=g.arena.device)
             self.lpart = (self._lpart, self._lpart.numel() // (2 * self.R))
         grp = int(group) if self.R % max(1, int(group)) == 0 else 1
-        wimg, wteam = g.decode_images() if tn == 1 else (None, None)     # weight images: single-position steps (M = rows x beams)
-        check(_lib.lib().cc_decode_fwd_x(C.byref(g.cfg), Ra, tn, self.pos, self.ctx_max, _p(g.arena.w32), _p(g.arena.w16),
-                                        _p(wimg) if wimg is not None else None, _p(wteam) if (wteam is not None and grp >= 2) else None, _p(x), _p(self.kv),
-                                        _p(self.row_map), grp, _p(self._workspace(tn)), _p(logits), Vp,
-                                        _p(self._lpart) if partials else None, _stream(g.arena.device)), "cc_decode_fwd_x")
+        wimg, wteam = g.decode_images() if (tn == 1 and _lib.IS_LAB) else (None, None)     # lab library: weight images of the decode experiments
+        if wimg is not None or wteam is not None:
+            check(_lib.lib().cc_decode_fwd_x(C.byref(g.cfg), Ra, tn, self.pos, self.ctx_max, _p(g.arena.w32), _p(g.arena.w16),
+                                            _p(wimg) if wimg is not None else None, _p(wteam) if (wteam is not None and grp >= 2) else None, _p(x), _p(self.kv),
+                                            _p(self.row_map), grp, _p(self._workspace(tn)), _p(logits), Vp,
+                                            _p(self._lpart) if partials else None, _stream(g.arena.device)), "cc_decode_fwd_x")
+        else:
+            check(_lib.lib().cc_decode_fwd_g(C.byref(g.cfg), Ra, tn, self.pos, self.ctx_max, _p(g.arena.w32), _p(g.arena.w16), _p(x), _p(self.kv),
+                                            _p(self.row_map), grp, _p(self._workspace(tn)), _p(logits), Vp,
+                                            _p(self._lpart) if partials else None, _stream(g.arena.device)), "cc_decode_fwd_g")
         self.pos += tn
         return logits[:, : g.dims["V"]]
 
     def check(self, tn: int = 1) -> None:
-        """Synchronises and raises if the last single-position step on this session's workspace gave up on an in-launch hand-off
-        (cc_decode_ws_check; a debugging aid — a correct run never trips it)."""
-        if tn in self._ws:
+        """Lab library: synchronises and raises if the last single-position step on this session's workspace gave up on an in-launch
+        hand-off of the persistent-launch experiments (cc_decode_ws_check).  The product path has no in-launch hand-offs: nothing to check."""
+        if _lib.IS_LAB and tn in self._ws:
             check(_lib.lib().cc_decode_ws_check(C.byref(self.g.cfg), self.R, tn, _p(self._ws[tn]), _stream(self.g.arena.device)), "cc_decode_ws_check")
 
     def reorder(self, src_rows: torch.Tensor) -> "DecodeSession":

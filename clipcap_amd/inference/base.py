@@ -49,9 +49,11 @@ def generate_beam_rounds(model, embeds: torch.Tensor, beam_size: int = 5, entry_
     R = S * beam_size
     V = g.dims["V"]
     rounds = max(1, int(rounds))
-    total = rounds * entry_length
-    if L0 + total > g.dims["NPOS"]:
-        raise RuntimeError(f"{rounds} generations of {entry_length} tokens behind a {L0}-position prefix exceed n_positions = {g.dims['NPOS']}")
+    # positions are allocated up to n_positions; like the reference (base.py:79-130), a large number_to_generate only fails if generation
+    # actually REACHES the position limit — beams normally stop far earlier
+    total = min(rounds * entry_length, g.dims["NPOS"] - L0)
+    if total < 1:
+        raise RuntimeError(f"a {L0}-position prefix leaves no room to generate (n_positions = {g.dims['NPOS']})")
     wte = lm.get_input_embeddings().weight.detach()
     scores = torch.zeros(R, dtype=torch.float32, device=dev)
     seq_lengths = torch.ones(R, dtype=torch.float32, device=dev)
@@ -74,10 +76,12 @@ def generate_beam_rounds(model, embeds: torch.Tensor, beam_size: int = 5, entry_
     for r in range(rounds):
         for i in range(1 if r == 0 else 0, entry_length):
             # base.py:120-121 breaks as soon as every beam has stopped.  Steps taken after that point only append token 0 to frozen
-            # beams (scores, lengths and the truncated outputs are unchanged), so polling the flag every 4th step — one host sync
+            # beams (lengths and the truncated outputs are unchanged; scores are re-sorted and change by ulps at most), so polling the flag every 4th step — one host sync
             # instead of four — cannot change the result.  (i == 0 of a later round is never skipped: the reference takes that step.)
             if i % 4 == 1 and bool(has_stopped.all()):
                 break
+            if n >= total:
+                raise RuntimeError(f"generation reached n_positions = {g.dims['NPOS']} ({L0}-position prefix + {n} tokens; round {r + 1} of {rounds})")
             logits = sess.forward(x, partials=True, group=beam_size)            # x = wte[next_tokens] (base.py:117)
             next_tok, src = beam_step(logits, S, beam_size, temperature, False, stop_token, scores, seq_lengths, has_stopped, bufs, sess.lpart)
             sess.beam_advance(beam_size, next_tok, src, wte, n, tok[(n - 1) & 1], tok[n & 1], x)   # base.py:104-117

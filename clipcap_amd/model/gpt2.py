@@ -69,9 +69,13 @@ class _Embedding(nn.Module):
         if w.is_cuda and not need_grad and ids.numel() > 0:
             # inference / frozen-LM paths: the library's gather (cc_embed_tokens, reference inference/base.py:117,184) — exact, like F.embedding
             from clipcap_amd.engine import embed_tokens
-            lo, hi = int(ids.min()), int(ids.max())       # this is the public get_input_embeddings() surface: F.embedding raises on a bad id, so does this
-            if lo < 0 or hi >= w.shape[0]:
-                raise IndexError(f"token id out of range for the {w.shape[0]}-row embedding table: min {lo}, max {hi}")
+            # the public get_input_embeddings() surface: F.embedding raises on a bad id.  Host-resident ids are checked here for free; ids
+            # already on the device are NOT read back (two blocking syncs per generated token in the sampling loops) —
+            # k_embed_tokens clamps them, so a bad id cannot fault, it reads the nearest valid row
+            if not ids.is_cuda:
+                lo, hi = int(ids.min()), int(ids.max())
+                if lo < 0 or hi >= w.shape[0]:
+                    raise IndexError(f"token id out of range for the {w.shape[0]}-row embedding table: min {lo}, max {hi}")
             out = torch.empty(*ids.shape, w.shape[1], dtype=torch.float32, device=w.device)
             embed_tokens(self._owner.engine, ids.to(device=w.device, dtype=torch.int32).contiguous().view(-1), out.view(-1, w.shape[1]))
             return out

@@ -184,6 +184,8 @@ class EmbedDataset(torch.utils.data.IterableDataset):
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
         pieces = self.pieces()
         par = int(self.reader_parallel_pieces)
+        if par > 0:      # one pool per rank: share the host's cores between the ranks of the node (8 ranks x 10 workers = 80 torch-importing processes otherwise)
+            par = max(1, min(par, (os.cpu_count() or par) // max(1, int(self.world_size))))
         if par <= 0:
             for lo, hi in pieces:
                 yield from self.load_piece(lo, hi)

@@ -102,6 +102,18 @@ def train(args: Namespace, tokenizer=None, language_model=None, step_hook=None) 
             logger = wandb.init(project=args.wandb_project)
         except ImportError:
             logger = None
+    try:
+        step = _run_epochs(args, model, dataset, device, sched, reducer, saver, sharded, rank, logger, first_epoch, step, step_hook)
+    finally:
+        if hasattr(dataset, "close"):
+            dataset.close()          # the reader's worker processes (do not leave them to interpreter exit)
+    opt = CheckpointSaver.optimizer_state(model) if sharded else None
+    if rank == 0:
+        saver.save_final_checkpoint(model, step=step, **({"optimizer_state": opt} if opt is not None else {}))
+    return 0
+
+
+def _run_epochs(args, model, dataset, device, sched, reducer, saver, sharded, rank, logger, first_epoch, step, step_hook):
     for epoch in range(first_epoch, args.epochs):
         for batch in DevicePrefetcher(dataset, device):
             loss = model.fused_step(batch, lr=args.optimizer_lr * sched(step), reducer=reducer)
@@ -117,10 +129,7 @@ def train(args: Namespace, tokenizer=None, language_model=None, step_hook=None) 
         opt = CheckpointSaver.optimizer_state(model) if sharded and epoch % saver.save_every_n_epochs == 0 else None
         if rank == 0:
             saver.on_epoch_end(model, epoch, step=step, **({"optimizer_state": opt} if opt is not None else {}))
-    opt = CheckpointSaver.optimizer_state(model) if sharded else None
-    if rank == 0:
-        saver.save_final_checkpoint(model, step=step, **({"optimizer_state": opt} if opt is not None else {}))
-    return 0
+    return step
 
 
 def start_training() -> int:

@@ -12,13 +12,12 @@
  *     as void*; NULL = default stream), so calls on different streams / from different host threads are independent.
  *     Per-step settings (GPT-2 dropout, loss scale) travel in the call's own arguments.  The only process-wide state is
  *     the test / measurement hooks at the end of this file (cc_gemm_tile_mode, cc_gemm_skinny_mode, cc_decode_mode,
- *     cc_decode_last_path, cc_prof_*), which the product path never touches.  libclipcap_hip.so does not read the environment
+ *     cc_prof_*), which the product path never touches.  libclipcap_hip.so does not read the environment
  *     (getenv is not among its imports) and exports exactly the functions declared here (csrc/exports.map).  The kernels and A/B
- *     code paths that were built, measured and lost — the persistent decode-layer launch, the XCD-team decode engine, fp32-MFMA
- *     attention — and the CC_* environment switches that select them live in the LAB build only (`make -C clipcap_amd/csrc lab` ->
- *     libclipcap_hip_lab.so, -DCC_EXPERIMENTS, csrc/lab_env.h; CLIPCAP_HIP_LIB=lab makes the Python binding load it).  In the
- *     product library the entry points that would use them (cc_decode_mode bits 1 / 2, cc_decode_fwd_x with an image) keep the
- *     launch-per-op path and cc_decode_xt_image_bytes returns 0.
+ *     code paths that were built, measured and lost — the persistent decode-layer launch, the XCD-team decode engine, decode GEMMs on
+ *     fragment-ordered weight images, fp32-MFMA attention — their entry points (include/clipcap_hip_lab.h) and the CC_* environment
+ *     switches that select them live in the LAB build only (`make -C clipcap_amd/csrc lab` -> libclipcap_hip_lab.so, -DCC_EXPERIMENTS,
+ *     csrc/lab_env.h; CLIPCAP_HIP_LIB=lab makes the Python binding load it).
  *   - return value: 0 = ok, <0 = error (CC_ERR_*), never throws across the ABI.
  *   - OPERAND TYPE.  GEMM / attention operands and the stored 16-bit activations are bf16 (CC_OP_BF16, default) or IEEE
  *     fp16 (CC_OP_FP16 = the reference's `--fp-precision 16`, clipcap/train/args.py:30-34), selected per model by
@@ -62,8 +61,9 @@ extern "C" {
  * would be written out of bounds, so clipcap_amd/_lib.py refuses a library whose version differs.  Entry points ADDED since 2:
  * cc_adamw_step_cast, cc_mapper_transpose_weights, cc_gpt2_transpose_weights, cc_comm_count, cc_decode_part_floats, cc_decode_fwd_p,
  * cc_beam_step_p; since 3: cc_decode_fwd_g, cc_decode_ws_check, cc_decode_mode, cc_grad_wire_pack, cc_grad_wire_unpack,
- * cc_sample_step_lp, cc_broadcast_bucket; round 5 (still 3: nothing existing changed): cc_decode_image_bytes, cc_decode_image,
- * cc_decode_xt_image_bytes, cc_decode_xt_image, cc_decode_fwd_x, cc_decode_last_path; operand mode ADDED: CC_OP_BF16X3 */
+ * cc_sample_step_lp, cc_broadcast_bucket; operand mode ADDED: CC_OP_BF16X3.  Round 6 (still 3): the default-off decode experiments
+ * (cc_decode_image*, cc_decode_xt_image*, cc_decode_fwd_x, cc_decode_ws_check, cc_decode_last_path) moved to include/clipcap_hip_lab.h —
+ * the lab library exports them, the product library does not. */
 #define CC_ABI_VERSION 3
 int cc_abi_version(void);
 
@@ -237,30 +237,6 @@ int cc_decode_fwd_p(const cc_gpt2_cfg* cfg, int32_t R, int32_t Tnew, int32_t pos
 int cc_decode_fwd_g(const cc_gpt2_cfg* cfg, int32_t R, int32_t Tnew, int32_t pos0, int32_t ctx_max, const float* w32,
                     const uint16_t* w16, const float* x, uint16_t* kv, const int32_t* row_map, int32_t group, void* ws, float* logits,
                     int64_t ldl, float* lpart, void* stream);
-/* Single-position group steps (cc_decode_fwd_g, Tnew == 1, bf16 / fp16 operands, head dim 64, R <= 512) run the whole layer stack as ONE
- * persistent launch whose workgroups hand activations to each other through arrival counters in `ws`; every wait in it is bounded, and a
- * wait that gives up raises an error word in `ws`.  cc_decode_ws_check synchronises `stream` and returns CC_ERR_STATE if the last step on
- * this workspace gave up (its logits are then garbage), CC_OK otherwise.  A debugging / test aid: a correct run never trips it. */
-int cc_decode_ws_check(const cc_gpt2_cfg* cfg, int32_t R, int32_t Tnew, const void* ws, void* stream);
-/* Decode weight images (bf16 / fp16 operands; rebuilt whenever the weights change, after cc_gpt2_sync_weights):
- *   cc_decode_image_bytes / cc_decode_image: the four GEMM weights of every GPT-2 block in MFMA FRAGMENT ORDER (per 64-column x 64-k tile the
- *       eight 1-KiB pieces its four waves feed to v_mfma_f32_32x32x16, lane-contiguous), at the offsets the weights have in the operand
- *       arena (the image is a permutation of each matrix: cc_gpt2_param_count elements).  With it the decode-sized GEMMs whose K is split
- *       over the waves (c_attn, mlp.c_proj at rows x beams = 320) load the weight operand global -> VGPR and keep it out of LDS entirely
- *       (gemm_nt_s64kwb_kernel); 0 bytes = operand type / width not covered.
- *   cc_decode_xt_image_bytes / cc_decode_xt_image: LAB BUILD ONLY (0 / CC_ERR_SHAPE in the product library) — the image of the XCD-team
- *       engine (decode_xt.hip: every XCD runs the whole layer stack of a single-position group step for its own rows, weights streamed into
- *       registers per (workgroup, wave) in consumption order; D = 512 or 1024, head dim 64, at most 48 rows per XCD, cc_decode_mode bit 2).
- *   cc_decode_fwd_x: cc_decode_fwd_g with the images (either may be NULL: exactly cc_decode_fwd_g then).  Results equal cc_decode_fwd_g's to
- *       fp32 summation order.  The engine's waits are bounded like the persistent launch's; cc_decode_ws_check reports a step that gave up
- *       (sticky until the workspace is zeroed). */
-int64_t cc_decode_image_bytes(const cc_gpt2_cfg* cfg);
-int cc_decode_image(const cc_gpt2_cfg* cfg, const uint16_t* w16, uint16_t* wimg, void* stream);
-int64_t cc_decode_xt_image_bytes(const cc_gpt2_cfg* cfg);
-int cc_decode_xt_image(const cc_gpt2_cfg* cfg, const uint16_t* w16, uint16_t* wteam, void* stream);
-int cc_decode_fwd_x(const cc_gpt2_cfg* cfg, int32_t R, int32_t Tnew, int32_t pos0, int32_t ctx_max, const float* w32,
-                    const uint16_t* w16, const uint16_t* wimg, const uint16_t* wteam, const float* x, uint16_t* kv, const int32_t* row_map,
-                    int32_t group, void* ws, float* logits, int64_t ldl, float* lpart, void* stream);
 /* reorder / expand cache rows after a beam step: kv_dst[:, :, r] = kv_src[:, :, src[r]] for positions < ctx and
  * r < R_dst (base.py:93,113: embeds.expand / embeds[next_tokens_source]); the two caches may have different row counts. */
 int cc_decode_reorder(const cc_gpt2_cfg* cfg, int32_t R_src, int32_t R_dst, int32_t ctx, int32_t ctx_max, const uint16_t* kv_src,
@@ -397,16 +373,9 @@ int cc_gemm_tile_mode(int32_t mode);
  * tools/small_gemm_bench.py. */
 int cc_gemm_skinny_mode(int32_t mode);
 /* How cc_decode_fwd_g runs a single-position group step.  bit 0 (default on): beam-group attention (every distinct KV row of a group read
- * once); bit 1 (default off): the whole layer stack as ONE persistent launch with in-launch hand-offs (decode_pk.hip; bf16 / fp16 operands) —
- * results equal the per-op launches to rounding, and on MI355X it measured SLOWER than them, so it is an A/B switch, not
- * the product path; bit 2 (default off; lab build only: measured slower than the per-op launches): cc_decode_fwd_x may use the XCD-team engine when it is
- * handed that engine's image; bit 3 (default off): the K-split decode GEMMs read the weight operand global -> VGPR from the fragment-ordered image of cc_decode_image when one is
- * passed (bit-identical results; faster only with cache-resident weights, 1-3 % slower in the real chain where they stream from HBM: an A/B switch).  mode < 0 only queries.
- * PROCESS-WIDE test knob; returns the previous mode (env CC_DEC_GROUP / CC_DEC_PK / CC_DEC_XT preset it). */
+ * once; off = one attention launch per row set, the A/B arm of tests/test_gpu_decode_group.py).  The other bits select lab-build experiments
+ * (include/clipcap_hip_lab.h) and do nothing in the product library.  mode < 0 only queries.  PROCESS-WIDE test knob; returns the previous mode. */
 int cc_decode_mode(int32_t mode);
-/* which path the most recent single-position group step of cc_decode_fwd_x / cc_decode_fwd_g took: 0 = launch per op, 1 = persistent launch
- * (decode_pk.hip), 2 = XCD-team engine (decode_xt.hip).  PROCESS-WIDE test / measurement hook. */
-int cc_decode_last_path(void);
 int cc_layernorm_fwd(int32_t op_dtype, const float* x, const float* gamma, const float* beta, uint16_t* y, float* mean, float* rstd, int32_t rows,
                      int32_t D, void* stream);
 int cc_attention_fwd(int32_t op_dtype, const uint16_t* qkv, int32_t B, int32_t S, int32_t H, int32_t hd, int32_t causal, uint16_t* out, float* lse,

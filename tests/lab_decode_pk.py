@@ -1,6 +1,6 @@
 """LAB BUILD ONLY (libclipcap_hip_lab.so, run by tests/test_gpu_lab.py with CLIPCAP_HIP_LIB=lab): cc_decode_mode bit 1 — the whole layer stack of a
 group step as ONE persistent launch whose workgroups hand activations over through arrival counters (clipcap_amd/csrc/decode_pk.hip).  An A/B
-switch (measured 2x slower than the per-op launches), held to the bars of tests/test_gpu_decode_group.py, plus
+switch (measured 2x slower than the per-op launches, HISTORY.md 4.5), held to the bars of tests/test_gpu_decode_group.py, plus
 cc_decode_ws_check (no hand-off gave up).  Reference semantics: the full re-forward per generated token, clipcap/inference/base.py:80-121."""
 import pytest
 import torch  # noqa: F401

@@ -70,13 +70,19 @@ def test_library_exports_exactly_the_header_and_nothing_else():
     assert exported == declared, (sorted(exported - declared)[:10], sorted(declared - exported)[:10])
     assert "getenv" not in _nm(lib, "--undefined-only"), "the product library must not read the environment"
     blob = open(lib, "rb").read()
-    for marker in (b"k_decode_xt", b"k_decode_layers", b"k_attn_fwd_f32mfma"):
+    for marker in (b"k_decode_xt", b"k_decode_layers", b"k_attn_fwd_f32mfma", b"gemm_nt_s64kwb_kernel", b"k_skinny_image"):
         assert marker not in blob, f"experiment kernel {marker!r} in the product library"
+    # (round 6) the default-off decode experiments' entry points are declared in include/clipcap_hip_lab.h and exported by the lab library only
+    lhdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "clipcap_hip_lab.h")).read(), flags=re.S)
+    lab_declared = set(re.findall(r"^(?:int|int64_t)\s+(cc_\w+)\s*\(", lhdr, flags=re.M))
+    assert lab_declared and not (lab_declared & declared)
+    for name in ("cc_decode_fwd_x", "cc_decode_image", "cc_decode_xt_image", "cc_decode_ws_check", "cc_decode_last_path"):
+        assert name in lab_declared and name not in exported
     lab = os.path.join(ROOT, "clipcap_amd", "libclipcap_hip_lab.so")
     if os.path.exists(lab):
-        assert {n for n in _nm(lab, "--defined-only") if n.startswith("cc_")} == declared
+        assert {n for n in _nm(lab, "--defined-only") if n.startswith("cc_")} == declared | lab_declared
         lblob = open(lab, "rb").read()
-        assert b"k_decode_xt" in lblob and b"k_decode_layers" in lblob and b"k_attn_fwd_f32mfma" in lblob
+        assert b"k_decode_xt" in lblob and b"k_decode_layers" in lblob and b"k_attn_fwd_f32mfma" in lblob and b"gemm_nt_s64kwb_kernel" in lblob
 
 
 def test_abi_dispatch_file_is_current():
