@@ -25,7 +25,12 @@ def main():
                 args = (rng.randint(1, 5), rng.randint(1, 100), rng.randint(1, 5), hd, rng.randint(0, 1), 1)
                 K.test_attention_fwd_bwd(*args)
             elif kind == "tile":
-                args = (rng.choice([3, 4, 5, 6, 6]), 8 * rng.randint(1, 150), 8 * rng.randint(1, 120), 32 * rng.randint(1, 40))
+                mode = rng.choice([3, 4, 5, 6, 7, 7, 7])
+                # mode 7 (round 6): the persistent 4-wave kernel — K in multiples of 64 so that both of its rings (K % 192 == 0, K % 128 == 0) and the
+                # fall-back to the staggered kernel are drawn; now and then more tiles than CUs (the workgroups then walk several tiles)
+                K_ = 64 * rng.randint(1, 40) if mode == 7 else 32 * rng.randint(1, 40)
+                big = mode == 7 and rng.random() < 0.15
+                args = (mode, 8 * rng.randint(1, 150) * (6 if big else 1), 8 * rng.randint(1, 120) * (4 if big else 1), K_)
                 K.test_gemm_nt_256_row_tiles(*args)
             elif kind == "skinny":      # the decode-sized 64-row / 80-row tile kernels (round 5: mode 4 = 80 x 64, K over the waves), single pass and K slices
                 ks = rng.choice([1, 1, 1, 2, 3])

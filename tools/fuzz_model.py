@@ -28,7 +28,7 @@ def one_step(rng):
     V = rng.randint(50, 1500)
     B, cap = rng.randint(1, 7), rng.randint(1, 14)
     prec = rng.choice([None, 16, 32])
-    mode = rng.choice([-1, -1, 0, 3, 4, 5, 6])
+    mode = rng.choice([-1, -1, 0, 3, 4, 5, 6, 7])
     if "FUZZ_TILE" in os.environ:
         mode = int(os.environ["FUZZ_TILE"])
     if "FUZZ_PREC" in os.environ:
@@ -114,7 +114,7 @@ def one_full(rng):
     P, L, N, n_layer = rng.randint(1, 4), rng.randint(1, 4), rng.randint(1, 2), rng.randint(1, 2)
     E_, V, B, cap = 8 * rng.randint(1, 8), rng.randint(60, 900), rng.randint(1, 5), rng.randint(1, 10)
     use_drop = hd == 64 and rng.random() < 0.6
-    mode = rng.choice([-1, -1, 0, 3, 4, 5, 6])
+    mode = rng.choice([-1, -1, 0, 3, 4, 5, 6, 7])
     args = dict(full=True, E=E_, D=D, P=P, L=L, H=H, N=N, n_head=n_head, n_layer=n_layer, V=V, B=B, cap=cap, drop=use_drop, tile=mode)
     LAST.update(args=args)
     eng, sd, cfg = TD._build(E_, D, P, L, H, N, n_head, n_layer, V, L + cap + 2, seed=rng.randint(0, 999))
