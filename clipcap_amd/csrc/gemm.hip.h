@@ -35,6 +35,7 @@ struct GemmShape {
     int k_chunk;  // K extent handled by one blockIdx.z slice (multiple of 64); == K rounded up when no split
     int group_m;  // m-tiles per band of the tile order (tile_coords)
     int stagger;  // 128 x 128 two-blocks-per-CU kernel: s_sleep units (64 cycles) the second block of every CU waits before its first tile
+    int flags = 0;  // bit 0 (lab A/B, CC_Q4_LAST=0): the 4-wave kernel keeps its dummy tail stream on a workgroup's last tile
 };
 
 __device__ __forceinline__ int g_lds_off(int row, int chunk) {
@@ -2252,6 +2253,8 @@ inline int launch_gemm(int al, int bl, const op16_t* A, int lda, const op16_t* B
                 static const bool q4_on = []() { const char* e = cc_lab_env("CC_GEMM_Q4"); return !e || atoi(e) != 0; }();
                 const bool fits32 = (size_t)M * (size_t)lda * 2 < 0xffff0000ull && (size_t)N * (size_t)ldb * 2 < 0xffff0000ull;
                 const int ns = (K % 192 == 0 && K >= 384) ? 3 : ((K % 128 == 0 && K >= 256) ? 2 : 0);
+                static const bool q4_last = []() { const char* e = cc_lab_env("CC_Q4_LAST"); return !e || atoi(e) != 0; }();
+                g.flags = q4_last ? 0 : 1;
                 if (ns && fits32 && ksplit == 1 && s256 != 6 && (q4_on || s256 == 7)) {
                     static const int ncu = []() { int n = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
                     const int tiles = ((M + 159) / 160) * ((N + 255) / 256);

@@ -11,8 +11,7 @@ A stage is consumed in two half-steps of 32 K-columns; fragments are double-buff
                           |  NI + 8 ds_read_b128: K half 0 of stage T + 1 -> set 0
                           |  ND x { s_add_u32 m0 ; global_load_lds_dwordx4 ; v_add_u32 offset, 128 }: stage T + NS -> the buffer just consumed
 
-The tile's statement = head (NS stages; the first `b` barrier waits on nothing: its stage was awaited before the previous tile's
-epilogue), main loop (NS stages per iteration), tail (NS stages whose DMA instructions stream the NEXT tile's first NS stages).
+The tile's statement = head (NS stages), main loop (NS stages per iteration), tail (NS stages whose DMA instructions stream the NEXT tile's first NS stages).
 All registers are constraint operands (accumulators "+a", fragments "v"), so hipcc allocates them and nothing inside the statement is
 visible to its scheduler.  Hazards handled in the text: SALU write of M0 -> LDS-DMA needs one wait state (an MFMA sits between), the
 statement opens with s_nop 4 (fresh readfirstlane SGPRs read by VMEM) and ends with s_nop 7 x 2 (MFMA result -> compiler's accvgpr reads).
@@ -93,9 +92,9 @@ class Gen:
                     self.emit(f)
                 k += 1
 
-    def stage(self, buf, first=False):
+    def stage(self, buf, first=False, dma=True, vm=-1):
         self.half(buf, 0, None, False)
-        self.half(buf, 1, None if first else (self.ns - 2) * self.nd, True)
+        self.half(buf, 1, None if first else ((self.ns - 2) * self.nd if vm == -1 else vm), dma)
 
     def set_offsets(self, src, add):
         for i in range(self.na):
@@ -104,11 +103,15 @@ class Gen:
             self.emit(("v_add_u32 %%[tb%d], %d, %%[%sb%d]" % (j, add, src, j)) if add else ("v_mov_b32 %%[tb%d], %%[%sb%d]" % (j, src, j)))
 
     def tile(self):
+        """One tile of one workgroup.  The tail (the tile's last NS stages) exists twice, chosen by the scalar %[more]: with a next tile its b half-steps
+        stream that tile's stages 0 .. NS-1; on the workgroup's final tile they issue no DMA (the dummy stream cost 3 of 12 + 3 stages' worth of
+        LDS-DMA on a K = 768 launch) and wait for exactly the stages still in flight.  Both tails in ONE statement: two asm statements on the two
+        sides of a C++ branch made the compiler copy the accumulators (119 spilled registers)."""
         ns = self.ns
         self.emit("s_nop 4")
         self.set_offsets("o", 128 * ns)            # head: the DMA stream continues inside this tile at stage NS
         for b in range(ns):
-            self.stage(b, first=(b == 0))
+            self.stage(b)        # (stage 0's b barrier waits like every other: a single-tile launch then starts on stage 0 alone, the prologue awaits no more)
         self.emit("s_cmp_eq_u32 %[nmain], 0")
         self.emit("s_cbranch_scc1 Q4_TAIL_%=")
         self.emit("s_mov_b32 %[cnt], %[nmain]")
@@ -119,11 +122,21 @@ class Gen:
         self.emit("s_cmp_lg_u32 %[cnt], 0")
         self.emit("s_cbranch_scc1 Q4_LOOP_%=")
         self.emit("Q4_TAIL_%=:")
+        self.emit("s_cmp_eq_u32 %[more], 0")
+        self.emit("s_cbranch_scc1 Q4_FINAL_%=")
         self.set_offsets("n", 0)                   # tail: the next tile's stages 0 .. NS-1
         for b in range(ns):
             self.stage(b)
         # next tile: stages 0 and 1 landed (NS = 2: everything), the fragments of its first half-step are in set 0
         self.emit("s_waitcnt vmcnt(%d) lgkmcnt(0)" % ((ns - 2) * self.nd))
+        self.emit("s_branch Q4_END_%=")
+        self.emit("Q4_FINAL_%=:")
+        # stage T = nbig - NS + b: still in flight behind it are the stages up to nbig - 1 -> (NS - 2 - b) of them may stay out at its b barrier
+        for b in range(ns):
+            left = ns - 2 - b
+            self.stage(b, dma=False, vm=(left * self.nd if left >= 0 else None))
+        self.emit("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        self.emit("Q4_END_%=:")
         self.emit("s_nop 7")
         self.emit("s_nop 7")
 
@@ -171,7 +184,7 @@ class Gen:
             for kk in range(2):
                 ins.append("[la%d_%d] \"v\"(q4_la[%d][%d])" % (b, kk, b, kk))
                 ins.append("[lb%d_%d] \"v\"(q4_lb[%d][%d])" % (b, kk, b, kk))
-        for t in ("pa", "pb", "slds", "nmain"):
+        for t in ("pa", "pb", "slds", "nmain", "more"):
             ins.append("[%s] \"s\"(q4_%s)" % (t, t))
         return ("#define %s_OUTS \\\n    " % name + ", \\\n    ".join(outs) + "\n" +
                 "#define %s_INS \\\n    " % name + ", \\\n    ".join(ins) + "\n")
