@@ -127,6 +127,7 @@ SIGNATURES = {
     "cc_comm_create": (_I, [C.POINTER(_P), _I, _I, _P]),
     "cc_allreduce_bucket": (_I, [_P, _P, _L, _I, _P]),
     "cc_broadcast_bucket": (_I, [_P, _P, _L, _I, _I, _P]),
+    "cc_reduce_bucket": (_I, [_P, _P, _L, _I, _I, _P]),
     "cc_comm_destroy": (_I, [_P]),
     "cc_comm_count": (_I, [_P, C.POINTER(_I)]),
     "cc_prof_start": (_I, [_I, _I]),

@@ -102,6 +102,7 @@ struct Rccl {
     ncclResult_t (*destroy)(ncclComm_t) = nullptr;
     ncclResult_t (*count)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*bcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
     bool ok = false;
     Rccl() {
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
@@ -114,6 +115,7 @@ struct Rccl {
         destroy = reinterpret_cast<decltype(destroy)>(dlsym(h, "ncclCommDestroy"));
         count = reinterpret_cast<decltype(count)>(dlsym(h, "ncclCommCount"));
         bcast = reinterpret_cast<decltype(bcast)>(dlsym(h, "ncclBroadcast"));
+        reduce = reinterpret_cast<decltype(reduce)>(dlsym(h, "ncclReduce"));
         ok = get_uid && init_rank && all_reduce && destroy;
     }
 };
@@ -159,6 +161,15 @@ int cc_broadcast_bucket(void* comm, void* buf, int64_t count, int32_t dtype, int
     if (count == 0) return CC_OK;
     const ncclDataType_t t = dtype == CC_RED_F32 ? ncclFloat32 : dtype == CC_RED_BF16 ? ncclBfloat16 : ncclFloat16;
     return rccl().bcast(buf, buf, (size_t)count, t, root, static_cast<ncclComm_t>(comm), static_cast<hipStream_t>(stream)) == ncclSuccess
+               ? CC_OK : CC_ERR_LAUNCH;
+}
+
+int cc_reduce_bucket(void* comm, void* buf, int64_t count, int32_t dtype, int32_t root, void* stream) {
+    if (!comm || !buf || count < 0 || root < 0 || dtype < CC_RED_F32 || dtype > CC_RED_F16) return CC_ERR_ARG;
+    if (!rccl().ok || !rccl().reduce) return CC_ERR_STATE;
+    if (count == 0) return CC_OK;
+    const ncclDataType_t t = dtype == CC_RED_F32 ? ncclFloat32 : dtype == CC_RED_BF16 ? ncclBfloat16 : ncclFloat16;
+    return rccl().reduce(buf, buf, (size_t)count, t, ncclSum, root, static_cast<ncclComm_t>(comm), static_cast<hipStream_t>(stream)) == ncclSuccess
                ? CC_OK : CC_ERR_LAUNCH;
 }
 

@@ -536,13 +536,17 @@ class ClipCapEngine:
     def arenas(self) -> List[_Arena]:
         return [self.mapper.arena] + ([self.gpt2.arena] if self.train_lm else [])
 
-    def optimizer_step(self, lr: float, step: int, **adamw_kw) -> None:
+    def optimizer_step(self, lr: float, step: int, sync_flag=None, **adamw_kw) -> None:
         """AdamW over every trained arena (reference model.py:67-91).  With fp16 operands: overflow check of the scaled gradients
-        (after any all-reduce), the step is skipped on the device if they overflowed, then the loss scale is adjusted."""
+        (after any all-reduce), the step is skipped on the device if they overflowed, then the loss scale is adjusted.
+        ``sync_flag(found_inf)``: optional in-place SUM over the ranks (ddp.GradReducer.reduce_flag) — with partitioned gradients
+        (ZeRO stage 2) a rank only sees its own slice summed, so the ranks agree on the overflow flag before anyone steps."""
         sc = self.scaler
         if sc is not None:
             for a in self.arenas():
                 sc.check(a)
+            if sync_flag is not None:
+                sync_flag(sc.found_inf)
         for a in self.arenas():
             a.adamw_step(lr, step, scaler=sc, **adamw_kw)
         if sc is not None:

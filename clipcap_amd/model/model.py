@@ -112,7 +112,7 @@ class ClipCapModel(nn.Module):
         else:
             loss = eng.forward_backward(tokens, embeds, dropout=self._dropout())
         self._opt_step += 1
-        eng.optimizer_step(lr, self._opt_step, weight_decay=self._weight_decay())
+        eng.optimizer_step(lr, self._opt_step, weight_decay=self._weight_decay(), sync_flag=(reducer.reduce_flag if reducer is not None else None))
         return loss
 
     def _weight_decay(self) -> float:

@@ -1,7 +1,7 @@
 """``add_training_args`` — the reference's training / data / deepspeed / wandb flags with identical names, types and defaults
 (clipcap/train/args.py:3-113).  Flags that configured Lightning/DeepSpeed are accepted for command-line compatibility;
-``--deepspeed-strategy`` with a ZeRO stage >= 1 shards the AdamW moments over the ranks (train/ddp.py ZeroShard; multi-GPU is always one
-process per GPU + RCCL); ``--enable-deepspeed`` keeps its one numerical effect, the optimizer's weight decay (0.0 under DeepSpeed's FusedAdam, 0.01 under torch.optim.AdamW)."""
+``--deepspeed-strategy`` with a ZeRO stage >= 1 shards the AdamW moments over the ranks (train/ddp.py ZeroShard), stage >= 2 also reduces every
+gradient slice onto its owner only (GradReducer.set_owners); multi-GPU is always one process per GPU + RCCL; ``--enable-deepspeed`` keeps its one numerical effect, the optimizer's weight decay (0.0 under DeepSpeed's FusedAdam, 0.01 under torch.optim.AdamW)."""
 from argparse import ArgumentParser
 
 
@@ -33,8 +33,9 @@ _GROUPS = {
         ("--enable-deepspeed", bool, False, "No DeepSpeed here (one process per GPU + RCCL always); kept for its one numerical effect in the reference: "
          "FusedAdam's default weight decay 0.0 instead of torch AdamW's 0.01 (clipcap/model/model.py:72-77)."),
         ("--deepspeed-strategy", str, None, "ZeRO stage by Lightning's names (deepspeed_stage_1 / _2 / _3 ...): any stage >= 1 shards the AdamW "
-         "moments over the ranks (each rank steps its own slice of the flat parameter arena, the slices are broadcast back); gradients and "
-         "parameters stay replicated."),
+         "moments over the ranks (each rank steps its own slice of the flat parameter arena, the slices are broadcast back); stage 2 / 3 (and plain "
+         "'deepspeed') also partition the gradients on the wire: a slice is summed only onto the rank that owns it (reduce instead of all-reduce). "
+         "The flat parameter / gradient arenas stay resident on every rank (the kernels read and write them)."),
     ],
     "wandb": [
         ("--enable-wandb", bool, False, "Log the loss to Weights & Biases if the package is installed."),

@@ -6,7 +6,10 @@ shard its data (clipcap/train/dataloader.py:84-91), so the spec here is ours (SU
   * the loss divisor is the GLOBAL number of kept targets: a 2-float [loss_sum, kept_count] all-reduce before backward
     (``reduce_stats``), so summing the ranks' gradients reproduces the single-process global-batch gradient exactly;
   * gradient arenas are all-reduced (SUM) in large buckets (``all_reduce``): xGMI is point-to-point, a ring moves
-    2(N-1)/N of the payload over one link, so few large collectives beat many small ones.
+    2(N-1)/N of the payload over one link, so few large collectives beat many small ones;
+  * ``--deepspeed-strategy`` stage 1 shards the AdamW moments (``ZeroShard``); stage 2 / 3 also partition the gradients ON THE WIRE
+    (``GradReducer.set_owners``): a gradient slice is summed only onto the rank that owns its moments (reduce, not all-reduce —
+    half the bytes), the updated parameter slices travel back by one broadcast per owner.
 This module is compute-agnostic (it only sees tensors), which is what lets tests/test_ddp_gloo.py run it on CPU with gloo.
 """
 from __future__ import annotations
@@ -69,6 +72,14 @@ class CAbiComm:
         self._lib.check(self._lib.lib().cc_allreduce_bucket(self._comm, self._C.c_void_p(t.data_ptr()), t.numel(), code,
                                                             self._C.c_void_p(st.cuda_stream)), "cc_allreduce_bucket")
 
+    def reduce_(self, t: torch.Tensor, root: int, stream: Optional[torch.cuda.Stream] = None) -> None:
+        """In-place SUM onto rank ``root`` (cc_reduce_bucket = ncclReduce); the other ranks' tensors keep their own contribution."""
+        code = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[t.dtype]
+        assert t.is_contiguous() and t.device == self.device
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        self._lib.check(self._lib.lib().cc_reduce_bucket(self._comm, self._C.c_void_p(t.data_ptr()), t.numel(), code, root,
+                                                         self._C.c_void_p(st.cuda_stream)), "cc_reduce_bucket")
+
     def count(self) -> int:
         """ncclCommCount: the ranks RCCL connected for this communicator."""
         n = self._C.c_int32(0)
@@ -109,24 +120,30 @@ class ZeroShard:
         for w in works:
             w.wait()
 
-    def apply(self, arenas) -> None:
+    def apply(self, arenas) -> List[List[Tuple[int, int]]]:
+        """Shards every arena's optimizer state; returns the owner ranges per arena (what ``GradReducer.set_owners`` takes for stage 2)."""
         for a in arenas:
             a.shard_optimizer_state(self.rank, self.world, self.gather)
+        return [list(a.zero[1]) for a in arenas]
 
 
 def zero_stage(strategy: Optional[str]) -> int:
-    """``--deepspeed-strategy`` (Lightning's names: deepspeed_stage_1 / _2 / _2_offload / _3 / _3_offload, or a bare digit) -> 0 (replicated
-    optimizer state) or 1 (sharded).  Stages 2 and 3 also shard gradients / parameters in DeepSpeed; the flat arenas here stay replicated
-    (they are what the kernels read), so every stage >= 1 shards the optimizer state — the largest of the three for AdamW."""
+    """``--deepspeed-strategy`` (Lightning's names: deepspeed / deepspeed_stage_1 / _2 / _2_offload / _3 / _3_offload, or a bare digit) ->
+    0: replicated optimizer state, gradients all-reduced;
+    1: AdamW moments sharded over the ranks (``ZeroShard``), gradients all-reduced;
+    2: + gradients partitioned on the wire: each slice is SUM-reduced only onto the rank that owns its moments (``GradReducer.set_owners``).
+    DeepSpeed's stage 3 (parameter partitioning) and the offload variants map to 2: the flat parameter and gradient arenas stay
+    resident on every rank because they are what the kernels read and write — what stages 2 / 3 change here is the traffic
+    (reduce + broadcast = one all-reduce's bytes in total, instead of all-reduce + broadcast), not the arena footprint."""
     if not strategy:
         return 0
     s = str(strategy).strip().lower()
     import re
     if s == "deepspeed":                       # Lightning's plain "deepspeed" strategy is ZeRO stage 2
-        return 1
+        return 2
     m = re.fullmatch(r"(?:deepspeed_)?(?:stage_)?([0-3])(?:_offload(?:_nvme)?)?", s) or re.fullmatch(r"zero_?([0-3])", s)
     if m:
-        return 1 if int(m.group(1)) >= 1 else 0
+        return min(int(m.group(1)), 2)
     import warnings
     warnings.warn(f"--deepspeed-strategy {strategy!r} is not one of Lightning's DeepSpeed strategy names (deepspeed, deepspeed_stage_1/2/3[_offload]); "
                   "optimizer state stays replicated")
@@ -151,7 +168,7 @@ def _wire_cast(src: torch.Tensor, dst: torch.Tensor) -> None:
 
 
 class GradReducer:
-    """Bucketed SUM all-reduce of flat gradient arenas plus the loss-statistics reduction.  Collectives go through torch.distributed
+    """Bucketed SUM all-reduce (or, with ``set_owners``, reduce-to-owner) of flat gradient arenas plus the loss-statistics reduction.  Collectives go through torch.distributed
     (backend "nccl" = RCCL) or, with ``comm=CAbiComm(...)``, through the library's own C-ABI communicator."""
 
     def __init__(self, flats: Sequence[torch.Tensor], bucket_bytes: int = 256 << 20, group=None, comm: Optional[CAbiComm] = None,
@@ -166,12 +183,57 @@ class GradReducer:
         self.wire_dtype = wire_dtype
         self.stage = [torch.empty_like(f, dtype=wire_dtype) for f in self.flats] if wire_dtype != torch.float32 else None
         self._pending = []       # (arena, lo, hi, work) of bf16 slices still to be widened back
+        self.owners = None       # set_owners(): per arena, the (lo, hi) each rank owns -> reduce onto the owner instead of all-reduce
+        self.rank = None
         self.buckets: List[torch.Tensor] = []
         for f in self.flats:
             assert f.dim() == 1 and f.is_contiguous()
             per = max(1, bucket_bytes // f.element_size())
             for lo in range(0, f.numel(), per):
                 self.buckets.append(f[lo:lo + per])
+
+    def set_owners(self, owners: Optional[Sequence[Sequence[Tuple[int, int]]]], rank: Optional[int] = None) -> None:
+        """Gradient partitioning (ZeRO stage 2): ``owners[arena][r] = (lo, hi)`` is the slice of gradient arena ``arena`` whose AdamW
+        moments rank r holds (``ZeroShard.apply``'s return value).  From here on a slice is SUM-reduced onto its owner only — the other
+        ranks never read its sum (``_Arena.adamw_step`` steps the own range) — so their copy keeps the local contribution.  None: back to
+        all-reduce."""
+        if owners is not None:
+            assert len(owners) == len(self.flats)
+            for f, rs in zip(self.flats, owners):
+                assert rs[0][0] == 0 and rs[-1][1] == f.numel() and all(rs[i][1] == rs[i + 1][0] for i in range(len(rs) - 1)), "owner ranges must tile the arena"
+        self.owners = [list(rs) for rs in owners] if owners is not None else None
+        self.rank = rank if rank is not None else (self.comm.rank if self.comm is not None else dist.get_rank(self.group))
+
+    def _pieces(self, arena: int, lo: int, hi: int):
+        """[lo, hi) of an arena as (lo, hi, root) collectives: root None = all-reduce, else reduce onto group rank ``root``."""
+        if self.owners is None:
+            return [(lo, hi, None)]
+        return [(max(lo, a), min(hi, b), r) for r, (a, b) in enumerate(self.owners[arena]) if min(hi, b) > max(lo, a)]
+
+    def _collective(self, t: torch.Tensor, root: Optional[int], side=None):
+        """One SUM collective on ``t``: RCCL through the C ABI (enqueued on ``side`` or the current stream; returns None) or
+        torch.distributed (async; returns the work handle)."""
+        if self.comm is not None:
+            if root is None:
+                self.comm.all_reduce_(t, side)
+            else:
+                self.comm.reduce_(t, root, side)
+            return None
+        if root is None:
+            return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        dst = dist.get_global_rank(self.group, root) if self.group is not None else root
+        return dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def reduce_flag(self, flag: torch.Tensor) -> None:
+        """SUM all-reduce of a small device flag on the current stream.  With partitioned gradients each rank's overflow check sees only
+        its own slice summed, so the fp16 loss scaler's found_inf must be agreed on before any rank steps (a skipped step is skipped
+        everywhere).  A no-op with all-reduced gradients: every rank already checked the same sums."""
+        if self.owners is None:
+            return
+        if self.comm is not None:
+            self.comm.all_reduce_(flag)
+            return
+        dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=self.group)
 
     def reduce_stats(self, stats: torch.Tensor) -> None:
         if self.comm is not None:
@@ -181,7 +243,7 @@ class GradReducer:
 
     def all_reduce(self) -> None:
         """Non-overlapped form: everything at once, after backward."""
-        if self.stage is not None:
+        if self.stage is not None or self.owners is not None:
             self.begin()
             for i, f in enumerate(self.flats):
                 self.on_grads_ready(i, 0, f.numel())
@@ -202,31 +264,29 @@ class GradReducer:
         self._covered = [0] * len(self.flats)
 
     def on_grads_ready(self, arena: int, lo: int, hi: int) -> None:
-        """Backward has enqueued every kernel that writes flats[arena][lo:hi]: start its all-reduce now.  The collective is
+        """Backward has enqueued every kernel that writes flats[arena][lo:hi]: start its reduction now.  The collective is
         ordered after those kernels (ProcessGroupNCCL waits on the current stream) and runs on RCCL's own stream, i.e. under
-        the backward kernels of the layers below."""
+        the backward kernels of the layers below.  With owners set (stage 2) the slice is cut at the owner boundaries and each
+        piece is reduced onto its owner."""
         if hi <= lo:
             return
-        if self.stage is not None:
-            st = self.stage[arena][lo:hi]
-            _wire_cast(self.flats[arena][lo:hi], st)                             # fp32 -> bf16 on the compute stream (one library launch)
-            if self.comm is not None:
-                side = self.comm.stream
-                side.wait_stream(torch.cuda.current_stream(self.comm.device))
-                self.comm.all_reduce_(st, side)
-                work = None
-            else:
-                work = dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self._pending.append((arena, lo, hi, work))
-            self._covered[arena] += hi - lo
-            return
+        side = None
         if self.comm is not None:
             side = self.comm.stream
-            side.wait_stream(torch.cuda.current_stream(self.comm.device))    # after the kernels that produced the slice
-            self.comm.all_reduce_(self.flats[arena][lo:hi], side)
-            self._covered[arena] += hi - lo
-            return
-        self._works.append(dist.all_reduce(self.flats[arena][lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self.stage is not None:
+            _wire_cast(self.flats[arena][lo:hi], self.stage[arena][lo:hi])          # fp32 -> bf16 on the compute stream (one library launch)
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream(self.comm.device))           # after the kernels that produced (and cast) the slice
+        for plo, phi, root in self._pieces(arena, lo, hi):
+            buf = (self.stage if self.stage is not None else self.flats)[arena][plo:phi]
+            work = self._collective(buf, root, side)
+            if self.stage is not None:
+                if root is None or root == self.rank:                                # only a rank that reads the sum widens it back
+                    self._pending.append((arena, plo, phi, work))
+                elif work is not None:
+                    self._works.append(work)
+            elif work is not None:
+                self._works.append(work)
         self._covered[arena] += hi - lo
 
     def finish(self) -> None:

@@ -87,13 +87,18 @@ def train(args: Namespace, tokenizer=None, language_model=None, step_hook=None) 
         print(f"clipcap_amd: operand mode: {mode[model.transformer_mapper.engine.op_dtype]}; gradient wire: {str(wire).replace('torch.', '')}"
               + (f" over {world} ranks" if world > 1 else ""), flush=True)
     reducer = GradReducer([a.grads() for a in arenas], wire_dtype=wire) if world > 1 else None
-    sharded = world > 1 and zero_stage(getattr(args, "deepspeed_strategy", None)) > 0
+    stage = zero_stage(getattr(args, "deepspeed_strategy", None)) if world > 1 else 0
+    sharded = stage > 0
     if sharded:
         # --deepspeed-strategy (args.py:87-92): AdamW moments sharded over the ranks (ZeRO stage 1); after the resume broadcast above, so
-        # that full moments of a resumed run are cut down to each rank's own range
-        ZeroShard(rank, world).apply(arenas)
+        # that full moments of a resumed run are cut down to each rank's own range.  Stage 2 / 3: the gradient slices are then reduced
+        # onto their owners only (half an all-reduce's bytes); the arenas themselves stay whole — the kernels read and write them
+        owners = ZeroShard(rank, world).apply(arenas)
+        if stage >= 2:
+            reducer.set_owners(owners, rank)
         if rank == 0:
-            print(f"clipcap_amd: optimizer state sharded over {world} ranks (--deepspeed-strategy {args.deepspeed_strategy})", flush=True)
+            print(f"clipcap_amd: optimizer state sharded over {world} ranks" + (", gradients reduced onto their owners" if stage >= 2 else "")
+                  + f" (--deepspeed-strategy {args.deepspeed_strategy})", flush=True)
     sched = linear_warmup_decay(args.scheduler_warmup_steps, args.total_steps)
     logger = None
     if args.enable_wandb and rank == 0:

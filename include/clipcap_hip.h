@@ -61,7 +61,7 @@ extern "C" {
  * would be written out of bounds, so clipcap_amd/_lib.py refuses a library whose version differs.  Entry points ADDED since 2:
  * cc_adamw_step_cast, cc_mapper_transpose_weights, cc_gpt2_transpose_weights, cc_comm_count, cc_decode_part_floats, cc_decode_fwd_p,
  * cc_beam_step_p; since 3: cc_decode_fwd_g, cc_decode_ws_check, cc_decode_mode, cc_grad_wire_pack, cc_grad_wire_unpack,
- * cc_sample_step_lp, cc_broadcast_bucket; operand mode ADDED: CC_OP_BF16X3.  Round 6 (still 3): the default-off decode experiments
+ * cc_sample_step_lp, cc_broadcast_bucket, cc_reduce_bucket; operand mode ADDED: CC_OP_BF16X3.  Round 6 (still 3): the default-off decode experiments
  * (cc_decode_image*, cc_decode_xt_image*, cc_decode_fwd_x, cc_decode_ws_check, cc_decode_last_path) moved to include/clipcap_hip_lab.h —
  * the lab library exports them, the product library does not. */
 #define CC_ABI_VERSION 3
@@ -323,6 +323,10 @@ int cc_allreduce_bucket(void* comm, void* buf, int64_t count, int32_t dtype, voi
  * clipcap/train/args.py:87-92) every rank runs cc_adamw_step on its own slice of the parameter arena and the owners' slices are
  * broadcast back, one call per owner. */
 int cc_broadcast_bucket(void* comm, void* buf, int64_t count, int32_t dtype, int32_t root, void* stream);
+/* In-place ncclReduce (SUM) of buf[0, count) onto rank `root`; the other ranks' buffers keep their own contribution.  Gradient
+ * partitioning (--deepspeed-strategy stage 2 / 3, clipcap/train/args.py:87-92): a slice of the gradient arena is summed only where it is
+ * consumed — on the rank that owns the matching AdamW moments — which moves half of an all-reduce's bytes over xGMI. */
+int cc_reduce_bucket(void* comm, void* buf, int64_t count, int32_t dtype, int32_t root, void* stream);
 /* ncclCommCount of the communicator: the number of ranks RCCL actually connected (what bench.py prints as rccl_ranks) */
 int cc_comm_count(void* comm, int32_t* nranks);
 int cc_comm_destroy(void* comm);

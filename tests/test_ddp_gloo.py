@@ -249,4 +249,93 @@ def test_sharded_optimizer_state_three_ranks(tmp_path):
     for t in range(1, 4):
         _adamw_ref(w, torch.randn(n, generator=gen), m, v, 1e-2, t)
     assert np.array_equal(res["w"], w.numpy()) and np.array_equal(res["m"], m.numpy()) and np.array_equal(res["v"], v.numpy())
-    assert [zero_stage(s) for s in (None, "", "deepspeed_stage_1", "deepspeed_stage_2_offload", "deepspeed_stage_3", "2", "ddp")] == [0, 0, 1, 1, 1, 1, 0]
+    assert [zero_stage(s) for s in (None, "", "deepspeed_stage_1", "deepspeed_stage_2_offload", "deepspeed_stage_3", "2", "deepspeed", "zero1", "ddp")] == [0, 0, 1, 2, 2, 2, 2, 1, 0]
+
+
+def _zero2_worker(rank, world, port, out, wire):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from clipcap_amd.engine import _Arena
+    from clipcap_amd.train.ddp import GradReducer, ZeroShard
+    sizes = (1003, 517)                                   # two arenas (mapper, language model), neither a multiple of world or of 8
+    arenas = []
+    for i, n in enumerate(sizes):
+        a = _Arena(n, "cpu")
+        a.w32.copy_(torch.randn(n, generator=torch.Generator().manual_seed(20 + i)))
+        arenas.append(a)
+    red = GradReducer([a.grads() for a in arenas], wire_dtype=torch.bfloat16 if wire == "bf16" else torch.float32)
+    owners = ZeroShard(rank, world).apply(arenas)
+    red.set_owners(owners, rank)
+    flag_seen = []
+    for t in range(1, 4):
+        for i, a in enumerate(arenas):                    # this rank's local gradient
+            a.grads().copy_(torch.randn(a.n, generator=torch.Generator().manual_seed(1000 * t + 10 * i + rank)))
+        red.begin()                                       # slices arrive the way backward hands them out: top first, cut anywhere
+        n0, n1 = sizes
+        red.on_grads_ready(1, 300, n1)
+        red.on_grads_ready(1, 0, 300)
+        red.on_grads_ready(0, 641, n0)
+        red.on_grads_ready(0, 0, 641)
+        red.finish()
+        flag = torch.tensor([1.0 if (t == 2 and rank == 1) else 0.0])      # one rank's slice overflowed: every rank must see it
+        red.reduce_flag(flag)
+        flag_seen.append(float(flag))
+        for a in arenas:
+            r, ranges, gather = a.zero
+            lo, hi = ranges[r]
+            if a.m is None:
+                a.m, a.v = torch.zeros(hi - lo), torch.zeros(hi - lo)
+            if flag_seen[-1] == 0.0:
+                _adamw_ref(a.w32[lo:hi], a.grads()[lo:hi], a.m, a.v, 1e-2, t)
+            gather(a.w32, ranges)
+    if rank == 0:
+        np.savez(out, w0=arenas[0].w32.numpy(), w1=arenas[1].w32.numpy(), flags=np.array(flag_seen))
+    dist.destroy_process_group()
+
+
+def _zero2_expected(world, wire):
+    sizes = (1003, 517)
+    ws = [torch.randn(n, generator=torch.Generator().manual_seed(20 + i)) for i, n in enumerate(sizes)]
+    ms = [torch.zeros(n) for n in sizes]
+    vs = [torch.zeros(n) for n in sizes]
+    for t in range(1, 4):
+        for i, n in enumerate(sizes):
+            parts = [torch.randn(n, generator=torch.Generator().manual_seed(1000 * t + 10 * i + r)) for r in range(world)]
+            if wire == "bf16":
+                acc = parts[0].to(torch.bfloat16)
+                for q in parts[1:]:
+                    acc = (acc.float() + q.to(torch.bfloat16).float()).to(torch.bfloat16)       # gloo's bf16 SUM: add in fp32, round per hop
+                g = acc.float()
+            else:
+                g = parts[0].clone()
+                for q in parts[1:]:
+                    g += q
+            if t != 2:
+                _adamw_ref(ws[i], g, ms[i], vs[i], 1e-2, t)
+    return ws
+
+
+def test_partitioned_gradients_two_ranks_fp32_and_bf16_wire(tmp_path):
+    """ZeRO stage 2 (--deepspeed-strategy deepspeed_stage_2): GradReducer.set_owners reduces every gradient slice onto its owner only, the
+    owner steps its slice and the slices are broadcast back — after three steps (one of them skipped everywhere because ONE rank flagged an
+    overflow) the parameters equal the replicated all-reduce + AdamW result bit for bit, for both wire formats."""
+    for wire in ("fp32", "bf16"):
+        out = str(tmp_path / f"zero2_{wire}.npz")
+        mp.spawn(_zero2_worker, args=(2, _free_port(), out, wire), nprocs=2, join=True)
+        res = np.load(out)
+        ws = _zero2_expected(2, wire)
+        assert list(res["flags"]) == [0.0, 1.0, 0.0]
+        assert np.array_equal(res["w0"], ws[0].numpy()) and np.array_equal(res["w1"], ws[1].numpy()), wire
+
+
+def test_partitioned_gradients_three_ranks(tmp_path):
+    """Same with three ranks (uneven owner ranges; slices that straddle two owner boundaries): fp32 wire, sums within 1 ulp-level tolerance
+    (the reduction order of three addends is the backend's)."""
+    out = str(tmp_path / "zero2_3.npz")
+    mp.spawn(_zero2_worker, args=(3, _free_port(), out, "fp32"), nprocs=3, join=True)
+    res = np.load(out)
+    ws = _zero2_expected(3, "fp32")
+    assert list(res["flags"]) == [0.0, 1.0, 0.0]
+    assert np.allclose(res["w0"], ws[0].numpy(), rtol=0, atol=2e-6) and np.allclose(res["w1"], ws[1].numpy(), rtol=0, atol=2e-6)
+

@@ -83,6 +83,9 @@ def test_c_abi_rccl_communicator_single_rank_and_overlapped_reducer():
             comm.all_reduce_(t)
             torch.cuda.synchronize()
             assert torch.equal(t, ref)
+            comm.reduce_(t, 0)                     # cc_reduce_bucket = ncclReduce onto rank 0
+            torch.cuda.synchronize()
+            assert torch.equal(t, ref)
         eng, tokens, embeds = _build("full")
         loss0 = eng.forward_backward(tokens.cuda(), embeds.cuda())
         torch.cuda.synchronize()
@@ -112,6 +115,27 @@ def test_c_abi_rccl_communicator_single_rank_and_overlapped_reducer():
             assert torch.equal(a.w32, w)
             m, v = a.full_moments()
             assert m.numel() == a.n and float(m.abs().max()) > 0
+        # ZeRO stage 2 over the same communicator: every slice reduced onto its owner (cc_reduce_bucket), fp32 and bf16 wire; with one
+        # rank the owner is this rank and the gradients must come out as the plain step's
+        eng.zero_grad()
+        eng.forward_backward(tokens.cuda(), embeds.cuda())             # the plain step at the updated parameters
+        ref = [a.g32.clone() for a in eng.arenas()]
+        for wire in (torch.float32, torch.bfloat16):
+            eng.zero_grad()
+            red2 = GradReducer([a.grads() for a in eng.arenas()], comm=comm, wire_dtype=wire)
+            red2.set_owners([a.zero[1] for a in eng.arenas()], 0)
+            red2.begin()
+            eng.forward_backward(tokens.cuda(), embeds.cuda(), reduce_stats=red2.reduce_stats, on_grads_ready=red2.on_grads_ready)
+            red2.finish()
+            flag = torch.zeros(1, device="cuda")
+            red2.reduce_flag(flag)
+            torch.cuda.synchronize()
+            assert float(flag) == 0.0
+            for a, r in zip(eng.arenas(), ref):
+                if wire == torch.float32:
+                    assert torch.allclose(a.g32, r, rtol=1e-4, atol=1e-7)
+                else:
+                    assert torch.allclose(a.g32, r.to(torch.bfloat16).float(), rtol=2e-2, atol=1e-6)
     finally:
         comm.close()
 
@@ -128,7 +152,18 @@ def _nccl_worker(out):
     loss = eng.forward_backward(tokens.cuda(), embeds.cuda(), reduce_stats=red.reduce_stats, on_grads_ready=red.on_grads_ready)
     red.finish()
     torch.cuda.synchronize()
-    np.savez(out, loss=float(loss), g=eng.mapper.arena.g32.cpu().numpy())
+    g_allreduce = eng.mapper.arena.g32.clone()
+    # ZeRO stage 2 on the same process group: dist.reduce onto the owner (one rank: this one)
+    from clipcap_amd.train.ddp import ZeroShard
+    owners = ZeroShard(0, 1).apply(eng.arenas())
+    red.set_owners(owners, 0)
+    eng.zero_grad()
+    red.begin()
+    eng.forward_backward(tokens.cuda(), embeds.cuda(), reduce_stats=red.reduce_stats, on_grads_ready=red.on_grads_ready)
+    red.finish()
+    torch.cuda.synchronize()
+    assert torch.allclose(eng.mapper.arena.g32, g_allreduce, rtol=1e-4, atol=1e-7)
+    np.savez(out, loss=float(loss), g=g_allreduce.cpu().numpy())
     dist.destroy_process_group()
 
 
