@@ -103,6 +103,7 @@ SIGNATURES = {
     "cc_beam_step": (_I, [_I, _I, _I, _P, _L, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "cc_beam_ws_bytes": (_L, [_I, _I, _I]),
     "cc_embed_tokens": (_I, [_GC, _I, _P, _P, _P, _P]),
+    "cc_embed_tokens_bwd": (_I, [_GC, _I, _P, _P, _P, _P]),
     "cc_beam_advance": (_I, [_GC, _I, _I, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P]),
     "cc_adamw_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P, _P, _P]),
     "cc_adamw_step_cast": (_I, [_I, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P, _P, _P, _P]),

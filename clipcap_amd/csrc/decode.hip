@@ -448,6 +448,16 @@ __global__ void k_embed_tokens(const float* __restrict__ wte, const int* __restr
     }
 }
 
+// Gradient of the gather: dwte[tok[r], :] += dout[r, :] (fp32 atomics; rows that share an id accumulate).  Ids clamped like the forward's.
+__global__ void k_embed_tokens_bwd(const float* __restrict__ dout, const int* __restrict__ tok, float* __restrict__ dwte, int R, int D, int rows) {
+    const size_t total = (size_t)R * D;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D), r = (int)(i / D);
+        const int id = min(max(tok[r], 0), rows - 1);
+        __hip_atomic_fetch_add(dwte + (size_t)id * D + d, dout[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // Bookkeeping between two beam steps in ONE launch (base.py:104-117: tokens = cat(tokens[src], next), embed(next), cache
 // ancestry): row r continues group row g = (r / beam) * beam + src[r].  Replaces ~10 small framework launches per generated token.
 __global__ __launch_bounds__(256) void k_beam_advance(int beam, int D, const float* __restrict__ wte, const int* __restrict__ next_tok,
@@ -1418,6 +1428,13 @@ int CC_API(cc_embed_tokens)(const cc_gpt2_cfg* c, int32_t R, const float* w32, c
     if (!cfg_ok(c) || R <= 0 || !w32 || !tokens || !out) return CC_ERR_ARG;
     const size_t total = (size_t)R * (c->D >> 2);
     hipLaunchKernelGGL(k_embed_tokens, dim3((int)std::min<size_t>((total + 255) / 256, 2048)), dim3(256), 0, S_(stream), w32, tokens, out, R, c->D, c->Vp);
+    return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
+}
+
+int CC_API(cc_embed_tokens_bwd)(const cc_gpt2_cfg* c, int32_t R, const float* dout, const int32_t* tokens, float* dwte, void* stream) {
+    if (!cfg_ok(c) || R <= 0 || !dout || !tokens || !dwte) return CC_ERR_ARG;
+    const size_t total = (size_t)R * c->D;
+    hipLaunchKernelGGL(k_embed_tokens_bwd, dim3((int)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, S_(stream), dout, tokens, dwte, R, c->D, c->Vp);
     return hipGetLastError() == hipSuccess ? CC_OK : CC_ERR_LAUNCH;
 }
 

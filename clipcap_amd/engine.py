@@ -741,6 +741,15 @@ def embed_tokens(gpt2: "Gpt2Engine", tokens: torch.Tensor, out: torch.Tensor) ->
     return out
 
 
+def embed_tokens_bwd(gpt2: "Gpt2Engine", tokens: torch.Tensor, dout: torch.Tensor) -> torch.Tensor:
+    """fp32 (V, D) gradient of ``embed_tokens`` with respect to wte: rows of ``dout`` (R, D) scattered by int32 ``tokens`` (R,), rows that
+    share an id accumulate (cc_embed_tokens_bwd; fp32 atomics, like torch's embedding backward on a GPU)."""
+    D, V, Vp = gpt2.dims["D"], gpt2.dims["V"], gpt2.dims["Vp"]
+    dw = torch.zeros(Vp, D, dtype=torch.float32, device=gpt2.arena.device)
+    check(_lib.lib().cc_embed_tokens_bwd(C.byref(gpt2.cfg), tokens.numel(), _p(dout), _p(tokens), _p(dw), _stream(gpt2.arena.device)), "cc_embed_tokens_bwd")
+    return dw[:V]
+
+
 def beam_buffers(device, samples: int, beam: int, V: int) -> tuple:
     """(next_tokens int32 (samples*beam,), src_rows int32 (samples*beam,), scratch) of cc_beam_step.  Owned by ONE decode (a
     generate_beam_tokens call allocates them once and reuses them from step to step: each step's outputs are consumed by

@@ -52,6 +52,28 @@ class _LogitsFn(torch.autograd.Function):
         return (None, dx0, None) + grads
 
 
+class _EmbedFn(torch.autograd.Function):
+    """wte[ids] with its gradient, both on the library's kernels (cc_embed_tokens / cc_embed_tokens_bwd): the autograd path of a full
+    finetune driven through Module.forward (reference model.py:44 ``get_input_embeddings()(tokens)``)."""
+
+    @staticmethod
+    def forward(ctx, weight, ids, engine):
+        from clipcap_amd.engine import embed_tokens
+        ids32 = ids.to(device=weight.device, dtype=torch.int32).contiguous().view(-1)
+        out = torch.empty(*ids.shape, weight.shape[1], dtype=torch.float32, device=weight.device)
+        embed_tokens(engine, ids32, out.view(-1, weight.shape[1]))
+        ctx.save_for_backward(ids32)
+        ctx.engine = engine
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from clipcap_amd.engine import embed_tokens_bwd
+        (ids32,) = ctx.saved_tensors
+        dw = embed_tokens_bwd(ctx.engine, ids32, dout.contiguous().view(ids32.numel(), -1).float())
+        return dw, None, None
+
+
 class _Embedding(nn.Module):
     """wte lookup on the fp32 master (a gather; exact)."""
 
@@ -79,7 +101,14 @@ class _Embedding(nn.Module):
             out = torch.empty(*ids.shape, w.shape[1], dtype=torch.float32, device=w.device)
             embed_tokens(self._owner.engine, ids.to(device=w.device, dtype=torch.int32).contiguous().view(-1), out.view(-1, w.shape[1]))
             return out
-        return torch.nn.functional.embedding(ids.to(w.device), w)       # autograd path (a full finetune through Module.forward) and CPU
+        if w.is_cuda and ids.numel() > 0:
+            # autograd path (a full finetune through Module.forward): the same gather, and its scatter-add gradient, on the library's kernels
+            if not ids.is_cuda:
+                lo, hi = int(ids.min()), int(ids.max())
+                if lo < 0 or hi >= w.shape[0]:
+                    raise IndexError(f"token id out of range for the {w.shape[0]}-row embedding table: min {lo}, max {hi}")
+            return _EmbedFn.apply(w, ids, self._owner.engine)
+        return torch.nn.functional.embedding(ids.to(w.device), w)       # CPU master (no device): torch's gather, exact
 
 
 class _TiedHead(nn.Module):

@@ -61,7 +61,7 @@ extern "C" {
  * would be written out of bounds, so clipcap_amd/_lib.py refuses a library whose version differs.  Entry points ADDED since 2:
  * cc_adamw_step_cast, cc_mapper_transpose_weights, cc_gpt2_transpose_weights, cc_comm_count, cc_decode_part_floats, cc_decode_fwd_p,
  * cc_beam_step_p; since 3: cc_decode_fwd_g, cc_decode_ws_check, cc_decode_mode, cc_grad_wire_pack, cc_grad_wire_unpack,
- * cc_sample_step_lp, cc_broadcast_bucket, cc_reduce_bucket; operand mode ADDED: CC_OP_BF16X3.  Round 6 (still 3): the default-off decode experiments
+ * cc_sample_step_lp, cc_broadcast_bucket, cc_reduce_bucket, cc_embed_tokens_bwd; operand mode ADDED: CC_OP_BF16X3.  Round 6 (still 3): the default-off decode experiments
  * (cc_decode_image*, cc_decode_xt_image*, cc_decode_fwd_x, cc_decode_ws_check, cc_decode_last_path) moved to include/clipcap_hip_lab.h —
  * the lab library exports them, the product library does not. */
 #define CC_ABI_VERSION 3
@@ -256,6 +256,9 @@ int cc_beam_step_p(int32_t S, int32_t beam, int32_t V, const float* logits, int6
 int64_t cc_beam_ws_bytes(int32_t S, int32_t beam, int32_t V);
 /* gathers wte rows for next tokens: out fp32 [R, D] (base.py:117) */
 int cc_embed_tokens(const cc_gpt2_cfg* cfg, int32_t R, const float* w32, const int32_t* tokens, float* out, void* stream);
+/* its gradient: dwte fp32 [Vp, D] += scatter of dout fp32 [R, D] by tokens (rows sharing an id accumulate; fp32 atomics) — what autograd runs
+ * for `language_model.get_input_embeddings()(tokens)` in a full finetune driven through Module.forward (clipcap/model/model.py:44) */
+int cc_embed_tokens_bwd(const cc_gpt2_cfg* cfg, int32_t R, const float* dout, const int32_t* tokens, float* dwte, void* stream);
 /* Everything between two beam steps in one launch (base.py:104-117): row r continues row g = (r / beam) * beam + src_rows[r] of its beam
  * group (src_rows NULL: g = r).  x_out fp32 [R, D] = wte[next_tokens[r]] (w32 points at wte);  row_map_out[r][j] = row_map_in[g][j] for
  * j < pos, r for the positions still to come (tables int32 [R][ctx_max], see cc_decode_fwd; NULL = skip);  tokens_out[r][:step] =

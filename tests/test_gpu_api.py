@@ -43,6 +43,30 @@ def test_module_forward_logits_and_to_device():
     assert emb.shape == (1, 2, 64)
 
 
+def test_input_embedding_autograd_runs_on_the_library_and_equals_torch():
+    """`language_model.get_input_embeddings()(tokens)` with gradients enabled (a full finetune through Module.forward, reference
+    model.py:44): gather and scatter-add gradient on cc_embed_tokens / cc_embed_tokens_bwd — values exact, the gradient equal to
+    torch.nn.functional.embedding's (repeated ids accumulate; fp32 atomics in another order: 1e-6 of the row scale)."""
+    m, g = _model_from_train_fixture("full")
+    emb = m.language_model.get_input_embeddings()
+    w = emb.weight
+    assert w.requires_grad and w.is_cuda
+    V, D = w.shape
+    ids = torch.randint(0, V, (5, 7), generator=torch.Generator().manual_seed(5)).cuda()
+    ids[0, :4] = 3                      # one id four times, and the last vocabulary row
+    ids[4, 6] = V - 1
+    up = torch.randn(5, 7, D, generator=torch.Generator().manual_seed(6)).cuda()
+    out = emb(ids)
+    assert out.requires_grad and torch.equal(out.detach(), w.detach()[ids])
+    (gw,) = torch.autograd.grad((out * up).sum(), w)
+    w2 = w.detach().clone().requires_grad_(True)
+    (gr,) = torch.autograd.grad((torch.nn.functional.embedding(ids, w2) * up).sum(), w2)
+    assert gw.shape == gr.shape == (V, D)
+    assert torch.allclose(gw, gr, rtol=1e-6, atol=1e-6) and float(gw[3].abs().max()) > 0 and float(gw[V - 1].abs().max()) > 0
+    with pytest.raises(IndexError):
+        emb(torch.tensor([[0, V]]))     # host ids are validated like F.embedding
+
+
 @pytest.mark.parametrize("mode", ["prefix_only", "full"])
 def test_three_optimizer_steps_track_the_reference(mode):
     """fused_step x3 with the reference's lr schedule: losses follow the golden trajectory; parameters move along the
