@@ -1568,14 +1568,19 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : (HD == 96 ? 2 : 1)) void k_attn
 #ifndef CC_ATTN_FUSED_OCC
 #define CC_ATTN_FUSED_OCC 2
 #endif
-template <int LD>
+// ROWS < 32: the tile holds rows 0 .. ROWS-1 only; reads of the rows above are redirected to row ROWS-1 (finite values that the
+// caller multiplies by exact zeros: those rows belong to keys / queries >= S)
+template <int LD, int ROWS = 32>
 __device__ __forceinline__ op16x8 frag_tr_ld(const op16_t* blk, int nb, int t, int lane) {
     typedef __attribute__((ext_vector_type(4))) short s16x4_t;
     typedef __attribute__((address_space(3))) s16x4_t* lp_t;
     const int half = lane >> 5, j = lane & 15, dsub = (lane >> 4) & 1;
-    const op16_t* p = blk + (16 * t + 4 * half + (j >> 2)) * LD + nb * 32 + 16 * dsub + 4 * (j & 3);
+    const int r0 = 16 * t + 4 * half + (j >> 2);
+    const op16_t* col = blk + nb * 32 + 16 * dsub + 4 * (j & 3);
+    const op16_t* p = col + (ROWS < 32 ? min(r0, ROWS - 1) : r0) * LD;
+    const op16_t* ph = col + (ROWS < 32 ? min(r0 + 8, ROWS - 1) : r0 + 8) * LD;
     const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)p);
-    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(p + 8 * LD));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)ph);
     typedef __attribute__((ext_vector_type(8))) short s16x8_t;
     const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(op16x8, v);
@@ -1602,7 +1607,10 @@ __device__ __forceinline__ void attn_store_tile(op16_t* T, const f32x16 (&acc)[H
     }
 }
 
-template <int HD, bool CAUSAL, bool DROP, int NBLK, int OCC>
+// DR: rows of the dS^T tile (its own LDS tile when the K copy has no spare columns).  Head dim 96 misses two resident workgroups per CU by
+// 2 KiB of LDS with 32 rows; with S <= 24 (the mapper: S = 20) the tile holds 24 and the launch asks for OCC = 2 — one round of 2048
+// (sample, head) waves instead of two rounds at one wave per SIMD.
+template <int HD, bool CAUSAL, bool DROP, int NBLK, int OCC, int DR = 32>
 __global__ __launch_bounds__(256, OCC) void k_attn_bwd_fused(const op16_t* __restrict__ qkv, const op16_t* __restrict__ dout, const op16_t* __restrict__ o,
                                                              const float* __restrict__ lse, int B, int S, int H, float scale,
                                                              op16_t* __restrict__ dqkv, Drop drop = Drop()) {
@@ -1614,7 +1622,8 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_fused(const op16_t* __res
     __shared__ __attribute__((aligned(16))) op16_t ksm[4][32 * LD];
     __shared__ __attribute__((aligned(16))) op16_t qsm[4][32 * LD];
     __shared__ __attribute__((aligned(16))) op16_t dsm[4][32 * LD];
-    __shared__ __attribute__((aligned(16))) op16_t dtx[SPARE ? 1 : 4][SPARE ? 8 : 32 * 32];
+    static_assert(DR == 32 || (!SPARE && NBLK == 1), "the short dS^T tile is for the single-block form with its own tile");
+    __shared__ __attribute__((aligned(16))) op16_t dtx[SPARE ? 1 : 4][SPARE ? 8 : DR * 32];
     __shared__ __attribute__((aligned(16))) float ldsm[4][NBLK][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int item = blockIdx.x * 4 + wave;
@@ -1737,11 +1746,13 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_fused(const op16_t* __res
             const op16x8 pf[2] = {pack_frag(p), pack_frag(p + 8)};
             const op16x8 dsf[2] = {pack_frag(ds), pack_frag(ds + 8)};
             // dS^T tile: row = key (this lane), columns = queries 8 g + 4 half + 0..3 (the register order of the accumulator layout)
+            if (DR == 32 || l31 < DR) {        // short tile: keys >= DR are >= S, their dS is zero and their rows are never stored
 #pragma unroll
-            for (int t = 0; t < 2; t++) {
-                const uint4 w = __builtin_bit_cast(uint4, dsf[t]);
-                *reinterpret_cast<uint2*>(dtm + l31 * LT + 16 * t + 4 * half) = make_uint2(w.x, w.y);
-                *reinterpret_cast<uint2*>(dtm + l31 * LT + 16 * t + 8 + 4 * half) = make_uint2(w.z, w.w);
+                for (int t = 0; t < 2; t++) {
+                    const uint4 w = __builtin_bit_cast(uint4, dsf[t]);
+                    *reinterpret_cast<uint2*>(dtm + l31 * LT + 16 * t + 4 * half) = make_uint2(w.x, w.y);
+                    *reinterpret_cast<uint2*>(dtm + l31 * LT + 16 * t + 8 + 4 * half) = make_uint2(w.z, w.w);
+                }
             }
 #pragma unroll
             for (int t = 0; t < 2; t++)
@@ -1752,7 +1763,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_fused(const op16_t* __res
                 }
 #pragma unroll
             for (int t = 0; t < 2; t++) {
-                const op16x8 dst = frag_tr_ld<LT>(dtm, 0, t, lane);
+                const op16x8 dst = frag_tr_ld<LT, DR>(dtm, 0, t, lane);
 #pragma unroll
                 for (int nb = 0; nb < NB; nb++) dq[i][nb] = CC_MFMA_32x32x16(frag_tr<HD>(ksm[wave], nb, t, lane), dst, dq[i][nb]);
             }
@@ -1776,7 +1787,16 @@ static void attn_bwd_fused_launch(const op16_t* qkv, const op16_t* dout, const o
     const dim3 grid((B * H + 3) / 4), blk(256);
     if (drop.thresh) hipLaunchKernelGGL((k_attn_bwd_fused<HD, true, true, NBLK, (HD == 64 ? OCC : 1)>), grid, blk, 0, st, qkv, dout, o, lse, B, S, H, scale, dqkv, drop);
     else if (causal) hipLaunchKernelGGL((k_attn_bwd_fused<HD, true, false, NBLK, (HD == 64 ? OCC : 1)>), grid, blk, 0, st, qkv, dout, o, lse, B, S, H, scale, dqkv, drop);
-    else hipLaunchKernelGGL((k_attn_bwd_fused<HD, false, false, NBLK, 1>), grid, blk, 0, st, qkv, dout, o, lse, B, S, H, scale, dqkv, drop);
+    else {
+        if constexpr (HD == 96 && NBLK == 1) {
+            static const bool short_on = []() { const char* e = cc_lab_env("CC_ATTN_BWD_SHORT"); return !e || atoi(e) != 0; }();     // lab A/B switch
+            if (S <= 24 && short_on) {
+                hipLaunchKernelGGL((k_attn_bwd_fused<HD, false, false, NBLK, 2, 24>), grid, blk, 0, st, qkv, dout, o, lse, B, S, H, scale, dqkv, drop);
+                return;
+            }
+        }
+        hipLaunchKernelGGL((k_attn_bwd_fused<HD, false, false, NBLK, 1>), grid, blk, 0, st, qkv, dout, o, lse, B, S, H, scale, dqkv, drop);
+    }
 }
 
 template <int HD>
