@@ -140,6 +140,7 @@ static void run(const char* name, int M, int N, int K, int grid) {
     check("stag 320x256", [&] { launch_stag<10>(A, B, g, e1); });
     check("stag 160x256", [&] { launch_stag<5>(A, B, g, e1); });
     check("stag 256x192", [&] { (launch_stag<8, 3>(A, B, g, e1)); });
+    check("stag 320x192", [&] { (launch_stag<10, 3>(A, B, g, e1)); });
     const bool ok2 = (K % 128) == 0 && K >= 256, ok3 = (K % 192) == 0 && K >= 384;
     if (ok2) check("q4 256x256 NS2 (4 waves, 64-deep full lines)", [&] { (launch_q4<8, 2>(A, B, g, e1, grid)); });
     if (ok3) check("q4 160x256 NS3", [&] { (launch_q4<5, 3>(A, B, g, e1, grid)); });
