@@ -25,7 +25,7 @@ OUT = os.path.join(ROOT, "clipcap_amd", "csrc", "gemm_q4_asm.inc")
 
 
 class Gen:
-    def __init__(self, ni, ns, read_every=2, first_read_slot=1, dma_first=2, nodma=False):
+    def __init__(self, ni, ns, read_every=2, first_read_slot=1, dma_first=2, nodma=False, noread=False):
         self.ni, self.ns = ni, ns
         self.sbm = 32 * ni
         self.sa = self.sbm * 128
@@ -35,6 +35,7 @@ class Gen:
         self.nd = self.na + self.nb
         self.nmfma = 8 * ni
         self.read_every, self.first_read_slot, self.dma_first, self.nodma = read_every, first_read_slot, dma_first, nodma
+        self.noread = noread
         self.dma_gap = (self.nmfma - dma_first - 3) // (self.nd - 1)
         assert self.dma_gap >= 2, "M0 write, one MFMA, the load: consecutive groups may overlap by one slot"
         assert ns * self.sstage <= 160 * 1024
@@ -69,7 +70,8 @@ class Gen:
         for i in range(ni):
             reads.append("ds_read_b128 %s, %%[la%d_%d] offset:%d" % (self.fa(rset, i), rbuf, rk, i * 2048))
         for r, text in enumerate(reads):
-            slots[self.first_read_slot + r * self.read_every].append(text)
+            if not self.noread:
+                slots[self.first_read_slot + r * self.read_every].append(text)
         if dma:
             dmas = []
             for i in range(self.na):
@@ -197,6 +199,7 @@ VARIANTS = {
     0: dict(),
     1: dict(read_every=1),
     2: dict(nodma=True),                          # ablation: no LDS-DMA (results meaningless)
+    3: dict(noread=True),                         # ablation: no fragment reads in the K loop (results meaningless): what the ds_read_b128 stream costs
 }
 
 

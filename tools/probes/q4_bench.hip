@@ -149,6 +149,8 @@ static void run(const char* name, int M, int N, int K, int grid) {
     if (ok3) check("q4 160x256 NS3 variant: read every MFMA", [&] { (launch_q4<5, 3, 1>(A, B, g, e1, grid)); });
     if (ok2) check("q4 256x256 NS2 ABLATION no LDS-DMA", [&] { (launch_q4<8, 2, 2>(A, B, g, e1, grid)); });
     if (ok3) check("q4 160x256 NS3 ABLATION no LDS-DMA", [&] { (launch_q4<5, 3, 2>(A, B, g, e1, grid)); });
+    if (ok2) check("q4 256x256 NS2 ABLATION no fragment reads", [&] { (launch_q4<8, 2, 3>(A, B, g, e1, grid)); });
+    if (ok3) check("q4 160x256 NS3 ABLATION no fragment reads", [&] { (launch_q4<5, 3, 3>(A, B, g, e1, grid)); });
     if (N == 2304 || N == 768) {      // product functors of the plain launches: bias (c_attn) — specialised vs run-time switches
         float* bias; hipMalloc(&bias, N * 4); hipMemset(bias, 0, N * 4);
         EpiBF16 f{C1, nullptr, bias, N, M, N, 0};
